@@ -1,0 +1,43 @@
+"""nrd-sample_amd: MI355X-native NRD denoiser dispatch backend (REBLUR / RELAX / SIGMA / REFERENCE).
+
+Layout:  csrc/      HIP kernels + the C-ABI (libnrdhip.so) + the C++ nrd:: API on top of it
+         api.py     ctypes twin of nrd::Integration over the C-ABI
+         synth.py   synthetic G-buffer / noisy radiance generator in the sample's encodings
+         harness.py the sample's per-frame call sequence (Sample::RenderFrame's NRD part), headless
+
+The directory name carries a hyphen, so import it through ``__graft_entry__.load_package()``
+(registers it as ``nrd_sample_amd``).
+"""
+import os
+
+from . import api, synth  # noqa: F401
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+HIP_LIB = os.path.join(PKG_DIR, "csrc", "libnrdhip.so")
+ORACLE_LIB = os.path.join(REPO_DIR, "oracle", "_build", "liboracle.so")
+
+
+def hip_backend(device="cuda:0"):
+    """The product path. Fails loudly when the HIP library is missing or no GPU is visible - there is no CPU fallback."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("nrd-sample_amd: no HIP device visible; the denoiser passes are HIP kernels and have no CPU fallback")
+    b = api.Backend(HIP_LIB, "nrdhip_", device)
+    b.check_abi()
+    return b
+
+
+def hip_library_symbols():
+    """Load libnrdhip.so without touching a device (CPU-side ABI checks)."""
+    b = api.Backend(HIP_LIB, "nrdhip_", "cuda:0")
+    b.check_abi()
+    return b
+
+
+def oracle_backend():
+    """TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline): the CPU oracle behind the same entry points."""
+    b = api.Backend(ORACLE_LIB, "orc_", "cpu")
+    b.check_abi()
+    return b

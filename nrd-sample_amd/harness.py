@@ -1,0 +1,109 @@
+"""Headless twin of the NRD part of Sample::RenderFrame (Source/NRDSample.cpp:3835-3879, :4068-4154, :4213-4227):
+NewFrame -> SetCommonSettings -> {SetDenoiserSettings -> Denoise}* with every resource slot bound the way
+Sample::Denoise does (:447-501). Works on numpy arrays (CPU oracle, tests only) or torch tensors (HIP backend)."""
+import numpy as np
+
+from . import api
+
+RT = api.ResourceType
+F = api.Format
+
+# slot -> (key in the synthetic frame dict, format)
+INPUT_SLOTS = {
+    RT.IN_MV: ("mv", F.RGBA16_SFLOAT),
+    RT.IN_NORMAL_ROUGHNESS: ("normal_roughness", F.R10_G10_B10_A2_UNORM),
+    RT.IN_VIEWZ: ("viewz", F.R32_SFLOAT),
+    RT.IN_DIFF_RADIANCE_HITDIST: ("diff", F.RGBA16_SFLOAT),
+    RT.IN_SPEC_RADIANCE_HITDIST: ("spec", F.RGBA16_SFLOAT),
+    RT.IN_DIFF_CONFIDENCE: ("confidence", F.RGBA16_SFLOAT),
+    RT.IN_SPEC_CONFIDENCE: ("confidence", F.RGBA16_SFLOAT),
+    RT.IN_PENUMBRA: ("penumbra", F.R16_SFLOAT),
+    RT.IN_TRANSLUCENCY: ("translucency", F.RGBA8_UNORM),
+    RT.IN_SIGNAL: ("signal", F.RGBA16_SFLOAT),
+}
+OUTPUT_SLOTS = {
+    RT.OUT_DIFF_RADIANCE_HITDIST: ("out_diff", F.RGBA16_SFLOAT, 8),
+    RT.OUT_SPEC_RADIANCE_HITDIST: ("out_spec", F.RGBA16_SFLOAT, 8),
+    RT.OUT_SHADOW_TRANSLUCENCY: ("out_shadow", F.RGBA8_UNORM, 4),
+    RT.OUT_VALIDATION: ("out_validation", F.RGBA8_UNORM, 4),
+}
+
+
+def as_bytes2d(a):
+    """view an [H, W(, C)] array as [H, row bytes] uint8 without copying"""
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint8).reshape(a.shape[0], -1)
+
+
+class Harness:
+    def __init__(self, backend, denoisers, width, height, **band):
+        """denoisers: list of api.Denoiser; identifier = enum value (the sample's NRD_ID macro, NRDSample.cpp:226)."""
+        self.backend, self.w, self.h = backend, width, height
+        self.nrd = api.Integration(backend)
+        r = self.nrd.recreate([(int(d), d) for d in denoisers], width, height, **band)
+        if r != api.Result.SUCCESS:
+            raise api.NrdError("Recreate", int(r))
+        self.denoisers = list(denoisers)
+        self.outputs = {}
+        for slot, (key, fmt, bpt) in OUTPUT_SLOTS.items():
+            self.outputs[key] = self._zeros(height, width * bpt)
+        self.resident = {}
+
+    def _zeros(self, rows, rowbytes):
+        if self.backend.is_device:
+            import torch
+            return torch.zeros((rows, rowbytes), dtype=torch.uint8, device=self.backend.device)
+        return np.zeros((rows, rowbytes), dtype=np.uint8)
+
+    def upload(self, frame):
+        """numpy frame dict -> byte planes resident where the backend computes"""
+        out = {}
+        for key in set(k for k, _ in INPUT_SLOTS.values()):
+            if key not in frame:
+                continue
+            b = as_bytes2d(frame[key])
+            if self.backend.is_device:
+                import torch
+                b = torch.from_numpy(b.copy()).to(self.backend.device)
+            else:
+                b = b.copy()
+            out[key] = b
+        return out
+
+    def bind(self, planes):
+        for slot, (key, fmt) in INPUT_SLOTS.items():
+            if key in planes:
+                buf = planes[key]
+                bpt = api.FORMAT_BYTES[fmt]
+                self.nrd.set_resource(slot, buf, fmt, width=buf.shape[1] // bpt, height=buf.shape[0])
+        for slot, (key, fmt, bpt) in OUTPUT_SLOTS.items():
+            self.nrd.set_resource(slot, self.outputs[key], fmt, width=self.w, height=self.h)
+        # REFERENCE runs in place: the sample binds the same texture to IN_SIGNAL and OUT_SIGNAL (NRDSample.cpp:484-485)
+        if "signal" in planes:
+            self.nrd.set_resource(RT.OUT_SIGNAL, planes["signal"], F.RGBA16_SFLOAT, width=self.w, height=self.h)
+
+    def frame(self, common, planes, settings=None, order=None):
+        """one frame: settings = {Denoiser: settings struct}; order = list of lists of denoisers per Denoise() call"""
+        settings = settings or {}
+        self.nrd.new_frame()
+        self.nrd.set_common_settings(common)
+        self.bind(planes)
+        calls = order or [[d] for d in self.denoisers]
+        for call in calls:
+            for d in call:
+                if d in settings:
+                    self.nrd.set_denoiser_settings(int(d), settings[d])
+            self.nrd.denoise([int(d) for d in call])
+
+    def fetch(self, buf):
+        if hasattr(buf, "cpu"):
+            return buf.cpu().numpy()
+        return buf
+
+    def output(self, key, dtype=np.float16, channels=4):
+        raw = self.fetch(self.outputs[key])
+        return raw.view(dtype).reshape(self.h, self.w, channels) if channels > 1 else raw.view(dtype).reshape(self.h, self.w)
+
+    def pool(self, name):
+        p = self.nrd.pool_plane(name)
+        return self.fetch(p["buf"])

@@ -1,0 +1,172 @@
+// orc_core.h - CPU ORACLE internals (test infrastructure, NOT product code; parity unpinned vs upstream NRD).
+// Instance bookkeeping, plane access, per-frame constants. See oracle/README.md.
+#pragma once
+
+#include "../include/NRDDescs.h"
+#include "../include/NRDSettings.h"
+#include "orc_math.h"
+
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace orc {
+
+struct Plane {
+    uint8_t* p = nullptr;
+    uint32_t pitch = 0;
+    uint32_t fmt = 0;
+    uint16_t w = 0, h = 0;
+    uint32_t bpt = 0; // bytes per texel
+    const char* name = "";
+};
+
+static inline uint32_t format_bytes(uint32_t f) {
+    using nrd::Format;
+    switch ((Format)f) {
+        case Format::R8_UNORM:
+        case Format::R8_UINT: return 1;
+        case Format::R16_UINT:
+        case Format::R16_SFLOAT: return 2;
+        case Format::RGBA8_UNORM:
+        case Format::RG16_SFLOAT:
+        case Format::R32_UINT:
+        case Format::R32_SFLOAT:
+        case Format::R10_G10_B10_A2_UNORM: return 4;
+        case Format::RGBA16_SFLOAT:
+        case Format::RG32_UINT: return 8;
+        case Format::RGBA32_SFLOAT:
+        case Format::RGBA32_UINT: return 16;
+        default: return 0;
+    }
+}
+
+// ---- raw texel access -------------------------------------------------------------------------
+static inline uint8_t* texel(const Plane& P, int x, int y) { return P.p + (size_t)y * P.pitch + (size_t)x * P.bpt; }
+static inline float ld_f32(const Plane& P, int x, int y, int off = 0) { float v; std::memcpy(&v, texel(P, x, y) + off, 4); return v; }
+static inline uint32_t ld_u32(const Plane& P, int x, int y, int off = 0) { uint32_t v; std::memcpy(&v, texel(P, x, y) + off, 4); return v; }
+static inline uint16_t ld_u16(const Plane& P, int x, int y, int off = 0) { uint16_t v; std::memcpy(&v, texel(P, x, y) + off, 2); return v; }
+static inline float ld_h(const Plane& P, int x, int y, int off = 0) { return f16_to_f32(ld_u16(P, x, y, off)); }
+static inline f4 ld_h4(const Plane& P, int x, int y, int off = 0) {
+    uint16_t v[4];
+    std::memcpy(v, texel(P, x, y) + off, 8);
+    return {f16_to_f32(v[0]), f16_to_f32(v[1]), f16_to_f32(v[2]), f16_to_f32(v[3])};
+}
+static inline void st_f32(const Plane& P, int x, int y, float v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 4); }
+static inline void st_u32(const Plane& P, int x, int y, uint32_t v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 4); }
+static inline void st_u16(const Plane& P, int x, int y, uint16_t v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 2); }
+static inline void st_h(const Plane& P, int x, int y, float v, int off = 0) { st_u16(P, x, y, f32_to_f16(clampf(v, -FP16_MAX, FP16_MAX)), off); }
+static inline void st_h4(const Plane& P, int x, int y, f4 v, int off = 0) {
+    uint16_t h[4] = {f32_to_f16(clampf(v.x, -FP16_MAX, FP16_MAX)), f32_to_f16(clampf(v.y, -FP16_MAX, FP16_MAX)),
+                     f32_to_f16(clampf(v.z, -FP16_MAX, FP16_MAX)), f32_to_f16(clampf(v.w, -FP16_MAX, FP16_MAX))};
+    std::memcpy(texel(P, x, y) + off, h, 8);
+}
+
+// ---- per-frame constants (derived from nrd::CommonSettings; DESIGN.md "frame constants") ---------
+struct Consts {
+    int W = 0, H = 0;         // rect size of the whole (global) frame
+    int Wprev = 0, Hprev = 0; // previous frame's rect
+    int resW = 0, resH = 0;   // local plane size
+    int yOff = 0;             // global row stored at local row 0 (row tiling), else 0
+    int ownY0 = 0, ownY1 = 0; // local rows this instance produces [ownY0, ownY1)
+    float invW = 0, invH = 0, invWprev = 0, invHprev = 0;
+    float fr[4] = {}, frPrev[4] = {}; // x0, y0, dx, dy : Xv.xy = z * (uv * d + o)
+    float pj[5] = {}, pjPrev[5] = {}; // m0, m5, m8, m9, s (clip.w = s * z)
+    float w2v[9] = {}, w2vPrev[9] = {}, v2w[9] = {}, v2wPrev[9] = {};
+    float camDelta[3] = {}; // camera position prev - current (world)
+    float unproject = 0, minRectDimMulUnproject = 0;
+    float denoisingRange = 0, disocclusionThreshold = 0, splitScreen = 0;
+    float mvScale[3] = {};
+    uint32_t frameIndex = 0;
+    bool mvWorld = false, confAvail = false, reset = false;
+    float rot[64][2] = {};
+};
+
+bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err);
+
+// view position from uv and (signed) viewZ
+static inline f3 reconstruct(const float* fr, float u, float v, float z) { return {z * (u * fr[2] + fr[0]), z * (v * fr[3] + fr[1]), z}; }
+// view position -> uv; false when the point is not in front of the camera
+static inline bool project(const float* pj, f3 X, float& u, float& v) {
+    float cw = pj[4] * X.z;
+    if (!(cw > 1e-6f))
+        return false;
+    float inv = 1.0f / cw;
+    u = 0.5f + 0.5f * ((pj[0] * X.x + pj[2] * X.z) * inv);
+    v = 0.5f - 0.5f * ((pj[1] * X.y + pj[3] * X.z) * inv);
+    return true;
+}
+
+// ---- denoiser bookkeeping -----------------------------------------------------------------------
+enum class Kind { REBLUR, RELAX, SIGMA, REFERENCE };
+
+struct PoolPlane {
+    const char* name;
+    uint32_t fmt;
+    uint32_t bpt;
+    uint16_t downsample;
+};
+
+struct Instance;
+struct DenoiserState;
+
+struct Pass {
+    const char* name;
+    const char* kernel;
+    uint16_t haloRows;
+    float bytesPerPixel;
+    std::vector<uint32_t> written; // (pool << 16) | index ; pool 2 = slot
+    std::vector<uint32_t> read;
+    std::function<void(Instance&, DenoiserState&, const Consts&, int y0, int y1)> run; // rows [y0,y1) local
+    bool tileGrid = false; // pass iterates over 16x16 tiles rather than pixels
+};
+
+struct DenoiserState {
+    uint32_t identifier = 0;
+    nrd::Denoiser denoiser = nrd::Denoiser::MAX_NUM;
+    Kind kind = Kind::REFERENCE;
+    bool hasDiff = false, hasSpec = false, sh = false, occlusion = false, translucency = false;
+    int nsig = 0;
+    uint32_t permBase = 0, transBase = 0; // first plane index in the instance pools
+    uint32_t frameCounter = 0;            // denoise calls so far (ping-pong selector)
+    bool historyValid = false;
+    uint32_t framesSinceReset = 0; // frames accumulated since the last history reset
+    nrd::ReblurSettings reblur;
+    nrd::RelaxSettings relax;
+    nrd::SigmaSettings sigma;
+    nrd::ReferenceSettings reference;
+    std::vector<Pass> passes; // rebuilt every denoise call
+};
+
+struct Instance {
+    int resW = 0, resH = 0, frameH = 0, yOff = 0, ownY0 = 0, ownRows = 0;
+    uint32_t flags = 0;
+    int threads = 1;
+    nrd::CommonSettings common;
+    bool commonSet = false;
+    std::vector<DenoiserState> denoisers;
+    std::vector<PoolPlane> permDesc, transDesc;
+    std::vector<Plane> perm, trans;
+    std::vector<std::vector<uint8_t>> owned; // internal storage when pools are not external
+    Plane slots[(size_t)nrd::ResourceType::MAX_NUM];
+    std::string error;
+};
+
+// pass-graph builders (one per denoiser family)
+void reference_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans);
+void reference_build(Instance& I, DenoiserState& d);
+void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans);
+void reblur_build(Instance& I, DenoiserState& d);
+void sigma_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans);
+void sigma_build(Instance& I, DenoiserState& d);
+void relax_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans);
+void relax_build(Instance& I, DenoiserState& d);
+
+static inline uint32_t enc_perm(uint32_t i) { return (0u << 16) | i; }
+static inline uint32_t enc_trans(uint32_t i) { return (1u << 16) | i; }
+static inline uint32_t enc_slot(nrd::ResourceType t) { return (2u << 16) | (uint32_t)t; }
+
+// 8-tap Poisson disk (unit radius) + per-tap Gaussian-like weight; frozen table
+extern const float g_poisson8[8][3];
+
+} // namespace orc

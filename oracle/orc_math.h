@@ -1,0 +1,292 @@
+// orc_math.h - scalar math of the CPU ORACLE (test infrastructure, NOT product code).
+//
+// PARITY UNPINNED vs upstream NRD: the reference tree does not contain the NRD sources
+// (External/NRD is an empty submodule) and holds no golden vectors for this path,
+// so this oracle is the build's frozen restatement of the algorithm; see DESIGN.md.
+//
+// Every function here is plain IEEE-754 binary32 arithmetic (+ - * / sqrt, compares, integer bit
+// operations) evaluated in source order; the library is compiled with -ffp-contract=off so the HIP
+// kernels (also contract-off) can match bit for bit. No libm transcendental is used anywhere on the
+// pixel path: exp2/log2/atan are the polynomials below.
+//
+// Encodings restated here follow the reference call sites:
+//   normal/roughness/materialID pack .. Shaders/TraceOpaque.cs.hlsl:657, Shaders/Composition.cs.hlsl:40
+//   REBLUR hit distance normalisation . Shaders/TraceOpaque.cs.hlsl:421, Shaders/DlssBefore.cs.hlsl:53-54
+//   radiance+hitDist pack (YCoCg) ..... Shaders/TraceOpaque.cs.hlsl:756-757, Shaders/Composition.cs.hlsl:165-166
+//   GetSpecMagicCurve ................. Shaders/Shared.hlsli:305-311 ("Taken out from NRD")
+//   SIGMA penumbra / translucency ..... Shaders/TraceOpaque.cs.hlsl:800-801, Shaders/Composition.cs.hlsl:60-64
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+
+namespace orc {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+static inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+static inline float fmin2(float a, float b) { return a < b ? a : b; }
+static inline float fmax2(float a, float b) { return a > b ? a : b; }
+static inline float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
+static inline float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
+static inline float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+static inline float smoothstep01(float x) { x = sat(x); return x * x * (3.0f - 2.0f * x); }
+static inline float absf(float x) { return x < 0.0f ? -x : x; }
+
+static inline f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline f3 normalize3(f3 a) {
+    float l2 = dot3(a, a);
+    float inv = 1.0f / sqrtf(fmax2(l2, 1e-30f));
+    return mul3(a, inv);
+}
+// 3x3 matrix (row-major m[r*3+c]) times vector
+static inline f3 rot3(const float* m, f3 v) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp16 <-> fp32, round-to-nearest-even, denormals honoured (matches v_cvt_f16_f32 / v_cvt_f32_f16)
+// ---------------------------------------------------------------------------------------------
+static inline uint16_t f32_to_f16(float f) {
+    uint32_t u = f2u(f);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) // inf / nan
+        return (uint16_t)(sign | 0x7c00u | (u > 0x7f800000u ? 0x200u : 0u));
+    if (u >= 0x477ff000u) // >= 65520 rounds to inf
+        return (uint16_t)(sign | 0x7c00u);
+    if (u < 0x38800000u) { // below the smallest normal half (2^-14): denormal or zero
+        if (u < 0x33000000u) // < 2^-25 -> 0 (2^-25 itself ties to even = 0)
+            return (uint16_t)sign;
+        uint32_t e = u >> 23;
+        uint32_t m = (u & 0x7fffffu) | 0x800000u;
+        uint32_t shift = 126u - e; // 14..24
+        uint32_t h = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t half = 1u << (shift - 1u);
+        if (rem > half || (rem == half && (h & 1u)))
+            h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t v = u - 0x38000000u; // rebias exponent 127 -> 15
+    uint32_t h = v >> 13;
+    uint32_t rem = v & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u)))
+        h++;
+    return (uint16_t)(sign | h);
+}
+
+static inline float f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0)
+            return u2f(sign);
+        // denormal: m * 2^-24
+        float v = (float)m * 5.9604644775390625e-08f;
+        return u2f(f2u(v) | sign);
+    }
+    if (e == 31)
+        return u2f(sign | 0x7f800000u | (m << 13));
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+static const float FP16_MAX = 65504.0f;
+
+// ---------------------------------------------------------------------------------------------
+// Polynomial transcendentals (frozen; the HIP kernels carry the same coefficients)
+// ---------------------------------------------------------------------------------------------
+// 2^x, x clamped to [-126, 126]; reduction to [-0.5, 0.5], degree-6 polynomial (rel. err ~1e-7)
+static inline float exp2_poly(float x) {
+    x = clampf(x, -126.0f, 126.0f);
+    float fi = floorf(x + 0.5f);
+    float f = x - fi;
+    float p = 1.535336188319500e-4f;
+    p = p * f + 1.339887440266574e-3f;
+    p = p * f + 9.618437357674640e-3f;
+    p = p * f + 5.550332471162809e-2f;
+    p = p * f + 2.402264791363012e-1f;
+    p = p * f + 6.931472028550421e-1f;
+    p = p * f + 1.0f;
+    int32_t e = (int32_t)fi;
+    float scale = u2f((uint32_t)(e + 127) << 23);
+    return p * scale;
+}
+
+// log2(x) for normal positive x (x <= 0 returns -126)
+static inline float log2_poly(float x) {
+    if (!(x > 1.17549435e-38f))
+        return -126.0f;
+    uint32_t u = f2u(x);
+    int32_t e = (int32_t)((u >> 23) & 0xffu) - 127;
+    float m = u2f((u & 0x7fffffu) | 0x3f800000u); // [1, 2)
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float t = m - 1.0f;
+    float z = t * t;
+    float p = 7.0376836292e-2f;
+    p = p * t - 1.1514610310e-1f;
+    p = p * t + 1.1676998740e-1f;
+    p = p * t - 1.2420140846e-1f;
+    p = p * t + 1.4249322787e-1f;
+    p = p * t - 1.6668057665e-1f;
+    p = p * t + 2.0000714765e-1f;
+    p = p * t - 2.4999993993e-1f;
+    p = p * t + 3.3333331174e-1f;
+    float y = t * z * p;
+    y = y - 0.5f * z;
+    float ln = t + y;
+    return ln * 1.44269504f + (float)e;
+}
+
+// pow(saturate(x), y), y >= 0
+static inline float pow01(float x, float y) {
+    x = sat(x);
+    if (x <= 0.0f)
+        return 0.0f;
+    return exp2_poly(y * log2_poly(x));
+}
+
+// atan(x), x >= 0 (Abramowitz-Stegun 4.4.49 on [0,1], reflected above 1)
+static inline float atan_pos(float x) {
+    bool inv = x > 1.0f;
+    float t = inv ? 1.0f / x : x;
+    float s = t * t;
+    float p = 0.0208351f;
+    p = p * s - 0.0851330f;
+    p = p * s + 0.1801410f;
+    p = p * s - 0.3302995f;
+    p = p * s + 0.9998660f;
+    p = p * t;
+    return inv ? 1.57079633f - p : p;
+}
+
+// acos(x) ~ sqrt(2) * sqrt(1 - x), x in [0, 1] (small-angle exact, monotonic)
+static inline float acos_approx(float x) { return 1.41421356f * sqrtf(sat(1.0f - x)); }
+
+// exp(-3 |x|) look-alike used for "exponential" weights: 1 / (x^2 - x + 1) evaluated at x = -3|x|
+static inline float exp_weight(float ax) {
+    float x = -3.0f * ax;
+    return 1.0f / (x * x - x + 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packing
+// ---------------------------------------------------------------------------------------------
+static inline float sign_nz(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
+
+// octahedral unit vector <-> [0,1]^2
+static inline f2 oct_encode(f3 n) {
+    float inv = 1.0f / (absf(n.x) + absf(n.y) + absf(n.z));
+    float x = n.x * inv, y = n.y * inv;
+    if (n.z < 0.0f) {
+        float ox = (1.0f - absf(y)) * sign_nz(x);
+        float oy = (1.0f - absf(x)) * sign_nz(y);
+        x = ox;
+        y = oy;
+    }
+    return {x * 0.5f + 0.5f, y * 0.5f + 0.5f};
+}
+
+static inline f3 oct_decode(f2 p) {
+    float fx = p.x * 2.0f - 1.0f, fy = p.y * 2.0f - 1.0f;
+    float nz = 1.0f - absf(fx) - absf(fy);
+    float t = sat(-nz);
+    float nx = fx + (fx >= 0.0f ? -t : t);
+    float ny = fy + (fy >= 0.0f ? -t : t);
+    return normalize3({nx, ny, nz});
+}
+
+static inline uint32_t unorm_bits(float v, float maxv) { return (uint32_t)floorf(sat(v) * maxv + 0.5f); }
+
+// NRD_FrontEnd_PackNormalAndRoughness, NRD_NORMAL_ENCODING = 2 (R10G10B10A2), roughness LINEAR
+static inline uint32_t pack_normal_roughness(f3 n, float roughness, uint32_t materialID) {
+    f2 o = oct_encode(n);
+    uint32_t x = unorm_bits(o.x, 1023.0f), y = unorm_bits(o.y, 1023.0f), z = unorm_bits(roughness, 1023.0f);
+    return x | (y << 10) | (z << 20) | ((materialID & 3u) << 30);
+}
+
+struct NormalRoughness {
+    f3 n;
+    float roughness;
+    uint32_t materialID;
+};
+
+static inline NormalRoughness unpack_normal_roughness(uint32_t p) {
+    NormalRoughness r;
+    f2 o = {(float)(p & 1023u) / 1023.0f, (float)((p >> 10) & 1023u) / 1023.0f};
+    r.n = oct_decode(o);
+    r.roughness = (float)((p >> 20) & 1023u) / 1023.0f;
+    r.materialID = p >> 30;
+    return r;
+}
+
+static inline f3 linear_to_ycocg(f3 c) {
+    float Y = c.x * 0.25f + c.y * 0.5f + c.z * 0.25f;
+    float Co = c.x * 0.5f - c.z * 0.5f;
+    float Cg = c.y * 0.5f - c.x * 0.25f - c.z * 0.25f;
+    return {Y, Co, Cg};
+}
+
+static inline f3 ycocg_to_linear(f3 c) {
+    float t = c.x - c.z;
+    f3 r = {t + c.y, c.x + c.z, t - c.y};
+    return {fmax2(r.x, 0.0f), fmax2(r.y, 0.0f), fmax2(r.z, 0.0f)};
+}
+
+// (1 - 2^(-200 r^2)) * sqrt(r)   [Shaders/Shared.hlsli:305-311]
+static inline float spec_magic_curve(float roughness) {
+    float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
+    return f * sqrtf(sat(roughness));
+}
+
+// REBLUR hit distance normalisation: (A + |z| B) * lerp(1, C, 2^(D r^2))
+static inline float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
+    float e = exp2_poly(hp[3] * roughness * roughness);
+    return (hp[0] + absViewZ * hp[1]) * lerpf(1.0f, hp[2], e);
+}
+
+// specular lobe half angle: atan(r^2 * k / (1 - k)), k = 0.75
+static inline float spec_lobe_half_angle(float roughness) {
+    float m = sat(roughness);
+    m = m * m;
+    return atan_pos(m * 3.0f);
+}
+
+// Frostbite-style dominant direction factor
+static inline float spec_dominant_factor(float roughness) {
+    float s = sat(1.0f - roughness);
+    return s * (sqrtf(s) + roughness);
+}
+
+// integer hash -> rotation table index
+static inline uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
+    uint32_t h = (x * 73856093u) ^ (y * 19349663u) ^ (frame * 83492791u) ^ (salt * 2654435761u);
+    h ^= h >> 13;
+    h *= 0x5bd1e995u;
+    h ^= h >> 15;
+    return h;
+}
+
+// tangent basis of a unit vector (branchless Frisvad/Duff form)
+static inline void basis3(f3 n, f3& t, f3& b) {
+    float sz = n.z >= 0.0f ? 1.0f : -1.0f;
+    float a = -1.0f / (sz + n.z);
+    float bb = n.x * n.y * a;
+    t = {1.0f + sz * n.x * n.x * a, sz * bb, -sz * n.x};
+    b = {bb, sz + n.y * n.y * a, -n.y};
+}
+
+} // namespace orc

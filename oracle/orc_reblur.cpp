@@ -1,0 +1,914 @@
+// orc_reblur.cpp - CPU ORACLE of REBLUR_DIFFUSE / REBLUR_SPECULAR / REBLUR_DIFFUSE_SPECULAR.
+// Test infrastructure only; PARITY UNPINNED vs upstream NRD (External/NRD is absent from the reference tree,
+// SURVEY.md section 0). This file is the frozen restatement the HIP kernels are checked against.
+//
+// Contract followed (reference call sites, relative to /root/reference):
+//   slots & formats ............ Source/NRDSample.cpp:447-462 (bind), :2971-2990 (formats)
+//   settings fed ............... Source/NRDSample.cpp:563-585, :2169-2184, :4090-4126
+//   CommonSettings ............. Source/NRDSample.cpp:3835-3876
+//   input encodings ............ Shaders/TraceOpaque.cs.hlsl:609-620 (MV, viewZ, sky = +-INF), :657 (normal/roughness/material),
+//                                :418-421 + :756-757 (YCoCg radiance + normalised hit distance), Shaders/Shared.hlsli:318-335 (2.5D motion)
+//   output decoding ............ Shaders/Composition.cs.hlsl:165-166
+// Pass graph: ClassifyTiles(+guide packing) -> PrePass -> TemporalAccumulation -> HistoryFix ->
+// Blur -> PostBlur -> TemporalStabilization (+ split screen). DESIGN.md section "REBLUR" documents every formula.
+#include "orc_core.h"
+
+namespace orc {
+
+namespace {
+
+// pool plane indices relative to permBase / transBase
+enum Perm { P_GUIDE_A, P_GUIDE_B, P_DATA1_A, P_DATA1_B, P_HIST, P_FAST_A, P_FAST_B, P_STAB_A, P_STAB_B, P_NUM };
+enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_NUM };
+
+const float MAX_ACCUM = 63.0f;
+const float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
+const float POST_BLUR_RADIUS_SCALE = 2.0f;
+const float NORMAL_ANGLE_MIN = 0.02f;
+const float PREV_NORMAL_COS = 0.7f;
+
+struct Guide {
+    float z; // signed view z (already multiplied by viewZScale)
+    f3 n;
+    float roughness;
+    uint32_t mat;
+    bool sky;
+};
+
+static inline Guide load_guide(const Plane& G, int x, int y, float range) {
+    Guide g;
+    g.z = ld_f32(G, x, y, 0);
+    NormalRoughness nr = unpack_normal_roughness(ld_u32(G, x, y, 4));
+    g.n = nr.n;
+    g.roughness = nr.roughness;
+    g.mat = nr.materialID;
+    g.sky = !(absf(g.z) <= range);
+    return g;
+}
+
+static inline f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+static inline f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+static inline f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
+
+static inline void unpack_data1(uint16_t v, float& diffA, float& specA) {
+    diffA = (float)(v & 0xffu) * 0.25f;
+    specA = (float)(v >> 8) * 0.25f;
+}
+static inline uint16_t pack_data1(float diffA, float specA) {
+    uint32_t d = (uint32_t)floorf(clampf(diffA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
+    uint32_t s = (uint32_t)floorf(clampf(specA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
+    return (uint16_t)(d | (s << 8));
+}
+
+struct Ctx {
+    Instance& I;
+    DenoiserState& d;
+    const Consts& c;
+    int cur; // ping-pong parity
+    const Plane& perm(int i) const { return I.perm[d.permBase + i]; }
+    const Plane& trans(int i) const { return I.trans[d.transBase + i]; }
+    const Plane& slot(nrd::ResourceType t) const { return I.slots[(size_t)t]; }
+    const Plane& guide() const { return perm(P_GUIDE_A + cur); }
+    const Plane& guidePrev() const { return perm(P_GUIDE_A + (cur ^ 1)); }
+    int sigDiff() const { return 0; }
+    int sigSpec() const { return d.hasDiff ? 1 : 0; }
+};
+
+// material comparison: ids differ and the larger one takes part in material-aware filtering
+static inline bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
+
+// --------------------------------------------------------------------------------------------------
+// K0 ClassifyTiles + guide packing: guide = {viewZ * viewZScale, packed normal/roughness}; tile = 1 if all sky
+// --------------------------------------------------------------------------------------------------
+void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int ty1) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const Plane& inZ = k.slot(nrd::ResourceType::IN_VIEWZ);
+    const Plane& inNR = k.slot(nrd::ResourceType::IN_NORMAL_ROUGHNESS);
+    const Plane& G = k.guide();
+    const Plane& T = k.trans(T_TILES);
+    float zs = I.common.viewZScale;
+    int tilesX = (c.W + 15) / 16;
+    for (int ty = ty0; ty < ty1; ty++)
+        for (int tx = 0; tx < tilesX; tx++) {
+            bool allSky = true;
+            for (int j = 0; j < 16; j++)
+                for (int i = 0; i < 16; i++) {
+                    int x = tx * 16 + i, y = ty * 16 + j;
+                    if (x >= c.W || y >= c.resH || y + c.yOff >= c.H || y + c.yOff < 0)
+                        continue;
+                    float z = ld_f32(inZ, x, y) * zs;
+                    st_f32(G, x, y, z, 0);
+                    st_u32(G, x, y, ld_u32(inNR, x, y), 4);
+                    if (absf(z) <= c.denoisingRange)
+                        allSky = false;
+                }
+            *texel(T, tx, ty) = allSky ? 1 : 0;
+        }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Spatial filter shared by PrePass / Blur / PostBlur
+// --------------------------------------------------------------------------------------------------
+enum Variant { PRE = 0, BLUR = 1, POST = 2 };
+
+struct SpatialIO {
+    const Plane* in[2];  // per signal slot
+    int inOff[2];        // byte offset of the signal inside the texel
+    const Plane* out[2];
+    int outOff[2];
+};
+
+void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1) {
+    const Consts& c = k.c;
+    const nrd::ReblurSettings& s = k.d.reblur;
+    const Plane& G = k.guide();
+    const Plane& D1 = k.perm(P_DATA1_A + k.cur);
+    const Plane& HT = k.trans(T_HITTRACK);
+    const float* hp = &s.hitDistanceParameters.A;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            if (g.sky) {
+                for (int sig = 0; sig < k.d.nsig; sig++)
+                    st_h4(*io.out[sig], x, y, {0, 0, 0, 0}, io.outOff[sig]);
+                if (variant == PRE && k.d.hasSpec)
+                    st_h(HT, x, y, 0.0f);
+                continue;
+            }
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+            f3 Xv = reconstruct(c.fr, u, v, g.z);
+            f3 Nv = rot3(c.w2v, g.n);
+            f3 V = mul3(normalize3(Xv), -1.0f);
+            float absZ = absf(g.z);
+            float frustumSize = c.minRectDimMulUnproject * absZ;
+            float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
+            float geoB = -dot3(Nv, Xv) * geoA;
+            uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, (uint32_t)variant + 1u);
+            float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
+            float diffA = 0.0f, specA = 0.0f;
+            if (variant != PRE)
+                unpack_data1(ld_u16(D1, x, y), diffA, specA);
+
+            for (int sig = 0; sig < k.d.nsig; sig++) {
+                bool isSpec = (sig == k.sigSpec()) && k.d.hasSpec;
+                float rough = isSpec ? g.roughness : 1.0f;
+                uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
+                f4 center = ld_h4(*io.in[sig], x, y, io.inOff[sig]);
+                float hitNorm = reblur_hitdist_norm(absZ, hp, rough);
+                float hitDist = center.w * hitNorm;
+                float hitDistFactor = sat(hitDist / frustumSize);
+                float A = isSpec ? specA : diffA;
+                float nonLin = variant == PRE ? 1.0f : 1.0f / (1.0f + A);
+                float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
+                float radius;
+                if (variant == PRE) {
+                    radius = (isSpec ? s.specularPrepassBlurRadius : s.diffusePrepassBlurRadius) * hitDistFactor * smc;
+                } else {
+                    float r = s.maxBlurRadius * lerpf(MIN_CONVERGED_RADIUS_SCALE, 1.0f, nonLin) * lerpf(hitDistFactor, 1.0f, nonLin) + s.minBlurRadius;
+                    r *= variant == POST ? POST_BLUR_RADIUS_SCALE : 1.0f;
+                    r *= smc;
+                    radius = s.maxBlurRadius != 0.0f ? r : 0.0f;
+                }
+                f4 sum = center;
+                float wsum = 1.0f;
+                float minHit = hitDist;
+                if (radius > 0.0f) {
+                    float worldRadius = radius * c.unproject * absZ;
+                    // kernel basis in view space
+                    f3 T, B;
+                    basis3(Nv, T, B);
+                    if (isSpec) {
+                        float NoV = dot3(Nv, V);
+                        f3 R = sub3(mul3(Nv, 2.0f * NoV), V);
+                        float df = spec_dominant_factor(rough);
+                        f3 D = normalize3(add3(Nv, mul3(sub3(R, Nv), df)));
+                        float NoD = dot3(Nv, D);
+                        if (NoD < 0.999f && rough < 0.95f) {
+                            f3 Dr = sub3(mul3(Nv, 2.0f * NoD), D);
+                            T = normalize3(cross3(Nv, Dr));
+                            B = cross3(Dr, T);
+                            float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
+                            T = mul3(T, skew);
+                        }
+                    }
+                    T = mul3(T, worldRadius);
+                    B = mul3(B, worldRadius);
+                    float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
+                    float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                    float hitA = 1.0f / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
+                    float hitB = -center.w * hitA;
+                    float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                    float roughB = -rough * roughA;
+                    for (int t = 0; t < 8; t++) {
+                        float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
+                        float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
+                        f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
+                        float tu, tv;
+                        if (!project(c.pj, Xt, tu, tv))
+                            continue;
+                        float fpx = floorf(tu * (float)c.W), fpy = floorf(tv * (float)c.H);
+                        if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
+                            continue;
+                        int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+                        if (py < 0 || py >= c.resH)
+                            continue;
+                        Guide gs = load_guide(G, px, py, c.denoisingRange);
+                        if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                            continue;
+                        f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
+                        float w = g_poisson8[t][2];
+                        w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+                        w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                        if (isSpec)
+                            w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                        f4 sv = ld_h4(*io.in[sig], px, py, io.inOff[sig]);
+                        w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(sv.w * hitA + hitB)));
+                        sum = add4(sum, mul4(sv, w));
+                        wsum += w;
+                        if (w > 0.0f)
+                            minHit = fmin2(minHit, sv.w * hitNorm);
+                    }
+                }
+                float inv = 1.0f / wsum;
+                st_h4(*io.out[sig], x, y, mul4(sum, inv), io.outOff[sig]);
+                if (variant == PRE && isSpec)
+                    st_h(HT, x, y, minHit);
+            }
+        }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Reprojection helpers shared by TemporalAccumulation and TemporalStabilization
+// --------------------------------------------------------------------------------------------------
+struct Reproj {
+    float su, sv; // surface motion based previous uv
+    f3 Xw;        // camera-relative world position
+    f3 XwPrev;    // world position in the previous frame (relative to the CURRENT camera)
+    f3 XvPrev;    // previous view position
+    float zPrev;
+};
+
+static inline Reproj reproject(const Consts& c, f3 Xv, float u, float v, f4 mvRaw) {
+    Reproj r;
+    r.Xw = rot3(c.v2w, Xv);
+    f3 mv = {mvRaw.x * c.mvScale[0], mvRaw.y * c.mvScale[1], mvRaw.z * c.mvScale[2]};
+    if (c.mvWorld) {
+        r.XwPrev = add3(r.Xw, mv);
+        f3 rel = sub3(r.XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+        r.XvPrev = rot3(c.w2vPrev, rel);
+        r.zPrev = r.XvPrev.z;
+        if (!project(c.pjPrev, r.XvPrev, r.su, r.sv)) {
+            r.su = -10.0f;
+            r.sv = -10.0f;
+        }
+    } else {
+        r.su = u + mv.x;
+        r.sv = v + mv.y;
+        if (c.mvScale[2] != 0.0f) {
+            r.zPrev = Xv.z + mv.z;
+            r.XvPrev = reconstruct(c.frPrev, r.su, r.sv, r.zPrev);
+            // world position of the previous-frame point, relative to the current camera
+            r.XwPrev = add3(rot3(c.v2wPrev, r.XvPrev), {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+        } else {
+            r.XwPrev = r.Xw; // static point
+            f3 rel = sub3(r.XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+            r.XvPrev = rot3(c.w2vPrev, rel);
+            r.zPrev = r.XvPrev.z;
+        }
+    }
+    return r;
+}
+
+struct Footprint {
+    int ix, iy; // global coordinates of tap (0,0)
+    float w[4]; // bilinear weights * validity, order (0,0) (1,0) (0,1) (1,1)
+    float wsum;
+    uint32_t bits;
+};
+
+// bilinear footprint in the previous frame with per-tap occlusion test against the plane (NvPrev, XvPrev)
+static inline Footprint footprint(const Ctx& k, float pu, float pv, f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
+    const Consts& c = k.c;
+    const Plane& GP = k.guidePrev();
+    Footprint f;
+    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+    float fx0 = floorf(px), fy0 = floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+    f.ix = sane ? (int)fx0 : -4;
+    f.iy = sane ? (int)fy0 : -4;
+    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+    f.wsum = 0.0f;
+    f.bits = 0;
+    float planeRef = dot3(NvPrev, XvPrev);
+    for (int i = 0; i < 4; i++) {
+        int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
+        bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
+        if (ok) {
+            Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
+            f3 Xp = reconstruct(c.frPrev, ((float)tx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, gp.z);
+            ok = !gp.sky && absf(dot3(NvPrev, Xp) - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
+        }
+        f.w[i] = ok ? bw[i] : 0.0f;
+        f.wsum += f.w[i];
+        f.bits |= ok ? (1u << i) : 0u;
+    }
+    return f;
+}
+
+static inline f4 fetch4(const Ctx& k, const Plane& P, int off, const Footprint& f) {
+    f4 s = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        if (f.w[i] > 0.0f)
+            s = add4(s, mul4(ld_h4(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off), f.w[i]));
+    return mul4(s, 1.0f / f.wsum);
+}
+static inline float fetch1(const Ctx& k, const Plane& P, int off, const Footprint& f) {
+    float s = 0.0f;
+    for (int i = 0; i < 4; i++)
+        if (f.w[i] > 0.0f)
+            s += ld_h(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off) * f.w[i];
+    return s * (1.0f / f.wsum);
+}
+static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, float& dA, float& sA) {
+    dA = sA = 0.0f;
+    for (int i = 0; i < 4; i++)
+        if (f.w[i] > 0.0f) {
+            float a, b;
+            unpack_data1(ld_u16(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff), a, b);
+            dA += a * f.w[i];
+            sA += b * f.w[i];
+        }
+    float inv = 1.0f / f.wsum;
+    dA *= inv;
+    sA *= inv;
+}
+
+// virtual-motion previous uv of the specular reflection (shared by TA and TS)
+static inline bool virtual_uv(const Consts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
+    f3 toCam = normalize3(r.Xw); // direction camera -> surface
+    float f = spec_dominant_factor(roughness);
+    f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
+    f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
+    f3 rel = sub3(XvirtPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+    f3 Xp = rot3(c.w2vPrev, rel);
+    return project(c.pjPrev, Xp, vu, vv);
+}
+
+// bilinear sample of the (any-resolution) confidence plane, channel x
+static inline float sample_confidence(const Plane& P, float u, float v) {
+    if (!P.p)
+        return 1.0f;
+    float px = u * (float)P.w - 0.5f, py = v * (float)P.h - 0.5f;
+    float fx0 = floorf(px), fy0 = floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    auto at = [&](int x, int y) {
+        x = x < 0 ? 0 : (x >= P.w ? P.w - 1 : x);
+        y = y < 0 ? 0 : (y >= P.h ? P.h - 1 : y);
+        return ld_h(P, x, y, 0);
+    };
+    float a = lerpf(at(x0, y0), at(x0 + 1, y0), fx);
+    float b = lerpf(at(x0, y0 + 1), at(x0 + 1, y0 + 1), fx);
+    return sat(lerpf(a, b, fy));
+}
+
+// surface-motion specular accumulation limit under parallax
+static inline float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
+    float acos01sq = sat(1.0f - NoV * 0.99999f);
+    float a = pow01(acos01sq, 0.5f);
+    float b = 1.1f + roughness * roughness;
+    float parallaxSensitivity = (b + a) / (b - a);
+    float powerScale = 1.0f + parallaxSensitivity * parallaxPx * 2.0f;
+    float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
+    f *= pow01(roughness, 0.5f * powerScale);
+    return MAX_ACCUM * f;
+}
+
+// --------------------------------------------------------------------------------------------------
+// K3 TemporalAccumulation
+// --------------------------------------------------------------------------------------------------
+void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const nrd::ReblurSettings& s = d.reblur;
+    const Plane& G = k.guide();
+    const Plane& MV = k.slot(nrd::ResourceType::IN_MV);
+    const Plane& IN = k.trans(T_TMP1);
+    const Plane& OUT = k.trans(T_TMP2);
+    const Plane& HIST = k.perm(P_HIST);
+    const Plane& FASTP = k.perm(P_FAST_A + (k.cur ^ 1));
+    const Plane& FASTC = k.perm(P_FAST_A + k.cur);
+    const Plane& D1P = k.perm(P_DATA1_A + (k.cur ^ 1));
+    const Plane& D1T = k.trans(T_DATA1);
+    const Plane& D2 = k.trans(T_DATA2);
+    const Plane& HT = k.trans(T_HITTRACK);
+    const Plane& confD = k.slot(nrd::ResourceType::IN_DIFF_CONFIDENCE);
+    const Plane& confS = k.slot(nrd::ResourceType::IN_SPEC_CONFIDENCE);
+    bool historyOk = d.historyValid && !c.reset;
+    float maxA = (float)std::min<uint32_t>(s.maxAccumulatedFrameNum, 63);
+    float maxFastA = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            if (g.sky) {
+                for (int sig = 0; sig < d.nsig; sig++) {
+                    st_h4(OUT, x, y, {0, 0, 0, 0}, sig * 8);
+                    st_h(FASTC, x, y, 0.0f, sig * 2);
+                }
+                st_u16(D1T, x, y, 0);
+                st_u32(D2, x, y, 0);
+                continue;
+            }
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+            f3 Xv = reconstruct(c.fr, u, v, g.z);
+            f3 Nv = rot3(c.w2v, g.n);
+            f3 V = mul3(normalize3(Xv), -1.0f);
+            float NoV = absf(dot3(Nv, V));
+            Reproj r = reproject(c, Xv, u, v, ld_h4(MV, x, y));
+            f3 NvPrev = rot3(c.w2vPrev, g.n);
+            float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(r.zPrev);
+            uint32_t minMatAny = std::min<uint32_t>(s.minMaterialForDiffuse, s.minMaterialForSpecular);
+            Footprint smb = footprint(k, r.su, r.sv, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
+            bool smbOk = historyOk && smb.wsum > 0.0f;
+            float prevDiffA = 0.0f, prevSpecA = 0.0f;
+            if (smbOk)
+                fetchA(k, D1P, smb, prevDiffA, prevSpecA);
+            // "+1": the stored value is the accumulation speed the previous frame USED
+            prevDiffA = smbOk ? fmin2(prevDiffA + 1.0f, maxA) : 0.0f;
+            prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, maxA) : 0.0f;
+            float quality = smbOk ? smb.wsum : 0.0f;
+            float outDiffA = 0.0f, outSpecA = 0.0f;
+            uint32_t data2 = smbOk ? smb.bits : 0u;
+
+            if (d.hasDiff) {
+                int sig = k.sigDiff();
+                f4 in = ld_h4(IN, x, y, sig * 8);
+                float A = prevDiffA;
+                if (c.confAvail)
+                    A *= sample_confidence(confD, u, v);
+                A *= lerpf(quality, 1.0f, 1.0f / (1.0f + A));
+                float nonLin = 1.0f / (1.0f + A);
+                f4 hist = smbOk ? fetch4(k, HIST, sig * 8, smb) : in;
+                float fastHist = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
+                st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
+                st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
+                outDiffA = A;
+            }
+            if (d.hasSpec) {
+                int sig = k.sigSpec();
+                f4 in = ld_h4(IN, x, y, sig * 8);
+                float hitDist = ld_h(HT, x, y);
+                // parallax (pixels) of the point seen from the previous camera position
+                f3 Xpar = sub3(r.XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+                f3 XparV = rot3(c.w2v, Xpar);
+                float pu, pv, parallax = 0.0f;
+                if (project(c.pj, XparV, pu, pv)) {
+                    float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
+                    parallax = sqrtf(dx * dx + dy * dy);
+                }
+                float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
+                // virtual motion
+                float vu, vv;
+                float amount = 0.0f, Avmb = 0.0f;
+                f4 vmbHist = in;
+                float vmbFast = in.x;
+                Footprint vmb;
+                vmb.bits = 0;
+                vmb.wsum = 0.0f;
+                if (historyOk && virtual_uv(c, r, hitDist, g.roughness, vu, vv)) {
+                    vmb = footprint(k, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, s.minMaterialForSpecular, threshold);
+                    if (vmb.wsum > 0.0f) {
+                        // roughness similarity of the virtual footprint
+                        float prevRough = 0.0f;
+                        for (int i = 0; i < 4; i++)
+                            if (vmb.w[i] > 0.0f)
+                                prevRough += unpack_normal_roughness(ld_u32(k.guidePrev(), vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff, 4)).roughness * vmb.w[i];
+                        prevRough *= 1.0f / vmb.wsum;
+                        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * s.roughnessFraction));
+                        float rconf = smoothstep01(1.0f - absf(prevRough * roughA - g.roughness * roughA));
+                        amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
+                        float dA, sA;
+                        fetchA(k, D1P, vmb, dA, sA);
+                        Avmb = fmin2(sA + 1.0f, maxA);
+                        vmbHist = fetch4(k, HIST, sig * 8, vmb);
+                        vmbFast = fetch1(k, FASTP, sig * 2, vmb);
+                    }
+                }
+                f4 smbHist = smbOk ? fetch4(k, HIST, sig * 8, smb) : in;
+                float smbFast = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
+                if (!smbOk)
+                    Asmb = 0.0f;
+                float A = lerpf(Asmb, Avmb, amount);
+                if (c.confAvail)
+                    A *= sample_confidence(confS, u, v);
+                float q = lerpf(quality, 1.0f, amount);
+                A *= lerpf(q, 1.0f, 1.0f / (1.0f + A));
+                // responsive accumulation for very smooth surfaces
+                if (s.responsiveAccumulationSettings.roughnessThreshold > 0.0f) {
+                    float t = smoothstep01(g.roughness / s.responsiveAccumulationSettings.roughnessThreshold);
+                    A = fmin2(A, lerpf((float)s.responsiveAccumulationSettings.minAccumulatedFrameNum, maxA, t));
+                }
+                float nonLin = 1.0f / (1.0f + A);
+                f4 hist = lerp4(smbHist, vmbHist, amount);
+                float fastHist = lerpf(smbFast, vmbFast, amount);
+                st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
+                st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
+                outSpecA = A;
+                data2 |= (vmb.bits << 4) | ((uint32_t)floorf(sat(amount) * 255.0f + 0.5f) << 8);
+            }
+            st_u16(D1T, x, y, pack_data1(outDiffA, outSpecA));
+            st_u32(D2, x, y, data2);
+        }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K4 HistoryFix: sparse 5x5 reconstruction for short histories + fast-history clamping
+// --------------------------------------------------------------------------------------------------
+void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const nrd::ReblurSettings& s = d.reblur;
+    const Plane& G = k.guide();
+    const Plane& IN = k.trans(T_TMP2);
+    const Plane& OUT = k.trans(T_TMP1);
+    const Plane& FAST = k.perm(P_FAST_A + k.cur);
+    const Plane& D1T = k.trans(T_DATA1);
+    const Plane& D1C = k.perm(P_DATA1_A + k.cur);
+    float maxFastA = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
+    bool clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            if (g.sky) {
+                for (int sig = 0; sig < d.nsig; sig++)
+                    st_h4(OUT, x, y, {0, 0, 0, 0}, sig * 8);
+                st_u16(D1C, x, y, 0);
+                continue;
+            }
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+            f3 Xv = reconstruct(c.fr, u, v, g.z);
+            f3 Nv = rot3(c.w2v, g.n);
+            float frustumSize = c.minRectDimMulUnproject * absf(g.z);
+            float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
+            float geoB = -dot3(Nv, Xv) * geoA;
+            float A[2];
+            unpack_data1(ld_u16(D1T, x, y), A[0], A[1]);
+            float outA[2] = {A[0], A[1]};
+            for (int sig = 0; sig < d.nsig; sig++) {
+                bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+                int ai = isSpec ? 1 : 0;
+                float rough = isSpec ? g.roughness : 1.0f;
+                uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
+                f4 val = ld_h4(IN, x, y, sig * 8);
+                float Acur = A[ai];
+                // ---- history reconstruction
+                if (Acur < (float)s.historyFixFrameNum && s.historyFixFrameNum > 0) {
+                    float normA = sat(Acur / (float)s.historyFixFrameNum);
+                    int stride = (int)floorf((float)s.historyFixBasePixelStride * (1.0f - normA) + 0.5f);
+                    if (stride > 0) {
+                        float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, 1.0f / (1.0f + Acur));
+                        float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                        float roughB = -rough * roughA;
+                        f4 sum = mul4(val, 1.0f + Acur);
+                        float wsum = 1.0f + Acur;
+                        for (int j = -2; j <= 2; j++)
+                            for (int i = -2; i <= 2; i++) {
+                                if ((i == 0 && j == 0) || (i * i == 4 && j * j == 4))
+                                    continue;
+                                int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
+                                if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                                    continue;
+                                Guide gs = load_guide(G, px, py, c.denoisingRange);
+                                if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                                    continue;
+                                f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
+                                float w = 1.0f / (1.0f + (float)(i * i + j * j));
+                                w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+                                w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                                if (isSpec)
+                                    w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                                float tA[2];
+                                unpack_data1(ld_u16(D1T, px, py), tA[0], tA[1]);
+                                w *= 1.0f + tA[ai];
+                                sum = add4(sum, mul4(ld_h4(IN, px, py, sig * 8), w));
+                                wsum += w;
+                            }
+                        val = mul4(sum, 1.0f / wsum);
+                    }
+                }
+                // ---- fast history clamping (5x5 moments of the fast luma history)
+                if (clampEnabled) {
+                    float fc = ld_h(FAST, x, y, sig * 2);
+                    float m1 = 0.0f, m2 = 0.0f;
+                    for (int j = -2; j <= 2; j++)
+                        for (int i = -2; i <= 2; i++) {
+                            int px = x + i, py = y + j, gy = py + c.yOff;
+                            float f = fc;
+                            if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
+                                float zt = ld_f32(G, px, py, 0);
+                                if (absf(zt) <= c.denoisingRange)
+                                    f = ld_h(FAST, px, py, sig * 2);
+                            }
+                            m1 += f;
+                            m2 += f * f;
+                        }
+                    m1 *= 1.0f / 25.0f;
+                    m2 *= 1.0f / 25.0f;
+                    float sigma = sqrtf(fmax2(m2 - m1 * m1, 0.0f)) * s.fastHistoryClampingSigmaScale;
+                    float Y = val.x;
+                    float Yc = clampf(Y, m1 - sigma, m1 + sigma);
+                    float scale = (Yc + 1e-6f) / (Y + 1e-6f);
+                    val.x = Yc;
+                    val.y *= scale;
+                    val.z *= scale;
+                    float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
+                    outA[ai] = lerpf(Acur, fmin2(Acur, maxFastA), f);
+                }
+                st_h4(OUT, x, y, val, sig * 8);
+            }
+            st_u16(D1C, x, y, pack_data1(outA[0], outA[1]));
+        }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K7 TemporalStabilization (+ split screen)
+// --------------------------------------------------------------------------------------------------
+void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const nrd::ReblurSettings& s = d.reblur;
+    const Plane& G = k.guide();
+    const Plane& MV = k.slot(nrd::ResourceType::IN_MV);
+    const Plane& HIST = k.perm(P_HIST);
+    const Plane& STABP = k.perm(P_STAB_A + (k.cur ^ 1));
+    const Plane& STABC = k.perm(P_STAB_A + k.cur);
+    const Plane& D1 = k.perm(P_DATA1_A + k.cur);
+    const Plane& D2 = k.trans(T_DATA2);
+    const Plane& HT = k.trans(T_HITTRACK);
+    const Plane* outP[2] = {nullptr, nullptr};
+    const Plane* inP[2] = {nullptr, nullptr};
+    if (d.hasDiff) {
+        outP[k.sigDiff()] = &k.slot(nrd::ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+        inP[k.sigDiff()] = &k.slot(nrd::ResourceType::IN_DIFF_RADIANCE_HITDIST);
+    }
+    if (d.hasSpec) {
+        outP[k.sigSpec()] = &k.slot(nrd::ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+        inP[k.sigSpec()] = &k.slot(nrd::ResourceType::IN_SPEC_RADIANCE_HITDIST);
+    }
+    bool historyOk = d.historyValid && !c.reset;
+    float maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+            bool split = u < c.splitScreen;
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            if (g.sky) {
+                for (int sig = 0; sig < d.nsig; sig++) {
+                    st_h4(*outP[sig], x, y, split ? ld_h4(*inP[sig], x, y) : f4{0, 0, 0, 0});
+                    st_h(STABC, x, y, 0.0f, sig * 2);
+                }
+                continue;
+            }
+            f3 Xv = reconstruct(c.fr, u, v, g.z);
+            Reproj r = reproject(c, Xv, u, v, ld_h4(MV, x, y));
+            uint32_t data2 = ld_u32(D2, x, y);
+            float A[2];
+            unpack_data1(ld_u16(D1, x, y), A[0], A[1]);
+            for (int sig = 0; sig < d.nsig; sig++) {
+                bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+                f4 cur = ld_h4(HIST, x, y, sig * 8);
+                // 5x5 local luma moments
+                float m1 = 0.0f, m2 = 0.0f;
+                for (int j = -2; j <= 2; j++)
+                    for (int i = -2; i <= 2; i++) {
+                        int px = x + i, py = y + j, gy = py + c.yOff;
+                        float f = cur.x;
+                        if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
+                            float zt = ld_f32(G, px, py, 0);
+                            if (absf(zt) <= c.denoisingRange)
+                                f = ld_h(HIST, px, py, sig * 8);
+                        }
+                        m1 += f;
+                        m2 += f * f;
+                    }
+                m1 *= 1.0f / 25.0f;
+                m2 *= 1.0f / 25.0f;
+                float sigma = sqrtf(fmax2(m2 - m1 * m1, 0.0f));
+                // stabilized luma history: surface motion footprint (validity bits from TA), virtual motion for specular
+                auto fetchStab = [&](float pu, float pv, uint32_t bits, float& out) -> bool {
+                    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+                    float fx0 = floorf(px), fy0 = floorf(py);
+                    float fx = px - fx0, fy = py - fy0;
+                    bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+                    if (!sane)
+                        return false;
+                    int ix = (int)fx0, iy = (int)fy0;
+                    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+                    float sum = 0.0f, wsum = 0.0f;
+                    for (int i = 0; i < 4; i++)
+                        if (bits & (1u << i)) {
+                            sum += ld_h(STABP, ix + (i & 1), iy + (i >> 1) - c.yOff, sig * 2) * bw[i];
+                            wsum += bw[i];
+                        }
+                    if (!(wsum > 0.0f))
+                        return false;
+                    out = sum * (1.0f / wsum);
+                    return true;
+                };
+                float Yhist = cur.x;
+                bool have = false;
+                if (historyOk) {
+                    float smbY = 0.0f;
+                    bool smbOk = fetchStab(r.su, r.sv, data2 & 15u, smbY);
+                    if (isSpec) {
+                        float amount = (float)((data2 >> 8) & 255u) / 255.0f;
+                        float vu, vv, vmbY = 0.0f;
+                        bool vmbOk = amount > 0.0f && virtual_uv(c, r, ld_h(HT, x, y), g.roughness, vu, vv) && fetchStab(vu, vv, (data2 >> 4) & 15u, vmbY);
+                        if (smbOk && vmbOk) {
+                            Yhist = lerpf(smbY, vmbY, amount);
+                            have = true;
+                        } else if (smbOk) {
+                            Yhist = smbY;
+                            have = true;
+                        } else if (vmbOk) {
+                            Yhist = vmbY;
+                            have = true;
+                        }
+                    } else if (smbOk) {
+                        Yhist = smbY;
+                        have = true;
+                    }
+                }
+                float Acur = A[isSpec ? 1 : 0];
+                float Y = cur.x;
+                float band = sigma * s.antilagSettings.luminanceSigmaScale;
+                float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) / (fmax2(Yhist, m1) + 1e-6f);
+                float antilag = 1.0f / (1.0f + dlt * s.antilagSettings.luminanceSensitivity * Acur);
+                float Yclamped = clampf(Yhist, m1 - band, m1 + band);
+                float stabFrames = have ? fmin2(Acur, maxStab) * antilag : 0.0f;
+                float wHist = stabFrames / (1.0f + stabFrames);
+                float Yout = lerpf(Y, Yclamped, wHist);
+                float scale = (Yout + 1e-6f) / (Y + 1e-6f);
+                f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
+                st_h(STABC, x, y, Yout, sig * 2);
+                st_h4(*outP[sig], x, y, split ? ld_h4(*inP[sig], x, y) : o);
+            }
+        }
+}
+
+} // namespace
+
+void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
+    uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
+    uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
+    uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+    perm.push_back({"REBLUR::Guide_A", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"REBLUR::Guide_B", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"REBLUR::Data1_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
+    perm.push_back({"REBLUR::Data1_B", (uint32_t)nrd::Format::R16_UINT, 2, 1});
+    perm.push_back({"REBLUR::History", fmtRad, bRad, 1});
+    perm.push_back({"REBLUR::FastHistory_A", fmtLum, bLum, 1});
+    perm.push_back({"REBLUR::FastHistory_B", fmtLum, bLum, 1});
+    perm.push_back({"REBLUR::StabilizedLuma_A", fmtLum, bLum, 1});
+    perm.push_back({"REBLUR::StabilizedLuma_B", fmtLum, bLum, 1});
+    trans.push_back({"REBLUR::Tiles", (uint32_t)nrd::Format::R8_UINT, 1, 16});
+    trans.push_back({"REBLUR::Tmp1", fmtRad, bRad, 1});
+    trans.push_back({"REBLUR::Tmp2", fmtRad, bRad, 1});
+    trans.push_back({"REBLUR::Data1_Tmp", (uint32_t)nrd::Format::R16_UINT, 2, 1});
+    trans.push_back({"REBLUR::Data2", (uint32_t)nrd::Format::R32_UINT, 4, 1});
+    trans.push_back({"REBLUR::SpecHitDistForTracking", (uint32_t)nrd::Format::R16_SFLOAT, 2, 1});
+}
+
+void reblur_build(Instance& I, DenoiserState& d) {
+    (void)I;
+    using RT = nrd::ResourceType;
+    int cur = (int)(d.frameCounter & 1);
+    uint32_t pb = d.permBase, tb = d.transBase;
+    auto P = [&](int i) { return enc_perm(pb + i); };
+    auto T = [&](int i) { return enc_trans(tb + i); };
+    float n = (float)d.nsig;
+    const nrd::ReblurSettings& s = d.reblur;
+    uint16_t blurHalo = (uint16_t)(s.maxBlurRadius + s.minBlurRadius + 2.0f);
+    uint16_t preHalo = (uint16_t)(fmax2(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) + 2.0f);
+
+    {
+        Pass p;
+        p.name = "REBLUR::ClassifyTiles";
+        p.kernel = "nrd_reblur_classify_tiles";
+        p.haloRows = 0;
+        p.bytesPerPixel = 4 + 4 + 8 + 1.0f / 256.0f;
+        p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
+        p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
+        p.tileGrid = true;
+        p.run = classify_tiles;
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "REBLUR::PrePass";
+        p.kernel = "nrd_reblur_prepass";
+        p.haloRows = preHalo;
+        p.bytesPerPixel = 8 + 8 * n + 8 * n + (d.hasSpec ? 2 : 0);
+        p.read = {P(P_GUIDE_A + cur)};
+        if (d.hasDiff)
+            p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+        if (d.hasSpec)
+            p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        p.written = {T(T_TMP1), T(T_HITTRACK)};
+        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+            Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+            SpatialIO io = {};
+            for (int sig = 0; sig < d.nsig; sig++) {
+                bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+                io.in[sig] = &k.slot(isSpec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+                io.inOff[sig] = 0;
+                io.out[sig] = &k.trans(T_TMP1);
+                io.outOff[sig] = sig * 8;
+            }
+            spatial_filter(k, PRE, io, y0, y1);
+        };
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "REBLUR::TemporalAccumulation";
+        p.kernel = "nrd_reblur_temporal_accumulation";
+        p.haloRows = 0; // previous-frame planes are read at motion-displaced rows: the tiler adds its motion margin
+        p.bytesPerPixel = 8 + 8 + 8 + 2 + 8 * n + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n + 2 + 4;
+        p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1)), T(T_HITTRACK)};
+        p.written = {T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
+        p.run = temporal_accumulation;
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "REBLUR::HistoryFix";
+        p.kernel = "nrd_reblur_history_fix";
+        p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
+        p.bytesPerPixel = 8 + 2 + 8 * n + 2 * n + 8 * n + 2;
+        p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
+        p.written = {T(T_TMP1), P(P_DATA1_A + cur)};
+        p.run = history_fix;
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "REBLUR::Blur";
+        p.kernel = "nrd_reblur_blur";
+        p.haloRows = blurHalo;
+        p.bytesPerPixel = 8 + 2 + 8 * n + 8 * n;
+        p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
+        p.written = {T(T_TMP2)};
+        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+            Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+            SpatialIO io = {};
+            for (int sig = 0; sig < d.nsig; sig++) {
+                io.in[sig] = &k.trans(T_TMP1);
+                io.out[sig] = &k.trans(T_TMP2);
+                io.inOff[sig] = io.outOff[sig] = sig * 8;
+            }
+            spatial_filter(k, BLUR, io, y0, y1);
+        };
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "REBLUR::PostBlur";
+        p.kernel = "nrd_reblur_post_blur";
+        p.haloRows = (uint16_t)(2 * blurHalo);
+        p.bytesPerPixel = 8 + 2 + 8 * n + 8 * n;
+        p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
+        p.written = {P(P_HIST)};
+        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+            Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+            SpatialIO io = {};
+            for (int sig = 0; sig < d.nsig; sig++) {
+                io.in[sig] = &k.trans(T_TMP2);
+                io.out[sig] = &k.perm(P_HIST);
+                io.inOff[sig] = io.outOff[sig] = sig * 8;
+            }
+            spatial_filter(k, POST, io, y0, y1);
+        };
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "REBLUR::TemporalStabilization";
+        p.kernel = "nrd_reblur_temporal_stabilization";
+        p.haloRows = 2;
+        p.bytesPerPixel = 8 + 2 + 4 + 8 + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n;
+        p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2), enc_slot(RT::IN_MV), P(P_HIST), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
+        p.written = {P(P_STAB_A + cur)};
+        if (d.hasDiff) {
+            p.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
+            p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+        }
+        if (d.hasSpec) {
+            p.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
+            p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        }
+        p.run = temporal_stabilization;
+        d.passes.push_back(p);
+    }
+}
+
+} // namespace orc
