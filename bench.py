@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py - Mpixels/s of the full REBLUR diffuse+specular pipeline on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload reblur_ds_4k|...]
+
+A "step" is one frame through every pass of the denoiser (ClassifyTiles, PrePass, TemporalAccumulation, HistoryFix, Blur,
+PostBlur, TemporalStabilization) with all inputs already resident in HBM. N = 1: the 3840x2160 frame BASELINE.json quotes its
+target on. N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is row-tiled, every rank owns a
+3840x2160 band of a 3840 x (2160 N) frame (weak scaling) and exchanges halo rows with its <= 2 row neighbours through
+torch.distributed (backend nccl = RCCL over xGMI) between passes (SURVEY.md 8e scheme A).
+
+One JSON line on stdout (rank 0). `roofline` is computed for the slowest kernel from HIP events recorded on the launch
+stream around every dispatch of the timed region; `cpu_baseline` times the CPU oracle (a scalar C++ port, oracle/) on a
+bounded sample of the same workload on this box's host cores - a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (width, height, denoisers, synthetic-scene kind)
+    "reblur_ds_4k": (3840, 2160, ["REBLUR_DIFFUSE_SPECULAR"]),
+    "reblur_d_1080p": (1920, 1080, ["REBLUR_DIFFUSE"]),
+    "reblur_ds_sigma_1440p": (2560, 1440, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY"]),
+    "reblur_ds_1080p": (1920, 1080, ["REBLUR_DIFFUSE_SPECULAR"]),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--workload", default="reblur_ds_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, denoiser_names, settings_of):
+    """Oracle (scalar C++ port, all host threads) on a bounded sample: 960x540, 2 warm-up + 3 timed frames."""
+    api, synth, harness = pkg.api, pkg.synth, pkg.harness
+    if not os.path.exists(pkg.ORACLE_LIB):
+        return None
+    orc = pkg.oracle_backend()
+    w, h, frames, warm = 960, 540, 3, 2
+    cores = os.cpu_count() or 1
+    scene = synth.Scene(w, h, dolly=0.004)
+    dens = [api.Denoiser[n] for n in denoiser_names]
+    hz = harness.Harness(orc, dens, w, h)
+    orc.lib.orc_set_threads(hz.nrd.handle, cores)
+    st = settings_of(api, scene, dens)
+    data = [scene.frame(f) for f in range(warm + frames)]
+    planes = [hz.upload(d) for d in data]
+    for f in range(warm):
+        hz.frame(scene.common_settings(api, data[f], f, reset=(f == 0)), planes[f], st)
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        hz.frame(scene.common_settings(api, data[f], f), planes[f], st)
+    dt = time.perf_counter() - t0
+    return {"value": round(w * h * frames / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d, %d frames after %d warm-up, same pipeline (%s), oracle/ row-striped over %d threads" % (w, h, frames, warm, "+".join(denoiser_names), cores)}
+
+
+def settings_of(api, scene, dens):
+    s = {}
+    for d in dens:
+        if d.name.startswith("REBLUR"):
+            # the sample's operating point (Source/NRDSample.cpp:563-585): material-aware filtering on, clamp sigma 1.5
+            s[d] = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1, fastHistoryClampingSigmaScale=1.5,
+                                      maxAccumulatedFrameNum=30, maxFastAccumulatedFrameNum=6, maxStabilizedFrameNum=30)
+        elif d.name.startswith("SIGMA"):
+            s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
+        else:
+            s[d] = api.ReferenceSettings()
+    return s
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    pkg = graft.load_package()
+    api, synth, harness = pkg.api, pkg.synth, pkg.harness
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the denoiser passes are HIP kernels, there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    w, band_h, den_names = WORKLOADS[args.workload]
+    dens = [api.Denoiser[n] for n in den_names]
+    hip = pkg.hip_backend(dev)
+
+    if world == 1:
+        from nrd_sample_amd.harness import Harness
+
+        scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev)
+        hz = Harness(hip, dens, w, band_h)
+        runner = SingleRunner(api, hz, scene, dens, args.unique_frames, settings_of(api, scene, dens))
+        frame_h = band_h
+    else:
+        from nrd_sample_amd.tiler import TiledRunner
+
+        frame_h = band_h * world
+        runner = TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of)
+
+    ids = [int(d) for d in dens]
+    # ---- warm-up (untimed) ----
+    for f in range(args.warmup):
+        runner.step(f, reset=(f == 0))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps, HIP events around every dispatch on the launch stream ----
+    runner.enable_events(True)
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        runner.step(f, reset=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    per_pass = runner.pass_times_ms()  # {name: (avg ms, bytes per pixel)}
+    if rank == 0:
+        pixels_band = w * band_h
+        total_pixels = w * frame_h * args.steps
+        value = total_pixels / dt / 1e6
+        dom = max(per_pass.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_ms, dom_bpp) = dom
+        achieved = dom_bpp * pixels_band / (dom_ms * 1e-3) / 1e9
+        sum_ms = sum(v[0] for v in per_pass.values())
+        sum_bpp = sum(v[1] for v in per_pass.values())
+        out = {
+            "metric": "Mpixels/s full REBLUR diff+spec pipeline", "value": round(value, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16 planes)", "data": "synthetic",
+            "config": {"workload": "%s: %s, %dx%d%s, steady state (accumulation saturated)" % (
+                args.workload, "+".join(den_names), w, frame_h, "" if world == 1 else " row-tiled %d x %d rows, RCCL halo exchange" % (world, band_h)),
+                "unique_input_frames": args.unique_frames, "algorithmic_bytes_per_pixel": round(sum_bpp, 2)},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "pipeline_frac": round(sum_bpp * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "passes_ms": {k: round(v[0], 4) for k, v in per_pass.items()},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of)
+            except Exception as e:  # the baseline is a reported extra; never fail the GPU number because of it
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def pingpong(n, f):
+    """camera path position of step f: 0,1,..,n-1,n-2,..,1,0,1,.. (consistent motion vectors in both directions)"""
+    if n == 1:
+        return 0
+    period = 2 * (n - 1)
+    k = f % period
+    return k if k < n else period - k
+
+
+class SingleRunner:
+    """one GPU: the sample's per-frame call sequence through nrd-sample_amd/harness.py, dispatch by dispatch.
+    `unique` frames along a camera dolly are generated on the device once and replayed forwards then backwards; every frame
+    carries two motion-vector planes (previous camera = the neighbour on either side) so reprojection is always consistent."""
+
+    def __init__(self, api, hz, scene, dens, unique, settings):
+        import torch
+
+        self.api, self.hz, self.scene, self.dens, self.settings = api, hz, scene, dens, settings
+        self.ids = [int(d) for d in dens]
+        self.unique = unique
+        self.frames = []
+        for i in range(unique):
+            fwd = scene.frame(i, prev_index=max(i - 1, 0))
+            bwd = scene.frame(i, prev_index=min(i + 1, unique - 1))
+            planes = hz.upload(fwd)
+            mv_b = hz.upload({"mv": bwd["mv"]})["mv"]
+            self.frames.append(dict(planes=planes, mv_f=planes["mv"], mv_b=mv_b, fwd=fwd, bwd=bwd))
+        torch.cuda.synchronize()
+        self.events_on = False
+        self.events = []
+        self.names = None
+
+    def enable_events(self, on):
+        self.events_on = on
+
+    def step(self, f, reset):
+        import torch
+
+        hz, api = self.hz, self.api
+        cur = pingpong(self.unique, f)
+        prev = pingpong(self.unique, f - 1) if f > 0 else min(1, self.unique - 1)
+        fr = self.frames[cur]
+        backward = prev > cur
+        planes = dict(fr["planes"])
+        planes["mv"] = fr["mv_b"] if backward else fr["mv_f"]
+        cs = self.scene.common_settings(api, fr["bwd"] if backward else fr["fwd"], f, reset=reset)
+        hz.nrd.new_frame()
+        hz.nrd.set_common_settings(cs)
+        hz.bind(planes)
+        for d in self.dens:
+            hz.nrd.set_denoiser_settings(int(d), self.settings[d])
+        if not self.events_on:
+            hz.nrd.denoise(self.ids)
+            return
+        if self.names is None:
+            info = hz.nrd.dispatches(self.ids)
+            self.names = [(x["name"], x["bytes_per_pixel"]) for x in info]
+        evs = []
+        for i in range(len(self.names)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            hz.nrd.denoise_range(self.ids, i, 1)
+            b.record()
+            evs.append((a, b))
+        self.events.append(evs)
+
+    def pass_times_ms(self):
+        import torch
+
+        torch.cuda.synchronize()
+        acc = {}
+        for evs in self.events:
+            for (name, bpp), (a, b) in zip(self.names, evs):
+                t, n, _ = acc.get(name, (0.0, 0, bpp))
+                acc[name] = (t + a.elapsed_time(b), n + 1, bpp)
+        return {k: (t / n, bpp) for k, (t, n, bpp) in acc.items()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,277 @@
+// nrd_device.h - device-side arithmetic and plane access of the MI355X NRD backend (gfx950, wave64).
+//
+// Every float expression here is evaluated as separately rounded IEEE binary32 operations (the library is
+// built with -ffp-contract=off, IEEE divide/sqrt) so that results are reproducible bit for bit run to run,
+// 1 GPU vs N GPUs, and against the CPU oracle used by the tests (DESIGN.md "numerics contract").
+// Transcendentals are fixed polynomials (no ocml calls on the pixel path).
+//
+// Encodings (reference call sites): normal/roughness/materialID R10G10B10A2 pack Shaders/TraceOpaque.cs.hlsl:657;
+// REBLUR hit distance normalisation Shaders/TraceOpaque.cs.hlsl:421; YCoCg radiance Shaders/TraceOpaque.cs.hlsl:756-757;
+// GetSpecMagicCurve Shaders/Shared.hlsli:305-311; SIGMA penumbra/translucency Shaders/TraceOpaque.cs.hlsl:800-801.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NRD_DEV static __device__ __forceinline__
+
+namespace nrdhip {
+
+// ---- per-frame constants, identical layout on host and device -----------------------------------------------
+struct FrameConsts {
+    int W, H;         // rect of the whole (global) frame
+    int Wprev, Hprev; // previous rect
+    int resW, resH;   // local plane size
+    int yOff;         // global row stored at local row 0 (row tiling)
+    int ownY0, ownY1; // local rows this instance produces
+    float invW, invH, invWprev, invHprev;
+    float fr[4], frPrev[4]; // x0, y0, dx, dy
+    float pj[5], pjPrev[5]; // m0, m5, m8, m9, s
+    float w2v[9], w2vPrev[9], v2w[9], v2wPrev[9];
+    float camDelta[3];
+    float unproject, minRectDimMulUnproject;
+    float denoisingRange, disocclusionThreshold, splitScreen;
+    float mvScale[3];
+    float viewZScale;
+    uint32_t frameIndex;
+    int mvWorld, confAvail, historyOk;
+    int tilesX, tilesY; // tile grid covering the owned rows: tile row 0 starts at local row tileY0 * 16
+    int tileY0;
+    float rot[64][2];
+};
+
+struct PlaneRef {
+    uint8_t* p;
+    uint32_t pitch;
+    uint16_t w, h; // only meaningful for planes sampled by uv (confidence)
+};
+
+// ---- small vector types ---------------------------------------------------------------------------------------
+struct f3 {
+    float x, y, z;
+};
+struct f4 {
+    float x, y, z, w;
+};
+
+NRD_DEV float fmin2(float a, float b) { return a < b ? a : b; }
+NRD_DEV float fmax2(float a, float b) { return a > b ? a : b; }
+NRD_DEV float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
+NRD_DEV float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
+NRD_DEV float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+NRD_DEV float smoothstep01(float x) {
+    x = sat(x);
+    return x * x * (3.0f - 2.0f * x);
+}
+NRD_DEV float absf(float x) { return x < 0.0f ? -x : x; }
+
+NRD_DEV f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+NRD_DEV f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+NRD_DEV f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+NRD_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NRD_DEV f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+NRD_DEV f3 normalize3(f3 a) {
+    float l2 = dot3(a, a);
+    float inv = 1.0f / __builtin_sqrtf(fmax2(l2, 1e-30f));
+    return mul3(a, inv);
+}
+NRD_DEV f3 rot3(const float* m, f3 v) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+NRD_DEV f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+NRD_DEV f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+NRD_DEV f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
+
+NRD_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+NRD_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ---- fp16 (hardware RNE converts, denormals on) ------------------------------------------------------------------
+#define NRD_FP16_MAX 65504.0f
+NRD_DEV float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+NRD_DEV uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)clampf(f, -NRD_FP16_MAX, NRD_FP16_MAX)); }
+NRD_DEV f4 unpack_h4(uint2 v) { return {h2f((uint16_t)(v.x & 0xffffu)), h2f((uint16_t)(v.x >> 16)), h2f((uint16_t)(v.y & 0xffffu)), h2f((uint16_t)(v.y >> 16))}; }
+NRD_DEV uint2 pack_h4(f4 v) { return {(uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16), (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16)}; }
+
+// ---- polynomial transcendentals (coefficients frozen) ------------------------------------------------
+NRD_DEV float exp2_poly(float x) {
+    x = clampf(x, -126.0f, 126.0f);
+    float fi = __builtin_floorf(x + 0.5f);
+    float f = x - fi;
+    float p = 1.535336188319500e-4f;
+    p = p * f + 1.339887440266574e-3f;
+    p = p * f + 9.618437357674640e-3f;
+    p = p * f + 5.550332471162809e-2f;
+    p = p * f + 2.402264791363012e-1f;
+    p = p * f + 6.931472028550421e-1f;
+    p = p * f + 1.0f;
+    int e = (int)fi;
+    return p * u2f((uint32_t)(e + 127) << 23);
+}
+
+NRD_DEV float log2_poly(float x) {
+    if (!(x > 1.17549435e-38f))
+        return -126.0f;
+    uint32_t u = f2u(x);
+    int e = (int)((u >> 23) & 0xffu) - 127;
+    float m = u2f((u & 0x7fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float t = m - 1.0f;
+    float z = t * t;
+    float p = 7.0376836292e-2f;
+    p = p * t - 1.1514610310e-1f;
+    p = p * t + 1.1676998740e-1f;
+    p = p * t - 1.2420140846e-1f;
+    p = p * t + 1.4249322787e-1f;
+    p = p * t - 1.6668057665e-1f;
+    p = p * t + 2.0000714765e-1f;
+    p = p * t - 2.4999993993e-1f;
+    p = p * t + 3.3333331174e-1f;
+    float y = t * z * p;
+    y = y - 0.5f * z;
+    float ln = t + y;
+    return ln * 1.44269504f + (float)e;
+}
+
+NRD_DEV float pow01(float x, float y) {
+    x = sat(x);
+    if (x <= 0.0f)
+        return 0.0f;
+    return exp2_poly(y * log2_poly(x));
+}
+
+NRD_DEV float atan_pos(float x) {
+    bool inv = x > 1.0f;
+    float t = inv ? 1.0f / x : x;
+    float s = t * t;
+    float p = 0.0208351f;
+    p = p * s - 0.0851330f;
+    p = p * s + 0.1801410f;
+    p = p * s - 0.3302995f;
+    p = p * s + 0.9998660f;
+    p = p * t;
+    return inv ? 1.57079633f - p : p;
+}
+
+NRD_DEV float acos_approx(float x) { return 1.41421356f * __builtin_sqrtf(sat(1.0f - x)); }
+
+NRD_DEV float exp_weight(float ax) {
+    float x = -3.0f * ax;
+    return 1.0f / (x * x - x + 1.0f);
+}
+
+// ---- packing -----------------------------------------------------------------------------------------------------
+NRD_DEV f3 oct_decode(float px, float py) {
+    float fx = px * 2.0f - 1.0f, fy = py * 2.0f - 1.0f;
+    float nz = 1.0f - absf(fx) - absf(fy);
+    float t = sat(-nz);
+    float nx = fx + (fx >= 0.0f ? -t : t);
+    float ny = fy + (fy >= 0.0f ? -t : t);
+    return normalize3({nx, ny, nz});
+}
+
+struct Guide {
+    float z;
+    f3 n;
+    float roughness;
+    uint32_t mat;
+    bool sky;
+};
+
+NRD_DEV f3 unpack_normal(uint32_t p) { return oct_decode((float)(p & 1023u) / 1023.0f, (float)((p >> 10) & 1023u) / 1023.0f); }
+NRD_DEV float unpack_roughness(uint32_t p) { return (float)((p >> 20) & 1023u) / 1023.0f; }
+
+NRD_DEV Guide decode_guide(uint2 g, float range) {
+    Guide r;
+    r.z = u2f(g.x);
+    r.n = unpack_normal(g.y);
+    r.roughness = unpack_roughness(g.y);
+    r.mat = g.y >> 30;
+    r.sky = !(absf(r.z) <= range);
+    return r;
+}
+
+NRD_DEV float spec_magic_curve(float roughness) {
+    float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
+    return f * __builtin_sqrtf(sat(roughness));
+}
+
+NRD_DEV float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
+    float e = exp2_poly(hp[3] * roughness * roughness);
+    return (hp[0] + absViewZ * hp[1]) * lerpf(1.0f, hp[2], e);
+}
+
+NRD_DEV float spec_lobe_half_angle(float roughness) {
+    float m = sat(roughness);
+    m = m * m;
+    return atan_pos(m * 3.0f);
+}
+
+NRD_DEV float spec_dominant_factor(float roughness) {
+    float s = sat(1.0f - roughness);
+    return s * (__builtin_sqrtf(s) + roughness);
+}
+
+NRD_DEV uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
+    uint32_t h = (x * 73856093u) ^ (y * 19349663u) ^ (frame * 83492791u) ^ (salt * 2654435761u);
+    h ^= h >> 13;
+    h *= 0x5bd1e995u;
+    h ^= h >> 15;
+    return h;
+}
+
+NRD_DEV void basis3(f3 n, f3& t, f3& b) {
+    float sz = n.z >= 0.0f ? 1.0f : -1.0f;
+    float a = -1.0f / (sz + n.z);
+    float bb = n.x * n.y * a;
+    t = {1.0f + sz * n.x * n.x * a, sz * bb, -sz * n.x};
+    b = {bb, sz + n.y * n.y * a, -n.y};
+}
+
+NRD_DEV f3 reconstruct(const float* fr, float u, float v, float z) { return {z * (u * fr[2] + fr[0]), z * (v * fr[3] + fr[1]), z}; }
+NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
+    float cw = pj[4] * X.z;
+    if (!(cw > 1e-6f))
+        return false;
+    float inv = 1.0f / cw;
+    u = 0.5f + 0.5f * ((pj[0] * X.x + pj[2] * X.z) * inv);
+    v = 0.5f - 0.5f * ((pj[1] * X.y + pj[3] * X.z) * inv);
+    return true;
+}
+
+NRD_DEV bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
+
+// ---- plane access ------------------------------------------------------------------------------------------------
+template <typename T>
+NRD_DEV T ld(const PlaneRef& P, int x, int y, int bpt, int off = 0) {
+    return *reinterpret_cast<const T*>(P.p + (size_t)y * P.pitch + (size_t)x * bpt + off);
+}
+template <typename T>
+NRD_DEV void st(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
+    *reinterpret_cast<T*>(P.p + (size_t)y * P.pitch + (size_t)x * bpt + off) = v;
+}
+
+// 8-tap Poisson disk + weight (same frozen table as the oracle)
+__device__ static const float g_poisson8[8][3] = {
+    {-0.4706069f, -0.4427112f, 0.7592f}, {-0.9057375f, 0.3003471f, 0.5483f}, {-0.3487388f, 0.4037880f, 0.8287f},
+    {0.1023042f, 0.6439373f, 0.7554f},   {0.5699277f, 0.3513750f, 0.7439f},  {0.2939128f, -0.1131226f, 0.9366f},
+    {0.7836658f, -0.4208784f, 0.5932f},  {0.1564120f, -0.8198990f, 0.6314f}};
+
+// XCD-aware tile assignment: the dispatcher round-robins consecutive workgroups over the 8 XCDs, so give each XCD a
+// contiguous run of tiles (row-major) - stencil/gather overlap between neighbouring tiles then stays in ONE XCD's L2.
+NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
+    int total = c.tilesX * c.tilesY;
+    int chunk = (total + 7) >> 3;
+    int b = (int)blockIdx.x;
+    int tile = (b & 7) * chunk + (b >> 3);
+    if (tile >= total)
+        return false;
+    ty = tile / c.tilesX;
+    tx = tile - ty * c.tilesX;
+    ty += c.tileY0;
+    return true;
+}
+
+} // namespace nrdhip

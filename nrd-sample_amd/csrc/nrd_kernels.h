@@ -1,0 +1,57 @@
+// nrd_kernels.h - kernel parameter blocks and launch entry points shared by the host dispatch core (nrdhip.cpp)
+// and the HIP kernels (*.hip). One launch_* per pass of the pass graph.
+#pragma once
+
+#include "nrd_device.h"
+
+namespace nrdhip {
+
+struct ReblurParams {
+    FrameConsts c;
+    // nrd::ReblurSettings (Source/NRDSample.cpp:563-585 defaults, :4090-4124 per frame)
+    float hp[4];
+    float planeDistanceSensitivity, lobeAngleFraction, roughnessFraction, minHitDistanceWeight;
+    float minBlurRadius, maxBlurRadius, diffusePrepassBlurRadius, specularPrepassBlurRadius;
+    float fastHistoryClampingSigmaScale, antilagSigmaScale, antilagSensitivity;
+    float responsiveRoughnessThreshold, responsiveMinAccum;
+    float maxA, maxFastA, maxStab;
+    int historyFixFrameNum, historyFixStride;
+    uint32_t minMatDiff, minMatSpec;
+    int clampEnabled;
+    int hasDiff, hasSpec;
+    // resource slots
+    PlaneRef inZ, inNR, inMV, inDiff, inSpec, confD, confS, outDiff, outSpec;
+    // pools
+    PlaneRef guide, guidePrev, data1, data1Prev, data1Tmp, data2, hist, fast, fastPrev, stab, stabPrev, tiles, tmp1, tmp2, hitTrack;
+};
+
+struct SigmaParams {
+    FrameConsts c;
+    float planeDistanceSensitivity, maxStab;
+    int translucency, outBpt;
+    PlaneRef inZ, inNR, inMV, inPen, inTransl, out;
+    PlaneRef guide, guidePrev, hist, histPrev, tiles, tilesSmooth, shadow1, pen1, shadow2;
+};
+
+struct ReferenceParams {
+    FrameConsts c;
+    float weight; // 1 / (1 + min(frames, maxAccumulatedFrameNum)), 1 on restart
+    int restart;
+    PlaneRef in, out, hist;
+};
+
+// grid = XCD-swizzled 16x16 tiles over the owned rows (nrd_device.h xcd_tile)
+void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s);
+
+void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s);
+void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); // 0 PrePass, 1 Blur, 2 PostBlur
+void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s);
+void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s);
+void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s);
+
+void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s);
+void launch_sigma_smooth_tiles(const SigmaParams& p, hipStream_t s);
+void launch_sigma_blur(const SigmaParams& p, int pass, hipStream_t s);
+void launch_sigma_temporal_stabilization(const SigmaParams& p, hipStream_t s);
+
+} // namespace nrdhip

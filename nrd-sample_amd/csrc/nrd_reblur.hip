@@ -1,0 +1,730 @@
+// nrd_reblur.hip - REBLUR_DIFFUSE / REBLUR_SPECULAR / REBLUR_DIFFUSE_SPECULAR passes as gfx950 HIP kernels.
+//
+// Replaces the REBLUR HLSL pass set of the reference's absent External/NRD submodule behind nrd::Integration::Denoise
+// (Source/NRDSample.cpp:521). Pass graph per SURVEY.md 8a-5:
+//   ClassifyTiles(+guide packing) -> PrePass -> TemporalAccumulation -> HistoryFix -> Blur -> PostBlur -> TemporalStabilization
+// Data layout (DESIGN.md "HBM layout"): one 8-byte guide texel {viewZ, R10G10B10A2 normal/roughness/material} per pixel so a
+// bilateral tap costs one 8-byte gather for all guides; diffuse+specular radiance interleaved in one 16-byte texel;
+// accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles, assigned to XCDs in contiguous runs
+// (nrd_device.h xcd_tile) so stencil / gather overlap between neighbouring tiles is served by one XCD's L2.
+// These are HBM/L2-bound gathers and stencils: no MFMA. 5x5 moment stencils stage their tile (+2 halo) in LDS.
+#include "nrd_kernels.h"
+
+namespace nrdhip {
+
+namespace {
+
+constexpr float MAX_ACCUM = 63.0f;
+constexpr float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
+constexpr float POST_BLUR_RADIUS_SCALE = 2.0f;
+constexpr float NORMAL_ANGLE_MIN = 0.02f;
+constexpr float PREV_NORMAL_COS = 0.7f;
+
+NRD_DEV void unpack_data1(uint32_t v, float& diffA, float& specA) {
+    diffA = (float)(v & 0xffu) * 0.25f;
+    specA = (float)(v >> 8) * 0.25f;
+}
+NRD_DEV uint16_t pack_data1(float diffA, float specA) {
+    uint32_t d = (uint32_t)__builtin_floorf(clampf(diffA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
+    uint32_t s = (uint32_t)__builtin_floorf(clampf(specA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
+    return (uint16_t)(d | (s << 8));
+}
+
+// pixel of this thread inside its XCD-swizzled tile; false = nothing to do
+NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
+    if (!xcd_tile(c, tx, ty))
+        return false;
+    x = tx * 16 + (int)threadIdx.x;
+    y = ty * 16 + (int)threadIdx.y;
+    return x < c.W && y >= c.ownY0 && y < c.ownY1;
+}
+
+// =====================================================================================================================
+// K0 ClassifyTiles + guide packing
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    bool valid = x < c.W && y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
+    int notSky = 0;
+    if (valid) {
+        float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
+        uint32_t nr = ld<uint32_t>(p.inNR, x, y, 4);
+        st<uint2>(p.guide, x, y, 8, uint2{f2u(z), nr});
+        notSky = absf(z) <= c.denoisingRange ? 1 : 0;
+    }
+    int any = __syncthreads_or(notSky);
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+        st<uint8_t>(p.tiles, tx, ty, 1, any ? 0 : 1);
+}
+
+// =====================================================================================================================
+// Spatial filter: PrePass (VARIANT 0), Blur (1), PostBlur (2)
+// =====================================================================================================================
+template <int VARIANT, bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int RBPT = 8 * NSIG; // bytes per texel of the internal radiance planes
+    constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    const FrameConsts& c = p.c;
+    int x, y, tx, ty;
+    if (!my_pixel(c, x, y, tx, ty))
+        return;
+    const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
+    const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
+
+    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    if (g.sky) {
+        for (int sig = 0; sig < NSIG; sig++)
+            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+        if (VARIANT == 0 && HAS_SPEC)
+            st<uint16_t>(p.hitTrack, x, y, 2, (uint16_t)0);
+        return;
+    }
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    f3 Xv = reconstruct(c.fr, u, v, g.z);
+    f3 Nv = rot3(c.w2v, g.n);
+    f3 V = mul3(normalize3(Xv), -1.0f);
+    float absZ = absf(g.z);
+    float frustumSize = c.minRectDimMulUnproject * absZ;
+    float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
+    float geoB = -dot3(Nv, Xv) * geoA;
+    uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, (uint32_t)VARIANT + 1u);
+    float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
+    float diffA = 0.0f, specA = 0.0f;
+    if (VARIANT != 0)
+        unpack_data1(ld<uint16_t>(p.data1, x, y, 2), diffA, specA);
+
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        float rough = isSpec ? g.roughness : 1.0f;
+        uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
+        const PlaneRef& srcP = VARIANT == 0 ? (isSpec ? p.inSpec : p.inDiff) : inP;
+        const int srcBpt = VARIANT == 0 ? 8 : RBPT;
+        const int srcOff = VARIANT == 0 ? 0 : sig * 8;
+        f4 center = unpack_h4(ld<uint2>(srcP, x, y, srcBpt, srcOff));
+        float hitNorm = reblur_hitdist_norm(absZ, p.hp, rough);
+        float hitDist = center.w * hitNorm;
+        float hitDistFactor = sat(hitDist / frustumSize);
+        float A = isSpec ? specA : diffA;
+        float nonLin = VARIANT == 0 ? 1.0f : 1.0f / (1.0f + A);
+        float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
+        float radius;
+        if (VARIANT == 0) {
+            radius = (isSpec ? p.specularPrepassBlurRadius : p.diffusePrepassBlurRadius) * hitDistFactor * smc;
+        } else {
+            float r = p.maxBlurRadius * lerpf(MIN_CONVERGED_RADIUS_SCALE, 1.0f, nonLin) * lerpf(hitDistFactor, 1.0f, nonLin) + p.minBlurRadius;
+            r *= VARIANT == 2 ? POST_BLUR_RADIUS_SCALE : 1.0f;
+            r *= smc;
+            radius = p.maxBlurRadius != 0.0f ? r : 0.0f;
+        }
+        f4 sum = center;
+        float wsum = 1.0f;
+        float minHit = hitDist;
+        if (radius > 0.0f) {
+            float worldRadius = radius * c.unproject * absZ;
+            f3 T, B;
+            basis3(Nv, T, B);
+            if (isSpec) {
+                float NoV = dot3(Nv, V);
+                f3 R = sub3(mul3(Nv, 2.0f * NoV), V);
+                float df = spec_dominant_factor(rough);
+                f3 D = normalize3(add3(Nv, mul3(sub3(R, Nv), df)));
+                float NoD = dot3(Nv, D);
+                if (NoD < 0.999f && rough < 0.95f) {
+                    f3 Dr = sub3(mul3(Nv, 2.0f * NoD), D);
+                    T = normalize3(cross3(Nv, Dr));
+                    B = cross3(Dr, T);
+                    float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
+                    T = mul3(T, skew);
+                }
+            }
+            T = mul3(T, worldRadius);
+            B = mul3(B, worldRadius);
+            float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
+            float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+            float hitA = 1.0f / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
+            float hitB = -center.w * hitA;
+            float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+            float roughB = -rough * roughA;
+#pragma unroll 2
+            for (int t = 0; t < 8; t++) {
+                float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
+                float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
+                f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
+                float tu, tv;
+                if (!project(c.pj, Xt, tu, tv))
+                    continue;
+                float fpx = __builtin_floorf(tu * (float)c.W), fpy = __builtin_floorf(tv * (float)c.H);
+                if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
+                    continue;
+                int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+                if (py < 0 || py >= c.resH)
+                    continue;
+                Guide gs = decode_guide(ld<uint2>(p.guide, px, py, 8), c.denoisingRange);
+                if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                    continue;
+                f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
+                float w = g_poisson8[t][2];
+                w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+                w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                if (isSpec)
+                    w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                f4 sv = unpack_h4(ld<uint2>(srcP, px, py, srcBpt, srcOff));
+                w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(sv.w * hitA + hitB)));
+                sum = add4(sum, mul4(sv, w));
+                wsum += w;
+                if (w > 0.0f)
+                    minHit = fmin2(minHit, sv.w * hitNorm);
+            }
+        }
+        float inv = 1.0f / wsum;
+        st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, inv)), sig * 8);
+        if (VARIANT == 0 && isSpec)
+            st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit));
+    }
+}
+
+// =====================================================================================================================
+// Reprojection helpers (TemporalAccumulation + TemporalStabilization)
+// =====================================================================================================================
+struct Reproj {
+    float su, sv;
+    f3 Xw, XwPrev, XvPrev;
+    float zPrev;
+};
+
+NRD_DEV Reproj reproject(const FrameConsts& c, f3 Xv, float u, float v, f4 mvRaw) {
+    Reproj r;
+    r.Xw = rot3(c.v2w, Xv);
+    f3 mv = {mvRaw.x * c.mvScale[0], mvRaw.y * c.mvScale[1], mvRaw.z * c.mvScale[2]};
+    f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
+    if (c.mvWorld) {
+        r.XwPrev = add3(r.Xw, mv);
+        r.XvPrev = rot3(c.w2vPrev, sub3(r.XwPrev, cd));
+        r.zPrev = r.XvPrev.z;
+        if (!project(c.pjPrev, r.XvPrev, r.su, r.sv)) {
+            r.su = -10.0f;
+            r.sv = -10.0f;
+        }
+    } else {
+        r.su = u + mv.x;
+        r.sv = v + mv.y;
+        if (c.mvScale[2] != 0.0f) {
+            r.zPrev = Xv.z + mv.z;
+            r.XvPrev = reconstruct(c.frPrev, r.su, r.sv, r.zPrev);
+            r.XwPrev = add3(rot3(c.v2wPrev, r.XvPrev), cd);
+        } else {
+            r.XwPrev = r.Xw;
+            r.XvPrev = rot3(c.w2vPrev, sub3(r.XwPrev, cd));
+            r.zPrev = r.XvPrev.z;
+        }
+    }
+    return r;
+}
+
+struct Footprint {
+    int ix, iy;
+    float w[4];
+    float wsum;
+    uint32_t bits;
+};
+
+NRD_DEV Footprint footprint(const ReblurParams& p, float pu, float pv, f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
+    const FrameConsts& c = p.c;
+    Footprint f;
+    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+    f.ix = sane ? (int)fx0 : -4;
+    f.iy = sane ? (int)fy0 : -4;
+    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+    f.wsum = 0.0f;
+    f.bits = 0;
+    float planeRef = dot3(NvPrev, XvPrev);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
+        bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
+        if (ok) {
+            Guide gp = decode_guide(ld<uint2>(p.guidePrev, tx, ty, 8), c.denoisingRange);
+            f3 Xp = reconstruct(c.frPrev, ((float)tx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, gp.z);
+            ok = !gp.sky && absf(dot3(NvPrev, Xp) - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
+        }
+        f.w[i] = ok ? bw[i] : 0.0f;
+        f.wsum += f.w[i];
+        f.bits |= ok ? (1u << i) : 0u;
+    }
+    return f;
+}
+
+NRD_DEV f4 fetch4(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
+    f4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (f.w[i] > 0.0f)
+            s = add4(s, mul4(unpack_h4(ld<uint2>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)), f.w[i]));
+    return mul4(s, 1.0f / f.wsum);
+}
+NRD_DEV float fetch1(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (f.w[i] > 0.0f)
+            s += h2f(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)) * f.w[i];
+    return s * (1.0f / f.wsum);
+}
+NRD_DEV void fetchA(const FrameConsts& c, const PlaneRef& P, const Footprint& f, float& dA, float& sA) {
+    dA = sA = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (f.w[i] > 0.0f) {
+            float a, b;
+            unpack_data1(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, 2), a, b);
+            dA += a * f.w[i];
+            sA += b * f.w[i];
+        }
+    float inv = 1.0f / f.wsum;
+    dA *= inv;
+    sA *= inv;
+}
+
+NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
+    f3 toCam = normalize3(r.Xw);
+    float f = spec_dominant_factor(roughness);
+    f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
+    f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
+    f3 rel = sub3(XvirtPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+    f3 Xp = rot3(c.w2vPrev, rel);
+    return project(c.pjPrev, Xp, vu, vv);
+}
+
+NRD_DEV float sample_confidence(const PlaneRef& P, float u, float v) {
+    if (!P.p)
+        return 1.0f;
+    float px = u * (float)P.w - 0.5f, py = v * (float)P.h - 0.5f;
+    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int xa = x0 < 0 ? 0 : (x0 >= P.w ? P.w - 1 : x0), xb = x0 + 1 < 0 ? 0 : (x0 + 1 >= P.w ? P.w - 1 : x0 + 1);
+    int ya = y0 < 0 ? 0 : (y0 >= P.h ? P.h - 1 : y0), yb = y0 + 1 < 0 ? 0 : (y0 + 1 >= P.h ? P.h - 1 : y0 + 1);
+    float a = lerpf(h2f(ld<uint16_t>(P, xa, ya, 8)), h2f(ld<uint16_t>(P, xb, ya, 8)), fx);
+    float b = lerpf(h2f(ld<uint16_t>(P, xa, yb, 8)), h2f(ld<uint16_t>(P, xb, yb, 8)), fx);
+    return sat(lerpf(a, b, fy));
+}
+
+NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
+    float acos01sq = sat(1.0f - NoV * 0.99999f);
+    float a = pow01(acos01sq, 0.5f);
+    float b = 1.1f + roughness * roughness;
+    float parallaxSensitivity = (b + a) / (b - a);
+    float powerScale = 1.0f + parallaxSensitivity * parallaxPx * 2.0f;
+    float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
+    f *= pow01(roughness, 0.5f * powerScale);
+    return MAX_ACCUM * f;
+}
+
+// =====================================================================================================================
+// K3 TemporalAccumulation
+// =====================================================================================================================
+template <bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    const FrameConsts& c = p.c;
+    int x, y, tx, ty;
+    if (!my_pixel(c, x, y, tx, ty))
+        return;
+    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    if (g.sky) {
+        for (int sig = 0; sig < NSIG; sig++) {
+            st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+            st<uint16_t>(p.fast, x, y, LBPT, (uint16_t)0, sig * 2);
+        }
+        st<uint16_t>(p.data1Tmp, x, y, 2, (uint16_t)0);
+        st<uint32_t>(p.data2, x, y, 4, 0u);
+        return;
+    }
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    f3 Xv = reconstruct(c.fr, u, v, g.z);
+    f3 Nv = rot3(c.w2v, g.n);
+    f3 V = mul3(normalize3(Xv), -1.0f);
+    float NoV = absf(dot3(Nv, V));
+    Reproj r = reproject(c, Xv, u, v, unpack_h4(ld<uint2>(p.inMV, x, y, 8)));
+    f3 NvPrev = rot3(c.w2vPrev, g.n);
+    float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(r.zPrev);
+    uint32_t minMatAny = p.minMatDiff < p.minMatSpec ? p.minMatDiff : p.minMatSpec;
+    const bool historyOk = c.historyOk != 0;
+    Footprint smb = footprint(p, r.su, r.sv, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
+    bool smbOk = historyOk && smb.wsum > 0.0f;
+    float prevDiffA = 0.0f, prevSpecA = 0.0f;
+    if (smbOk)
+        fetchA(c, p.data1Prev, smb, prevDiffA, prevSpecA);
+    prevDiffA = smbOk ? fmin2(prevDiffA + 1.0f, p.maxA) : 0.0f;
+    prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, p.maxA) : 0.0f;
+    float quality = smbOk ? smb.wsum : 0.0f;
+    float outDiffA = 0.0f, outSpecA = 0.0f;
+    uint32_t data2 = smbOk ? smb.bits : 0u;
+
+    if (HAS_DIFF) {
+        f4 in = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, 0));
+        float A = prevDiffA;
+        if (c.confAvail)
+            A *= sample_confidence(p.confD, u, v);
+        A *= lerpf(quality, 1.0f, 1.0f / (1.0f + A));
+        float nonLin = 1.0f / (1.0f + A);
+        f4 hist = smbOk ? fetch4(c, p.hist, RBPT, 0, smb) : in;
+        float fastHist = smbOk ? fetch1(c, p.fastPrev, LBPT, 0, smb) : in.x;
+        st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), 0);
+        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), 0);
+        outDiffA = A;
+    }
+    if (HAS_SPEC) {
+        constexpr int so = SIG_SPEC * 8, lo = SIG_SPEC * 2;
+        f4 in = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, so));
+        float hitDist = h2f(ld<uint16_t>(p.hitTrack, x, y, 2));
+        f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
+        f3 XparV = rot3(c.w2v, sub3(r.XwPrev, cd));
+        float pu, pv, parallax = 0.0f;
+        if (project(c.pj, XparV, pu, pv)) {
+            float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
+            parallax = __builtin_sqrtf(dx * dx + dy * dy);
+        }
+        float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
+        float vu, vv;
+        float amount = 0.0f, Avmb = 0.0f;
+        f4 vmbHist = in;
+        float vmbFast = in.x;
+        uint32_t vmbBits = 0;
+        if (historyOk && virtual_uv(c, r, hitDist, g.roughness, vu, vv)) {
+            Footprint vmb = footprint(p, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
+            vmbBits = vmb.bits;
+            if (vmb.wsum > 0.0f) {
+                float prevRough = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (vmb.w[i] > 0.0f)
+                        prevRough += unpack_roughness(ld<uint32_t>(p.guidePrev, vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff, 8, 4)) * vmb.w[i];
+                prevRough *= 1.0f / vmb.wsum;
+                float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction));
+                float rconf = smoothstep01(1.0f - absf(prevRough * roughA - g.roughness * roughA));
+                amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
+                float dA, sA;
+                fetchA(c, p.data1Prev, vmb, dA, sA);
+                Avmb = fmin2(sA + 1.0f, p.maxA);
+                vmbHist = fetch4(c, p.hist, RBPT, so, vmb);
+                vmbFast = fetch1(c, p.fastPrev, LBPT, lo, vmb);
+            }
+        }
+        f4 smbHist = smbOk ? fetch4(c, p.hist, RBPT, so, smb) : in;
+        float smbFast = smbOk ? fetch1(c, p.fastPrev, LBPT, lo, smb) : in.x;
+        if (!smbOk)
+            Asmb = 0.0f;
+        float A = lerpf(Asmb, Avmb, amount);
+        if (c.confAvail)
+            A *= sample_confidence(p.confS, u, v);
+        float q = lerpf(quality, 1.0f, amount);
+        A *= lerpf(q, 1.0f, 1.0f / (1.0f + A));
+        if (p.responsiveRoughnessThreshold > 0.0f) {
+            float t = smoothstep01(g.roughness / p.responsiveRoughnessThreshold);
+            A = fmin2(A, lerpf(p.responsiveMinAccum, p.maxA, t));
+        }
+        float nonLin = 1.0f / (1.0f + A);
+        f4 hist = lerp4(smbHist, vmbHist, amount);
+        float fastHist = lerpf(smbFast, vmbFast, amount);
+        st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
+        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), lo);
+        outSpecA = A;
+        data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(sat(amount) * 255.0f + 0.5f) << 8);
+    }
+    st<uint16_t>(p.data1Tmp, x, y, 2, pack_data1(outDiffA, outSpecA));
+    st<uint32_t>(p.data2, x, y, 4, data2);
+}
+
+// =====================================================================================================================
+// 5x5 luma tile in LDS: 20x20 floats, NaN marks "sky / outside" (the consumer substitutes its own centre value)
+// =====================================================================================================================
+template <typename Fetch>
+NRD_DEV void stage_luma_tile(const FrameConsts& c, const PlaneRef& guide, int tx, int ty, float* tile, Fetch fetch) {
+    int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    for (int i = tid; i < 400; i += 256) {
+        int lx = i % 20, ly = i / 20;
+        int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
+        float val = u2f(0x7fc00000u);
+        if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
+            float zt = ld<float>(guide, px, py, 8, 0);
+            if (absf(zt) <= c.denoisingRange)
+                val = fetch(px, py);
+        }
+        tile[i] = val;
+    }
+}
+
+NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, float& m1, float& m2) {
+    m1 = 0.0f;
+    m2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            float f = tile[(ly + j) * 20 + lx + i];
+            f = f != f ? centre : f;
+            m1 += f;
+            m2 += f * f;
+        }
+    m1 *= 1.0f / 25.0f;
+    m2 *= 1.0f / 25.0f;
+}
+
+// =====================================================================================================================
+// K4 HistoryFix
+// =====================================================================================================================
+template <bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    __shared__ float tile[NSIG][400];
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    if (p.clampEnabled) {
+        for (int sig = 0; sig < NSIG; sig++)
+            stage_luma_tile(c, p.guide, tx, ty, tile[sig], [&](int px, int py) { return h2f(ld<uint16_t>(p.fast, px, py, LBPT, sig * 2)); });
+        __syncthreads();
+    }
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+        return;
+    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    if (g.sky) {
+        for (int sig = 0; sig < NSIG; sig++)
+            st<uint2>(p.tmp1, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+        st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
+        return;
+    }
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    f3 Xv = reconstruct(c.fr, u, v, g.z);
+    f3 Nv = rot3(c.w2v, g.n);
+    float frustumSize = c.minRectDimMulUnproject * absf(g.z);
+    float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
+    float geoB = -dot3(Nv, Xv) * geoA;
+    float A[2];
+    unpack_data1(ld<uint16_t>(p.data1Tmp, x, y, 2), A[0], A[1]);
+    float outA[2] = {A[0], A[1]};
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        const int ai = isSpec ? 1 : 0;
+        float rough = isSpec ? g.roughness : 1.0f;
+        uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
+        f4 val = unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * 8));
+        float Acur = A[ai];
+        if (Acur < (float)p.historyFixFrameNum && p.historyFixFrameNum > 0) {
+            float normA = sat(Acur / (float)p.historyFixFrameNum);
+            int stride = (int)__builtin_floorf((float)p.historyFixStride * (1.0f - normA) + 0.5f);
+            if (stride > 0) {
+                float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, 1.0f / (1.0f + Acur));
+                float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+                float roughB = -rough * roughA;
+                f4 sum = mul4(val, 1.0f + Acur);
+                float wsum = 1.0f + Acur;
+                for (int j = -2; j <= 2; j++)
+                    for (int i = -2; i <= 2; i++) {
+                        if ((i == 0 && j == 0) || (i * i == 4 && j * j == 4))
+                            continue;
+                        int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
+                        if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                            continue;
+                        Guide gs = decode_guide(ld<uint2>(p.guide, px, py, 8), c.denoisingRange);
+                        if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                            continue;
+                        f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
+                        float w = 1.0f / (1.0f + (float)(i * i + j * j));
+                        w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+                        w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                        if (isSpec)
+                            w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                        float tA[2];
+                        unpack_data1(ld<uint16_t>(p.data1Tmp, px, py, 2), tA[0], tA[1]);
+                        w *= 1.0f + tA[ai];
+                        sum = add4(sum, mul4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * 8)), w));
+                        wsum += w;
+                    }
+                val = mul4(sum, 1.0f / wsum);
+            }
+        }
+        if (p.clampEnabled) {
+            float fc = h2f(ld<uint16_t>(p.fast, x, y, LBPT, sig * 2));
+            float m1, m2;
+            moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, m1, m2);
+            float sigma = __builtin_sqrtf(fmax2(m2 - m1 * m1, 0.0f)) * p.fastHistoryClampingSigmaScale;
+            float Y = val.x;
+            float Yc = clampf(Y, m1 - sigma, m1 + sigma);
+            float scale = (Yc + 1e-6f) / (Y + 1e-6f);
+            val.x = Yc;
+            val.y *= scale;
+            val.z *= scale;
+            float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
+            outA[ai] = lerpf(Acur, fmin2(Acur, p.maxFastA), f);
+        }
+        st<uint2>(p.tmp1, x, y, RBPT, pack_h4(val), sig * 8);
+    }
+    st<uint16_t>(p.data1, x, y, 2, pack_data1(outA[0], outA[1]));
+}
+
+// =====================================================================================================================
+// K7 TemporalStabilization (+ split screen)
+// =====================================================================================================================
+NRD_DEV bool fetch_stab(const FrameConsts& c, const PlaneRef& P, int bpt, int off, float pu, float pv, uint32_t bits, float& out) {
+    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+    if (!sane)
+        return false;
+    int ix = (int)fx0, iy = (int)fy0;
+    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+    float sum = 0.0f, wsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (bits & (1u << i)) {
+            sum += h2f(ld<uint16_t>(P, ix + (i & 1), iy + (i >> 1) - c.yOff, bpt, off)) * bw[i];
+            wsum += bw[i];
+        }
+    if (!(wsum > 0.0f))
+        return false;
+    out = sum * (1.0f / wsum);
+    return true;
+}
+
+template <bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    __shared__ float tile[NSIG][400];
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    for (int sig = 0; sig < NSIG; sig++)
+        stage_luma_tile(c, p.guide, tx, ty, tile[sig], [&](int px, int py) { return h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * 8)); });
+    __syncthreads();
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+        return;
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    bool split = u < c.splitScreen;
+    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    if (g.sky) {
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
+            const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+            st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
+            st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
+        }
+        return;
+    }
+    f3 Xv = reconstruct(c.fr, u, v, g.z);
+    Reproj r = reproject(c, Xv, u, v, unpack_h4(ld<uint2>(p.inMV, x, y, 8)));
+    uint32_t data2 = ld<uint32_t>(p.data2, x, y, 4);
+    float A[2];
+    unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
+    const bool historyOk = c.historyOk != 0;
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        f4 cur = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * 8));
+        float m1, m2;
+        moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, m1, m2);
+        float sigma = __builtin_sqrtf(fmax2(m2 - m1 * m1, 0.0f));
+        float Yhist = cur.x;
+        bool have = false;
+        if (historyOk) {
+            float smbY = 0.0f;
+            bool smbOk = fetch_stab(c, p.stabPrev, LBPT, sig * 2, r.su, r.sv, data2 & 15u, smbY);
+            if (isSpec) {
+                float amount = (float)((data2 >> 8) & 255u) / 255.0f;
+                float vu, vv, vmbY = 0.0f;
+                bool vmbOk = amount > 0.0f && virtual_uv(c, r, h2f(ld<uint16_t>(p.hitTrack, x, y, 2)), g.roughness, vu, vv) &&
+                             fetch_stab(c, p.stabPrev, LBPT, sig * 2, vu, vv, (data2 >> 4) & 15u, vmbY);
+                if (smbOk && vmbOk) {
+                    Yhist = lerpf(smbY, vmbY, amount);
+                    have = true;
+                } else if (smbOk) {
+                    Yhist = smbY;
+                    have = true;
+                } else if (vmbOk) {
+                    Yhist = vmbY;
+                    have = true;
+                }
+            } else if (smbOk) {
+                Yhist = smbY;
+                have = true;
+            }
+        }
+        float Acur = A[isSpec ? 1 : 0];
+        float Y = cur.x;
+        float band = sigma * p.antilagSigmaScale;
+        float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) / (fmax2(Yhist, m1) + 1e-6f);
+        float antilag = 1.0f / (1.0f + dlt * p.antilagSensitivity * Acur);
+        float Yclamped = clampf(Yhist, m1 - band, m1 + band);
+        float stabFrames = have ? fmin2(Acur, p.maxStab) * antilag : 0.0f;
+        float wHist = stabFrames / (1.0f + stabFrames);
+        float Yout = lerpf(Y, Yclamped, wHist);
+        float scale = (Yout + 1e-6f) / (Y + 1e-6f);
+        f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
+        st<uint16_t>(p.stab, x, y, LBPT, f2h(Yout), sig * 2);
+        const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
+        const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+        st<uint2>(op, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : pack_h4(o));
+    }
+}
+
+dim3 grid_for(const FrameConsts& c) {
+    int total = c.tilesX * c.tilesY;
+    int chunk = (total + 7) / 8;
+    return dim3((unsigned)(chunk * 8), 1, 1);
+}
+
+} // namespace
+
+#define NRD_LAUNCH3(KERNEL, ...)                                                                                 \
+    do {                                                                                                          \
+        if (p.hasDiff && p.hasSpec)                                                                               \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);        \
+        else if (p.hasDiff)                                                                                       \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
+        else                                                                                                      \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
+    } while (0)
+
+void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+}
+
+void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
+    if (variant == 0)
+        NRD_LAUNCH3(k_spatial, 0, );
+    else if (variant == 1)
+        NRD_LAUNCH3(k_spatial, 1, );
+    else
+        NRD_LAUNCH3(k_spatial, 2, );
+}
+
+void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_accumulation, ); }
+void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_history_fix, ); }
+void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_stabilization, ); }
+
+} // namespace nrdhip

@@ -1,0 +1,363 @@
+// nrd_sigma.hip - SIGMA_SHADOW / SIGMA_SHADOW_TRANSLUCENCY passes as gfx950 HIP kernels, plus the REFERENCE accumulator.
+//
+// Replaces the SIGMA / REFERENCE HLSL passes of the reference's absent External/NRD submodule behind
+// nrd::Integration::Denoise (Source/NRDSample.cpp:4082 shadow denoising, :4224 reference accumulation).
+// Inputs: IN_PENUMBRA R16F / IN_TRANSLUCENCY RGBA8 (Shaders/TraceOpaque.cs.hlsl:800-804); output RGBA8, sqrt-encoded
+// (Shaders/Composition.cs.hlsl:60-64 squares it). Pass graph: ClassifyTiles(+guide) -> SmoothTiles -> Blur -> PostBlur ->
+// TemporalStabilization. Same 16x16 XCD-swizzled tiling and packed 8-byte guide texel as REBLUR; the 5x5 clamp stencil of
+// the stabilization pass stages its 20x20 RGBA tile in LDS.
+#include "nrd_kernels.h"
+
+namespace nrdhip {
+
+namespace {
+
+constexpr float MAX_PIXEL_RADIUS = 48.0f;
+constexpr float PREV_NORMAL_COS = 0.7f;
+constexpr float STAB_SIGMA_SCALE = 2.0f;
+
+NRD_DEV f4 input_visibility(const SigmaParams& p, int x, int y, float pen) {
+    if (pen >= NRD_FP16_MAX)
+        return {1, 1, 1, 1};
+    if (!p.translucency)
+        return {0, 0, 0, 0};
+    uint32_t t = ld<uint32_t>(p.inTransl, x, y, 4);
+    return {0.0f, (float)((t >> 8) & 255u) / 255.0f, (float)((t >> 16) & 255u) / 255.0f, (float)(t >> 24) / 255.0f};
+}
+
+NRD_DEV uint32_t encode_shadow(f4 v) {
+    uint32_t r = (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.x)) * 255.0f + 0.5f);
+    r |= (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.y)) * 255.0f + 0.5f) << 8;
+    r |= (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.z)) * 255.0f + 0.5f) << 16;
+    r |= (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.w)) * 255.0f + 0.5f) << 24;
+    return r;
+}
+NRD_DEV f4 decode_shadow(uint32_t p) {
+    float a = (float)(p & 255u) / 255.0f, b = (float)((p >> 8) & 255u) / 255.0f, c = (float)((p >> 16) & 255u) / 255.0f, d = (float)(p >> 24) / 255.0f;
+    return {a * a, b * b, c * c, d * d};
+}
+
+__global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams p) {
+    __shared__ float smax[4];
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    bool valid = x < c.W && y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
+    int shadowed = 0, lit = 0;
+    float r = 0.0f;
+    if (valid) {
+        float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
+        st<uint2>(p.guide, x, y, 8, uint2{f2u(z), ld<uint32_t>(p.inNR, x, y, 4)});
+        if (absf(z) <= c.denoisingRange) {
+            float pen = h2f(ld<uint16_t>(p.inPen, x, y, 2));
+            if (pen >= NRD_FP16_MAX)
+                lit = 1;
+            else {
+                shadowed = 1;
+                r = fmin2(pen / (c.unproject * absf(z)), 255.0f);
+            }
+        }
+    }
+    int anyShadow = __syncthreads_or(shadowed);
+    int anyLit = __syncthreads_or(lit);
+    // max is exact in any order: wave64 butterfly, then across the 4 waves through LDS
+    for (int o = 32; o > 0; o >>= 1)
+        r = fmax2(r, __shfl_xor(r, o, 64));
+    int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    if ((tid & 63) == 0)
+        smax[tid >> 6] = r;
+    __syncthreads();
+    if (tid == 0) {
+        float m = fmax2(fmax2(smax[0], smax[1]), fmax2(smax[2], smax[3]));
+        uint32_t ri = (uint32_t)__builtin_floorf(m + 0.999f);
+        ri = ri > 255u ? 255u : ri;
+        st<uint16_t>(p.tiles, tx, ty, 2, (uint16_t)((anyShadow ? 1u : 0u) | (anyLit ? 2u : 0u) | (ri << 8)));
+    }
+}
+
+// one thread per tile
+__global__ __launch_bounds__(256) void k_sigma_smooth_tiles(const SigmaParams p) {
+    const FrameConsts& c = p.c;
+    int total = c.tilesX * c.tilesY;
+    int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= total)
+        return;
+    int ty = i / c.tilesX, tx = i - ty * c.tilesX;
+    ty += c.tileY0;
+    int tilesYAll = (c.resH + 15) / 16;
+    uint32_t flags = 0, r = 0;
+    for (int j = -1; j <= 1; j++)
+        for (int k = -1; k <= 1; k++) {
+            int x = tx + k, y = ty + j;
+            if (x < 0 || x >= c.tilesX || y < 0 || y >= tilesYAll)
+                continue;
+            uint32_t t = ld<uint16_t>(p.tiles, x, y, 2);
+            flags |= t & 3u;
+            r = r > (t >> 8) ? r : (t >> 8);
+        }
+    st<uint16_t>(p.tilesSmooth, tx, ty, 2, (uint16_t)((flags == 3u ? 1u : 0u) | (r << 8)));
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+        return;
+    const PlaneRef& inPen = PASS == 0 ? p.inPen : p.pen1;
+    const PlaneRef& outSh = PASS == 0 ? p.shadow1 : p.shadow2;
+    uint2 graw = ld<uint2>(p.guide, x, y, 8);
+    float z = u2f(graw.x);
+    if (!(absf(z) <= c.denoisingRange)) {
+        st<uint2>(outSh, x, y, 8, uint2{0u, 0u});
+        if (PASS == 0)
+            st<uint16_t>(p.pen1, x, y, 2, (uint16_t)0);
+        return;
+    }
+    float absZ = absf(z);
+    float pen = h2f(ld<uint16_t>(inPen, x, y, 2));
+    bool lit = PASS == 0 ? pen >= NRD_FP16_MAX : !(pen > 0.0f);
+    f4 center = PASS == 0 ? input_visibility(p, x, y, pen) : unpack_h4(ld<uint2>(p.shadow1, x, y, 8));
+    uint32_t tile = ld<uint16_t>(p.tilesSmooth, tx, ty, 2);
+    if (!(tile & 1u)) {
+        st<uint2>(outSh, x, y, 8, pack_h4(center));
+        if (PASS == 0)
+            st<uint16_t>(p.pen1, x, y, 2, f2h(lit ? 0.0f : pen));
+        return;
+    }
+    float pixelWorld = c.unproject * absZ;
+    float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
+    radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
+    float worldRadius = radiusPx * pixelWorld;
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    f3 Xv = reconstruct(c.fr, u, v, z);
+    f3 N = unpack_normal(graw.y);
+    f3 Nv = rot3(c.w2v, N);
+    float frustumSize = c.minRectDimMulUnproject * absZ;
+    float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
+    float geoB = -dot3(Nv, Xv) * geoA;
+    f3 T, B;
+    basis3(Nv, T, B);
+    T = mul3(T, worldRadius);
+    B = mul3(B, worldRadius);
+    uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, 17u + (uint32_t)PASS);
+    float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
+    f4 sum = center;
+    float wsum = 1.0f;
+    float penSum = lit ? 0.0f : pen, penW = lit ? 0.0f : 1.0f;
+    if (radiusPx > 0.0f) {
+#pragma unroll 2
+        for (int t = 0; t < 8; t++) {
+            float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
+            float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
+            f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
+            float tu, tv;
+            if (!project(c.pj, Xt, tu, tv))
+                continue;
+            float fpx = __builtin_floorf(tu * (float)c.W), fpy = __builtin_floorf(tv * (float)c.H);
+            if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
+                continue;
+            int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+            if (py < 0 || py >= c.resH)
+                continue;
+            float zs = ld<float>(p.guide, px, py, 8, 0);
+            if (!(absf(zs) <= c.denoisingRange))
+                continue;
+            f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, zs);
+            float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+            float ps = h2f(ld<uint16_t>(inPen, px, py, 2));
+            bool lits = PASS == 0 ? ps >= NRD_FP16_MAX : !(ps > 0.0f);
+            f4 sv = PASS == 0 ? input_visibility(p, px, py, ps) : unpack_h4(ld<uint2>(p.shadow1, px, py, 8));
+            sum = add4(sum, mul4(sv, w));
+            wsum += w;
+            if (!lits) {
+                penSum += ps * w;
+                penW += w;
+            }
+        }
+    }
+    st<uint2>(outSh, x, y, 8, pack_h4(mul4(sum, 1.0f / wsum)));
+    if (PASS == 0)
+        st<uint16_t>(p.pen1, x, y, 2, f2h(penW > 0.0f ? penSum / penW : 0.0f));
+}
+
+NRD_DEV void store_out(const SigmaParams& p, int x, int y, uint32_t packed) {
+    if (p.outBpt == 1)
+        st<uint8_t>(p.out, x, y, 1, (uint8_t)(packed & 255u));
+    else
+        st<uint32_t>(p.out, x, y, 4, packed);
+}
+
+__global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const SigmaParams p) {
+    __shared__ uint2 tile[400]; // RGBA16F texels, 0xffffffff marks "sky / outside"
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    for (int i = tid; i < 400; i += 256) {
+        int lx = i % 20, ly = i / 20;
+        int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
+        uint2 val = uint2{0xffffffffu, 0xffffffffu};
+        if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
+            float zt = ld<float>(p.guide, px, py, 8, 0);
+            if (absf(zt) <= c.denoisingRange)
+                val = ld<uint2>(p.shadow2, px, py, 8);
+        }
+        tile[i] = val;
+    }
+    __syncthreads();
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+        return;
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    bool split = u < c.splitScreen;
+    uint2 graw = ld<uint2>(p.guide, x, y, 8);
+    float z = u2f(graw.x);
+    if (!(absf(z) <= c.denoisingRange)) {
+        st<uint32_t>(p.hist, x, y, 4, 0u);
+        store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : 0u);
+        return;
+    }
+    f4 cur = unpack_h4(ld<uint2>(p.shadow2, x, y, 8));
+    float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            uint2 raw = tile[((int)threadIdx.y + j) * 20 + (int)threadIdx.x + i];
+            f4 f = raw.x == 0xffffffffu && raw.y == 0xffffffffu ? cur : unpack_h4(raw);
+            m1[0] += f.x;
+            m2[0] += f.x * f.x;
+            m1[1] += f.y;
+            m2[1] += f.y * f.y;
+            m1[2] += f.z;
+            m2[2] += f.z * f.z;
+            m1[3] += f.w;
+            m2[3] += f.w * f.w;
+        }
+    f3 Xv = reconstruct(c.fr, u, v, z);
+    f3 N = unpack_normal(graw.y);
+    f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
+    f3 Xw = rot3(c.v2w, Xv);
+    f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
+    float su, sv;
+    f3 XvPrev;
+    bool uvOk = true;
+    if (c.mvWorld) {
+        f3 XwPrev = add3(Xw, {mvRaw.x * c.mvScale[0], mvRaw.y * c.mvScale[1], mvRaw.z * c.mvScale[2]});
+        XvPrev = rot3(c.w2vPrev, sub3(XwPrev, cd));
+        uvOk = project(c.pjPrev, XvPrev, su, sv);
+    } else {
+        su = u + mvRaw.x * c.mvScale[0];
+        sv = v + mvRaw.y * c.mvScale[1];
+        if (c.mvScale[2] != 0.0f)
+            XvPrev = reconstruct(c.frPrev, su, sv, z + mvRaw.z * c.mvScale[2]);
+        else
+            XvPrev = rot3(c.w2vPrev, sub3(Xw, cd));
+    }
+    f4 hist = cur;
+    bool have = false;
+    if (c.historyOk && uvOk) {
+        f3 NvPrev = rot3(c.w2vPrev, N);
+        float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(XvPrev.z);
+        float px = su * (float)c.Wprev - 0.5f, py = sv * (float)c.Hprev - 0.5f;
+        float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+        float fx = px - fx0, fy = py - fy0;
+        bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+        if (sane) {
+            int ix = (int)fx0, iy = (int)fy0;
+            float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+            float planeRef = dot3(NvPrev, XvPrev);
+            f4 sum = {0, 0, 0, 0};
+            float wsum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
+                if (ttx < 0 || ttx >= c.Wprev || gy < 0 || gy >= c.Hprev || tty < 0 || tty >= c.resH)
+                    continue;
+                uint2 gp = ld<uint2>(p.guidePrev, ttx, tty, 8);
+                float zp = u2f(gp.x);
+                if (!(absf(zp) <= c.denoisingRange))
+                    continue;
+                f3 Xp = reconstruct(c.frPrev, ((float)ttx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, zp);
+                f3 Np = unpack_normal(gp.y);
+                if (!(absf(dot3(NvPrev, Xp) - planeRef) <= threshold) || !(dot3(N, Np) > PREV_NORMAL_COS))
+                    continue;
+                sum = add4(sum, mul4(decode_shadow(ld<uint32_t>(p.histPrev, ttx, tty, 4)), bw[i]));
+                wsum += bw[i];
+            }
+            if (wsum > 0.0f) {
+                hist = mul4(sum, 1.0f / wsum);
+                have = true;
+            }
+        }
+    }
+    float w = have ? p.maxStab / (1.0f + p.maxStab) : 0.0f;
+    float hc[4] = {hist.x, hist.y, hist.z, hist.w}, cc[4] = {cur.x, cur.y, cur.z, cur.w}, o[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {
+        float a = m1[ch] * (1.0f / 25.0f), b = m2[ch] * (1.0f / 25.0f);
+        float sigma = __builtin_sqrtf(fmax2(b - a * a, 0.0f)) * STAB_SIGMA_SCALE;
+        float hcl = clampf(hc[ch], a - sigma, a + sigma);
+        o[ch] = lerpf(cc[ch], hcl, w);
+    }
+    uint32_t packed = encode_shadow({o[0], o[1], o[2], o[3]});
+    st<uint32_t>(p.hist, x, y, 4, packed);
+    store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : packed);
+}
+
+// REFERENCE: running mean in an RGBA32F history (Source/NRDSample.cpp:4213-4224; in place, :484-485)
+__global__ __launch_bounds__(256) void k_reference_accumulate(const ReferenceParams p) {
+    const FrameConsts& c = p.c;
+    int tx, ty;
+    if (!xcd_tile(c, tx, ty))
+        return;
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+        return;
+    f4 s = unpack_h4(ld<uint2>(p.in, x, y, 8));
+    f4 h = s;
+    if (!p.restart) {
+        float4 hv = ld<float4>(p.hist, x, y, 16);
+        h = lerp4({hv.x, hv.y, hv.z, hv.w}, s, p.weight);
+    }
+    st<float4>(p.hist, x, y, 16, float4{h.x, h.y, h.z, h.w});
+    float u = ((float)x + 0.5f) * c.invW;
+    st<uint2>(p.out, x, y, 8, pack_h4(u < c.splitScreen ? s : h));
+}
+
+dim3 grid_for(const FrameConsts& c) {
+    int total = c.tilesX * c.tilesY;
+    int chunk = (total + 7) / 8;
+    return dim3((unsigned)(chunk * 8), 1, 1);
+}
+
+} // namespace
+
+void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_sigma_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+}
+void launch_sigma_smooth_tiles(const SigmaParams& p, hipStream_t s) {
+    int total = p.c.tilesX * p.c.tilesY;
+    hipLaunchKernelGGL(k_sigma_smooth_tiles, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+void launch_sigma_blur(const SigmaParams& p, int pass, hipStream_t s) {
+    if (pass == 0)
+        hipLaunchKernelGGL(k_sigma_blur<0>, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+    else
+        hipLaunchKernelGGL(k_sigma_blur<1>, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+}
+void launch_sigma_temporal_stabilization(const SigmaParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_sigma_temporal_stabilization, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+}
+void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_reference_accumulate, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+}
+
+} // namespace nrdhip

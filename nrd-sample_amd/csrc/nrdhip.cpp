@@ -1,0 +1,821 @@
+// nrdhip.cpp - host dispatch core + C-ABI of the MI355X-native NRD backend (include/nrdhip.h).
+//
+// This is the nrd::Instance / NRD-Integration equivalent: it turns {denoiser ids, CommonSettings, per-denoiser settings,
+// bound resource slots} into an ordered list of HIP kernel launches on the caller's stream, the way the reference's
+// nrd::Integration::Denoise records compute dispatches into an nri::CommandBuffer (Source/NRDSample.cpp:440-531).
+// No CPU fallback exists: every pass is a HIP kernel (nrd_reblur.hip, nrd_sigma.hip).
+#include "../../include/NRDDescs.h"
+#include "../../include/NRDSettings.h"
+#include "../../include/nrdhip.h"
+#include "nrd_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace nrdhip;
+
+namespace {
+
+enum class Kind { REBLUR, RELAX, SIGMA, REFERENCE };
+
+struct Plane {
+    uint8_t* p = nullptr;
+    uint32_t pitch = 0;
+    uint32_t fmt = 0;
+    uint16_t w = 0, h = 0;
+    uint32_t bpt = 0;
+    const char* name = "";
+    bool owned = false;
+    PlaneRef ref() const { return PlaneRef{p, pitch, w, h}; }
+};
+
+struct PoolPlane {
+    const char* name;
+    nrd::Format fmt;
+    uint32_t bpt;
+    uint16_t downsample;
+};
+
+uint32_t format_bytes(uint32_t f) {
+    using nrd::Format;
+    switch ((Format)f) {
+        case Format::R8_UNORM:
+        case Format::R8_UINT: return 1;
+        case Format::R16_UINT:
+        case Format::R16_SFLOAT: return 2;
+        case Format::RGBA8_UNORM:
+        case Format::RG16_SFLOAT:
+        case Format::R32_UINT:
+        case Format::R32_SFLOAT:
+        case Format::R10_G10_B10_A2_UNORM: return 4;
+        case Format::RGBA16_SFLOAT:
+        case Format::RG32_UINT: return 8;
+        case Format::RGBA32_SFLOAT:
+        case Format::RGBA32_UINT: return 16;
+        default: return 0;
+    }
+}
+
+struct Dispatch {
+    const char* name;
+    const char* kernel;
+    uint16_t halo;
+    float bpp;
+    std::vector<uint32_t> written, read;
+    std::function<void(hipStream_t)> launch;
+};
+
+struct DenoiserState {
+    uint32_t identifier = 0;
+    nrd::Denoiser denoiser = nrd::Denoiser::MAX_NUM;
+    Kind kind = Kind::REFERENCE;
+    bool hasDiff = false, hasSpec = false, translucency = false;
+    int nsig = 0;
+    uint32_t permBase = 0, permEnd = 0, transBase = 0;
+    uint32_t frameCounter = 0, framesSinceReset = 0;
+    bool historyValid = false;
+    nrd::ReblurSettings reblur;
+    nrd::RelaxSettings relax;
+    nrd::SigmaSettings sigma;
+    nrd::ReferenceSettings reference;
+    std::vector<Dispatch> dispatches;
+};
+
+inline uint32_t enc_perm(uint32_t i) { return i; }
+inline uint32_t enc_trans(uint32_t i) { return (1u << 16) | i; }
+inline uint32_t enc_slot(nrd::ResourceType t) { return (2u << 16) | (uint32_t)t; }
+
+} // namespace
+
+struct nrdhip_instance {
+    int resW = 0, resH = 0, frameH = 0, yOff = 0, ownY0 = 0, ownRows = 0;
+    uint32_t flags = 0;
+    nrd::CommonSettings common;
+    bool commonSet = false;
+    std::vector<DenoiserState> denoisers;
+    std::vector<Plane> perm, trans;
+    Plane slots[(size_t)nrd::ResourceType::MAX_NUM];
+    std::string error;
+};
+
+namespace {
+
+std::string g_createError;
+
+DenoiserState* find(nrdhip_instance& I, uint32_t id) {
+    for (auto& d : I.denoisers)
+        if (d.identifier == id)
+            return &d;
+    return nullptr;
+}
+
+bool classify(nrd::Denoiser dn, DenoiserState& d) {
+    using D = nrd::Denoiser;
+    d.denoiser = dn;
+    switch (dn) {
+        case D::REBLUR_DIFFUSE: d.kind = Kind::REBLUR; d.hasDiff = true; break;
+        case D::REBLUR_SPECULAR: d.kind = Kind::REBLUR; d.hasSpec = true; break;
+        case D::REBLUR_DIFFUSE_SPECULAR: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = true; break;
+        case D::SIGMA_SHADOW: d.kind = Kind::SIGMA; break;
+        case D::SIGMA_SHADOW_TRANSLUCENCY: d.kind = Kind::SIGMA; d.translucency = true; break;
+        case D::REFERENCE: d.kind = Kind::REFERENCE; break;
+        default: return false;
+    }
+    d.nsig = (d.hasDiff ? 1 : 0) + (d.hasSpec ? 1 : 0);
+    return true;
+}
+
+// ---- pool descriptions (indices must match the enums used by the builders below) ----------------------------------
+namespace rb { // REBLUR
+enum Perm { GUIDE_A, GUIDE_B, DATA1_A, DATA1_B, HIST, FAST_A, FAST_B, STAB_A, STAB_B };
+enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK };
+} // namespace rb
+namespace sg { // SIGMA
+enum Perm { GUIDE_A, GUIDE_B, HIST_A, HIST_B };
+enum Trans { TILES, TILES_SMOOTH, SHADOW1, PEN1, SHADOW2 };
+} // namespace sg
+
+void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
+    using F = nrd::Format;
+    if (d.kind == Kind::REBLUR) {
+        F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
+        F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
+        uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+        perm.push_back({"REBLUR::Guide_A", F::RG32_UINT, 8, 1});
+        perm.push_back({"REBLUR::Guide_B", F::RG32_UINT, 8, 1});
+        perm.push_back({"REBLUR::Data1_A", F::R16_UINT, 2, 1});
+        perm.push_back({"REBLUR::Data1_B", F::R16_UINT, 2, 1});
+        perm.push_back({"REBLUR::History", fmtRad, bRad, 1});
+        perm.push_back({"REBLUR::FastHistory_A", fmtLum, bLum, 1});
+        perm.push_back({"REBLUR::FastHistory_B", fmtLum, bLum, 1});
+        perm.push_back({"REBLUR::StabilizedLuma_A", fmtLum, bLum, 1});
+        perm.push_back({"REBLUR::StabilizedLuma_B", fmtLum, bLum, 1});
+        trans.push_back({"REBLUR::Tiles", F::R8_UINT, 1, 16});
+        trans.push_back({"REBLUR::Tmp1", fmtRad, bRad, 1});
+        trans.push_back({"REBLUR::Tmp2", fmtRad, bRad, 1});
+        trans.push_back({"REBLUR::Data1_Tmp", F::R16_UINT, 2, 1});
+        trans.push_back({"REBLUR::Data2", F::R32_UINT, 4, 1});
+        trans.push_back({"REBLUR::SpecHitDistForTracking", F::R16_SFLOAT, 2, 1});
+    } else if (d.kind == Kind::SIGMA) {
+        perm.push_back({"SIGMA::Guide_A", F::RG32_UINT, 8, 1});
+        perm.push_back({"SIGMA::Guide_B", F::RG32_UINT, 8, 1});
+        perm.push_back({"SIGMA::History_A", F::RGBA8_UNORM, 4, 1});
+        perm.push_back({"SIGMA::History_B", F::RGBA8_UNORM, 4, 1});
+        trans.push_back({"SIGMA::Tiles", F::R16_UINT, 2, 16});
+        trans.push_back({"SIGMA::SmoothTiles", F::R16_UINT, 2, 16});
+        trans.push_back({"SIGMA::Shadow1", F::RGBA16_SFLOAT, 8, 1});
+        trans.push_back({"SIGMA::Penumbra1", F::R16_SFLOAT, 2, 1});
+        trans.push_back({"SIGMA::Shadow2", F::RGBA16_SFLOAT, 8, 1});
+    } else if (d.kind == Kind::REFERENCE) {
+        perm.push_back({"REFERENCE::History", F::RGBA32_SFLOAT, 16, 1});
+    }
+}
+
+// ---- CommonSettings -> FrameConsts (column-major 4x4 matrices, Source/NRDSample.cpp:3836-3839) ------------------------
+bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
+    const nrd::CommonSettings& cs = I.common;
+    std::memset(&c, 0, sizeof(c));
+    c.W = cs.rectSize[0];
+    c.H = cs.rectSize[1];
+    c.Wprev = cs.rectSizePrev[0] ? cs.rectSizePrev[0] : c.W;
+    c.Hprev = cs.rectSizePrev[1] ? cs.rectSizePrev[1] : c.H;
+    c.resW = I.resW;
+    c.resH = I.resH;
+    c.yOff = I.yOff;
+    if (c.W <= 0 || c.H <= 0 || c.W > I.resW) {
+        err = "rectSize invalid";
+        return false;
+    }
+    if (I.frameH == I.resH && I.yOff == 0 && c.H > I.resH) {
+        err = "rectSize exceeds resourceSize";
+        return false;
+    }
+    c.ownY0 = I.ownY0;
+    c.ownY1 = I.ownRows ? I.ownY0 + I.ownRows : I.resH;
+    c.ownY0 = std::max(c.ownY0, -I.yOff);
+    c.ownY1 = std::min(c.ownY1, c.H - I.yOff);
+    c.ownY1 = std::min(c.ownY1, I.resH);
+    if (c.ownY1 < c.ownY0)
+        c.ownY1 = c.ownY0;
+    c.tilesX = (c.W + 15) / 16;
+    c.tileY0 = c.ownY0 / 16;
+    c.tilesY = (c.ownY1 + 15) / 16 - c.tileY0;
+    c.invW = 1.0f / (float)c.W;
+    c.invH = 1.0f / (float)c.H;
+    c.invWprev = 1.0f / (float)c.Wprev;
+    c.invHprev = 1.0f / (float)c.Hprev;
+
+    auto projection = [](const float* M, float* pj, float* fr) {
+        float s = M[11];
+        if (s == 0.0f || M[0] == 0.0f || M[5] == 0.0f)
+            return false; // orthographic / degenerate: unsupported
+        s = s > 0.0f ? 1.0f : -1.0f;
+        pj[0] = M[0];
+        pj[1] = M[5];
+        pj[2] = M[8];
+        pj[3] = M[9];
+        pj[4] = s;
+        fr[2] = 2.0f * s / M[0];
+        fr[0] = (-s - M[8]) / M[0];
+        fr[3] = -2.0f * s / M[5];
+        fr[1] = (s - M[9]) / M[5];
+        return true;
+    };
+    if (!projection(cs.viewToClipMatrix, c.pj, c.fr) || !projection(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev)) {
+        err = "only perspective projections are supported";
+        return false;
+    }
+    auto camera = [](const float* M, float* R, float* Rt, float* pos) {
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++) {
+                R[r * 3 + k] = M[k * 4 + r];
+                Rt[k * 3 + r] = M[k * 4 + r];
+            }
+        for (int i = 0; i < 3; i++)
+            pos[i] = -(R[0 * 3 + i] * M[12] + R[1 * 3 + i] * M[13] + R[2 * 3 + i] * M[14]);
+    };
+    float pos[3], posPrev[3];
+    camera(cs.worldToViewMatrix, c.w2v, c.v2w, pos);
+    camera(cs.worldToViewMatrixPrev, c.w2vPrev, c.v2wPrev, posPrev);
+    for (int i = 0; i < 3; i++)
+        c.camDelta[i] = posPrev[i] - pos[i];
+    c.unproject = 1.0f / (0.5f * (float)c.H * std::fabs(c.pj[1]));
+    c.minRectDimMulUnproject = (float)std::min(c.W, c.H) * c.unproject;
+    c.denoisingRange = cs.denoisingRange;
+    c.disocclusionThreshold = cs.disocclusionThreshold;
+    c.splitScreen = cs.splitScreen;
+    for (int i = 0; i < 3; i++)
+        c.mvScale[i] = cs.motionVectorScale[i];
+    c.viewZScale = cs.viewZScale;
+    c.frameIndex = cs.frameIndex;
+    c.mvWorld = cs.isMotionVectorInWorldSpace ? 1 : 0;
+    c.confAvail = cs.isHistoryConfidenceAvailable ? 1 : 0;
+    for (int k = 0; k < 64; k++) {
+        double a = 6.283185307179586 * (double)k / 64.0;
+        c.rot[k][0] = (float)std::cos(a);
+        c.rot[k][1] = (float)std::sin(a);
+    }
+    return true;
+}
+
+// ---- dispatch lists ------------------------------------------------------------------------------------------------
+void build_reference(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
+    using RT = nrd::ResourceType;
+    ReferenceParams p;
+    p.c = c;
+    bool restart = !c.historyOk;
+    uint32_t n = std::min(d.framesSinceReset, d.reference.maxAccumulatedFrameNum);
+    p.weight = restart ? 1.0f : 1.0f / (1.0f + (float)n);
+    p.restart = restart ? 1 : 0;
+    p.in = I.slots[(size_t)RT::IN_SIGNAL].ref();
+    p.out = I.slots[(size_t)RT::OUT_SIGNAL].ref();
+    p.hist = I.perm[d.permBase].ref();
+    Dispatch x{"REFERENCE::TemporalAccumulation", "nrd_reference_accumulate", 0, 8 + 16 + 16 + 8, {}, {}, nullptr};
+    x.read = {enc_slot(RT::IN_SIGNAL), enc_perm(d.permBase)};
+    x.written = {enc_perm(d.permBase), enc_slot(RT::OUT_SIGNAL)};
+    x.launch = [p](hipStream_t s) { launch_reference_accumulate(p, s); };
+    d.dispatches.push_back(x);
+}
+
+void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
+    using RT = nrd::ResourceType;
+    const nrd::ReblurSettings& s = d.reblur;
+    int cur = (int)(d.frameCounter & 1);
+    uint32_t pb = d.permBase, tb = d.transBase;
+    auto P = [&](int i) { return enc_perm(pb + i); };
+    auto T = [&](int i) { return enc_trans(tb + i); };
+    auto PP = [&](int i) { return I.perm[pb + i].ref(); };
+    auto TP = [&](int i) { return I.trans[tb + i].ref(); };
+    auto SP = [&](RT t) { return I.slots[(size_t)t].ref(); };
+
+    ReblurParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.c = c;
+    p.hp[0] = s.hitDistanceParameters.A;
+    p.hp[1] = s.hitDistanceParameters.B;
+    p.hp[2] = s.hitDistanceParameters.C;
+    p.hp[3] = s.hitDistanceParameters.D;
+    p.planeDistanceSensitivity = s.planeDistanceSensitivity;
+    p.lobeAngleFraction = s.lobeAngleFraction;
+    p.roughnessFraction = s.roughnessFraction;
+    p.minHitDistanceWeight = s.minHitDistanceWeight;
+    p.minBlurRadius = s.minBlurRadius;
+    p.maxBlurRadius = s.maxBlurRadius;
+    p.diffusePrepassBlurRadius = s.diffusePrepassBlurRadius;
+    p.specularPrepassBlurRadius = s.specularPrepassBlurRadius;
+    p.fastHistoryClampingSigmaScale = s.fastHistoryClampingSigmaScale;
+    p.antilagSigmaScale = s.antilagSettings.luminanceSigmaScale;
+    p.antilagSensitivity = s.antilagSettings.luminanceSensitivity;
+    p.responsiveRoughnessThreshold = s.responsiveAccumulationSettings.roughnessThreshold;
+    p.responsiveMinAccum = (float)s.responsiveAccumulationSettings.minAccumulatedFrameNum;
+    p.maxA = (float)std::min<uint32_t>(s.maxAccumulatedFrameNum, 63);
+    p.maxFastA = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
+    p.maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
+    p.historyFixFrameNum = (int)s.historyFixFrameNum;
+    p.historyFixStride = (int)s.historyFixBasePixelStride;
+    p.minMatDiff = s.minMaterialForDiffuse;
+    p.minMatSpec = s.minMaterialForSpecular;
+    p.clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum ? 1 : 0;
+    p.hasDiff = d.hasDiff;
+    p.hasSpec = d.hasSpec;
+    p.inZ = SP(RT::IN_VIEWZ);
+    p.inNR = SP(RT::IN_NORMAL_ROUGHNESS);
+    p.inMV = SP(RT::IN_MV);
+    p.inDiff = SP(RT::IN_DIFF_RADIANCE_HITDIST);
+    p.inSpec = SP(RT::IN_SPEC_RADIANCE_HITDIST);
+    p.confD = SP(RT::IN_DIFF_CONFIDENCE);
+    p.confS = SP(RT::IN_SPEC_CONFIDENCE);
+    p.outDiff = SP(RT::OUT_DIFF_RADIANCE_HITDIST);
+    p.outSpec = SP(RT::OUT_SPEC_RADIANCE_HITDIST);
+    p.guide = PP(rb::GUIDE_A + cur);
+    p.guidePrev = PP(rb::GUIDE_A + (cur ^ 1));
+    p.data1 = PP(rb::DATA1_A + cur);
+    p.data1Prev = PP(rb::DATA1_A + (cur ^ 1));
+    p.hist = PP(rb::HIST);
+    p.fast = PP(rb::FAST_A + cur);
+    p.fastPrev = PP(rb::FAST_A + (cur ^ 1));
+    p.stab = PP(rb::STAB_A + cur);
+    p.stabPrev = PP(rb::STAB_A + (cur ^ 1));
+    p.tiles = TP(rb::TILES);
+    p.tmp1 = TP(rb::TMP1);
+    p.tmp2 = TP(rb::TMP2);
+    p.data1Tmp = TP(rb::DATA1_TMP);
+    p.data2 = TP(rb::DATA2);
+    p.hitTrack = TP(rb::HITTRACK);
+
+    float n = (float)d.nsig;
+    float sp = d.hasSpec ? 2.0f : 0.0f;
+    uint16_t blurHalo = (uint16_t)(s.maxBlurRadius + s.minBlurRadius + 2.0f);
+    uint16_t preHalo = (uint16_t)(std::max(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) + 2.0f);
+    {
+        Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + 8 + 1.0f / 256.0f, {}, {}, nullptr};
+        x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
+        x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
+        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, 8 + 8 * n + 8 * n + sp, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur)};
+        if (d.hasDiff)
+            x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+        if (d.hasSpec)
+            x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        x.written = {T(rb::TMP1), T(rb::HITTRACK)};
+        x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"REBLUR::TemporalAccumulation", "nrd_reblur_temporal_accumulation", 0,
+                   8 + 8 + 8 + 2 + 8 * n + 8 * n + 2 * n + sp + 8 * n + 2 * n + 2 + 4, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST),
+                  P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1)), T(rb::HITTRACK)};
+        x.written = {T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
+        x.launch = [p](hipStream_t st) { launch_reblur_temporal_accumulation(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"REBLUR::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
+                   8 + 2 + 8 * n + 2 * n + 8 * n + 2, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
+        x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
+        x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, 8 + 2 + 8 * n + 8 * n, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
+        x.written = {T(rb::TMP2)};
+        x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 1, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", (uint16_t)(2 * blurHalo), 8 + 2 + 8 * n + 8 * n, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
+        x.written = {P(rb::HIST)};
+        x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 2, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"REBLUR::TemporalStabilization", "nrd_reblur_temporal_stabilization", 2,
+                   8 + 2 + 4 + 8 + 8 * n + 2 * n + sp + 8 * n + 2 * n, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::DATA2), enc_slot(RT::IN_MV), P(rb::HIST), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
+        x.written = {P(rb::STAB_A + cur)};
+        if (d.hasDiff) {
+            x.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
+            x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+        }
+        if (d.hasSpec) {
+            x.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
+            x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        }
+        x.launch = [p](hipStream_t st) { launch_reblur_temporal_stabilization(p, st); };
+        d.dispatches.push_back(x);
+    }
+}
+
+void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
+    using RT = nrd::ResourceType;
+    int cur = (int)(d.frameCounter & 1);
+    uint32_t pb = d.permBase, tb = d.transBase;
+    auto P = [&](int i) { return enc_perm(pb + i); };
+    auto T = [&](int i) { return enc_trans(tb + i); };
+    auto PP = [&](int i) { return I.perm[pb + i].ref(); };
+    auto TP = [&](int i) { return I.trans[tb + i].ref(); };
+    auto SP = [&](RT t) { return I.slots[(size_t)t].ref(); };
+    SigmaParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.c = c;
+    p.planeDistanceSensitivity = d.sigma.planeDistanceSensitivity;
+    p.maxStab = (float)std::min<uint32_t>(d.sigma.maxStabilizedFrameNum, nrd::SIGMA_MAX_HISTORY_FRAME_NUM);
+    p.translucency = d.translucency ? 1 : 0;
+    p.outBpt = (int)I.slots[(size_t)RT::OUT_SHADOW_TRANSLUCENCY].bpt;
+    p.inZ = SP(RT::IN_VIEWZ);
+    p.inNR = SP(RT::IN_NORMAL_ROUGHNESS);
+    p.inMV = SP(RT::IN_MV);
+    p.inPen = SP(RT::IN_PENUMBRA);
+    p.inTransl = SP(RT::IN_TRANSLUCENCY);
+    p.out = SP(RT::OUT_SHADOW_TRANSLUCENCY);
+    p.guide = PP(sg::GUIDE_A + cur);
+    p.guidePrev = PP(sg::GUIDE_A + (cur ^ 1));
+    p.hist = PP(sg::HIST_A + cur);
+    p.histPrev = PP(sg::HIST_A + (cur ^ 1));
+    p.tiles = TP(sg::TILES);
+    p.tilesSmooth = TP(sg::TILES_SMOOTH);
+    p.shadow1 = TP(sg::SHADOW1);
+    p.pen1 = TP(sg::PEN1);
+    p.shadow2 = TP(sg::SHADOW2);
+    float tr = d.translucency ? 4.0f : 0.0f;
+    {
+        Dispatch x{"SIGMA::ClassifyTiles", "nrd_sigma_classify_tiles", 0, 4 + 4 + 2 + 8 + 2.0f / 256.0f, {}, {}, nullptr};
+        x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS), enc_slot(RT::IN_PENUMBRA)};
+        x.written = {P(sg::GUIDE_A + cur), T(sg::TILES)};
+        x.launch = [p](hipStream_t st) { launch_sigma_classify_tiles(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"SIGMA::SmoothTiles", "nrd_sigma_smooth_tiles", 16, 4.0f / 256.0f, {}, {}, nullptr};
+        x.read = {T(sg::TILES)};
+        x.written = {T(sg::TILES_SMOOTH)};
+        x.launch = [p](hipStream_t st) { launch_sigma_smooth_tiles(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"SIGMA::Blur", "nrd_sigma_blur", 50, 8 + 2 + tr + 8 + 2, {}, {}, nullptr};
+        x.read = {P(sg::GUIDE_A + cur), T(sg::TILES_SMOOTH), enc_slot(RT::IN_PENUMBRA)};
+        if (d.translucency)
+            x.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
+        x.written = {T(sg::SHADOW1), T(sg::PEN1)};
+        x.launch = [p](hipStream_t st) { launch_sigma_blur(p, 0, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"SIGMA::PostBlur", "nrd_sigma_post_blur", 50, 8 + 8 + 2 + 8, {}, {}, nullptr};
+        x.read = {P(sg::GUIDE_A + cur), T(sg::TILES_SMOOTH), T(sg::SHADOW1), T(sg::PEN1)};
+        x.written = {T(sg::SHADOW2)};
+        x.launch = [p](hipStream_t st) { launch_sigma_blur(p, 1, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"SIGMA::TemporalStabilization", "nrd_sigma_temporal_stabilization", 2, 8 + 8 + 8 + 8 + 4 + 4 + 4, {}, {}, nullptr};
+        x.read = {P(sg::GUIDE_A + cur), P(sg::GUIDE_A + (cur ^ 1)), P(sg::HIST_A + (cur ^ 1)), T(sg::SHADOW2), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
+        if (d.translucency)
+            x.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
+        x.written = {P(sg::HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};
+        x.launch = [p](hipStream_t st) { launch_sigma_temporal_stabilization(p, st); };
+        d.dispatches.push_back(x);
+    }
+}
+
+struct Flat {
+    DenoiserState* d;
+    uint32_t index;
+};
+
+int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Flat>& out) {
+    out.clear();
+    if (!I.commonSet) {
+        I.error = "SetCommonSettings has not been called";
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    }
+    FrameConsts c;
+    if (!derive_consts(I, c, I.error))
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    bool reset = I.common.accumulationMode != nrd::AccumulationMode::CONTINUE;
+    for (uint32_t i = 0; i < n; i++) {
+        DenoiserState* d = find(I, ids[i]);
+        if (!d) {
+            I.error = "unknown identifier";
+            return (int)nrd::Result::INVALID_ARGUMENT;
+        }
+        d->dispatches.clear();
+        c.historyOk = (d->historyValid && !reset) ? 1 : 0;
+        switch (d->kind) {
+            case Kind::REFERENCE: build_reference(I, *d, c); break;
+            case Kind::REBLUR: build_reblur(I, *d, c); break;
+            case Kind::SIGMA: build_sigma(I, *d, c); break;
+            default: break;
+        }
+        for (uint32_t k = 0; k < d->dispatches.size(); k++)
+            out.push_back({d, k});
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** out) {
+    if (!desc || !out || !desc->denoisers || !desc->denoisers_num || !desc->resource_width || !desc->resource_height) {
+        g_createError = "invalid creation desc";
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    }
+    auto* I = new nrdhip_instance();
+    I->resW = desc->resource_width;
+    I->resH = desc->resource_height;
+    I->frameH = desc->frame_height ? desc->frame_height : desc->resource_height;
+    I->yOff = desc->band_row0;
+    I->ownY0 = desc->band_own_first;
+    I->ownRows = desc->band_own_rows;
+    I->flags = desc->flags;
+    std::vector<PoolPlane> permDesc, transDesc;
+    for (uint32_t i = 0; i < desc->denoisers_num; i++) {
+        DenoiserState d;
+        d.identifier = desc->denoisers[i].identifier;
+        if (find(*I, d.identifier)) {
+            g_createError = "non unique identifier";
+            delete I;
+            return (int)nrd::Result::NON_UNIQUE_IDENTIFIER;
+        }
+        if (desc->denoisers[i].denoiser >= (uint32_t)nrd::Denoiser::MAX_NUM || !classify((nrd::Denoiser)desc->denoisers[i].denoiser, d)) {
+            g_createError = "unsupported denoiser";
+            delete I;
+            return (int)nrd::Result::UNSUPPORTED;
+        }
+        d.permBase = (uint32_t)permDesc.size();
+        d.transBase = (uint32_t)transDesc.size();
+        describe(d, permDesc, transDesc);
+        d.permEnd = (uint32_t)permDesc.size();
+        I->denoisers.push_back(d);
+    }
+    auto make = [&](std::vector<PoolPlane>& descs, std::vector<Plane>& planes) -> bool {
+        for (auto& pd : descs) {
+            Plane P;
+            P.fmt = (uint32_t)pd.fmt;
+            P.bpt = pd.bpt;
+            P.name = pd.name;
+            P.w = (uint16_t)((I->resW + pd.downsample - 1) / pd.downsample);
+            P.h = (uint16_t)((I->resH + pd.downsample - 1) / pd.downsample);
+            P.pitch = P.w * P.bpt;
+            if (!(I->flags & NRDHIP_FLAG_EXTERNAL_POOLS)) {
+                size_t bytes = (size_t)P.pitch * P.h;
+                if (hipMalloc((void**)&P.p, bytes) != hipSuccess)
+                    return false;
+                hipMemset(P.p, 0, bytes);
+                P.owned = true;
+            }
+            planes.push_back(P);
+        }
+        return true;
+    };
+    if (!make(permDesc, I->perm) || !make(transDesc, I->trans)) {
+        g_createError = "hipMalloc failed (is a HIP device visible?)";
+        nrdhip_destroy(I);
+        return (int)nrd::Result::FAILURE;
+    }
+    *out = I;
+    return 0;
+}
+
+NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
+    if (!inst)
+        return;
+    for (auto* v : {&inst->perm, &inst->trans})
+        for (auto& P : *v)
+            if (P.owned && P.p)
+                hipFree(P.p);
+    delete inst;
+}
+
+NRDHIP_API int nrdhip_new_frame(nrdhip_instance* inst) { return inst ? 0 : (int)nrd::Result::INVALID_ARGUMENT; }
+
+NRDHIP_API int nrdhip_set_common(nrdhip_instance* inst, const void* settings, size_t size) {
+    if (!inst || !settings || size != sizeof(nrd::CommonSettings))
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    std::memcpy(&inst->common, settings, size);
+    inst->commonSet = true;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_set_denoiser(nrdhip_instance* inst, uint32_t identifier, const void* settings, size_t size) {
+    if (!inst || !settings)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    DenoiserState* d = find(*inst, identifier);
+    if (!d)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    void* dst = nullptr;
+    size_t want = 0;
+    switch (d->kind) {
+        case Kind::REBLUR: dst = &d->reblur; want = sizeof(d->reblur); break;
+        case Kind::RELAX: dst = &d->relax; want = sizeof(d->relax); break;
+        case Kind::SIGMA: dst = &d->sigma; want = sizeof(d->sigma); break;
+        case Kind::REFERENCE: dst = &d->reference; want = sizeof(d->reference); break;
+    }
+    if (size != want)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    std::memcpy(dst, settings, size);
+    return 0;
+}
+
+NRDHIP_API int nrdhip_bind(nrdhip_instance* inst, uint32_t slot, void* ptr, uint32_t pitch, uint32_t format, uint16_t w, uint16_t h) {
+    if (!inst || slot >= (uint32_t)nrd::ResourceType::TRANSIENT_POOL)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    Plane& P = inst->slots[slot];
+    P.p = (uint8_t*)ptr;
+    P.pitch = pitch;
+    P.fmt = format;
+    P.w = w;
+    P.h = h;
+    P.bpt = format_bytes(format);
+    return 0;
+}
+
+NRDHIP_API int nrdhip_pool_size(nrdhip_instance* inst, uint32_t pool, uint32_t* count) {
+    if (!inst || !count || pool > 1)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    *count = (uint32_t)(pool == 0 ? inst->perm.size() : inst->trans.size());
+    return 0;
+}
+
+NRDHIP_API int nrdhip_pool_info(nrdhip_instance* inst, uint32_t pool, uint32_t index, nrdhip_plane_info* out) {
+    if (!inst || !out || pool > 1)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    auto& v = pool == 0 ? inst->perm : inst->trans;
+    if (index >= v.size())
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    const Plane& P = v[index];
+    out->ptr = P.p;
+    out->pitch_bytes = P.pitch;
+    out->format = P.fmt;
+    out->width = P.w;
+    out->height = P.h;
+    out->bytes_per_texel = P.bpt;
+    out->name = P.name;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_bind_pool(nrdhip_instance* inst, uint32_t pool, uint32_t index, void* ptr, uint32_t pitch) {
+    if (!inst || pool > 1)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    auto& v = pool == 0 ? inst->perm : inst->trans;
+    if (index >= v.size() || pitch < v[index].w * v[index].bpt || v[index].owned)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    v[index].p = (uint8_t*)ptr;
+    v[index].pitch = pitch;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_dispatch_count(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t* count) {
+    if (!inst || !count)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    std::vector<Flat> fl;
+    int r = flatten(*inst, ids, n, fl);
+    *count = (uint32_t)fl.size();
+    return r;
+}
+
+NRDHIP_API int nrdhip_dispatch_info_get(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t index, nrdhip_dispatch_info* out) {
+    if (!inst || !out)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    std::vector<Flat> fl;
+    int r = flatten(*inst, ids, n, fl);
+    if (r)
+        return r;
+    if (index >= fl.size())
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    const Dispatch& x = fl[index].d->dispatches[fl[index].index];
+    std::memset(out, 0, sizeof(*out));
+    out->name = x.name;
+    out->kernel = x.kernel;
+    out->identifier = fl[index].d->identifier;
+    out->grid_width = (uint16_t)((inst->common.rectSize[0] + 15) / 16);
+    out->grid_height = (uint16_t)((inst->common.rectSize[1] + 15) / 16);
+    out->halo_rows = x.halo;
+    out->written_num = (uint16_t)std::min<size_t>(x.written.size(), 12);
+    for (uint32_t i = 0; i < out->written_num; i++)
+        out->written[i] = x.written[i];
+    out->read_num = (uint32_t)std::min<size_t>(x.read.size(), 24);
+    for (uint32_t i = 0; i < out->read_num; i++)
+        out->read[i] = x.read[i];
+    out->algorithmic_bytes_per_pixel = x.bpp;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_denoise_range(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, void* stream) {
+    if (!inst)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    nrdhip_instance& I = *inst;
+    hipStream_t st = (hipStream_t)stream;
+    for (auto* v : {&I.perm, &I.trans})
+        for (auto& P : *v)
+            if (!P.p) {
+                I.error = "pool plane not bound";
+                return (int)nrd::Result::INVALID_ARGUMENT;
+            }
+    std::vector<Flat> fl;
+    int r = flatten(I, ids, n, fl);
+    if (r)
+        return r;
+    if (first > fl.size() || first + count > fl.size())
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    bool reset = I.common.accumulationMode != nrd::AccumulationMode::CONTINUE;
+    for (uint32_t i = first; i < first + count; i++) {
+        DenoiserState& d = *fl[i].d;
+        Dispatch& x = d.dispatches[fl[i].index];
+        for (auto* lst : {&x.read, &x.written})
+            for (uint32_t s : *lst)
+                if ((s >> 16) == 2 && !I.slots[s & 0xffff].p) {
+                    // confidence inputs are optional (sampled as 1 when absent)
+                    if ((s & 0xffff) == (uint32_t)nrd::ResourceType::IN_DIFF_CONFIDENCE || (s & 0xffff) == (uint32_t)nrd::ResourceType::IN_SPEC_CONFIDENCE)
+                        continue;
+                    I.error = std::string("resource slot not bound for pass ") + x.name;
+                    return (int)nrd::Result::INVALID_ARGUMENT;
+                }
+        if (fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
+            for (uint32_t k = d.permBase; k < d.permEnd; k++)
+                hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);
+        x.launch(st);
+        if (fl[i].index + 1 == d.dispatches.size()) {
+            d.framesSinceReset = (reset || !d.historyValid) ? 1 : d.framesSinceReset + 1;
+            d.frameCounter++;
+            d.historyValid = true;
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        I.error = std::string("HIP launch failed: ") + hipGetErrorString(e);
+        return (int)nrd::Result::FAILURE;
+    }
+    return 0;
+}
+
+NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, void* stream) {
+    uint32_t count = 0;
+    int r = nrdhip_dispatch_count(inst, ids, n, &count);
+    if (r)
+        return r;
+    return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+}
+
+NRDHIP_API int nrdhip_get_memory_mb(nrdhip_instance* inst, float out[3]) {
+    if (!inst || !out)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    double p = 0, t = 0;
+    for (auto& P : inst->perm)
+        p += (double)P.pitch * P.h;
+    for (auto& P : inst->trans)
+        t += (double)P.pitch * P.h;
+    out[0] = (float)((p + t) / 1048576.0);
+    out[1] = (float)(p / 1048576.0);
+    out[2] = (float)(t / 1048576.0);
+    return 0;
+}
+
+NRDHIP_API int nrdhip_library_desc(uint32_t out[5]) {
+    out[0] = NRD_VERSION_MAJOR;
+    out[1] = NRD_VERSION_MINOR;
+    out[2] = NRD_VERSION_BUILD;
+    out[3] = NRD_NORMAL_ENCODING;
+    out[4] = NRD_ROUGHNESS_ENCODING;
+    return 0;
+}
+
+NRDHIP_API const char* nrdhip_denoiser_string(uint32_t denoiser) {
+    static const char* names[] = {"REBLUR_DIFFUSE", "REBLUR_DIFFUSE_OCCLUSION", "REBLUR_DIFFUSE_SH", "REBLUR_SPECULAR", "REBLUR_SPECULAR_OCCLUSION",
+                                  "REBLUR_SPECULAR_SH", "REBLUR_DIFFUSE_SPECULAR", "REBLUR_DIFFUSE_SPECULAR_OCCLUSION", "REBLUR_DIFFUSE_SPECULAR_SH",
+                                  "REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION", "RELAX_DIFFUSE", "RELAX_DIFFUSE_SH", "RELAX_SPECULAR", "RELAX_SPECULAR_SH",
+                                  "RELAX_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH", "SIGMA_SHADOW", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"};
+    return denoiser < (uint32_t)nrd::Denoiser::MAX_NUM ? names[denoiser] : "UNKNOWN";
+}
+
+NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which) {
+    switch (which) {
+        case 0: return sizeof(nrd::CommonSettings);
+        case 1: return sizeof(nrd::ReblurSettings);
+        case 2: return sizeof(nrd::RelaxSettings);
+        case 3: return sizeof(nrd::SigmaSettings);
+        case 4: return sizeof(nrd::ReferenceSettings);
+        case 5: return sizeof(nrdhip_create_desc);
+        case 6: return sizeof(nrdhip_plane_info);
+        case 7: return sizeof(nrdhip_dispatch_info);
+    }
+    return 0;
+}
+
+NRDHIP_API const char* nrdhip_last_error(nrdhip_instance* inst) { return inst ? inst->error.c_str() : g_createError.c_str(); }
+}

@@ -61,6 +61,11 @@ class Harness:
         for key in set(k for k, _ in INPUT_SLOTS.values()):
             if key not in frame:
                 continue
+            if hasattr(frame[key], "data_ptr"):  # already a device tensor (frames generated on the GPU)
+                import torch
+                t = frame[key].contiguous()
+                out[key] = t.view(torch.uint8).reshape(t.shape[0], -1)
+                continue
             b = as_bytes2d(frame[key])
             if self.backend.is_device:
                 import torch

@@ -86,22 +86,30 @@ def world_to_view(pos, yaw=0.0, pitch=0.0):
 
 
 class Scene:
+    """Analytic scene rendered with torch (CPU or the HIP device); ``frame()`` returns numpy arrays on CPU and device tensors
+    on a GPU so that large (4K/8K) frames are produced where the denoiser consumes them."""
+
     def __init__(self, width, height, seed=0x9E3779B9, hfov=90.0, dolly=0.01, denoiser="REBLUR", rough_bands=True,
-                 translucent_sphere=True):
+                 translucent_sphere=True, device="cpu", frame_height=None, row0=0):
         self.w, self.h, self.seed = width, height, seed
         self.hfov, self.dolly = hfov, dolly
         self.relax = denoiser == "RELAX"
         self.rough_bands = rough_bands
         self.translucent_sphere = translucent_sphere
-        self.proj = perspective(hfov, width / height)
+        self.device = device
+        # row band of a taller frame (row tiling): this scene renders rows [row0, row0 + height) of a frame_height-row image
+        self.frame_h = frame_height or height
+        self.row0 = row0
+        self.proj = perspective(hfov, width / self.frame_h)
         # spheres: centre, radius, roughness, materialID
         self.spheres = [((-1.6, 0.7, 4.0), 0.7, 0.05, 1), ((0.3, 1.0, 5.5), 1.0, 0.3, 0), ((2.2, 0.6, 3.5), 0.6, 0.7, 1)]
         self.wall_z = 9.0
         az, el = math.radians(-147.0), math.radians(45.0)
-        # sample's sun direction uses z-up; this scene is y-up: swap
-        self.sun = np.array([math.cos(az) * math.cos(el), math.sin(el), math.sin(az) * math.cos(el)])
-        self.sun = -self.sun if self.sun[2] > 0 else self.sun  # keep the sun behind the camera so shadows fall into view
-        self.sun = self.sun / np.linalg.norm(self.sun)
+        # the sample's sun direction is z-up (Source/NRDSample.cpp:587-594); this scene is y-up: swap
+        sun = np.array([math.cos(az) * math.cos(el), math.sin(el), math.sin(az) * math.cos(el)])
+        sun = -sun if sun[2] > 0 else sun  # keep the sun behind the camera so shadows fall into view
+        sun[1] = abs(sun[1])
+        self.sun = sun / np.linalg.norm(sun)
         self.tan_sun = math.tan(math.radians(0.533) * 0.5)
         self.scene_radius = 12.0
 
@@ -109,168 +117,200 @@ class Scene:
     def cam_pos(self, frame):
         return np.array([-0.3 + self.dolly * frame, 1.4, -0.5])
 
-    def matrices(self, frame):
-        return world_to_view(self.cam_pos(frame), 0.0, 0.12), world_to_view(self.cam_pos(max(frame - 1, 0)), 0.0, 0.12)
+    def matrices(self, frame, prev_frame=None):
+        prev_frame = max(frame - 1, 0) if prev_frame is None else prev_frame
+        return world_to_view(self.cam_pos(frame), 0.0, 0.12), world_to_view(self.cam_pos(prev_frame), 0.0, 0.12)
 
-    def _rot_pos(self, m):
+    @staticmethod
+    def _rot_pos(m):
         m4 = m.reshape(4, 4).T.astype(np.float64)
         return m4[:3, :3], -m4[:3, :3].T @ m4[:3, 3]
 
-    # ---- ray casting ----------------------------------------------------------------------------
-    def _intersect(self, o, d, skip_translucent=False):
-        """nearest hit of rays o + t d. Returns t (inf on miss), object id (-1 miss, 0 ground, 1 wall, 2.. spheres)."""
-        t = np.full(d.shape[:-1], np.inf)
-        obj = np.full(d.shape[:-1], -1, dtype=np.int32)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            tg = -o[..., 1] / d[..., 1]
-        ok = (tg > 1e-4) & np.isfinite(tg)
-        t = np.where(ok & (tg < t), tg, t)
-        obj = np.where(ok & (tg == t), 0, obj)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            tw = (self.wall_z - o[..., 2]) / d[..., 2]
-        ok = (tw > 1e-4) & np.isfinite(tw) & (tw < t) & ((o[..., 1] + tw * d[..., 1]) < 5.0)
-        t = np.where(ok, tw, t)
-        obj = np.where(ok, 1, obj)
+    # ---- ray casting (torch) ----------------------------------------------------------------------
+    def _t(self, a):
+        import torch
+        return torch.as_tensor(np.asarray(a, dtype=np.float64), device=self.device)
+
+    def _intersect(self, o, d):
+        """nearest hit of rays o + t d: t (inf on miss), object id (-1 miss, 0 ground, 1 wall, 2.. spheres)"""
+        import torch
+        inf = float("inf")
+        t = torch.full(d.shape[:-1], inf, dtype=torch.float64, device=d.device)
+        obj = torch.full(d.shape[:-1], -1, dtype=torch.int32, device=d.device)
+        tg = -o[..., 1] / d[..., 1]
+        ok = (tg > 1e-4) & torch.isfinite(tg)
+        t = torch.where(ok, tg, t)
+        obj = torch.where(ok, torch.zeros_like(obj), obj)
+        tw = (self.wall_z - o[..., 2]) / d[..., 2]
+        ok = (tw > 1e-4) & torch.isfinite(tw) & (tw < t) & ((o[..., 1] + tw * d[..., 1]) < 5.0)
+        t = torch.where(ok, tw, t)
+        obj = torch.where(ok, torch.ones_like(obj), obj)
         for i, (c, r, _, _) in enumerate(self.spheres):
-            if skip_translucent and self.translucent_sphere and i == 1:
-                continue
-            oc = o - np.asarray(c)
+            oc = o - self._t(c)
             b = (oc * d).sum(-1)
             cc = (oc * oc).sum(-1) - r * r
             disc = b * b - cc
-            sq = np.sqrt(np.maximum(disc, 0))
+            sq = torch.sqrt(torch.clamp(disc, min=0))
             ts = -b - sq
-            ts = np.where(ts > 1e-4, ts, -b + sq)
+            ts = torch.where(ts > 1e-4, ts, -b + sq)
             ok = (disc > 0) & (ts > 1e-4) & (ts < t)
-            t = np.where(ok, ts, t)
-            obj = np.where(ok, 2 + i, obj)
+            t = torch.where(ok, ts, t)
+            obj = torch.where(ok, torch.full_like(obj, 2 + i), obj)
         return t, obj
 
     def _normal(self, p, obj):
-        n = np.zeros(p.shape)
-        n[obj == 0] = (0, 1, 0)
-        n[obj == 1] = (0, 0, -1)
+        import torch
+        n = torch.zeros_like(p)
+        n = torch.where((obj == 0)[..., None], self._t((0, 1, 0)), n)
+        n = torch.where((obj == 1)[..., None], self._t((0, 0, -1)), n)
         for i, (c, r, _, _) in enumerate(self.spheres):
-            m = obj == 2 + i
-            n[m] = (p[m] - np.asarray(c)) / r
+            n = torch.where((obj == 2 + i)[..., None], (p - self._t(c)) / r, n)
         return n
 
     def _env(self, d):
-        """smooth environment radiance along direction d"""
-        up = np.clip(d[..., 1] * 0.5 + 0.5, 0, 1)
-        sky = np.stack([0.35 + 0.25 * up, 0.45 + 0.3 * up, 0.6 + 0.4 * up], -1)
-        s = np.clip((d * self.sun).sum(-1), 0, 1) ** 64
-        return sky + s[..., None] * np.array([6.0, 5.0, 4.0])
+        import torch
+        up = torch.clamp(d[..., 1] * 0.5 + 0.5, 0, 1)
+        sky = torch.stack([0.35 + 0.25 * up, 0.45 + 0.3 * up, 0.6 + 0.4 * up], -1)
+        s = torch.clamp((d * self._t(self.sun)).sum(-1), 0, 1) ** 64
+        return sky + s[..., None] * self._t((6.0, 5.0, 4.0))
 
     # ---- one frame ------------------------------------------------------------------------------
-    def frame(self, index, noise=True):
+    def frame(self, index, noise=True, prev_index=None):
+        """inputs of frame `index`; motion vectors / previous matrices refer to camera position `prev_index` (default index - 1)"""
+        import torch
         w, h = self.w, self.h
-        rng = np.random.default_rng((self.seed ^ (index * 0x85EBCA6B)) & 0xFFFFFFFF)
-        w2v, w2v_prev = self.matrices(index)
+        dev = self.device
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int((self.seed ^ (index * 0x85EBCA6B) ^ (self.row0 * 0x27D4EB2F)) & 0x7FFFFFFF))
+
+        def randn(*shape):
+            return torch.randn(*shape, dtype=torch.float64, device=dev, generator=gen)
+
+        w2v, w2v_prev = self.matrices(index, prev_index)
         rot, pos = self._rot_pos(w2v)
         rot_p, pos_p = self._rot_pos(w2v_prev)
+        rot_t, rot_pt, pos_t, pos_pt = self._t(rot), self._t(rot_p), self._t(pos), self._t(pos_p)
         m0, m5 = float(self.proj[0]), float(self.proj[5])
-        u = (np.arange(w) + 0.5) / w
-        v = (np.arange(h) + 0.5) / h
-        uu, vv = np.meshgrid(u, v)
-        dv = np.stack([(2 * uu - 1) / m0, (1 - 2 * vv) / m5, np.ones_like(uu)], -1)  # view-space ray, z = 1
-        dw = dv @ rot  # R^T applied to row vectors
-        dlen = np.sqrt((dw * dw).sum(-1, keepdims=True))
+        u = (torch.arange(w, dtype=torch.float64, device=dev) + 0.5) / w
+        v = (torch.arange(h, dtype=torch.float64, device=dev) + self.row0 + 0.5) / self.frame_h
+        vv, uu = torch.meshgrid(v, u, indexing="ij")
+        dv = torch.stack([(2 * uu - 1) / m0, (1 - 2 * vv) / m5, torch.ones_like(uu)], -1)  # view-space ray, z = 1
+        dw = dv @ rot_t  # R^T applied to row vectors
+        dlen = torch.sqrt((dw * dw).sum(-1, keepdim=True))
         dn = dw / dlen
-        o = np.broadcast_to(pos, dn.shape)
+        o = pos_t.expand_as(dn)
         t, obj = self._intersect(o, dn)
         hit = obj >= 0
-        tt = np.where(hit, t, 0.0)
+        tt = torch.where(hit, t, torch.zeros_like(t))
         p = o + dn * tt[..., None]
-        view_z = np.where(hit, tt / dlen[..., 0], INF).astype(np.float32)
+        view_z = torch.where(hit, tt / dlen[..., 0], torch.full_like(tt, INF))
         n = self._normal(p, obj)
-        n[~hit] = (0, 0, -1)
+        n = torch.where(hit[..., None], n, self._t((0, 0, -1)))
 
         # roughness / material
-        rough = np.full((h, w), 0.5)
-        mat = np.zeros((h, w), dtype=np.uint32)
+        rough = torch.full((h, w), 0.5, dtype=torch.float64, device=dev)
+        mat = torch.zeros((h, w), dtype=torch.int64, device=dev)
         if self.rough_bands:
-            band = np.floor(p[..., 0] * 0.5 + 100).astype(np.int64) % 3
-            rough = np.where(obj == 0, np.choose(band, [0.05, 0.3, 0.7]), rough)
-        rough = np.where(obj == 1, 0.6, rough)
+            band = torch.floor(p[..., 0] * 0.5 + 100).to(torch.int64) % 3
+            rb = torch.where(band == 0, 0.05, torch.where(band == 1, 0.3, 0.7)).to(torch.float64)
+            rough = torch.where(obj == 0, rb, rough)
+        rough = torch.where(obj == 1, torch.full_like(rough, 0.6), rough)
         for i, (_, _, r, m) in enumerate(self.spheres):
-            rough = np.where(obj == 2 + i, r, rough)
-            mat = np.where(obj == 2 + i, m, mat)
+            rough = torch.where(obj == 2 + i, torch.full_like(rough, r), rough)
+            mat = torch.where(obj == 2 + i, torch.full_like(mat, m), mat)
 
         # motion: previous-frame projection of the same (static) world point
-        pv_prev = (p - pos_p) @ rot_p.T
-        zp = np.where(hit, pv_prev[..., 2], 1.0)
+        pv_prev = (p - pos_pt) @ rot_pt.T
+        zp = torch.where(hit, pv_prev[..., 2], torch.ones_like(tt))
         up = 0.5 + 0.5 * (m0 * pv_prev[..., 0] / zp)
         vp = 0.5 - 0.5 * (m5 * pv_prev[..., 1] / zp)
-        mv = np.zeros((h, w, 4), dtype=np.float32)
-        mv[..., 0] = np.where(hit, (up - uu) * w, 0)
-        mv[..., 1] = np.where(hit, (vp - vv) * h, 0)
-        mv[..., 2] = np.where(hit, zp - view_z, 0)
+        zero = torch.zeros_like(tt)
+        mv = torch.stack([torch.where(hit, (up - uu) * w, zero), torch.where(hit, (vp - vv) * self.frame_h, zero),
+                          torch.where(hit, zp - view_z, zero), zero], -1)
 
         # lighting ("ground truth" demodulated signals)
+        sun_t = self._t(self.sun)
         shadow_o = p + n * 1e-3
-        sun_dirs = np.broadcast_to(self.sun, p.shape)
+        sun_dirs = sun_t.expand_as(p)
         if noise:
-            j = rng.standard_normal((h, w, 3)) * self.tan_sun * 0.7
-            sun_dirs = _normalize(sun_dirs + j)
+            sun_dirs = sun_dirs + randn(h, w, 3) * (self.tan_sun * 0.7)
+            sun_dirs = sun_dirs / torch.sqrt((sun_dirs * sun_dirs).sum(-1, keepdim=True))
         ts, sobj = self._intersect(shadow_o, sun_dirs)
-        ndl = np.clip((n * self.sun).sum(-1), 0, 1)
+        ndl = torch.clamp((n * sun_t).sum(-1), 0, 1)
         lit = (sobj < 0) & (ndl > 0)
-        glass = self.translucent_sphere & (sobj == 3)
-        # ambient occlusion-like term from the distance to the nearest sphere
-        dmin = np.full((h, w), 10.0)
+        glass = (sobj == 3) if self.translucent_sphere else torch.zeros_like(lit)
+        dmin = torch.full((h, w), 10.0, dtype=torch.float64, device=dev)
         for c, r, _, _ in self.spheres:
-            dmin = np.minimum(dmin, np.abs(np.sqrt(((p - np.asarray(c)) ** 2).sum(-1)) - r))
-        ao = np.clip(0.35 + 0.65 * dmin / 1.5, 0, 1)
-        sky_irr = np.stack([0.45, 0.55, 0.75]) * ao[..., None] * (0.6 + 0.4 * np.clip(n[..., 1:2], 0, 1))
-        diff = sky_irr  # sun goes through SIGMA, not the diffuse signal
-        refl = dn - 2 * (dn * n).sum(-1, keepdims=True) * n
+            dmin = torch.minimum(dmin, torch.abs(torch.sqrt(((p - self._t(c)) ** 2).sum(-1)) - r))
+        ao = torch.clamp(0.35 + 0.65 * dmin / 1.5, 0, 1)
+        sky_irr = self._t((0.45, 0.55, 0.75)) * ao[..., None] * (0.6 + 0.4 * torch.clamp(n[..., 1:2], 0, 1))
+        diff = sky_irr  # the sun goes through SIGMA, not through the diffuse signal
+        refl = dn - 2 * (dn * n).sum(-1, keepdim=True) * n
         tr, robj = self._intersect(shadow_o, refl)
-        spec = self._env(refl) * np.where(robj[..., None] >= 0, 0.35, 1.0)
-        diff_hit = np.clip(dmin * 1.5 + 0.2, 0.05, 8.0)
-        spec_hit = np.where(robj >= 0, np.minimum(tr, 50.0), 50.0)
+        spec = self._env(refl) * torch.where(robj[..., None] >= 0, 0.35, 1.0)
+        diff_hit = torch.clamp(dmin * 1.5 + 0.2, 0.05, 8.0)
+        spec_hit = torch.where(robj >= 0, torch.clamp(tr, max=50.0), torch.full_like(tr, 50.0))
         if noise:
             sigma = 1.0
-            diff = diff * np.exp(sigma * rng.standard_normal((h, w, 1)) - 0.5 * sigma * sigma)
+            diff = diff * torch.exp(sigma * randn(h, w, 1) - 0.5 * sigma * sigma)
             sig_s = 0.3 + 0.9 * rough[..., None]
-            spec = spec * np.exp(sig_s * rng.standard_normal((h, w, 1)) - 0.5 * sig_s * sig_s)
-            diff_hit = diff_hit * np.exp(0.5 * rng.standard_normal((h, w)))
-            spec_hit = spec_hit * np.exp(0.3 * rough * rng.standard_normal((h, w)))
+            spec = spec * torch.exp(sig_s * randn(h, w, 1) - 0.5 * sig_s * sig_s)
+            diff_hit = diff_hit * torch.exp(0.5 * randn(h, w))
+            spec_hit = spec_hit * torch.exp(0.3 * rough * randn(h, w))
+
+        def ycocg(c):
+            r_, g_, b_ = c[..., 0], c[..., 1], c[..., 2]
+            return torch.stack([0.25 * r_ + 0.5 * g_ + 0.25 * b_, 0.5 * r_ - 0.5 * b_, -0.25 * r_ + 0.5 * g_ - 0.25 * b_], -1)
+
+        def hitnorm(z, r_):
+            return (3.0 + torch.abs(z) * 0.1) * (1.0 + 19.0 * torch.exp2(-25.0 * r_ * r_))
 
         out = {}
-        out["viewz"] = view_z
-        out["mv"] = mv.astype(np.float16)
-        out["normal_roughness"] = pack_normal_roughness(n, rough, mat)
+        out["viewz"] = view_z.to(torch.float32)
+        out["mv"] = mv.to(torch.float16)
+        # R10G10B10A2 pack (int64 arithmetic, stored as the int32 bit pattern)
+        na = n / torch.abs(n).sum(-1, keepdim=True)
+        nx, ny, nz = na[..., 0], na[..., 1], na[..., 2]
+        sx = torch.where(nx >= 0, 1.0, -1.0)
+        sy = torch.where(ny >= 0, 1.0, -1.0)
+        ox = torch.where(nz < 0, (1 - torch.abs(ny)) * sx, nx) * 0.5 + 0.5
+        oy = torch.where(nz < 0, (1 - torch.abs(nx)) * sy, ny) * 0.5 + 0.5
+        q = lambda a: torch.floor(torch.clamp(a, 0, 1) * 1023 + 0.5).to(torch.int64)
+        packed = q(ox) | (q(oy) << 10) | (q(rough) << 20) | ((mat & 3) << 30)
+        packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
+        out["normal_roughness"] = packed
         if self.relax:
-            d4 = np.concatenate([np.minimum(diff, FP16_MAX), diff_hit[..., None]], -1)
-            s4 = np.concatenate([np.minimum(spec, FP16_MAX), spec_hit[..., None]], -1)
+            d4 = torch.cat([torch.clamp(diff, max=FP16_MAX), diff_hit[..., None]], -1)
+            s4 = torch.cat([torch.clamp(spec, max=FP16_MAX), spec_hit[..., None]], -1)
         else:
-            nd = np.clip(diff_hit / reblur_hitdist_norm(view_z, 1.0), 0, 1)
-            ns = np.clip(spec_hit / reblur_hitdist_norm(view_z, rough), 0, 1)
-            d4 = np.concatenate([linear_to_ycocg(diff), nd[..., None]], -1)
-            s4 = np.concatenate([linear_to_ycocg(spec), ns[..., None]], -1)
-        d4[~hit] = 0
-        s4[~hit] = 0
-        out["diff"] = d4.astype(np.float16)
-        out["spec"] = s4.astype(np.float16)
-        pen = np.where(lit, FP16_MAX, np.minimum(np.where(np.isfinite(ts), ts, 0.0) * self.tan_sun, 1000.0))
-        pen = np.where(ndl > 0, pen, 0.0)  # back-facing: fully shadowed at distance 0
-        pen[~hit] = FP16_MAX
-        out["penumbra"] = pen.astype(np.float16)
-        tl = np.zeros((h, w, 4), dtype=np.uint8)
-        tl[..., 0] = np.where(lit, 255, 0)
-        tint = np.array([230, 150, 80], dtype=np.uint8)
-        tl[..., 1:] = np.where((glass & ~lit)[..., None], tint, 0)
+            nd = torch.clamp(diff_hit / hitnorm(view_z, torch.ones_like(rough)), 0, 1)
+            ns = torch.clamp(spec_hit / hitnorm(view_z, rough), 0, 1)
+            d4 = torch.cat([ycocg(diff), nd[..., None]], -1)
+            s4 = torch.cat([ycocg(spec), ns[..., None]], -1)
+        d4 = torch.where(hit[..., None], d4, torch.zeros_like(d4))
+        s4 = torch.where(hit[..., None], s4, torch.zeros_like(s4))
+        out["diff"] = d4.to(torch.float16)
+        out["spec"] = s4.to(torch.float16)
+        pen = torch.where(lit, torch.full_like(ts, FP16_MAX), torch.clamp(torch.where(torch.isfinite(ts), ts, torch.zeros_like(ts)) * self.tan_sun, max=1000.0))
+        pen = torch.where(ndl > 0, pen, torch.zeros_like(pen))  # back-facing: fully shadowed at distance 0
+        pen = torch.where(hit, pen, torch.full_like(pen, FP16_MAX))
+        out["penumbra"] = pen.to(torch.float16)
+        tl = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+        tl[..., 0] = torch.where(lit, 255, 0).to(torch.uint8)
+        tint = torch.tensor([230, 150, 80], dtype=torch.uint8, device=dev)
+        tl[..., 1:] = torch.where((glass & ~lit)[..., None], tint, torch.zeros_like(tint))
         out["translucency"] = tl
         cw, ch = (w + 4) // 5, (h + 4) // 5
-        conf = np.zeros((ch, cw, 4), dtype=np.float16)
+        conf = torch.zeros((ch, cw, 4), dtype=torch.float16, device=dev)
         conf[..., 0] = 1.0
         out["confidence"] = conf
-        comp = ycocg_to_linear(d4[..., :3]) * 0.8 + ycocg_to_linear(s4[..., :3]) * 0.2 if not self.relax else d4[..., :3] * 0.8 + s4[..., :3] * 0.2
-        out["signal"] = np.concatenate([comp, np.ones((h, w, 1))], -1).astype(np.float16)
+        comp = d4[..., :3] * 0.8 + s4[..., :3] * 0.2
+        out["signal"] = torch.cat([comp, torch.ones((h, w, 1), dtype=torch.float64, device=dev)], -1).to(torch.float16)
+        out["clean_diff"] = sky_irr.to(torch.float32)
+        if dev == "cpu":
+            out = {k: (x.numpy().view(np.uint32) if k == "normal_roughness" else x.numpy()) for k, x in out.items()}
         out["world_to_view"], out["world_to_view_prev"] = w2v, w2v_prev
         out["view_to_clip"] = self.proj
-        out["clean_diff"] = sky_irr.astype(np.float32)
         return out
 
     def common_settings(self, api, frame_data, index, reset=False):
@@ -281,11 +321,11 @@ class Scene:
             cs.worldToViewMatrix[i] = float(frame_data["world_to_view"][i])
             cs.worldToViewMatrixPrev[i] = float(frame_data["world_to_view_prev"][i])
         cs.motionVectorScale[0] = 1.0 / self.w
-        cs.motionVectorScale[1] = 1.0 / self.h
+        cs.motionVectorScale[1] = 1.0 / self.frame_h
         cs.motionVectorScale[2] = 1.0
         for k in ("resourceSize", "resourceSizePrev", "rectSize", "rectSizePrev"):
             getattr(cs, k)[0] = self.w
-            getattr(cs, k)[1] = self.h
+            getattr(cs, k)[1] = self.frame_h
         cs.viewZScale = 1.0
         cs.denoisingRange = 4.0 * self.scene_radius
         cs.disocclusionThreshold = 0.01

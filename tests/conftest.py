@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return graft.load_package()
+
+
+@pytest.fixture(scope="session")
+def api(pkg):
+    return pkg.api
+
+
+@pytest.fixture(scope="session")
+def oracle(pkg):
+    """CPU oracle backend (test infrastructure)."""
+    if not os.path.exists(pkg.ORACLE_LIB):
+        graft.build_oracle()
+    return pkg.oracle_backend()
+
+
+@pytest.fixture(scope="session")
+def emulated(pkg):
+    """The product kernel sources compiled for the host (tests/hip_emu) - CPU-side check of the kernels themselves."""
+    path = graft.build_emulated()
+    b = pkg.api.Backend(path, "nrdhip_", "cpu")
+    b.check_abi()
+    return b
+
+
+@pytest.fixture(scope="session")
+def hip(pkg):
+    """The product: libnrdhip.so on cuda:0. Fails (does not skip) when the library or the device is missing."""
+    return pkg.hip_backend("cuda:0")

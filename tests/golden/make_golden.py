@@ -1,0 +1,65 @@
+"""Generates tests/golden/*.npz with the CPU oracle (the reference holds no golden vectors for this path, SURVEY.md 8c:
+"parity unpinned"; these fixtures pin the build's own oracle against drift and travel to the GPU box).
+Run from the repo root:  python tests/golden/make_golden.py
+Inputs are the synthetic scene of nrd-sample_amd/synth.py (64x48, 4 frames, moving camera); outputs are every OUT_* plane
+after every frame."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+CASES = {
+    "reblur_ds_sigma_reference": ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"],
+    "reblur_diffuse": ["REBLUR_DIFFUSE"],
+    "reblur_specular_sigma_shadow": ["REBLUR_SPECULAR", "SIGMA_SHADOW"],
+}
+W, H, FRAMES = 64, 48, 4
+INPUT_KEYS = ["viewz", "mv", "normal_roughness", "diff", "spec", "penumbra", "translucency", "confidence", "signal",
+              "world_to_view", "world_to_view_prev", "view_to_clip"]
+
+
+def settings_for(api, scene, dens):
+    D = api.Denoiser
+    s = {}
+    for d in dens:
+        if d.name.startswith("REBLUR"):
+            s[d] = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)  # the sample's values (NRDSample.cpp:566-567)
+        elif d.name.startswith("SIGMA"):
+            s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
+        else:
+            s[d] = api.ReferenceSettings()
+    return s
+
+
+def main():
+    pkg = graft.load_package()
+    graft.build_oracle()
+    api, synth, harness = pkg.api, pkg.synth, pkg.harness
+    orc = pkg.oracle_backend()
+    scene = synth.Scene(W, H, dolly=0.03)
+    frames = [scene.frame(f) for f in range(FRAMES)]
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    np.savez_compressed(os.path.join(out_dir, "inputs_64x48.npz"),
+                        **{"f%d_%s" % (f, k): frames[f][k] for f in range(FRAMES) for k in INPUT_KEYS})
+    for name, dn in CASES.items():
+        dens = [api.Denoiser[x] for x in dn]
+        hz = harness.Harness(orc, dens, W, H)
+        st = settings_for(api, scene, dens)
+        blob = {}
+        for f in range(FRAMES):
+            cs = scene.common_settings(api, frames[f], f, reset=(f == 0))
+            planes = hz.upload(frames[f])
+            hz.frame(cs, planes, st)
+            for k, v in hz.outputs.items():
+                blob["f%d_%s" % (f, k)] = hz.fetch(v).copy()
+            blob["f%d_signal" % f] = hz.fetch(planes["signal"]).copy()
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **blob)
+        print(name, "written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+// TEST INFRASTRUCTURE: a tiny host-side stand-in for <hip/hip_runtime.h> so the UNMODIFIED product kernel sources
+// (nrd-sample_amd/csrc/*.hip, nrdhip.cpp) can be compiled for the CPU with clang and checked against the oracle in the
+// GPU-less authoring container (tests/test_kernels_emulated.py). It is never part of the product build: libnrdhip.so is
+// always built by hipcc against the real HIP runtime, and this emulated library is only ever loaded by tests.
+//
+// Model: blocks run one after another; threads of a block run sequentially until one of them reaches a block-level
+// primitive (__syncthreads*, __shfl_xor), at which point the block is re-run with one OS thread per HIP thread and real
+// barriers (all kernels here are idempotent per block, so the re-run is safe).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct uint2 {
+    uint32_t x, y;
+};
+struct uint4 {
+    uint32_t x, y, z, w;
+};
+struct float4 {
+    float x, y, z, w;
+};
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+constexpr hipError_t hipSuccess = 0;
+
+namespace hipemu {
+struct Idx {
+    unsigned x, y, z;
+};
+struct NeedThreads {};
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int count = 0, waiting = 0, generation = 0;
+    void wait() {
+        std::unique_lock<std::mutex> l(m);
+        int g = generation;
+        if (++waiting == count) {
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else
+            cv.wait(l, [&] { return g != generation; });
+    }
+};
+inline thread_local Idx t_threadIdx, t_blockIdx;
+inline thread_local bool t_threaded = false;
+inline Barrier g_barrier;
+inline std::atomic<int> g_or{0};
+inline float g_shfl[1024];
+inline int g_blockThreads = 0;
+
+template <typename F>
+void launch(dim3 grid, dim3 block, F body) {
+    int nthreads = (int)(block.x * block.y * block.z);
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                bool needThreads = false;
+                t_threaded = false;
+                t_blockIdx = {bx, by, bz};
+                try {
+                    for (unsigned tz = 0; tz < block.z && !needThreads; tz++)
+                        for (unsigned ty = 0; ty < block.y; ty++)
+                            for (unsigned tx = 0; tx < block.x; tx++) {
+                                t_threadIdx = {tx, ty, tz};
+                                body();
+                            }
+                } catch (NeedThreads&) {
+                    needThreads = true;
+                }
+                if (!needThreads)
+                    continue;
+                g_barrier.count = nthreads;
+                g_barrier.waiting = 0;
+                g_blockThreads = nthreads;
+                std::vector<std::thread> th;
+                for (unsigned tz = 0; tz < block.z; tz++)
+                    for (unsigned ty = 0; ty < block.y; ty++)
+                        for (unsigned tx = 0; tx < block.x; tx++)
+                            th.emplace_back([=] {
+                                t_threaded = true;
+                                t_blockIdx = {bx, by, bz};
+                                t_threadIdx = {tx, ty, tz};
+                                body();
+                                // threads that left early keep servicing barriers until everybody is done
+                            });
+                for (auto& t : th)
+                    t.join();
+            }
+}
+inline void sync() {
+    if (!t_threaded)
+        throw NeedThreads();
+    g_barrier.wait();
+}
+} // namespace hipemu
+
+#define threadIdx (hipemu::t_threadIdx)
+#define blockIdx (hipemu::t_blockIdx)
+
+// NOTE: the emulated barrier requires every thread of the block to reach every barrier (true for the product kernels:
+// block-uniform early exits happen before the first barrier, per-thread exits after the last one).
+inline void __syncthreads() { hipemu::sync(); }
+inline int __syncthreads_or(int v) {
+    hipemu::sync();
+    if (v)
+        hipemu::g_or.store(1);
+    hipemu::sync();
+    int r = hipemu::g_or.load();
+    hipemu::sync();
+    if (hipemu::t_threadIdx.x == 0 && hipemu::t_threadIdx.y == 0 && hipemu::t_threadIdx.z == 0)
+        hipemu::g_or.store(0);
+    hipemu::sync();
+    return r;
+}
+inline float __shfl_xor(float v, int mask, int width) {
+    (void)width;
+    if (!hipemu::t_threaded)
+        throw hipemu::NeedThreads();
+    int tid = (int)(hipemu::t_threadIdx.y * 16 + hipemu::t_threadIdx.x); // product kernels use 16x16 blocks
+    hipemu::g_shfl[tid] = v;
+    hipemu::sync();
+    float r = hipemu::g_shfl[(tid & ~63) | ((tid ^ mask) & 63)];
+    hipemu::sync();
+    return r;
+}
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch(grid, block, [&] { kernel(__VA_ARGS__); })
+
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = std::malloc(n);
+    return *p ? hipSuccess : 1;
+}
+inline hipError_t hipFree(void* p) {
+    std::free(p);
+    return hipSuccess;
+}
+inline hipError_t hipMemset(void* p, int v, size_t n) {
+    std::memset(p, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemset2DAsync(void* p, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
+    for (size_t y = 0; y < h; y++)
+        std::memset((char*)p + y * pitch, v, w);
+    return hipSuccess;
+}
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
