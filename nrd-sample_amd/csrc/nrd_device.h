@@ -1,9 +1,12 @@
 // nrd_device.h - device-side arithmetic and plane access of the MI355X NRD backend (gfx950, wave64).
 //
-// Every float expression here is evaluated as separately rounded IEEE binary32 operations (the library is
-// built with -ffp-contract=off, IEEE divide/sqrt) so that results are reproducible bit for bit run to run,
-// 1 GPU vs N GPUs, and against the CPU oracle used by the tests (DESIGN.md "numerics contract").
-// Transcendentals are fixed polynomials (no ocml calls on the pixel path).
+// Numerics contract: every float expression is a sequence of separately rounded IEEE binary32 operations
+// (-ffp-contract=off, IEEE divide/sqrt); fusion happens ONLY where the source says fma_() (v_fma_f32). That makes results
+// reproducible bit for bit run to run, 1 GPU vs N GPUs, and against the CPU oracle of the tests. Transcendentals are fixed
+// polynomials (no ocml calls on the pixel path). The kernels are VALU-bound, so the per-tap arithmetic avoids IEEE
+// divisions and square roots: guides are pre-decoded once per pixel into a 16-byte texel, the normal weight works on the
+// squared angle, the hit-distance weight has compact support, and taps are placed with the pixel-space Jacobian of the
+// projection instead of a perspective divide per tap.
 //
 // Encodings (reference call sites): normal/roughness/materialID R10G10B10A2 pack Shaders/TraceOpaque.cs.hlsl:657;
 // REBLUR hit distance normalisation Shaders/TraceOpaque.cs.hlsl:421; YCoCg radiance Shaders/TraceOpaque.cs.hlsl:756-757;
@@ -26,6 +29,7 @@ struct FrameConsts {
     int ownY0, ownY1; // local rows this instance produces
     float invW, invH, invWprev, invHprev;
     float fr[4], frPrev[4]; // x0, y0, dx, dy
+    float pv[4], pvPrev[4]; // view ray of pixel (px, gy): (pv0 + pv2 px, pv1 + pv3 gy, 1)
     float pj[5], pjPrev[5]; // m0, m5, m8, m9, s
     float w2v[9], w2vPrev[9], v2w[9], v2wPrev[9];
     float camDelta[3];
@@ -54,11 +58,12 @@ struct f4 {
     float x, y, z, w;
 };
 
+NRD_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 NRD_DEV float fmin2(float a, float b) { return a < b ? a : b; }
 NRD_DEV float fmax2(float a, float b) { return a > b ? a : b; }
 NRD_DEV float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
 NRD_DEV float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
-NRD_DEV float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+NRD_DEV float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 NRD_DEV float smoothstep01(float x) {
     x = sat(x);
     return x * x * (3.0f - 2.0f * x);
@@ -68,7 +73,7 @@ NRD_DEV float absf(float x) { return x < 0.0f ? -x : x; }
 NRD_DEV f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 NRD_DEV f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 NRD_DEV f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-NRD_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NRD_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 NRD_DEV f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 NRD_DEV f3 normalize3(f3 a) {
     float l2 = dot3(a, a);
@@ -76,10 +81,10 @@ NRD_DEV f3 normalize3(f3 a) {
     return mul3(a, inv);
 }
 NRD_DEV f3 rot3(const float* m, f3 v) {
-    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+    return {fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[5], v.z, fma_(m[4], v.y, m[3] * v.x)), fma_(m[8], v.z, fma_(m[7], v.y, m[6] * v.x))};
 }
-NRD_DEV f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 NRD_DEV f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+NRD_DEV f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
 NRD_DEV f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
 
 NRD_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -98,12 +103,12 @@ NRD_DEV float exp2_poly(float x) {
     float fi = __builtin_floorf(x + 0.5f);
     float f = x - fi;
     float p = 1.535336188319500e-4f;
-    p = p * f + 1.339887440266574e-3f;
-    p = p * f + 9.618437357674640e-3f;
-    p = p * f + 5.550332471162809e-2f;
-    p = p * f + 2.402264791363012e-1f;
-    p = p * f + 6.931472028550421e-1f;
-    p = p * f + 1.0f;
+    p = fma_(p, f, 1.339887440266574e-3f);
+    p = fma_(p, f, 9.618437357674640e-3f);
+    p = fma_(p, f, 5.550332471162809e-2f);
+    p = fma_(p, f, 2.402264791363012e-1f);
+    p = fma_(p, f, 6.931472028550421e-1f);
+    p = fma_(p, f, 1.0f);
     int e = (int)fi;
     return p * u2f((uint32_t)(e + 127) << 23);
 }
@@ -121,14 +126,14 @@ NRD_DEV float log2_poly(float x) {
     float t = m - 1.0f;
     float z = t * t;
     float p = 7.0376836292e-2f;
-    p = p * t - 1.1514610310e-1f;
-    p = p * t + 1.1676998740e-1f;
-    p = p * t - 1.2420140846e-1f;
-    p = p * t + 1.4249322787e-1f;
-    p = p * t - 1.6668057665e-1f;
-    p = p * t + 2.0000714765e-1f;
-    p = p * t - 2.4999993993e-1f;
-    p = p * t + 3.3333331174e-1f;
+    p = fma_(p, t, -1.1514610310e-1f);
+    p = fma_(p, t, 1.1676998740e-1f);
+    p = fma_(p, t, -1.2420140846e-1f);
+    p = fma_(p, t, 1.4249322787e-1f);
+    p = fma_(p, t, -1.6668057665e-1f);
+    p = fma_(p, t, 2.0000714765e-1f);
+    p = fma_(p, t, -2.4999993993e-1f);
+    p = fma_(p, t, 3.3333331174e-1f);
     float y = t * z * p;
     y = y - 0.5f * z;
     float ln = t + y;
@@ -147,22 +152,23 @@ NRD_DEV float atan_pos(float x) {
     float t = inv ? 1.0f / x : x;
     float s = t * t;
     float p = 0.0208351f;
-    p = p * s - 0.0851330f;
-    p = p * s + 0.1801410f;
-    p = p * s - 0.3302995f;
-    p = p * s + 0.9998660f;
+    p = fma_(p, s, -0.0851330f);
+    p = fma_(p, s, 0.1801410f);
+    p = fma_(p, s, -0.3302995f);
+    p = fma_(p, s, 0.9998660f);
     p = p * t;
     return inv ? 1.57079633f - p : p;
 }
 
-NRD_DEV float acos_approx(float x) { return 1.41421356f * __builtin_sqrtf(sat(1.0f - x)); }
-
+// compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped
 NRD_DEV float exp_weight(float ax) {
-    float x = -3.0f * ax;
-    return 1.0f / (x * x - x + 1.0f);
+    float t = sat(1.0f - ax);
+    return t * t;
 }
+// normal weight on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; w2 = 1 / angleMax^2
+NRD_DEV float normal_weight(float cosa, float w2) { return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), w2, 1.0f)); }
 
-// ---- packing -----------------------------------------------------------------------------------------------------
+// ---- input decode (once per pixel, in the ClassifyTiles passes) ---------------------------------------------------
 NRD_DEV f3 oct_decode(float px, float py) {
     float fx = px * 2.0f - 1.0f, fy = py * 2.0f - 1.0f;
     float nz = 1.0f - absf(fx) - absf(fy);
@@ -170,6 +176,13 @@ NRD_DEV f3 oct_decode(float px, float py) {
     float nx = fx + (fx >= 0.0f ? -t : t);
     float ny = fy + (fy >= 0.0f ? -t : t);
     return normalize3({nx, ny, nz});
+}
+
+// guide texel (16 bytes): {viewZ f32 | nx f16, ny f16 | nz f16, roughness f16 | materialID u32}
+NRD_DEV uint4 encode_guide(float z, uint32_t packedNR) {
+    f3 n = oct_decode((float)(packedNR & 1023u) / 1023.0f, (float)((packedNR >> 10) & 1023u) / 1023.0f);
+    float roughness = (float)((packedNR >> 20) & 1023u) / 1023.0f;
+    return uint4{f2u(z), (uint32_t)f2h(n.x) | ((uint32_t)f2h(n.y) << 16), (uint32_t)f2h(n.z) | ((uint32_t)f2h(roughness) << 16), packedNR >> 30};
 }
 
 struct Guide {
@@ -180,15 +193,12 @@ struct Guide {
     bool sky;
 };
 
-NRD_DEV f3 unpack_normal(uint32_t p) { return oct_decode((float)(p & 1023u) / 1023.0f, (float)((p >> 10) & 1023u) / 1023.0f); }
-NRD_DEV float unpack_roughness(uint32_t p) { return (float)((p >> 20) & 1023u) / 1023.0f; }
-
-NRD_DEV Guide decode_guide(uint2 g, float range) {
+NRD_DEV Guide decode_guide(uint4 g, float range) {
     Guide r;
     r.z = u2f(g.x);
-    r.n = unpack_normal(g.y);
-    r.roughness = unpack_roughness(g.y);
-    r.mat = g.y >> 30;
+    r.n = {h2f((uint16_t)(g.y & 0xffffu)), h2f((uint16_t)(g.y >> 16)), h2f((uint16_t)(g.z & 0xffffu))};
+    r.roughness = h2f((uint16_t)(g.z >> 16));
+    r.mat = g.w;
     r.sky = !(absf(r.z) <= range);
     return r;
 }
@@ -200,7 +210,7 @@ NRD_DEV float spec_magic_curve(float roughness) {
 
 NRD_DEV float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
     float e = exp2_poly(hp[3] * roughness * roughness);
-    return (hp[0] + absViewZ * hp[1]) * lerpf(1.0f, hp[2], e);
+    return fma_(absViewZ, hp[1], hp[0]) * lerpf(1.0f, hp[2], e);
 }
 
 NRD_DEV float spec_lobe_half_angle(float roughness) {
@@ -231,6 +241,7 @@ NRD_DEV void basis3(f3 n, f3& t, f3& b) {
 }
 
 NRD_DEV f3 reconstruct(const float* fr, float u, float v, float z) { return {z * (u * fr[2] + fr[0]), z * (v * fr[3] + fr[1]), z}; }
+NRD_DEV f3 reconstruct_px(const float* pv, float px, float gy, float z) { return {z * fma_(pv[2], px, pv[0]), z * fma_(pv[3], gy, pv[1]), z}; }
 NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
     float cw = pj[4] * X.z;
     if (!(cw > 1e-6f))
@@ -242,6 +253,30 @@ NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
 }
 
 NRD_DEV bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
+
+// per-pixel geometry of the bilateral passes: plane-distance weight is |zs * (ga0 + gax px + gay gy) + geoB|
+struct PixelGeo {
+    f3 Xv, Nv;
+    float absZ, frustumSize;
+    float ga0, gax, gay, geoB;
+};
+NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, float planeDistSensitivity) {
+    PixelGeo p;
+    p.Xv = reconstruct_px(c.pv, (float)x, (float)gy, g.z);
+    p.Nv = rot3(c.w2v, g.n);
+    p.absZ = absf(g.z);
+    p.frustumSize = c.minRectDimMulUnproject * p.absZ;
+    float geoA = 1.0f / (planeDistSensitivity * p.frustumSize);
+    p.gax = p.Nv.x * c.pv[2] * geoA;
+    p.gay = p.Nv.y * c.pv[3] * geoA;
+    p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
+    p.geoB = -dot3(p.Nv, p.Xv) * geoA;
+    return p;
+}
+NRD_DEV float geo_weight(const PixelGeo& p, float px, float gy, float zs) {
+    float ga = fma_(p.gax, px, fma_(p.gay, gy, p.ga0));
+    return smoothstep01(1.0f - absf(fma_(zs, ga, p.geoB)));
+}
 
 // ---- plane access ------------------------------------------------------------------------------------------------
 template <typename T>

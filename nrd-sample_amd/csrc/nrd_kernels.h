@@ -16,6 +16,7 @@ struct ReblurParams {
     float responsiveRoughnessThreshold, responsiveMinAccum;
     float maxA, maxFastA, maxStab;
     int historyFixFrameNum, historyFixStride;
+    int reachPre, reachBlur, reachPost; // hard per-pass bound (pixels) on tap distance = halo rows of the pass
     uint32_t minMatDiff, minMatSpec;
     int clampEnabled;
     int hasDiff, hasSpec;

@@ -3,11 +3,12 @@
 // Replaces the REBLUR HLSL pass set of the reference's absent External/NRD submodule behind nrd::Integration::Denoise
 // (Source/NRDSample.cpp:521). Pass graph per SURVEY.md 8a-5:
 //   ClassifyTiles(+guide packing) -> PrePass -> TemporalAccumulation -> HistoryFix -> Blur -> PostBlur -> TemporalStabilization
-// Data layout (DESIGN.md "HBM layout"): one 8-byte guide texel {viewZ, R10G10B10A2 normal/roughness/material} per pixel so a
-// bilateral tap costs one 8-byte gather for all guides; diffuse+specular radiance interleaved in one 16-byte texel;
-// accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles, assigned to XCDs in contiguous runs
-// (nrd_device.h xcd_tile) so stencil / gather overlap between neighbouring tiles is served by one XCD's L2.
-// These are HBM/L2-bound gathers and stencils: no MFMA. 5x5 moment stencils stage their tile (+2 halo) in LDS.
+// Data layout (DESIGN.md "HBM layout"): one 16-byte guide texel {viewZ f32, normal 3 x f16, roughness f16, materialID} per
+// pixel so a bilateral tap costs ONE 16-byte gather and four converts for all guides; diffuse+specular radiance interleaved
+// in one 16-byte texel; accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles, assigned to XCDs
+// in contiguous runs (nrd_device.h xcd_tile) so stencil / gather overlap between neighbouring tiles is served by one XCD's
+// L2. These are gather / stencil filters (measured VALU-bound, profiles/): no MFMA. 5x5 moment stencils stage their tile
+// (+2 halo) in LDS.
 #include "nrd_kernels.h"
 
 namespace nrdhip {
@@ -25,8 +26,8 @@ NRD_DEV void unpack_data1(uint32_t v, float& diffA, float& specA) {
     specA = (float)(v >> 8) * 0.25f;
 }
 NRD_DEV uint16_t pack_data1(float diffA, float specA) {
-    uint32_t d = (uint32_t)__builtin_floorf(clampf(diffA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
-    uint32_t s = (uint32_t)__builtin_floorf(clampf(specA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
+    uint32_t d = (uint32_t)__builtin_floorf(fma_(clampf(diffA, 0.0f, MAX_ACCUM), 4.0f, 0.5f));
+    uint32_t s = (uint32_t)__builtin_floorf(fma_(clampf(specA, 0.0f, MAX_ACCUM), 4.0f, 0.5f));
     return (uint16_t)(d | (s << 8));
 }
 
@@ -52,8 +53,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     int notSky = 0;
     if (valid) {
         float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
-        uint32_t nr = ld<uint32_t>(p.inNR, x, y, 4);
-        st<uint2>(p.guide, x, y, 8, uint2{f2u(z), nr});
+        st<uint4>(p.guide, x, y, 16, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
         notSky = absf(z) <= c.denoisingRange ? 1 : 0;
     }
     int any = __syncthreads_or(notSky);
@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         return;
     const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
+    const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
 
-    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++)
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * 8);
@@ -84,15 +85,16 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             st<uint16_t>(p.hitTrack, x, y, 2, (uint16_t)0);
         return;
     }
-    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-    f3 Xv = reconstruct(c.fr, u, v, g.z);
-    f3 Nv = rot3(c.w2v, g.n);
-    f3 V = mul3(normalize3(Xv), -1.0f);
-    float absZ = absf(g.z);
-    float frustumSize = c.minRectDimMulUnproject * absZ;
-    float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
-    float geoB = -dot3(Nv, Xv) * geoA;
-    uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, (uint32_t)VARIANT + 1u);
+    const int gy0 = y + c.yOff;
+    PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
+    f3 V = mul3(normalize3(pg.Xv), -1.0f);
+    // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane)
+    float inv = 1.0f / (c.pj[4] * g.z);
+    float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
+    float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
+    float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
+    float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
+    uint32_t h = hash_px((uint32_t)x, (uint32_t)gy0, c.frameIndex, (uint32_t)VARIANT + 1u);
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)
@@ -107,9 +109,9 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         const int srcBpt = VARIANT == 0 ? 8 : RBPT;
         const int srcOff = VARIANT == 0 ? 0 : sig * 8;
         f4 center = unpack_h4(ld<uint2>(srcP, x, y, srcBpt, srcOff));
-        float hitNorm = reblur_hitdist_norm(absZ, p.hp, rough);
+        float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
         float hitDist = center.w * hitNorm;
-        float hitDistFactor = sat(hitDist / frustumSize);
+        float hitDistFactor = sat(hitDist / pg.frustumSize);
         float A = isSpec ? specA : diffA;
         float nonLin = VARIANT == 0 ? 1.0f : 1.0f / (1.0f + A);
         float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         if (VARIANT == 0) {
             radius = (isSpec ? p.specularPrepassBlurRadius : p.diffusePrepassBlurRadius) * hitDistFactor * smc;
         } else {
-            float r = p.maxBlurRadius * lerpf(MIN_CONVERGED_RADIUS_SCALE, 1.0f, nonLin) * lerpf(hitDistFactor, 1.0f, nonLin) + p.minBlurRadius;
+            float r = fma_(p.maxBlurRadius * lerpf(MIN_CONVERGED_RADIUS_SCALE, 1.0f, nonLin), lerpf(hitDistFactor, 1.0f, nonLin), p.minBlurRadius);
             r *= VARIANT == 2 ? POST_BLUR_RADIUS_SCALE : 1.0f;
             r *= smc;
             radius = p.maxBlurRadius != 0.0f ? r : 0.0f;
@@ -126,18 +128,18 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         float wsum = 1.0f;
         float minHit = hitDist;
         if (radius > 0.0f) {
-            float worldRadius = radius * c.unproject * absZ;
+            float worldRadius = radius * c.unproject * pg.absZ;
             f3 T, B;
-            basis3(Nv, T, B);
+            basis3(pg.Nv, T, B);
             if (isSpec) {
-                float NoV = dot3(Nv, V);
-                f3 R = sub3(mul3(Nv, 2.0f * NoV), V);
+                float NoV = dot3(pg.Nv, V);
+                f3 R = sub3(mul3(pg.Nv, 2.0f * NoV), V);
                 float df = spec_dominant_factor(rough);
-                f3 D = normalize3(add3(Nv, mul3(sub3(R, Nv), df)));
-                float NoD = dot3(Nv, D);
+                f3 D = normalize3(add3(pg.Nv, mul3(sub3(R, pg.Nv), df)));
+                float NoD = dot3(pg.Nv, D);
                 if (NoD < 0.999f && rough < 0.95f) {
-                    f3 Dr = sub3(mul3(Nv, 2.0f * NoD), D);
-                    T = normalize3(cross3(Nv, Dr));
+                    f3 Dr = sub3(mul3(pg.Nv, 2.0f * NoD), D);
+                    T = normalize3(cross3(pg.Nv, Dr));
                     B = cross3(Dr, T);
                     float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
                     T = mul3(T, skew);
@@ -145,45 +147,48 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             }
             T = mul3(T, worldRadius);
             B = mul3(B, worldRadius);
+            float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
+            float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
             float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
             float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+            float normalW2 = normalW * normalW;
             float hitA = 1.0f / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
             float hitB = -center.w * hitA;
             float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
             float roughB = -rough * roughA;
+            const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
 #pragma unroll 2
             for (int t = 0; t < 8; t++) {
-                float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
-                float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
-                f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
-                float tu, tv;
-                if (!project(c.pj, Xt, tu, tv))
-                    continue;
-                float fpx = __builtin_floorf(tu * (float)c.W), fpy = __builtin_floorf(tv * (float)c.H);
+                float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+                float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
+                float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
                 if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
                     continue;
                 int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+                int ddx = px - x, ddy = gy - gy0;
+                if (ddx > reach || -ddx > reach || ddy > reach || -ddy > reach)
+                    continue;
                 if (py < 0 || py >= c.resH)
                     continue;
-                Guide gs = decode_guide(ld<uint2>(p.guide, px, py, 8), c.denoisingRange);
+                Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
                 if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                     continue;
-                f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
                 float w = g_poisson8[t][2];
-                w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
-                w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                w *= geo_weight(pg, fpx, fpy, gs.z);
+                w *= normal_weight(dot3(g.n, gs.n), normalW2);
                 if (isSpec)
-                    w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                 f4 sv = unpack_h4(ld<uint2>(srcP, px, py, srcBpt, srcOff));
-                w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(sv.w * hitA + hitB)));
-                sum = add4(sum, mul4(sv, w));
+                w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
+                sum = fma4(sv, w, sum);
                 wsum += w;
                 if (w > 0.0f)
                     minHit = fmin2(minHit, sv.w * hitNorm);
             }
         }
-        float inv = 1.0f / wsum;
-        st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, inv)), sig * 8);
+        float invw = 1.0f / wsum;
+        st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, invw)), sig * 8);
         if (VARIANT == 0 && isSpec)
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit));
     }
@@ -237,7 +242,7 @@ struct Footprint {
 NRD_DEV Footprint footprint(const ReblurParams& p, float pu, float pv, f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
     const FrameConsts& c = p.c;
     Footprint f;
-    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
     float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
     float fx = px - fx0, fy = py - fy0;
     bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
@@ -247,14 +252,16 @@ NRD_DEV Footprint footprint(const ReblurParams& p, float pu, float pv, f3 NvPrev
     f.wsum = 0.0f;
     f.bits = 0;
     float planeRef = dot3(NvPrev, XvPrev);
+    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+    float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
         bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
         if (ok) {
-            Guide gp = decode_guide(ld<uint2>(p.guidePrev, tx, ty, 8), c.denoisingRange);
-            f3 Xp = reconstruct(c.frPrev, ((float)tx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, gp.z);
-            ok = !gp.sky && absf(dot3(NvPrev, Xp) - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
+            Guide gp = decode_guide(ld<uint4>(p.guidePrev, tx, ty, 16), c.denoisingRange);
+            float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+            ok = !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
         }
         f.w[i] = ok ? bw[i] : 0.0f;
         f.wsum += f.w[i];
@@ -268,7 +275,7 @@ NRD_DEV f4 fetch4(const FrameConsts& c, const PlaneRef& P, int bpt, int off, con
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
-            s = add4(s, mul4(unpack_h4(ld<uint2>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)), f.w[i]));
+            s = fma4(unpack_h4(ld<uint2>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)), f.w[i], s);
     return mul4(s, 1.0f / f.wsum);
 }
 NRD_DEV float fetch1(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
@@ -276,7 +283,7 @@ NRD_DEV float fetch1(const FrameConsts& c, const PlaneRef& P, int bpt, int off, 
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
-            s += h2f(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)) * f.w[i];
+            s = fma_(h2f(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)), f.w[i], s);
     return s * (1.0f / f.wsum);
 }
 NRD_DEV void fetchA(const FrameConsts& c, const PlaneRef& P, const Footprint& f, float& dA, float& sA) {
@@ -286,8 +293,8 @@ NRD_DEV void fetchA(const FrameConsts& c, const PlaneRef& P, const Footprint& f,
         if (f.w[i] > 0.0f) {
             float a, b;
             unpack_data1(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, 2), a, b);
-            dA += a * f.w[i];
-            sA += b * f.w[i];
+            dA = fma_(a, f.w[i], dA);
+            sA = fma_(b, f.w[i], sA);
         }
     float inv = 1.0f / f.wsum;
     dA *= inv;
@@ -307,7 +314,7 @@ NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, fl
 NRD_DEV float sample_confidence(const PlaneRef& P, float u, float v) {
     if (!P.p)
         return 1.0f;
-    float px = u * (float)P.w - 0.5f, py = v * (float)P.h - 0.5f;
+    float px = fma_(u, (float)P.w, -0.5f), py = fma_(v, (float)P.h, -0.5f);
     float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
     float fx = px - fx0, fy = py - fy0;
     int x0 = (int)fx0, y0 = (int)fy0;
@@ -320,10 +327,10 @@ NRD_DEV float sample_confidence(const PlaneRef& P, float u, float v) {
 
 NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
     float acos01sq = sat(1.0f - NoV * 0.99999f);
-    float a = pow01(acos01sq, 0.5f);
-    float b = 1.1f + roughness * roughness;
+    float a = __builtin_sqrtf(acos01sq);
+    float b = fma_(roughness, roughness, 1.1f);
     float parallaxSensitivity = (b + a) / (b - a);
-    float powerScale = 1.0f + parallaxSensitivity * parallaxPx * 2.0f;
+    float powerScale = fma_(parallaxSensitivity * parallaxPx, 2.0f, 1.0f);
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
     f *= pow01(roughness, 0.5f * powerScale);
     return MAX_ACCUM * f;
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     int x, y, tx, ty;
     if (!my_pixel(c, x, y, tx, ty))
         return;
-    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * 8);
@@ -351,8 +358,9 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         st<uint32_t>(p.data2, x, y, 4, 0u);
         return;
     }
-    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-    f3 Xv = reconstruct(c.fr, u, v, g.z);
+    const int gy0 = y + c.yOff;
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
+    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
     f3 Nv = rot3(c.w2v, g.n);
     f3 V = mul3(normalize3(Xv), -1.0f);
     float NoV = absf(dot3(Nv, V));
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         float pu, pv, parallax = 0.0f;
         if (project(c.pj, XparV, pu, pv)) {
             float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
-            parallax = __builtin_sqrtf(dx * dx + dy * dy);
+            parallax = __builtin_sqrtf(fma_(dx, dx, dy * dy));
         }
         float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
         float vu, vv;
@@ -410,10 +418,10 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     if (vmb.w[i] > 0.0f)
-                        prevRough += unpack_roughness(ld<uint32_t>(p.guidePrev, vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff, 8, 4)) * vmb.w[i];
+                        prevRough = fma_(h2f(ld<uint16_t>(p.guidePrev, vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff, 16, 10)), vmb.w[i], prevRough);
                 prevRough *= 1.0f / vmb.wsum;
                 float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction));
-                float rconf = smoothstep01(1.0f - absf(prevRough * roughA - g.roughness * roughA));
+                float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
                 amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
                 float dA, sA;
                 fetchA(c, p.data1Prev, vmb, dA, sA);
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
         st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), lo);
         outSpecA = A;
-        data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(sat(amount) * 255.0f + 0.5f) << 8);
+        data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8);
     }
     st<uint16_t>(p.data1Tmp, x, y, 2, pack_data1(outDiffA, outSpecA));
     st<uint32_t>(p.data2, x, y, 4, data2);
@@ -458,7 +466,7 @@ NRD_DEV void stage_luma_tile(const FrameConsts& c, const PlaneRef& guide, int tx
         int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
         float val = u2f(0x7fc00000u);
         if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
-            float zt = ld<float>(guide, px, py, 8, 0);
+            float zt = ld<float>(guide, px, py, 16, 0);
             if (absf(zt) <= c.denoisingRange)
                 val = fetch(px, py);
         }
@@ -476,7 +484,7 @@ NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, float& 
             float f = tile[(ly + j) * 20 + lx + i];
             f = f != f ? centre : f;
             m1 += f;
-            m2 += f * f;
+            m2 = fma_(f, f, m2);
         }
     m1 *= 1.0f / 25.0f;
     m2 *= 1.0f / 25.0f;
@@ -503,22 +511,19 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
         return;
-    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++)
             st<uint2>(p.tmp1, x, y, RBPT, uint2{0u, 0u}, sig * 8);
         st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
         return;
     }
-    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-    f3 Xv = reconstruct(c.fr, u, v, g.z);
-    f3 Nv = rot3(c.w2v, g.n);
-    float frustumSize = c.minRectDimMulUnproject * absf(g.z);
-    float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
-    float geoB = -dot3(Nv, Xv) * geoA;
+    const int gy0 = y + c.yOff;
     float A[2];
     unpack_data1(ld<uint16_t>(p.data1Tmp, x, y, 2), A[0], A[1]);
     float outA[2] = {A[0], A[1]};
+    bool geoReady = false;
+    PixelGeo pg;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
@@ -529,10 +534,15 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         float Acur = A[ai];
         if (Acur < (float)p.historyFixFrameNum && p.historyFixFrameNum > 0) {
             float normA = sat(Acur / (float)p.historyFixFrameNum);
-            int stride = (int)__builtin_floorf((float)p.historyFixStride * (1.0f - normA) + 0.5f);
+            int stride = (int)__builtin_floorf(fma_((float)p.historyFixStride, 1.0f - normA, 0.5f));
             if (stride > 0) {
+                if (!geoReady) {
+                    pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
+                    geoReady = true;
+                }
                 float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, 1.0f / (1.0f + Acur));
                 float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                float normalW2 = normalW * normalW;
                 float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
                 float roughB = -rough * roughA;
                 f4 sum = mul4(val, 1.0f + Acur);
@@ -544,19 +554,18 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                         int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
                         if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
                             continue;
-                        Guide gs = decode_guide(ld<uint2>(p.guide, px, py, 8), c.denoisingRange);
+                        Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
                         if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                             continue;
-                        f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
                         float w = 1.0f / (1.0f + (float)(i * i + j * j));
-                        w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
-                        w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                        w *= geo_weight(pg, (float)px, (float)gy, gs.z);
+                        w *= normal_weight(dot3(g.n, gs.n), normalW2);
                         if (isSpec)
-                            w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                            w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         float tA[2];
                         unpack_data1(ld<uint16_t>(p.data1Tmp, px, py, 2), tA[0], tA[1]);
                         w *= 1.0f + tA[ai];
-                        sum = add4(sum, mul4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * 8)), w));
+                        sum = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * 8)), w, sum);
                         wsum += w;
                     }
                 val = mul4(sum, 1.0f / wsum);
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             float fc = h2f(ld<uint16_t>(p.fast, x, y, LBPT, sig * 2));
             float m1, m2;
             moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, m1, m2);
-            float sigma = __builtin_sqrtf(fmax2(m2 - m1 * m1, 0.0f)) * p.fastHistoryClampingSigmaScale;
+            float sigma = __builtin_sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fastHistoryClampingSigmaScale;
             float Y = val.x;
             float Yc = clampf(Y, m1 - sigma, m1 + sigma);
             float scale = (Yc + 1e-6f) / (Y + 1e-6f);
@@ -585,7 +594,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
 // K7 TemporalStabilization (+ split screen)
 // =====================================================================================================================
 NRD_DEV bool fetch_stab(const FrameConsts& c, const PlaneRef& P, int bpt, int off, float pu, float pv, uint32_t bits, float& out) {
-    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
     float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
     float fx = px - fx0, fy = py - fy0;
     bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
@@ -597,7 +606,7 @@ NRD_DEV bool fetch_stab(const FrameConsts& c, const PlaneRef& P, int bpt, int of
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (bits & (1u << i)) {
-            sum += h2f(ld<uint16_t>(P, ix + (i & 1), iy + (i >> 1) - c.yOff, bpt, off)) * bw[i];
+            sum = fma_(h2f(ld<uint16_t>(P, ix + (i & 1), iy + (i >> 1) - c.yOff, bpt, off)), bw[i], sum);
             wsum += bw[i];
         }
     if (!(wsum > 0.0f))
@@ -622,9 +631,10 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
         return;
-    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    const int gy0 = y + c.yOff;
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     bool split = u < c.splitScreen;
-    Guide g = decode_guide(ld<uint2>(p.guide, x, y, 8), c.denoisingRange);
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         }
         return;
     }
-    f3 Xv = reconstruct(c.fr, u, v, g.z);
+    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
     Reproj r = reproject(c, Xv, u, v, unpack_h4(ld<uint2>(p.inMV, x, y, 8)));
     uint32_t data2 = ld<uint32_t>(p.data2, x, y, 4);
     float A[2];
@@ -648,14 +658,14 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         f4 cur = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * 8));
         float m1, m2;
         moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, m1, m2);
-        float sigma = __builtin_sqrtf(fmax2(m2 - m1 * m1, 0.0f));
+        float sigma = __builtin_sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f));
         float Yhist = cur.x;
         bool have = false;
         if (historyOk) {
             float smbY = 0.0f;
             bool smbOk = fetch_stab(c, p.stabPrev, LBPT, sig * 2, r.su, r.sv, data2 & 15u, smbY);
             if (isSpec) {
-                float amount = (float)((data2 >> 8) & 255u) / 255.0f;
+                float amount = (float)((data2 >> 8) & 255u) * (1.0f / 255.0f);
                 float vu, vv, vmbY = 0.0f;
                 bool vmbOk = amount > 0.0f && virtual_uv(c, r, h2f(ld<uint16_t>(p.hitTrack, x, y, 2)), g.roughness, vu, vv) &&
                              fetch_stab(c, p.stabPrev, LBPT, sig * 2, vu, vv, (data2 >> 4) & 15u, vmbY);
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         float Y = cur.x;
         float band = sigma * p.antilagSigmaScale;
         float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) / (fmax2(Yhist, m1) + 1e-6f);
-        float antilag = 1.0f / (1.0f + dlt * p.antilagSensitivity * Acur);
+        float antilag = 1.0f / fma_(dlt * p.antilagSensitivity, Acur, 1.0f);
         float Yclamped = clampf(Yhist, m1 - band, m1 + band);
         float stabFrames = have ? fmin2(Acur, p.maxStab) * antilag : 0.0f;
         float wHist = stabFrames / (1.0f + stabFrames);

@@ -4,8 +4,8 @@
 // nrd::Integration::Denoise (Source/NRDSample.cpp:4082 shadow denoising, :4224 reference accumulation).
 // Inputs: IN_PENUMBRA R16F / IN_TRANSLUCENCY RGBA8 (Shaders/TraceOpaque.cs.hlsl:800-804); output RGBA8, sqrt-encoded
 // (Shaders/Composition.cs.hlsl:60-64 squares it). Pass graph: ClassifyTiles(+guide) -> SmoothTiles -> Blur -> PostBlur ->
-// TemporalStabilization. Same 16x16 XCD-swizzled tiling and packed 8-byte guide texel as REBLUR; the 5x5 clamp stencil of
-// the stabilization pass stages its 20x20 RGBA tile in LDS.
+// TemporalStabilization. Same 16x16 XCD-swizzled tiling and 16-byte pre-decoded guide texel as REBLUR; the 5x5 clamp stencil
+// of the stabilization pass stages its 20x20 RGBA tile in LDS.
 #include "nrd_kernels.h"
 
 namespace nrdhip {
@@ -13,6 +13,7 @@ namespace nrdhip {
 namespace {
 
 constexpr float MAX_PIXEL_RADIUS = 48.0f;
+constexpr int BLUR_REACH = 56; // (int)(48 * 1.1) + 3
 constexpr float PREV_NORMAL_COS = 0.7f;
 constexpr float STAB_SIGMA_SCALE = 2.0f;
 
@@ -22,18 +23,19 @@ NRD_DEV f4 input_visibility(const SigmaParams& p, int x, int y, float pen) {
     if (!p.translucency)
         return {0, 0, 0, 0};
     uint32_t t = ld<uint32_t>(p.inTransl, x, y, 4);
-    return {0.0f, (float)((t >> 8) & 255u) / 255.0f, (float)((t >> 16) & 255u) / 255.0f, (float)(t >> 24) / 255.0f};
+    return {0.0f, (float)((t >> 8) & 255u) * (1.0f / 255.0f), (float)((t >> 16) & 255u) * (1.0f / 255.0f), (float)(t >> 24) * (1.0f / 255.0f)};
 }
 
 NRD_DEV uint32_t encode_shadow(f4 v) {
-    uint32_t r = (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.x)) * 255.0f + 0.5f);
-    r |= (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.y)) * 255.0f + 0.5f) << 8;
-    r |= (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.z)) * 255.0f + 0.5f) << 16;
-    r |= (uint32_t)__builtin_floorf(__builtin_sqrtf(sat(v.w)) * 255.0f + 0.5f) << 24;
+    uint32_t r = (uint32_t)__builtin_floorf(fma_(__builtin_sqrtf(sat(v.x)), 255.0f, 0.5f));
+    r |= (uint32_t)__builtin_floorf(fma_(__builtin_sqrtf(sat(v.y)), 255.0f, 0.5f)) << 8;
+    r |= (uint32_t)__builtin_floorf(fma_(__builtin_sqrtf(sat(v.z)), 255.0f, 0.5f)) << 16;
+    r |= (uint32_t)__builtin_floorf(fma_(__builtin_sqrtf(sat(v.w)), 255.0f, 0.5f)) << 24;
     return r;
 }
 NRD_DEV f4 decode_shadow(uint32_t p) {
-    float a = (float)(p & 255u) / 255.0f, b = (float)((p >> 8) & 255u) / 255.0f, c = (float)((p >> 16) & 255u) / 255.0f, d = (float)(p >> 24) / 255.0f;
+    float a = (float)(p & 255u) * (1.0f / 255.0f), b = (float)((p >> 8) & 255u) * (1.0f / 255.0f);
+    float c = (float)((p >> 16) & 255u) * (1.0f / 255.0f), d = (float)(p >> 24) * (1.0f / 255.0f);
     return {a * a, b * b, c * c, d * d};
 }
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams 
     float r = 0.0f;
     if (valid) {
         float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
-        st<uint2>(p.guide, x, y, 8, uint2{f2u(z), ld<uint32_t>(p.inNR, x, y, 4)});
+        st<uint4>(p.guide, x, y, 16, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
         if (absf(z) <= c.denoisingRange) {
             float pen = h2f(ld<uint16_t>(p.inPen, x, y, 2));
             if (pen >= NRD_FP16_MAX)
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
         return;
     const PlaneRef& inPen = PASS == 0 ? p.inPen : p.pen1;
     const PlaneRef& outSh = PASS == 0 ? p.shadow1 : p.shadow2;
-    uint2 graw = ld<uint2>(p.guide, x, y, 8);
+    uint4 graw = ld<uint4>(p.guide, x, y, 16);
     float z = u2f(graw.x);
     if (!(absf(z) <= c.denoisingRange)) {
         st<uint2>(outSh, x, y, 8, uint2{0u, 0u});
@@ -134,49 +136,59 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
     float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
     radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
     float worldRadius = radiusPx * pixelWorld;
-    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-    f3 Xv = reconstruct(c.fr, u, v, z);
-    f3 N = unpack_normal(graw.y);
-    f3 Nv = rot3(c.w2v, N);
+    const int gy0 = y + c.yOff;
+    Guide g = decode_guide(graw, c.denoisingRange);
+    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
+    f3 Nv = rot3(c.w2v, g.n);
     float frustumSize = c.minRectDimMulUnproject * absZ;
     float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
+    float gax = Nv.x * c.pv[2] * geoA, gay = Nv.y * c.pv[3] * geoA;
+    float ga0 = fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
     float geoB = -dot3(Nv, Xv) * geoA;
     f3 T, B;
     basis3(Nv, T, B);
     T = mul3(T, worldRadius);
     B = mul3(B, worldRadius);
-    uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, 17u + (uint32_t)PASS);
+    float inv = 1.0f / (c.pj[4] * z);
+    float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
+    float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
+    float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
+    float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
+    float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
+    float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
+    uint32_t h = hash_px((uint32_t)x, (uint32_t)gy0, c.frameIndex, 17u + (uint32_t)PASS);
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     f4 sum = center;
     float wsum = 1.0f;
     float penSum = lit ? 0.0f : pen, penW = lit ? 0.0f : 1.0f;
     if (radiusPx > 0.0f) {
+        const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
 #pragma unroll 2
         for (int t = 0; t < 8; t++) {
-            float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
-            float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
-            f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
-            float tu, tv;
-            if (!project(c.pj, Xt, tu, tv))
-                continue;
-            float fpx = __builtin_floorf(tu * (float)c.W), fpy = __builtin_floorf(tv * (float)c.H);
+            float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+            float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+            float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
+            float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
             if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
                 continue;
             int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+            int ddx = px - x, ddy = gy - gy0;
+            if (ddx > BLUR_REACH || -ddx > BLUR_REACH || ddy > BLUR_REACH || -ddy > BLUR_REACH)
+                continue;
             if (py < 0 || py >= c.resH)
                 continue;
-            float zs = ld<float>(p.guide, px, py, 8, 0);
+            float zs = ld<float>(p.guide, px, py, 16, 0);
             if (!(absf(zs) <= c.denoisingRange))
                 continue;
-            f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, zs);
-            float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+            float ga = fma_(gax, fpx, fma_(gay, fpy, ga0));
+            float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(fma_(zs, ga, geoB)));
             float ps = h2f(ld<uint16_t>(inPen, px, py, 2));
             bool lits = PASS == 0 ? ps >= NRD_FP16_MAX : !(ps > 0.0f);
             f4 sv = PASS == 0 ? input_visibility(p, px, py, ps) : unpack_h4(ld<uint2>(p.shadow1, px, py, 8));
-            sum = add4(sum, mul4(sv, w));
+            sum = fma4(sv, w, sum);
             wsum += w;
             if (!lits) {
-                penSum += ps * w;
+                penSum = fma_(ps, w, penSum);
                 penW += w;
             }
         }
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
         int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
         uint2 val = uint2{0xffffffffu, 0xffffffffu};
         if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
-            float zt = ld<float>(p.guide, px, py, 8, 0);
+            float zt = ld<float>(p.guide, px, py, 16, 0);
             if (absf(zt) <= c.denoisingRange)
                 val = ld<uint2>(p.shadow2, px, py, 8);
         }
@@ -215,9 +227,10 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
         return;
-    float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+    const int gy0 = y + c.yOff;
+    float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     bool split = u < c.splitScreen;
-    uint2 graw = ld<uint2>(p.guide, x, y, 8);
+    uint4 graw = ld<uint4>(p.guide, x, y, 16);
     float z = u2f(graw.x);
     if (!(absf(z) <= c.denoisingRange)) {
         st<uint32_t>(p.hist, x, y, 4, 0u);
@@ -233,16 +246,16 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
             uint2 raw = tile[((int)threadIdx.y + j) * 20 + (int)threadIdx.x + i];
             f4 f = raw.x == 0xffffffffu && raw.y == 0xffffffffu ? cur : unpack_h4(raw);
             m1[0] += f.x;
-            m2[0] += f.x * f.x;
+            m2[0] = fma_(f.x, f.x, m2[0]);
             m1[1] += f.y;
-            m2[1] += f.y * f.y;
+            m2[1] = fma_(f.y, f.y, m2[1]);
             m1[2] += f.z;
-            m2[2] += f.z * f.z;
+            m2[2] = fma_(f.z, f.z, m2[2]);
             m1[3] += f.w;
-            m2[3] += f.w * f.w;
+            m2[3] = fma_(f.w, f.w, m2[3]);
         }
-    f3 Xv = reconstruct(c.fr, u, v, z);
-    f3 N = unpack_normal(graw.y);
+    Guide g = decode_guide(graw, c.denoisingRange);
+    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
     f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
     f3 Xw = rot3(c.v2w, Xv);
     f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
@@ -254,19 +267,19 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
         XvPrev = rot3(c.w2vPrev, sub3(XwPrev, cd));
         uvOk = project(c.pjPrev, XvPrev, su, sv);
     } else {
-        su = u + mvRaw.x * c.mvScale[0];
-        sv = v + mvRaw.y * c.mvScale[1];
+        su = fma_(mvRaw.x, c.mvScale[0], u);
+        sv = fma_(mvRaw.y, c.mvScale[1], v);
         if (c.mvScale[2] != 0.0f)
-            XvPrev = reconstruct(c.frPrev, su, sv, z + mvRaw.z * c.mvScale[2]);
+            XvPrev = reconstruct(c.frPrev, su, sv, fma_(mvRaw.z, c.mvScale[2], z));
         else
             XvPrev = rot3(c.w2vPrev, sub3(Xw, cd));
     }
     f4 hist = cur;
     bool have = false;
     if (c.historyOk && uvOk) {
-        f3 NvPrev = rot3(c.w2vPrev, N);
+        f3 NvPrev = rot3(c.w2vPrev, g.n);
         float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(XvPrev.z);
-        float px = su * (float)c.Wprev - 0.5f, py = sv * (float)c.Hprev - 0.5f;
+        float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
         float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
         float fx = px - fx0, fy = py - fy0;
         bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
@@ -274,6 +287,8 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
             int ix = (int)fx0, iy = (int)fy0;
             float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
             float planeRef = dot3(NvPrev, XvPrev);
+            float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+            float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
             f4 sum = {0, 0, 0, 0};
             float wsum = 0.0f;
 #pragma unroll
@@ -281,15 +296,13 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
                 int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
                 if (ttx < 0 || ttx >= c.Wprev || gy < 0 || gy >= c.Hprev || tty < 0 || tty >= c.resH)
                     continue;
-                uint2 gp = ld<uint2>(p.guidePrev, ttx, tty, 8);
-                float zp = u2f(gp.x);
-                if (!(absf(zp) <= c.denoisingRange))
+                Guide gp = decode_guide(ld<uint4>(p.guidePrev, ttx, tty, 16), c.denoisingRange);
+                if (gp.sky)
                     continue;
-                f3 Xp = reconstruct(c.frPrev, ((float)ttx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, zp);
-                f3 Np = unpack_normal(gp.y);
-                if (!(absf(dot3(NvPrev, Xp) - planeRef) <= threshold) || !(dot3(N, Np) > PREV_NORMAL_COS))
+                float plane = gp.z * fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
+                if (!(absf(plane - planeRef) <= threshold) || !(dot3(g.n, gp.n) > PREV_NORMAL_COS))
                     continue;
-                sum = add4(sum, mul4(decode_shadow(ld<uint32_t>(p.histPrev, ttx, tty, 4)), bw[i]));
+                sum = fma4(decode_shadow(ld<uint32_t>(p.histPrev, ttx, tty, 4)), bw[i], sum);
                 wsum += bw[i];
             }
             if (wsum > 0.0f) {
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
         float a = m1[ch] * (1.0f / 25.0f), b = m2[ch] * (1.0f / 25.0f);
-        float sigma = __builtin_sqrtf(fmax2(b - a * a, 0.0f)) * STAB_SIGMA_SCALE;
+        float sigma = __builtin_sqrtf(fmax2(fma_(-a, a, b), 0.0f)) * STAB_SIGMA_SCALE;
         float hcl = clampf(hc[ch], a - sigma, a + sigma);
         o[ch] = lerpf(cc[ch], hcl, w);
     }

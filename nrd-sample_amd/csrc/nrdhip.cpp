@@ -145,8 +145,8 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
         uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
-        perm.push_back({"REBLUR::Guide_A", F::RG32_UINT, 8, 1});
-        perm.push_back({"REBLUR::Guide_B", F::RG32_UINT, 8, 1});
+        perm.push_back({"REBLUR::Guide_A", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"REBLUR::Guide_B", F::RGBA32_UINT, 16, 1});
         perm.push_back({"REBLUR::Data1_A", F::R16_UINT, 2, 1});
         perm.push_back({"REBLUR::Data1_B", F::R16_UINT, 2, 1});
         perm.push_back({"REBLUR::History", fmtRad, bRad, 1});
@@ -161,8 +161,8 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"REBLUR::Data2", F::R32_UINT, 4, 1});
         trans.push_back({"REBLUR::SpecHitDistForTracking", F::R16_SFLOAT, 2, 1});
     } else if (d.kind == Kind::SIGMA) {
-        perm.push_back({"SIGMA::Guide_A", F::RG32_UINT, 8, 1});
-        perm.push_back({"SIGMA::Guide_B", F::RG32_UINT, 8, 1});
+        perm.push_back({"SIGMA::Guide_A", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"SIGMA::Guide_B", F::RGBA32_UINT, 16, 1});
         perm.push_back({"SIGMA::History_A", F::RGBA8_UNORM, 4, 1});
         perm.push_back({"SIGMA::History_B", F::RGBA8_UNORM, 4, 1});
         trans.push_back({"SIGMA::Tiles", F::R16_UINT, 2, 16});
@@ -228,6 +228,15 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     if (!projection(cs.viewToClipMatrix, c.pj, c.fr) || !projection(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev)) {
         err = "only perspective projections are supported";
         return false;
+    }
+    for (int k = 0; k < 2; k++) {
+        float* pv = k ? c.pvPrev : c.pv;
+        const float* fr = k ? c.frPrev : c.fr;
+        float iw = k ? c.invWprev : c.invW, ih = k ? c.invHprev : c.invH;
+        pv[2] = fr[2] * iw;
+        pv[3] = fr[3] * ih;
+        pv[0] = fr[0] + 0.5f * pv[2];
+        pv[1] = fr[1] + 0.5f * pv[3];
     }
     auto camera = [](const float* M, float* R, float* Rt, float* pos) {
         for (int r = 0; r < 3; r++)
@@ -317,6 +326,9 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
     p.historyFixFrameNum = (int)s.historyFixFrameNum;
     p.historyFixStride = (int)s.historyFixBasePixelStride;
+    p.reachPre = (int)(std::max(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) * 1.1f) + 3;
+    p.reachBlur = (int)((s.maxBlurRadius + s.minBlurRadius) * 1.1f) + 3;
+    p.reachPost = (int)((s.maxBlurRadius + s.minBlurRadius) * 2.2f) + 3;
     p.minMatDiff = s.minMaterialForDiffuse;
     p.minMatSpec = s.minMaterialForSpecular;
     p.clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum ? 1 : 0;
@@ -349,17 +361,17 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
 
     float n = (float)d.nsig;
     float sp = d.hasSpec ? 2.0f : 0.0f;
-    uint16_t blurHalo = (uint16_t)(s.maxBlurRadius + s.minBlurRadius + 2.0f);
-    uint16_t preHalo = (uint16_t)(std::max(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) + 2.0f);
+    uint16_t blurHalo = (uint16_t)p.reachBlur, postHalo = (uint16_t)p.reachPost, preHalo = (uint16_t)p.reachPre;
+    const float GB = 16.0f; // guide texel bytes
     {
-        Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + 8 + 1.0f / 256.0f, {}, {}, nullptr};
+        Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
         x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, 8 + 8 * n + 8 * n + sp, {}, {}, nullptr};
+        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * n + 8 * n + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         if (d.hasDiff)
             x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
@@ -371,7 +383,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"REBLUR::TemporalAccumulation", "nrd_reblur_temporal_accumulation", 0,
-                   8 + 8 + 8 + 2 + 8 * n + 8 * n + 2 * n + sp + 8 * n + 2 * n + 2 + 4, {}, {}, nullptr};
+                   GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + sp + 8 * n + 2 * n + 2 + 4, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST),
                   P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1)), T(rb::HITTRACK)};
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
@@ -380,21 +392,21 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"REBLUR::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
-                   8 + 2 + 8 * n + 2 * n + 8 * n + 2, {}, {}, nullptr};
+                   GB + 2 + 8 * n + 2 * n + 8 * n + 2, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
         x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, 8 + 2 + 8 * n + 8 * n, {}, {}, nullptr};
+        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, GB + 2 + 8 * n + 8 * n, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
         x.written = {T(rb::TMP2)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 1, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", (uint16_t)(2 * blurHalo), 8 + 2 + 8 * n + 8 * n, {}, {}, nullptr};
+        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, GB + 2 + 8 * n + 8 * n, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
         x.written = {P(rb::HIST)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 2, st); };
@@ -402,7 +414,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"REBLUR::TemporalStabilization", "nrd_reblur_temporal_stabilization", 2,
-                   8 + 2 + 4 + 8 + 8 * n + 2 * n + sp + 8 * n + 2 * n, {}, {}, nullptr};
+                   GB + 2 + 4 + 8 + 8 * n + 2 * n + sp + 8 * n + 2 * n, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::DATA2), enc_slot(RT::IN_MV), P(rb::HIST), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
         x.written = {P(rb::STAB_A + cur)};
         if (d.hasDiff) {
@@ -450,8 +462,9 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.pen1 = TP(sg::PEN1);
     p.shadow2 = TP(sg::SHADOW2);
     float tr = d.translucency ? 4.0f : 0.0f;
+    const float GB = 16.0f;
     {
-        Dispatch x{"SIGMA::ClassifyTiles", "nrd_sigma_classify_tiles", 0, 4 + 4 + 2 + 8 + 2.0f / 256.0f, {}, {}, nullptr};
+        Dispatch x{"SIGMA::ClassifyTiles", "nrd_sigma_classify_tiles", 0, 4 + 4 + 2 + GB + 2.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS), enc_slot(RT::IN_PENUMBRA)};
         x.written = {P(sg::GUIDE_A + cur), T(sg::TILES)};
         x.launch = [p](hipStream_t st) { launch_sigma_classify_tiles(p, st); };
@@ -465,7 +478,7 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"SIGMA::Blur", "nrd_sigma_blur", 50, 8 + 2 + tr + 8 + 2, {}, {}, nullptr};
+        Dispatch x{"SIGMA::Blur", "nrd_sigma_blur", 56, GB + 2 + tr + 8 + 2, {}, {}, nullptr};
         x.read = {P(sg::GUIDE_A + cur), T(sg::TILES_SMOOTH), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             x.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
@@ -474,14 +487,14 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"SIGMA::PostBlur", "nrd_sigma_post_blur", 50, 8 + 8 + 2 + 8, {}, {}, nullptr};
+        Dispatch x{"SIGMA::PostBlur", "nrd_sigma_post_blur", 56, GB + 8 + 2 + 8, {}, {}, nullptr};
         x.read = {P(sg::GUIDE_A + cur), T(sg::TILES_SMOOTH), T(sg::SHADOW1), T(sg::PEN1)};
         x.written = {T(sg::SHADOW2)};
         x.launch = [p](hipStream_t st) { launch_sigma_blur(p, 1, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"SIGMA::TemporalStabilization", "nrd_sigma_temporal_stabilization", 2, 8 + 8 + 8 + 8 + 4 + 4 + 4, {}, {}, nullptr};
+        Dispatch x{"SIGMA::TemporalStabilization", "nrd_sigma_temporal_stabilization", 2, GB + GB + 8 + 8 + 4 + 4 + 4, {}, {}, nullptr};
         x.read = {P(sg::GUIDE_A + cur), P(sg::GUIDE_A + (cur ^ 1)), P(sg::HIST_A + (cur ^ 1)), T(sg::SHADOW2), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             x.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
@@ -576,7 +589,7 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
                 size_t bytes = (size_t)P.pitch * P.h;
                 if (hipMalloc((void**)&P.p, bytes) != hipSuccess)
                     return false;
-                hipMemset(P.p, 0, bytes);
+                (void)hipMemset(P.p, 0, bytes);
                 P.owned = true;
             }
             planes.push_back(P);
@@ -598,7 +611,7 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
     for (auto* v : {&inst->perm, &inst->trans})
         for (auto& P : *v)
             if (P.owned && P.p)
-                hipFree(P.p);
+                (void)hipFree(P.p);
     delete inst;
 }
 
@@ -748,7 +761,7 @@ NRDHIP_API int nrdhip_denoise_range(nrdhip_instance* inst, const uint32_t* ids, 
                 }
         if (fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
             for (uint32_t k = d.permBase; k < d.permEnd; k++)
-                hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);
+                (void)hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);
         x.launch(st);
         if (fl[i].index + 1 == d.dispatches.size()) {
             d.framesSinceReset = (reset || !d.historyValid) ? 1 : d.framesSinceReset + 1;

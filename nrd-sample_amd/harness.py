@@ -58,7 +58,7 @@ class Harness:
     def upload(self, frame):
         """numpy frame dict -> byte planes resident where the backend computes"""
         out = {}
-        for key in set(k for k, _ in INPUT_SLOTS.values()):
+        for key in sorted(set(k for k, _ in INPUT_SLOTS.values())):
             if key not in frame:
                 continue
             if hasattr(frame[key], "data_ptr"):  # already a device tensor (frames generated on the GPU)
@@ -112,3 +112,12 @@ class Harness:
     def pool(self, name):
         p = self.nrd.pool_plane(name)
         return self.fetch(p["buf"])
+
+
+def pingpong(n, f):
+    """camera path position of step f: 0,1,..,n-1,n-2,..,1,0,1,.. (motion vectors stay consistent in both directions)"""
+    if n == 1:
+        return 0
+    period = 2 * (n - 1)
+    k = f % period
+    return k if k < n else period - k

@@ -75,6 +75,15 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
         err = "only perspective projections are supported";
         return false;
     }
+    for (int k = 0; k < 2; k++) {
+        float* pv = k ? c.pvPrev : c.pv;
+        const float* fr = k ? c.frPrev : c.fr;
+        float iw = k ? c.invWprev : c.invW, ih = k ? c.invHprev : c.invH;
+        pv[2] = fr[2] * iw;
+        pv[3] = fr[3] * ih;
+        pv[0] = fr[0] + 0.5f * pv[2];
+        pv[1] = fr[1] + 0.5f * pv[3];
+    }
     auto rotpos = [&](const float* M, float* R, float* pos) {
         for (int r = 0; r < 3; r++)
             for (int col = 0; col < 3; col++)

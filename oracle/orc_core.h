@@ -71,6 +71,7 @@ struct Consts {
     int ownY0 = 0, ownY1 = 0; // local rows this instance produces [ownY0, ownY1)
     float invW = 0, invH = 0, invWprev = 0, invHprev = 0;
     float fr[4] = {}, frPrev[4] = {}; // x0, y0, dx, dy : Xv.xy = z * (uv * d + o)
+    float pv[4] = {}, pvPrev[4] = {}; // view ray of pixel (px, gy): (pv0 + pv2 * px, pv1 + pv3 * gy, 1)
     float pj[5] = {}, pjPrev[5] = {}; // m0, m5, m8, m9, s (clip.w = s * z)
     float w2v[9] = {}, w2vPrev[9] = {}, v2w[9] = {}, v2wPrev[9] = {};
     float camDelta[3] = {}; // camera position prev - current (world)
@@ -86,6 +87,8 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
 
 // view position from uv and (signed) viewZ
 static inline f3 reconstruct(const float* fr, float u, float v, float z) { return {z * (u * fr[2] + fr[0]), z * (v * fr[3] + fr[1]), z}; }
+// view position of the centre of pixel (px, gy) at (signed) viewZ
+static inline f3 reconstruct_px(const float* pv, float px, float gy, float z) { return {z * fma_(pv[2], px, pv[0]), z * fma_(pv[3], gy, pv[1]), z}; }
 // view position -> uv; false when the point is not in front of the camera
 static inline bool project(const float* pj, f3 X, float& u, float& v) {
     float cw = pj[4] * X.z;
@@ -95,6 +98,51 @@ static inline bool project(const float* pj, f3 X, float& u, float& v) {
     u = 0.5f + 0.5f * ((pj[0] * X.x + pj[2] * X.z) * inv);
     v = 0.5f - 0.5f * ((pj[1] * X.y + pj[3] * X.z) * inv);
     return true;
+}
+
+// ---- guide texel (16 bytes): {viewZ f32 | nx f16, ny f16 | nz f16, roughness f16 | materialID u32} ----------------
+// written once per pixel by the ClassifyTiles passes from IN_VIEWZ + IN_NORMAL_ROUGHNESS, so that every bilateral tap
+// decodes its guides with four f16 -> f32 converts instead of an octahedral decode + normalisation.
+struct Guide {
+    float z; // signed view z (already multiplied by viewZScale)
+    f3 n;
+    float roughness;
+    uint32_t mat;
+    bool sky;
+};
+static inline void store_guide(const Plane& G, int x, int y, float z, uint32_t packedNR) {
+    NormalRoughness nr = unpack_normal_roughness(packedNR);
+    st_f32(G, x, y, z, 0);
+    st_u16(G, x, y, f32_to_f16(nr.n.x), 4);
+    st_u16(G, x, y, f32_to_f16(nr.n.y), 6);
+    st_u16(G, x, y, f32_to_f16(nr.n.z), 8);
+    st_u16(G, x, y, f32_to_f16(nr.roughness), 10);
+    st_u32(G, x, y, nr.materialID, 12);
+}
+static inline Guide load_guide(const Plane& G, int x, int y, float range) {
+    Guide g;
+    g.z = ld_f32(G, x, y, 0);
+    g.n = {ld_h(G, x, y, 4), ld_h(G, x, y, 6), ld_h(G, x, y, 8)};
+    g.roughness = ld_h(G, x, y, 10);
+    g.mat = ld_u32(G, x, y, 12);
+    g.sky = !(absf(g.z) <= range);
+    return g;
+}
+static inline float guide_roughness(const Plane& G, int x, int y) { return ld_h(G, x, y, 10); }
+// material comparison: ids differ and the larger one takes part in material-aware filtering
+static inline bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
+
+// hard bound (pixels, rows and columns) on how far a bilateral tap may land from its centre; also the halo a row-tiled
+// instance needs for the pass
+struct ReblurReach {
+    int pre, blur, post;
+};
+static inline ReblurReach reblur_reach(const nrd::ReblurSettings& s) {
+    ReblurReach r;
+    r.pre = (int)(fmax2(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) * 1.1f) + 3;
+    r.blur = (int)((s.maxBlurRadius + s.minBlurRadius) * 1.1f) + 3;
+    r.post = (int)((s.maxBlurRadius + s.minBlurRadius) * 2.2f) + 3;
+    return r;
 }
 
 // ---- denoiser bookkeeping -----------------------------------------------------------------------

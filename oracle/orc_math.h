@@ -34,14 +34,16 @@ static inline float fmin2(float a, float b) { return a < b ? a : b; }
 static inline float fmax2(float a, float b) { return a > b ? a : b; }
 static inline float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
 static inline float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
-static inline float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+// fused multiply-add: ONE rounding (hardware FMA on both sides: x86 -mfma / v_fma_f32); everything else stays unfused
+static inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 static inline float smoothstep01(float x) { x = sat(x); return x * x * (3.0f - 2.0f * x); }
 static inline float absf(float x) { return x < 0.0f ? -x : x; }
 
 static inline f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 static inline f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 static inline f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 static inline f3 normalize3(f3 a) {
     float l2 = dot3(a, a);
@@ -50,7 +52,7 @@ static inline f3 normalize3(f3 a) {
 }
 // 3x3 matrix (row-major m[r*3+c]) times vector
 static inline f3 rot3(const float* m, f3 v) {
-    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+    return {fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[5], v.z, fma_(m[4], v.y, m[3] * v.x)), fma_(m[8], v.z, fma_(m[7], v.y, m[6] * v.x))};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -112,12 +114,12 @@ static inline float exp2_poly(float x) {
     float fi = floorf(x + 0.5f);
     float f = x - fi;
     float p = 1.535336188319500e-4f;
-    p = p * f + 1.339887440266574e-3f;
-    p = p * f + 9.618437357674640e-3f;
-    p = p * f + 5.550332471162809e-2f;
-    p = p * f + 2.402264791363012e-1f;
-    p = p * f + 6.931472028550421e-1f;
-    p = p * f + 1.0f;
+    p = fma_(p, f, 1.339887440266574e-3f);
+    p = fma_(p, f, 9.618437357674640e-3f);
+    p = fma_(p, f, 5.550332471162809e-2f);
+    p = fma_(p, f, 2.402264791363012e-1f);
+    p = fma_(p, f, 6.931472028550421e-1f);
+    p = fma_(p, f, 1.0f);
     int32_t e = (int32_t)fi;
     float scale = u2f((uint32_t)(e + 127) << 23);
     return p * scale;
@@ -137,14 +139,14 @@ static inline float log2_poly(float x) {
     float t = m - 1.0f;
     float z = t * t;
     float p = 7.0376836292e-2f;
-    p = p * t - 1.1514610310e-1f;
-    p = p * t + 1.1676998740e-1f;
-    p = p * t - 1.2420140846e-1f;
-    p = p * t + 1.4249322787e-1f;
-    p = p * t - 1.6668057665e-1f;
-    p = p * t + 2.0000714765e-1f;
-    p = p * t - 2.4999993993e-1f;
-    p = p * t + 3.3333331174e-1f;
+    p = fma_(p, t, -1.1514610310e-1f);
+    p = fma_(p, t, 1.1676998740e-1f);
+    p = fma_(p, t, -1.2420140846e-1f);
+    p = fma_(p, t, 1.4249322787e-1f);
+    p = fma_(p, t, -1.6668057665e-1f);
+    p = fma_(p, t, 2.0000714765e-1f);
+    p = fma_(p, t, -2.4999993993e-1f);
+    p = fma_(p, t, 3.3333331174e-1f);
     float y = t * z * p;
     y = y - 0.5f * z;
     float ln = t + y;
@@ -165,10 +167,10 @@ static inline float atan_pos(float x) {
     float t = inv ? 1.0f / x : x;
     float s = t * t;
     float p = 0.0208351f;
-    p = p * s - 0.0851330f;
-    p = p * s + 0.1801410f;
-    p = p * s - 0.3302995f;
-    p = p * s + 0.9998660f;
+    p = fma_(p, s, -0.0851330f);
+    p = fma_(p, s, 0.1801410f);
+    p = fma_(p, s, -0.3302995f);
+    p = fma_(p, s, 0.9998660f);
     p = p * t;
     return inv ? 1.57079633f - p : p;
 }
@@ -176,11 +178,13 @@ static inline float atan_pos(float x) {
 // acos(x) ~ sqrt(2) * sqrt(1 - x), x in [0, 1] (small-angle exact, monotonic)
 static inline float acos_approx(float x) { return 1.41421356f * sqrtf(sat(1.0f - x)); }
 
-// exp(-3 |x|) look-alike used for "exponential" weights: 1 / (x^2 - x + 1) evaluated at x = -3|x|
+// compact-support stand-in for exp(-3 |x|) used by the hit-distance weights: (1 - |x|)^2 clamped (division-free)
 static inline float exp_weight(float ax) {
-    float x = -3.0f * ax;
-    return 1.0f / (x * x - x + 1.0f);
+    float t = sat(1.0f - ax);
+    return t * t;
 }
+// normal weight on the SQUARED angle: angle^2 ~ 2 (1 - cos) (sqrt-free); w2 = 1 / angleMax^2
+static inline float normal_weight(float cosa, float w2) { return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), w2, 1.0f)); }
 
 // ---------------------------------------------------------------------------------------------
 // Packing
@@ -255,7 +259,7 @@ static inline float spec_magic_curve(float roughness) {
 // REBLUR hit distance normalisation: (A + |z| B) * lerp(1, C, 2^(D r^2))
 static inline float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
     float e = exp2_poly(hp[3] * roughness * roughness);
-    return (hp[0] + absViewZ * hp[1]) * lerpf(1.0f, hp[2], e);
+    return fma_(absViewZ, hp[1], hp[0]) * lerpf(1.0f, hp[2], e);
 }
 
 // specular lobe half angle: atan(r^2 * k / (1 - k)), k = 0.75

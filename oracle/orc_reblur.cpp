@@ -27,27 +27,9 @@ const float POST_BLUR_RADIUS_SCALE = 2.0f;
 const float NORMAL_ANGLE_MIN = 0.02f;
 const float PREV_NORMAL_COS = 0.7f;
 
-struct Guide {
-    float z; // signed view z (already multiplied by viewZScale)
-    f3 n;
-    float roughness;
-    uint32_t mat;
-    bool sky;
-};
-
-static inline Guide load_guide(const Plane& G, int x, int y, float range) {
-    Guide g;
-    g.z = ld_f32(G, x, y, 0);
-    NormalRoughness nr = unpack_normal_roughness(ld_u32(G, x, y, 4));
-    g.n = nr.n;
-    g.roughness = nr.roughness;
-    g.mat = nr.materialID;
-    g.sky = !(absf(g.z) <= range);
-    return g;
-}
-
 static inline f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 static inline f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+static inline f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
 static inline f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
 
 static inline void unpack_data1(uint16_t v, float& diffA, float& specA) {
@@ -55,8 +37,8 @@ static inline void unpack_data1(uint16_t v, float& diffA, float& specA) {
     specA = (float)(v >> 8) * 0.25f;
 }
 static inline uint16_t pack_data1(float diffA, float specA) {
-    uint32_t d = (uint32_t)floorf(clampf(diffA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
-    uint32_t s = (uint32_t)floorf(clampf(specA, 0.0f, MAX_ACCUM) * 4.0f + 0.5f);
+    uint32_t d = (uint32_t)floorf(fma_(clampf(diffA, 0.0f, MAX_ACCUM), 4.0f, 0.5f));
+    uint32_t s = (uint32_t)floorf(fma_(clampf(specA, 0.0f, MAX_ACCUM), 4.0f, 0.5f));
     return (uint16_t)(d | (s << 8));
 }
 
@@ -74,11 +56,8 @@ struct Ctx {
     int sigSpec() const { return d.hasDiff ? 1 : 0; }
 };
 
-// material comparison: ids differ and the larger one takes part in material-aware filtering
-static inline bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
-
 // --------------------------------------------------------------------------------------------------
-// K0 ClassifyTiles + guide packing: guide = {viewZ * viewZScale, packed normal/roughness}; tile = 1 if all sky
+// K0 ClassifyTiles + guide packing (orc_core.h encode_guide); tile = 1 if every pixel of the tile is sky
 // --------------------------------------------------------------------------------------------------
 void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int ty1) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
@@ -97,13 +76,37 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
                     if (x >= c.W || y >= c.resH || y + c.yOff >= c.H || y + c.yOff < 0)
                         continue;
                     float z = ld_f32(inZ, x, y) * zs;
-                    st_f32(G, x, y, z, 0);
-                    st_u32(G, x, y, ld_u32(inNR, x, y), 4);
+                    store_guide(G, x, y, z, ld_u32(inNR, x, y));
                     if (absf(z) <= c.denoisingRange)
                         allSky = false;
                 }
             *texel(T, tx, ty) = allSky ? 1 : 0;
         }
+}
+
+// per-pixel geometry shared by the bilateral passes
+struct PixelGeo {
+    f3 Xv, Nv;
+    float absZ, frustumSize;
+    float ga0, gax, gay, geoB; // plane-distance weight: |zs * (ga0 + gax px + gay gy) + geoB|
+};
+
+static inline PixelGeo pixel_geo(const Consts& c, const Guide& g, int x, int gy, float planeDistSensitivity) {
+    PixelGeo p;
+    p.Xv = reconstruct_px(c.pv, (float)x, (float)gy, g.z);
+    p.Nv = rot3(c.w2v, g.n);
+    p.absZ = absf(g.z);
+    p.frustumSize = c.minRectDimMulUnproject * p.absZ;
+    float geoA = 1.0f / (planeDistSensitivity * p.frustumSize);
+    p.gax = p.Nv.x * c.pv[2] * geoA;
+    p.gay = p.Nv.y * c.pv[3] * geoA;
+    p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
+    p.geoB = -dot3(p.Nv, p.Xv) * geoA;
+    return p;
+}
+static inline float geo_weight(const PixelGeo& p, float px, float gy, float zs) {
+    float ga = fma_(p.gax, px, fma_(p.gay, gy, p.ga0));
+    return smoothstep01(1.0f - absf(fma_(zs, ga, p.geoB)));
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -112,10 +115,11 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
 enum Variant { PRE = 0, BLUR = 1, POST = 2 };
 
 struct SpatialIO {
-    const Plane* in[2];  // per signal slot
-    int inOff[2];        // byte offset of the signal inside the texel
+    const Plane* in[2]; // per signal slot
+    int inOff[2];       // byte offset of the signal inside the texel
     const Plane* out[2];
     int outOff[2];
+    int reach; // taps farther than this many pixels (rows or columns) from the centre are rejected
 };
 
 void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1) {
@@ -135,15 +139,16 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     st_h(HT, x, y, 0.0f);
                 continue;
             }
-            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-            f3 Xv = reconstruct(c.fr, u, v, g.z);
-            f3 Nv = rot3(c.w2v, g.n);
-            f3 V = mul3(normalize3(Xv), -1.0f);
-            float absZ = absf(g.z);
-            float frustumSize = c.minRectDimMulUnproject * absZ;
-            float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
-            float geoB = -dot3(Nv, Xv) * geoA;
-            uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, (uint32_t)variant + 1u);
+            int gy0 = y + c.yOff;
+            PixelGeo pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
+            f3 V = mul3(normalize3(pg.Xv), -1.0f);
+            // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane)
+            float inv = 1.0f / (c.pj[4] * g.z);
+            float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
+            float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
+            float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
+            float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
+            uint32_t h = hash_px((uint32_t)x, (uint32_t)gy0, c.frameIndex, (uint32_t)variant + 1u);
             float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
             float diffA = 0.0f, specA = 0.0f;
             if (variant != PRE)
@@ -154,9 +159,9 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
                 f4 center = ld_h4(*io.in[sig], x, y, io.inOff[sig]);
-                float hitNorm = reblur_hitdist_norm(absZ, hp, rough);
+                float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
                 float hitDist = center.w * hitNorm;
-                float hitDistFactor = sat(hitDist / frustumSize);
+                float hitDistFactor = sat(hitDist / pg.frustumSize);
                 float A = isSpec ? specA : diffA;
                 float nonLin = variant == PRE ? 1.0f : 1.0f / (1.0f + A);
                 float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
@@ -164,7 +169,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 if (variant == PRE) {
                     radius = (isSpec ? s.specularPrepassBlurRadius : s.diffusePrepassBlurRadius) * hitDistFactor * smc;
                 } else {
-                    float r = s.maxBlurRadius * lerpf(MIN_CONVERGED_RADIUS_SCALE, 1.0f, nonLin) * lerpf(hitDistFactor, 1.0f, nonLin) + s.minBlurRadius;
+                    float r = fma_(s.maxBlurRadius * lerpf(MIN_CONVERGED_RADIUS_SCALE, 1.0f, nonLin), lerpf(hitDistFactor, 1.0f, nonLin), s.minBlurRadius);
                     r *= variant == POST ? POST_BLUR_RADIUS_SCALE : 1.0f;
                     r *= smc;
                     radius = s.maxBlurRadius != 0.0f ? r : 0.0f;
@@ -173,19 +178,19 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 float wsum = 1.0f;
                 float minHit = hitDist;
                 if (radius > 0.0f) {
-                    float worldRadius = radius * c.unproject * absZ;
+                    float worldRadius = radius * c.unproject * pg.absZ;
                     // kernel basis in view space
                     f3 T, B;
-                    basis3(Nv, T, B);
+                    basis3(pg.Nv, T, B);
                     if (isSpec) {
-                        float NoV = dot3(Nv, V);
-                        f3 R = sub3(mul3(Nv, 2.0f * NoV), V);
+                        float NoV = dot3(pg.Nv, V);
+                        f3 R = sub3(mul3(pg.Nv, 2.0f * NoV), V);
                         float df = spec_dominant_factor(rough);
-                        f3 D = normalize3(add3(Nv, mul3(sub3(R, Nv), df)));
-                        float NoD = dot3(Nv, D);
+                        f3 D = normalize3(add3(pg.Nv, mul3(sub3(R, pg.Nv), df)));
+                        float NoD = dot3(pg.Nv, D);
                         if (NoD < 0.999f && rough < 0.95f) {
-                            f3 Dr = sub3(mul3(Nv, 2.0f * NoD), D);
-                            T = normalize3(cross3(Nv, Dr));
+                            f3 Dr = sub3(mul3(pg.Nv, 2.0f * NoD), D);
+                            T = normalize3(cross3(pg.Nv, Dr));
                             B = cross3(Dr, T);
                             float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
                             T = mul3(T, skew);
@@ -193,44 +198,47 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     }
                     T = mul3(T, worldRadius);
                     B = mul3(B, worldRadius);
+                    // pixel offsets per unit of the (rotated) Poisson coordinates
+                    float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
+                    float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
                     float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
                     float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                    float normalW2 = normalW * normalW;
                     float hitA = 1.0f / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
                     float hitB = -center.w * hitA;
                     float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
                     float roughB = -rough * roughA;
                     for (int t = 0; t < 8; t++) {
-                        float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
-                        float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
-                        f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
-                        float tu, tv;
-                        if (!project(c.pj, Xt, tu, tv))
-                            continue;
-                        float fpx = floorf(tu * (float)c.W), fpy = floorf(tv * (float)c.H);
+                        float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+                        float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                        float fpx = floorf(fma_(ox, jtx, fma_(oy, jbx, (float)x + 0.5f)));
+                        float fpy = floorf(fma_(ox, jty, fma_(oy, jby, (float)gy0 + 0.5f)));
                         if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
                             continue;
                         int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+                        int ddx = px - x, ddy = gy - gy0;
+                        if (ddx > io.reach || -ddx > io.reach || ddy > io.reach || -ddy > io.reach)
+                            continue;
                         if (py < 0 || py >= c.resH)
                             continue;
                         Guide gs = load_guide(G, px, py, c.denoisingRange);
                         if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                             continue;
-                        f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
                         float w = g_poisson8[t][2];
-                        w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
-                        w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                        w *= geo_weight(pg, fpx, fpy, gs.z);
+                        w *= normal_weight(dot3(g.n, gs.n), normalW2);
                         if (isSpec)
-                            w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                            w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         f4 sv = ld_h4(*io.in[sig], px, py, io.inOff[sig]);
-                        w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(sv.w * hitA + hitB)));
-                        sum = add4(sum, mul4(sv, w));
+                        w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
+                        sum = fma4(sv, w, sum);
                         wsum += w;
                         if (w > 0.0f)
                             minHit = fmin2(minHit, sv.w * hitNorm);
                     }
                 }
-                float inv = 1.0f / wsum;
-                st_h4(*io.out[sig], x, y, mul4(sum, inv), io.outOff[sig]);
+                float invw = 1.0f / wsum;
+                st_h4(*io.out[sig], x, y, mul4(sum, invw), io.outOff[sig]);
                 if (variant == PRE && isSpec)
                     st_h(HT, x, y, minHit);
             }
@@ -252,10 +260,10 @@ static inline Reproj reproject(const Consts& c, f3 Xv, float u, float v, f4 mvRa
     Reproj r;
     r.Xw = rot3(c.v2w, Xv);
     f3 mv = {mvRaw.x * c.mvScale[0], mvRaw.y * c.mvScale[1], mvRaw.z * c.mvScale[2]};
+    f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
     if (c.mvWorld) {
         r.XwPrev = add3(r.Xw, mv);
-        f3 rel = sub3(r.XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
-        r.XvPrev = rot3(c.w2vPrev, rel);
+        r.XvPrev = rot3(c.w2vPrev, sub3(r.XwPrev, cd));
         r.zPrev = r.XvPrev.z;
         if (!project(c.pjPrev, r.XvPrev, r.su, r.sv)) {
             r.su = -10.0f;
@@ -267,12 +275,10 @@ static inline Reproj reproject(const Consts& c, f3 Xv, float u, float v, f4 mvRa
         if (c.mvScale[2] != 0.0f) {
             r.zPrev = Xv.z + mv.z;
             r.XvPrev = reconstruct(c.frPrev, r.su, r.sv, r.zPrev);
-            // world position of the previous-frame point, relative to the current camera
-            r.XwPrev = add3(rot3(c.v2wPrev, r.XvPrev), {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
+            r.XwPrev = add3(rot3(c.v2wPrev, r.XvPrev), cd); // relative to the current camera
         } else {
             r.XwPrev = r.Xw; // static point
-            f3 rel = sub3(r.XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
-            r.XvPrev = rot3(c.w2vPrev, rel);
+            r.XvPrev = rot3(c.w2vPrev, sub3(r.XwPrev, cd));
             r.zPrev = r.XvPrev.z;
         }
     }
@@ -291,7 +297,7 @@ static inline Footprint footprint(const Ctx& k, float pu, float pv, f3 NvPrev, f
     const Consts& c = k.c;
     const Plane& GP = k.guidePrev();
     Footprint f;
-    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
     float fx0 = floorf(px), fy0 = floorf(py);
     float fx = px - fx0, fy = py - fy0;
     bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
@@ -301,13 +307,15 @@ static inline Footprint footprint(const Ctx& k, float pu, float pv, f3 NvPrev, f
     f.wsum = 0.0f;
     f.bits = 0;
     float planeRef = dot3(NvPrev, XvPrev);
+    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+    float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
         bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
         if (ok) {
             Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
-            f3 Xp = reconstruct(c.frPrev, ((float)tx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, gp.z);
-            ok = !gp.sky && absf(dot3(NvPrev, Xp) - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
+            float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+            ok = !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
         }
         f.w[i] = ok ? bw[i] : 0.0f;
         f.wsum += f.w[i];
@@ -320,14 +328,14 @@ static inline f4 fetch4(const Ctx& k, const Plane& P, int off, const Footprint& 
     f4 s = {0, 0, 0, 0};
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
-            s = add4(s, mul4(ld_h4(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off), f.w[i]));
+            s = fma4(ld_h4(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off), f.w[i], s);
     return mul4(s, 1.0f / f.wsum);
 }
 static inline float fetch1(const Ctx& k, const Plane& P, int off, const Footprint& f) {
     float s = 0.0f;
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
-            s += ld_h(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off) * f.w[i];
+            s = fma_(ld_h(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off), f.w[i], s);
     return s * (1.0f / f.wsum);
 }
 static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, float& dA, float& sA) {
@@ -336,8 +344,8 @@ static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, floa
         if (f.w[i] > 0.0f) {
             float a, b;
             unpack_data1(ld_u16(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff), a, b);
-            dA += a * f.w[i];
-            sA += b * f.w[i];
+            dA = fma_(a, f.w[i], dA);
+            sA = fma_(b, f.w[i], sA);
         }
     float inv = 1.0f / f.wsum;
     dA *= inv;
@@ -359,7 +367,7 @@ static inline bool virtual_uv(const Consts& c, const Reproj& r, float hitDist, f
 static inline float sample_confidence(const Plane& P, float u, float v) {
     if (!P.p)
         return 1.0f;
-    float px = u * (float)P.w - 0.5f, py = v * (float)P.h - 0.5f;
+    float px = fma_(u, (float)P.w, -0.5f), py = fma_(v, (float)P.h, -0.5f);
     float fx0 = floorf(px), fy0 = floorf(py);
     float fx = px - fx0, fy = py - fy0;
     int x0 = (int)fx0, y0 = (int)fy0;
@@ -376,10 +384,10 @@ static inline float sample_confidence(const Plane& P, float u, float v) {
 // surface-motion specular accumulation limit under parallax
 static inline float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
     float acos01sq = sat(1.0f - NoV * 0.99999f);
-    float a = pow01(acos01sq, 0.5f);
-    float b = 1.1f + roughness * roughness;
+    float a = sqrtf(acos01sq);
+    float b = fma_(roughness, roughness, 1.1f);
     float parallaxSensitivity = (b + a) / (b - a);
-    float powerScale = 1.0f + parallaxSensitivity * parallaxPx * 2.0f;
+    float powerScale = fma_(parallaxSensitivity * parallaxPx, 2.0f, 1.0f);
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
     f *= pow01(roughness, 0.5f * powerScale);
     return MAX_ACCUM * f;
@@ -419,8 +427,9 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 st_u32(D2, x, y, 0);
                 continue;
             }
-            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-            f3 Xv = reconstruct(c.fr, u, v, g.z);
+            int gy0 = y + c.yOff;
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
+            f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
             f3 Nv = rot3(c.w2v, g.n);
             f3 V = mul3(normalize3(Xv), -1.0f);
             float NoV = absf(dot3(Nv, V));
@@ -464,7 +473,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 float pu, pv, parallax = 0.0f;
                 if (project(c.pj, XparV, pu, pv)) {
                     float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
-                    parallax = sqrtf(dx * dx + dy * dy);
+                    parallax = sqrtf(fma_(dx, dx, dy * dy));
                 }
                 float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
                 // virtual motion
@@ -482,10 +491,10 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                         float prevRough = 0.0f;
                         for (int i = 0; i < 4; i++)
                             if (vmb.w[i] > 0.0f)
-                                prevRough += unpack_normal_roughness(ld_u32(k.guidePrev(), vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff, 4)).roughness * vmb.w[i];
+                                prevRough = fma_(guide_roughness(k.guidePrev(), vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff), vmb.w[i], prevRough);
                         prevRough *= 1.0f / vmb.wsum;
                         float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * s.roughnessFraction));
-                        float rconf = smoothstep01(1.0f - absf(prevRough * roughA - g.roughness * roughA));
+                        float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
                         amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
                         float dA, sA;
                         fetchA(k, D1P, vmb, dA, sA);
@@ -514,7 +523,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
                 st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
                 outSpecA = A;
-                data2 |= (vmb.bits << 4) | ((uint32_t)floorf(sat(amount) * 255.0f + 0.5f) << 8);
+                data2 |= (vmb.bits << 4) | ((uint32_t)floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8);
             }
             st_u16(D1T, x, y, pack_data1(outDiffA, outSpecA));
             st_u32(D2, x, y, data2);
@@ -544,15 +553,12 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                 st_u16(D1C, x, y, 0);
                 continue;
             }
-            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-            f3 Xv = reconstruct(c.fr, u, v, g.z);
-            f3 Nv = rot3(c.w2v, g.n);
-            float frustumSize = c.minRectDimMulUnproject * absf(g.z);
-            float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
-            float geoB = -dot3(Nv, Xv) * geoA;
+            int gy0 = y + c.yOff;
             float A[2];
             unpack_data1(ld_u16(D1T, x, y), A[0], A[1]);
             float outA[2] = {A[0], A[1]};
+            bool geoReady = false;
+            PixelGeo pg;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
                 int ai = isSpec ? 1 : 0;
@@ -563,10 +569,15 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                 // ---- history reconstruction
                 if (Acur < (float)s.historyFixFrameNum && s.historyFixFrameNum > 0) {
                     float normA = sat(Acur / (float)s.historyFixFrameNum);
-                    int stride = (int)floorf((float)s.historyFixBasePixelStride * (1.0f - normA) + 0.5f);
+                    int stride = (int)floorf(fma_((float)s.historyFixBasePixelStride, 1.0f - normA, 0.5f));
                     if (stride > 0) {
+                        if (!geoReady) {
+                            pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
+                            geoReady = true;
+                        }
                         float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, 1.0f / (1.0f + Acur));
                         float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                        float normalW2 = normalW * normalW;
                         float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
                         float roughB = -rough * roughA;
                         f4 sum = mul4(val, 1.0f + Acur);
@@ -581,16 +592,15 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                 Guide gs = load_guide(G, px, py, c.denoisingRange);
                                 if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                                     continue;
-                                f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, gs.z);
                                 float w = 1.0f / (1.0f + (float)(i * i + j * j));
-                                w *= smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
-                                w *= smoothstep01(1.0f - acos_approx(dot3(g.n, gs.n)) * normalW);
+                                w *= geo_weight(pg, (float)px, (float)gy, gs.z);
+                                w *= normal_weight(dot3(g.n, gs.n), normalW2);
                                 if (isSpec)
-                                    w *= smoothstep01(1.0f - absf(gs.roughness * roughA + roughB));
+                                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 float tA[2];
                                 unpack_data1(ld_u16(D1T, px, py), tA[0], tA[1]);
                                 w *= 1.0f + tA[ai];
-                                sum = add4(sum, mul4(ld_h4(IN, px, py, sig * 8), w));
+                                sum = fma4(ld_h4(IN, px, py, sig * 8), w, sum);
                                 wsum += w;
                             }
                         val = mul4(sum, 1.0f / wsum);
@@ -610,11 +620,11 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                     f = ld_h(FAST, px, py, sig * 2);
                             }
                             m1 += f;
-                            m2 += f * f;
+                            m2 = fma_(f, f, m2);
                         }
                     m1 *= 1.0f / 25.0f;
                     m2 *= 1.0f / 25.0f;
-                    float sigma = sqrtf(fmax2(m2 - m1 * m1, 0.0f)) * s.fastHistoryClampingSigmaScale;
+                    float sigma = sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f)) * s.fastHistoryClampingSigmaScale;
                     float Y = val.x;
                     float Yc = clampf(Y, m1 - sigma, m1 + sigma);
                     float scale = (Yc + 1e-6f) / (Y + 1e-6f);
@@ -658,7 +668,8 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
     float maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
-            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+            int gy0 = y + c.yOff;
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
             bool split = u < c.splitScreen;
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
@@ -668,7 +679,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 }
                 continue;
             }
-            f3 Xv = reconstruct(c.fr, u, v, g.z);
+            f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
             Reproj r = reproject(c, Xv, u, v, ld_h4(MV, x, y));
             uint32_t data2 = ld_u32(D2, x, y);
             float A[2];
@@ -688,14 +699,14 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                                 f = ld_h(HIST, px, py, sig * 8);
                         }
                         m1 += f;
-                        m2 += f * f;
+                        m2 = fma_(f, f, m2);
                     }
                 m1 *= 1.0f / 25.0f;
                 m2 *= 1.0f / 25.0f;
-                float sigma = sqrtf(fmax2(m2 - m1 * m1, 0.0f));
+                float sigma = sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f));
                 // stabilized luma history: surface motion footprint (validity bits from TA), virtual motion for specular
                 auto fetchStab = [&](float pu, float pv, uint32_t bits, float& out) -> bool {
-                    float px = pu * (float)c.Wprev - 0.5f, py = pv * (float)c.Hprev - 0.5f;
+                    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
                     float fx0 = floorf(px), fy0 = floorf(py);
                     float fx = px - fx0, fy = py - fy0;
                     bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
@@ -706,7 +717,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     float sum = 0.0f, wsum = 0.0f;
                     for (int i = 0; i < 4; i++)
                         if (bits & (1u << i)) {
-                            sum += ld_h(STABP, ix + (i & 1), iy + (i >> 1) - c.yOff, sig * 2) * bw[i];
+                            sum = fma_(ld_h(STABP, ix + (i & 1), iy + (i >> 1) - c.yOff, sig * 2), bw[i], sum);
                             wsum += bw[i];
                         }
                     if (!(wsum > 0.0f))
@@ -720,7 +731,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     float smbY = 0.0f;
                     bool smbOk = fetchStab(r.su, r.sv, data2 & 15u, smbY);
                     if (isSpec) {
-                        float amount = (float)((data2 >> 8) & 255u) / 255.0f;
+                        float amount = (float)((data2 >> 8) & 255u) * (1.0f / 255.0f);
                         float vu, vv, vmbY = 0.0f;
                         bool vmbOk = amount > 0.0f && virtual_uv(c, r, ld_h(HT, x, y), g.roughness, vu, vv) && fetchStab(vu, vv, (data2 >> 4) & 15u, vmbY);
                         if (smbOk && vmbOk) {
@@ -742,7 +753,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 float Y = cur.x;
                 float band = sigma * s.antilagSettings.luminanceSigmaScale;
                 float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) / (fmax2(Yhist, m1) + 1e-6f);
-                float antilag = 1.0f / (1.0f + dlt * s.antilagSettings.luminanceSensitivity * Acur);
+                float antilag = 1.0f / fma_(dlt * s.antilagSettings.luminanceSensitivity, Acur, 1.0f);
                 float Yclamped = clampf(Yhist, m1 - band, m1 + band);
                 float stabFrames = have ? fmin2(Acur, maxStab) * antilag : 0.0f;
                 float wHist = stabFrames / (1.0f + stabFrames);
@@ -761,8 +772,8 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
     uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
     uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
     uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
-    perm.push_back({"REBLUR::Guide_A", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
-    perm.push_back({"REBLUR::Guide_B", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"REBLUR::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"REBLUR::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
     perm.push_back({"REBLUR::Data1_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     perm.push_back({"REBLUR::Data1_B", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     perm.push_back({"REBLUR::History", fmtRad, bRad, 1});
@@ -787,15 +798,14 @@ void reblur_build(Instance& I, DenoiserState& d) {
     auto T = [&](int i) { return enc_trans(tb + i); };
     float n = (float)d.nsig;
     const nrd::ReblurSettings& s = d.reblur;
-    uint16_t blurHalo = (uint16_t)(s.maxBlurRadius + s.minBlurRadius + 2.0f);
-    uint16_t preHalo = (uint16_t)(fmax2(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) + 2.0f);
-
+    ReblurReach rr = reblur_reach(s);
+    const float GB = 16.0f; // guide texel bytes
     {
         Pass p;
         p.name = "REBLUR::ClassifyTiles";
         p.kernel = "nrd_reblur_classify_tiles";
         p.haloRows = 0;
-        p.bytesPerPixel = 4 + 4 + 8 + 1.0f / 256.0f;
+        p.bytesPerPixel = 4 + 4 + GB + 1.0f / 256.0f;
         p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
         p.tileGrid = true;
@@ -806,8 +816,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         Pass p;
         p.name = "REBLUR::PrePass";
         p.kernel = "nrd_reblur_prepass";
-        p.haloRows = preHalo;
-        p.bytesPerPixel = 8 + 8 * n + 8 * n + (d.hasSpec ? 2 : 0);
+        p.haloRows = (uint16_t)rr.pre;
+        p.bytesPerPixel = GB + 8 * n + 8 * n + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
         if (d.hasDiff)
             p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
@@ -817,6 +827,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
             SpatialIO io = {};
+            io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
                 io.in[sig] = &k.slot(isSpec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
@@ -833,7 +844,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::TemporalAccumulation";
         p.kernel = "nrd_reblur_temporal_accumulation";
         p.haloRows = 0; // previous-frame planes are read at motion-displaced rows: the tiler adds its motion margin
-        p.bytesPerPixel = 8 + 8 + 8 + 2 + 8 * n + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n + 2 + 4;
+        p.bytesPerPixel = GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n + 2 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
         p.run = temporal_accumulation;
@@ -844,7 +855,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::HistoryFix";
         p.kernel = "nrd_reblur_history_fix";
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
-        p.bytesPerPixel = 8 + 2 + 8 * n + 2 * n + 8 * n + 2;
+        p.bytesPerPixel = GB + 2 + 8 * n + 2 * n + 8 * n + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
         p.written = {T(T_TMP1), P(P_DATA1_A + cur)};
         p.run = history_fix;
@@ -854,13 +865,14 @@ void reblur_build(Instance& I, DenoiserState& d) {
         Pass p;
         p.name = "REBLUR::Blur";
         p.kernel = "nrd_reblur_blur";
-        p.haloRows = blurHalo;
-        p.bytesPerPixel = 8 + 2 + 8 * n + 8 * n;
+        p.haloRows = (uint16_t)rr.blur;
+        p.bytesPerPixel = GB + 2 + 8 * n + 8 * n;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
         p.written = {T(T_TMP2)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
             SpatialIO io = {};
+            io.reach = reblur_reach(d.reblur).blur;
             for (int sig = 0; sig < d.nsig; sig++) {
                 io.in[sig] = &k.trans(T_TMP1);
                 io.out[sig] = &k.trans(T_TMP2);
@@ -874,13 +886,14 @@ void reblur_build(Instance& I, DenoiserState& d) {
         Pass p;
         p.name = "REBLUR::PostBlur";
         p.kernel = "nrd_reblur_post_blur";
-        p.haloRows = (uint16_t)(2 * blurHalo);
-        p.bytesPerPixel = 8 + 2 + 8 * n + 8 * n;
+        p.haloRows = (uint16_t)rr.post;
+        p.bytesPerPixel = GB + 2 + 8 * n + 8 * n;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
         p.written = {P(P_HIST)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
             SpatialIO io = {};
+            io.reach = reblur_reach(d.reblur).post;
             for (int sig = 0; sig < d.nsig; sig++) {
                 io.in[sig] = &k.trans(T_TMP2);
                 io.out[sig] = &k.perm(P_HIST);
@@ -895,7 +908,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::TemporalStabilization";
         p.kernel = "nrd_reblur_temporal_stabilization";
         p.haloRows = 2;
-        p.bytesPerPixel = 8 + 2 + 4 + 8 + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n;
+        p.bytesPerPixel = GB + 2 + 4 + 8 + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2), enc_slot(RT::IN_MV), P(P_HIST), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {P(P_STAB_A + cur)};
         if (d.hasDiff) {

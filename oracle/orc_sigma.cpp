@@ -18,6 +18,7 @@ enum Perm { P_GUIDE_A, P_GUIDE_B, P_HIST_A, P_HIST_B };
 enum Trans { T_TILES, T_TILES_SMOOTH, T_SHADOW1, T_PEN1, T_SHADOW2 };
 
 const float MAX_PIXEL_RADIUS = 48.0f;
+const int BLUR_REACH = 56; // (int)(48 * 1.1) + 3
 const float PREV_NORMAL_COS = 0.7f;
 const float STAB_SIGMA_SCALE = 2.0f;
 
@@ -31,8 +32,8 @@ struct Ctx {
     const Plane& slot(nrd::ResourceType t) const { return I.slots[(size_t)t]; }
 };
 
-static inline f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 static inline f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+static inline f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
 
 // visibility signal of a raw input texel: lit -> 1, shadowed -> (0, translucency)
 static inline f4 input_visibility(const Ctx& k, int x, int y, float pen) {
@@ -41,20 +42,20 @@ static inline f4 input_visibility(const Ctx& k, int x, int y, float pen) {
     if (!k.d.translucency)
         return {0, 0, 0, 0};
     const uint8_t* t = texel(k.slot(nrd::ResourceType::IN_TRANSLUCENCY), x, y);
-    return {0.0f, (float)t[1] / 255.0f, (float)t[2] / 255.0f, (float)t[3] / 255.0f};
+    return {0.0f, (float)t[1] * (1.0f / 255.0f), (float)t[2] * (1.0f / 255.0f), (float)t[3] * (1.0f / 255.0f)};
 }
 
 static inline uint32_t encode_shadow(f4 v) {
     uint32_t r = 0;
     float c[4] = {v.x, v.y, v.z, v.w};
     for (int i = 0; i < 4; i++)
-        r |= (uint32_t)floorf(sqrtf(sat(c[i])) * 255.0f + 0.5f) << (8 * i);
+        r |= (uint32_t)floorf(fma_(sqrtf(sat(c[i])), 255.0f, 0.5f)) << (8 * i);
     return r;
 }
 static inline f4 decode_shadow(uint32_t p) {
     float c[4];
     for (int i = 0; i < 4; i++) {
-        float b = (float)((p >> (8 * i)) & 255u) / 255.0f;
+        float b = (float)((p >> (8 * i)) & 255u) * (1.0f / 255.0f);
         c[i] = b * b;
     }
     return {c[0], c[1], c[2], c[3]};
@@ -79,8 +80,7 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
                     if (x >= c.W || y >= c.resH || y + c.yOff >= c.H || y + c.yOff < 0)
                         continue;
                     float z = ld_f32(inZ, x, y) * zs;
-                    st_f32(G, x, y, z, 0);
-                    st_u32(G, x, y, ld_u32(inNR, x, y), 4);
+                    store_guide(G, x, y, z, ld_u32(inNR, x, y));
                     if (!(absf(z) <= c.denoisingRange))
                         continue;
                     float pen = ld_h(inPen, x, y);
@@ -153,48 +153,57 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
             float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
             radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
             float worldRadius = radiusPx * pixelWorld;
-            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
-            f3 Xv = reconstruct(c.fr, u, v, z);
-            f3 N = unpack_normal_roughness(ld_u32(G, x, y, 4)).n;
-            f3 Nv = rot3(c.w2v, N);
+            int gy0 = y + c.yOff;
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
+            f3 Nv = rot3(c.w2v, g.n);
             float frustumSize = c.minRectDimMulUnproject * absZ;
             float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
+            float gax = Nv.x * c.pv[2] * geoA, gay = Nv.y * c.pv[3] * geoA;
+            float ga0 = fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
             float geoB = -dot3(Nv, Xv) * geoA;
             f3 T, B;
             basis3(Nv, T, B);
             T = mul3(T, worldRadius);
             B = mul3(B, worldRadius);
-            uint32_t h = hash_px((uint32_t)x, (uint32_t)(y + c.yOff), c.frameIndex, 17u + (uint32_t)pass);
+            float inv = 1.0f / (c.pj[4] * z);
+            float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
+            float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
+            float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
+            float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
+            float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
+            float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
+            uint32_t h = hash_px((uint32_t)x, (uint32_t)gy0, c.frameIndex, 17u + (uint32_t)pass);
             float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
             f4 sum = center;
             float wsum = 1.0f;
             float penSum = lit ? 0.0f : pen, penW = lit ? 0.0f : 1.0f;
             if (radiusPx > 0.0f)
                 for (int t = 0; t < 8; t++) {
-                    float ox = g_poisson8[t][0] * rc - g_poisson8[t][1] * rs;
-                    float oy = g_poisson8[t][0] * rs + g_poisson8[t][1] * rc;
-                    f3 Xt = add3(Xv, add3(mul3(T, ox), mul3(B, oy)));
-                    float tu, tv;
-                    if (!project(c.pj, Xt, tu, tv))
-                        continue;
-                    float fpx = floorf(tu * (float)c.W), fpy = floorf(tv * (float)c.H);
+                    float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+                    float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                    float fpx = floorf(fma_(ox, jtx, fma_(oy, jbx, (float)x + 0.5f)));
+                    float fpy = floorf(fma_(ox, jty, fma_(oy, jby, (float)gy0 + 0.5f)));
                     if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
                         continue;
                     int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+                    int ddx = px - x, ddy = gy - gy0;
+                    if (ddx > BLUR_REACH || -ddx > BLUR_REACH || ddy > BLUR_REACH || -ddy > BLUR_REACH)
+                        continue;
                     if (py < 0 || py >= c.resH)
                         continue;
                     float zs = ld_f32(G, px, py, 0);
                     if (!(absf(zs) <= c.denoisingRange))
                         continue;
-                    f3 Xs = reconstruct(c.fr, ((float)px + 0.5f) * c.invW, ((float)gy + 0.5f) * c.invH, zs);
-                    float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(dot3(Nv, Xs) * geoA + geoB));
+                    float ga = fma_(gax, fpx, fma_(gay, fpy, ga0));
+                    float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(fma_(zs, ga, geoB)));
                     float ps = ld_h(inPen, px, py);
                     bool lits = pass == 0 ? ps >= FP16_MAX : !(ps > 0.0f);
                     f4 sv = pass == 0 ? input_visibility(k, px, py, ps) : ld_h4(inSh, px, py);
-                    sum = add4(sum, mul4(sv, w));
+                    sum = fma4(sv, w, sum);
                     wsum += w;
                     if (!lits) {
-                        penSum += ps * w;
+                        penSum = fma_(ps, w, penSum);
                         penW += w;
                     }
                 }
@@ -225,7 +234,8 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
     };
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
-            float u = ((float)x + 0.5f) * c.invW, v = ((float)(y + c.yOff) + 0.5f) * c.invH;
+            int gy0 = y + c.yOff;
+            float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
             bool split = u < c.splitScreen;
             float z = ld_f32(G, x, y, 0);
             if (!(absf(z) <= c.denoisingRange)) {
@@ -248,35 +258,36 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     float fc[4] = {f.x, f.y, f.z, f.w};
                     for (int ch = 0; ch < 4; ch++) {
                         m1[ch] += fc[ch];
-                        m2[ch] += fc[ch] * fc[ch];
+                        m2[ch] = fma_(fc[ch], fc[ch], m2[ch]);
                     }
                 }
             // surface-motion reprojection with plane-distance occlusion test
-            f3 Xv = reconstruct(c.fr, u, v, z);
-            f3 N = unpack_normal_roughness(ld_u32(G, x, y, 4)).n;
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
             f4 mvRaw = ld_h4(MV, x, y);
             f3 Xw = rot3(c.v2w, Xv);
+            f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
             float su, sv;
             f3 XvPrev;
             bool uvOk = true;
             if (c.mvWorld) {
                 f3 XwPrev = add3(Xw, {mvRaw.x * c.mvScale[0], mvRaw.y * c.mvScale[1], mvRaw.z * c.mvScale[2]});
-                XvPrev = rot3(c.w2vPrev, sub3(XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]}));
+                XvPrev = rot3(c.w2vPrev, sub3(XwPrev, cd));
                 uvOk = project(c.pjPrev, XvPrev, su, sv);
             } else {
-                su = u + mvRaw.x * c.mvScale[0];
-                sv = v + mvRaw.y * c.mvScale[1];
+                su = fma_(mvRaw.x, c.mvScale[0], u);
+                sv = fma_(mvRaw.y, c.mvScale[1], v);
                 if (c.mvScale[2] != 0.0f)
-                    XvPrev = reconstruct(c.frPrev, su, sv, z + mvRaw.z * c.mvScale[2]);
+                    XvPrev = reconstruct(c.frPrev, su, sv, fma_(mvRaw.z, c.mvScale[2], z));
                 else
-                    XvPrev = rot3(c.w2vPrev, sub3(Xw, {c.camDelta[0], c.camDelta[1], c.camDelta[2]}));
+                    XvPrev = rot3(c.w2vPrev, sub3(Xw, cd));
             }
             f4 hist = cur;
             bool have = false;
             if (historyOk && uvOk) {
-                f3 NvPrev = rot3(c.w2vPrev, N);
+                f3 NvPrev = rot3(c.w2vPrev, g.n);
                 float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(XvPrev.z);
-                float px = su * (float)c.Wprev - 0.5f, py = sv * (float)c.Hprev - 0.5f;
+                float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
                 float fx0 = floorf(px), fy0 = floorf(py);
                 float fx = px - fx0, fy = py - fy0;
                 bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
@@ -284,20 +295,21 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     int ix = (int)fx0, iy = (int)fy0;
                     float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
                     float planeRef = dot3(NvPrev, XvPrev);
+                    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+                    float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
                     f4 sum = {0, 0, 0, 0};
                     float wsum = 0.0f;
                     for (int i = 0; i < 4; i++) {
                         int tx = ix + (i & 1), gy = iy + (i >> 1), ty = gy - c.yOff;
                         if (tx < 0 || tx >= c.Wprev || gy < 0 || gy >= c.Hprev || ty < 0 || ty >= c.resH)
                             continue;
-                        float zp = ld_f32(GP, tx, ty, 0);
-                        if (!(absf(zp) <= c.denoisingRange))
+                        Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
+                        if (gp.sky)
                             continue;
-                        f3 Xp = reconstruct(c.frPrev, ((float)tx + 0.5f) * c.invWprev, ((float)gy + 0.5f) * c.invHprev, zp);
-                        f3 Np = unpack_normal_roughness(ld_u32(GP, tx, ty, 4)).n;
-                        if (!(absf(dot3(NvPrev, Xp) - planeRef) <= threshold) || !(dot3(N, Np) > PREV_NORMAL_COS))
+                        float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+                        if (!(absf(plane - planeRef) <= threshold) || !(dot3(g.n, gp.n) > PREV_NORMAL_COS))
                             continue;
-                        sum = add4(sum, mul4(decode_shadow(ld_u32(HP, tx, ty)), bw[i]));
+                        sum = fma4(decode_shadow(ld_u32(HP, tx, ty)), bw[i], sum);
                         wsum += bw[i];
                     }
                     if (wsum > 0.0f) {
@@ -310,7 +322,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             float hc[4] = {hist.x, hist.y, hist.z, hist.w}, cc[4] = {cur.x, cur.y, cur.z, cur.w}, o[4];
             for (int ch = 0; ch < 4; ch++) {
                 float a = m1[ch] * (1.0f / 25.0f), b = m2[ch] * (1.0f / 25.0f);
-                float sigma = sqrtf(fmax2(b - a * a, 0.0f)) * STAB_SIGMA_SCALE;
+                float sigma = sqrtf(fmax2(fma_(-a, a, b), 0.0f)) * STAB_SIGMA_SCALE;
                 float hcl = clampf(hc[ch], a - sigma, a + sigma);
                 o[ch] = lerpf(cc[ch], hcl, w);
             }
@@ -323,8 +335,8 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
 } // namespace
 
 void sigma_describe(DenoiserState&, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
-    perm.push_back({"SIGMA::Guide_A", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
-    perm.push_back({"SIGMA::Guide_B", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"SIGMA::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"SIGMA::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
     perm.push_back({"SIGMA::History_A", (uint32_t)nrd::Format::RGBA8_UNORM, 4, 1});
     perm.push_back({"SIGMA::History_B", (uint32_t)nrd::Format::RGBA8_UNORM, 4, 1});
     trans.push_back({"SIGMA::Tiles", (uint32_t)nrd::Format::R16_UINT, 2, 16});
@@ -341,12 +353,13 @@ void sigma_build(Instance&, DenoiserState& d) {
     auto P = [&](int i) { return enc_perm(pb + i); };
     auto T = [&](int i) { return enc_trans(tb + i); };
     float tr = d.translucency ? 4.0f : 0.0f;
+    const float GB = 16.0f;
     {
         Pass p;
         p.name = "SIGMA::ClassifyTiles";
         p.kernel = "nrd_sigma_classify_tiles";
         p.haloRows = 0;
-        p.bytesPerPixel = 4 + 4 + 2 + 8 + 2.0f / 256.0f;
+        p.bytesPerPixel = 4 + 4 + 2 + GB + 2.0f / 256.0f;
         p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS), enc_slot(RT::IN_PENUMBRA)};
         p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
         p.tileGrid = true;
@@ -369,8 +382,8 @@ void sigma_build(Instance&, DenoiserState& d) {
         Pass p;
         p.name = "SIGMA::Blur";
         p.kernel = "nrd_sigma_blur";
-        p.haloRows = (uint16_t)MAX_PIXEL_RADIUS + 2;
-        p.bytesPerPixel = 8 + 2 + tr + 8 + 2;
+        p.haloRows = (uint16_t)BLUR_REACH;
+        p.bytesPerPixel = GB + 2 + tr + 8 + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TILES_SMOOTH), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             p.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
@@ -382,8 +395,8 @@ void sigma_build(Instance&, DenoiserState& d) {
         Pass p;
         p.name = "SIGMA::PostBlur";
         p.kernel = "nrd_sigma_post_blur";
-        p.haloRows = (uint16_t)MAX_PIXEL_RADIUS + 2;
-        p.bytesPerPixel = 8 + 8 + 2 + 8;
+        p.haloRows = (uint16_t)BLUR_REACH;
+        p.bytesPerPixel = GB + 8 + 2 + 8;
         p.read = {P(P_GUIDE_A + cur), T(T_TILES_SMOOTH), T(T_SHADOW1), T(T_PEN1)};
         p.written = {T(T_SHADOW2)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { blur(I, d, c, y0, y1, 1); };
@@ -394,7 +407,7 @@ void sigma_build(Instance&, DenoiserState& d) {
         p.name = "SIGMA::TemporalStabilization";
         p.kernel = "nrd_sigma_temporal_stabilization";
         p.haloRows = 2;
-        p.bytesPerPixel = 8 + 8 + 8 + 8 + 4 + 4 + 4;
+        p.bytesPerPixel = GB + GB + 8 + 8 + 4 + 4 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), P(P_HIST_A + (cur ^ 1)), T(T_SHADOW2), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             p.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));

@@ -35,4 +35,6 @@ def test_emulated_dispatch_lists_match(pkg, api, oracle, emulated):
         assert a["written"] == b["written"] and a["read"] == b["read"] and a["halo_rows"] == b["halo_rows"]
         assert abs(a["bytes_per_pixel"] - b["bytes_per_pixel"]) < 1e-4
     total = sum(x["bytes_per_pixel"] for x in lists[1] if x["name"].startswith("REBLUR"))
-    assert 330 < total < 360  # REBLUR_DIFFUSE_SPECULAR algorithmic bytes / pixel / frame (~352)
+    # REBLUR_DIFFUSE_SPECULAR algorithmic bytes / pixel / frame: SURVEY.md 8d estimated ~352 with 8-byte guides; this build
+    # keeps a 16-byte pre-decoded guide texel (+8 B in each of the 8 guide accesses), DESIGN.md "byte accounting"
+    assert 400 < total < 416

@@ -1,0 +1,48 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of the row tiler with the oracle as compute backend must be bit-identical
+to the single-instance run on the whole frame ("N-GPU output must be bit-identical to 1-GPU")."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,frame_h", [(2, 224), (3, 336)])
+def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h):
+    w, nframes, halo = 96, 3, 80
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo)]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    # single-instance run over the whole frame
+    D = api.Denoiser
+    dens = [D.REBLUR_DIFFUSE_SPECULAR, D.SIGMA_SHADOW_TRANSLUCENCY]
+    scene = pkg.synth.Scene(w, frame_h, dolly=0.03)
+    st = {D.REBLUR_DIFFUSE_SPECULAR: api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1),
+          D.SIGMA_SHADOW_TRANSLUCENCY: api.SigmaSettings(lightDirection=list(scene.sun))}
+    keep = []
+    hz = util.run_frames(api, pkg.harness, oracle, scene, dens, nframes, settings=st, keep=keep)
+    parts = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+    for f in range(nframes):
+        for key in ("out_diff", "out_spec", "out_shadow"):
+            tiled = np.concatenate([p["f%d_%s" % (f, key)] for p in parts], 0)
+            assert np.array_equal(tiled, keep[f][key]), (f, key)
+    hist = np.concatenate([p["history"] for p in parts], 0)
+    assert np.array_equal(hist, hz.pool("REBLUR::History"))
+    assert sum(int(p["bytes"][0]) for p in parts) > 0
+    assert [int(p["own0"][0]) for p in parts] == sorted(int(p["own0"][0]) for p in parts)
