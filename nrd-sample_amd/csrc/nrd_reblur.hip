@@ -94,7 +94,10 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
     float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
     float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
-    uint32_t h = hash_px((uint32_t)x, (uint32_t)gy0, c.frameIndex, (uint32_t)VARIANT + 1u);
+    // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
+    // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per pixel for Blur (decorrelation)
+    constexpr bool PER_PIXEL = VARIANT == 1;
+    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x : 0u, PER_PIXEL ? (uint32_t)gy0 : 0u, c.frameIndex, (uint32_t)VARIANT + 1u);
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)

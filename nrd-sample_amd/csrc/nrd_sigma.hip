@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
     float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
     float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
     float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
-    uint32_t h = hash_px((uint32_t)x, (uint32_t)gy0, c.frameIndex, 17u + (uint32_t)PASS);
+    constexpr bool PER_PIXEL = PASS == 0; // Blur rotates per pixel, PostBlur per frame (coalesced gathers)
+    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x : 0u, PER_PIXEL ? (uint32_t)gy0 : 0u, c.frameIndex, 17u + (uint32_t)PASS);
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     f4 sum = center;
     float wsum = 1.0f;

@@ -1,0 +1,71 @@
+"""The C++ host side (include/NRD.h + include/NRDIntegration.h, written against the C-ABI) driven by tools/nrd_harness.cpp the
+way Source/NRDSample.cpp drives the reference's NRD Integration (same call order: shadow -> opaque -> reference, same slot
+binding). On the GPU its outputs must be bit-identical to the Python-driven run; without a GPU it must fail loudly."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "nrd-sample_amd", "csrc", "nrd_harness")
+
+
+def write_inputs(pkg, d, w, h):
+    rng = np.random.default_rng(21)
+    fr = util.flat_frame(pkg, w, h, rng=rng)
+    fr["penumbra"][h // 3: h // 2, w // 4: w // 2] = 0.05  # a shadowed block with a small penumbra
+    fr["translucency"][h // 3: h // 2, w // 4: w // 2] = (0, 200, 120, 60)
+    for k in ("mv", "normal_roughness", "viewz", "diff", "spec", "penumbra", "translucency", "signal"):
+        np.ascontiguousarray(fr[k]).tofile(os.path.join(d, k + ".bin"))
+    return fr
+
+
+def test_harness_built():
+    assert os.path.exists(HARNESS), "nrd_harness missing: make -C nrd-sample_amd/csrc all"
+
+
+def test_harness_fails_loudly_without_gpu(tmp_path, pkg):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    write_inputs(pkg, str(tmp_path), 64, 48)
+    r = subprocess.run([HARNESS, str(tmp_path), "64", "48", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Recreate failed" in r.stderr  # no CPU fallback anywhere in the product path
+
+
+@pytest.mark.gpu
+def test_harness_matches_python_driver(tmp_path, pkg, api, hip):
+    w, h, frames = 320, 192, 5
+    fr = write_inputs(pkg, str(tmp_path), w, h)
+    r = subprocess.run([HARNESS, str(tmp_path), str(w), str(h), str(frames)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "NRD: allocated" in r.stdout
+    D = api.Denoiser
+    dens = [D.SIGMA_SHADOW_TRANSLUCENCY, D.REBLUR_DIFFUSE_SPECULAR, D.REFERENCE]
+    # identifiers: the harness uses NRD_ID(SIGMA_SHADOW) for the translucency variant like the sample (:48-52, :917)
+    hz = pkg.harness.Harness(hip, [D.REFERENCE], 16, 16)  # dummy to get the class; real instance below
+    nrd = api.Integration(hip)
+    assert nrd.recreate([(int(D.REBLUR_DIFFUSE_SPECULAR), D.REBLUR_DIFFUSE_SPECULAR), (int(D.SIGMA_SHADOW), D.SIGMA_SHADOW_TRANSLUCENCY),
+                         (int(D.REFERENCE), D.REFERENCE)], w, h) == api.Result.SUCCESS
+    hz.nrd, hz.w, hz.h = nrd, w, h
+    hz.outputs = {k: hz._zeros(h, w * bpt) for _, (k, _, bpt) in pkg.harness.OUTPUT_SLOTS.items()}
+    planes = hz.upload(fr)
+    st = [(int(D.SIGMA_SHADOW), api.SigmaSettings(lightDirection=[0, 0, -1])), (int(D.REBLUR_DIFFUSE_SPECULAR), api.ReblurSettings()),
+          (int(D.REFERENCE), api.ReferenceSettings())]
+    for f in range(frames):
+        cs = util.static_common(api, w, h, f, reset=(f == 0))
+        nrd.new_frame()
+        nrd.set_common_settings(cs)
+        hz.bind(planes)
+        for ident, s in st:
+            nrd.set_denoiser_settings(ident, s)
+            nrd.denoise([ident])
+    for key, fname in (("out_diff", "out_diff.bin"), ("out_spec", "out_spec.bin"), ("out_shadow", "out_shadow.bin")):
+        got = np.fromfile(os.path.join(tmp_path, fname), dtype=np.uint8).reshape(h, -1)
+        assert np.array_equal(got, hz.fetch(hz.outputs[key])), key
+    sig = np.fromfile(os.path.join(tmp_path, "out_signal.bin"), dtype=np.uint8).reshape(h, -1)
+    assert np.array_equal(sig, hz.fetch(planes["signal"]))
