@@ -31,6 +31,7 @@ WORKLOADS = {
     "reblur_d_1080p": (1920, 1080, ["REBLUR_DIFFUSE"]),
     "reblur_ds_sigma_1440p": (2560, 1440, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY"]),
     "reblur_ds_1080p": (1920, 1080, ["REBLUR_DIFFUSE_SPECULAR"]),
+    "relax_ds_4k": (3840, 2160, ["RELAX_DIFFUSE_SPECULAR"]),
 }
 
 
@@ -42,24 +43,29 @@ def parse():
     ap.add_argument("--workload", default="reblur_ds_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
     return ap.parse_args()
 
 
-def cpu_baseline(pkg, denoiser_names, settings_of):
-    """Oracle (scalar C++ port, all host threads) on a bounded sample: 960x540, 2 warm-up + 3 timed frames."""
+def cpu_baseline(pkg, denoiser_names, settings_of, device):
+    """Oracle (scalar C++ port of the same passes, oracle/) on a bounded sample of the same workload: 1920x1080, 2 warm-up +
+    3 timed frames, row-striped over the host's hardware threads. Frames are rendered on the GPU and copied to the host."""
     api, synth, harness = pkg.api, pkg.synth, pkg.harness
     if not os.path.exists(pkg.ORACLE_LIB):
         return None
     orc = pkg.oracle_backend()
-    w, h, frames, warm = 960, 540, 3, 2
-    cores = os.cpu_count() or 1
-    scene = synth.Scene(w, h, dolly=0.004)
+    w, h, frames, warm = 1920, 1080, 3, 2
+    cores = min(os.cpu_count() or 1, h // 8)
+    scene = synth.Scene(w, h, dolly=0.004, device=device, denoiser="RELAX" if denoiser_names[0].startswith("RELAX") else "REBLUR")
     dens = [api.Denoiser[n] for n in denoiser_names]
     hz = harness.Harness(orc, dens, w, h)
     orc.lib.orc_set_threads(hz.nrd.handle, cores)
     st = settings_of(api, scene, dens)
-    data = [scene.frame(f) for f in range(warm + frames)]
+    data = []
+    for f in range(warm + frames):
+        fr = scene.frame(f)
+        data.append({k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in fr.items()})
     planes = [hz.upload(d) for d in data]
     for f in range(warm):
         hz.frame(scene.common_settings(api, data[f], f, reset=(f == 0)), planes[f], st)
@@ -78,6 +84,8 @@ def settings_of(api, scene, dens):
             # the sample's operating point (Source/NRDSample.cpp:563-585): material-aware filtering on, clamp sigma 1.5
             s[d] = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1, fastHistoryClampingSigmaScale=1.5,
                                       maxAccumulatedFrameNum=30, maxFastAccumulatedFrameNum=6, maxStabilizedFrameNum=30)
+        elif d.name.startswith("RELAX"):
+            s[d] = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1, fastHistoryClampingSigmaScale=1.5)
         elif d.name.startswith("SIGMA"):
             s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
         else:
@@ -109,10 +117,10 @@ def main():
     dens = [api.Denoiser[n] for n in den_names]
     hip = pkg.hip_backend(dev)
 
-    if world == 1:
+    if world == 1 and not args.force_tiled:
         from nrd_sample_amd.harness import Harness
 
-        scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev)
+        scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR")
         hz = Harness(hip, dens, w, band_h)
         runner = SingleRunner(api, hz, scene, dens, args.unique_frames, settings_of(api, scene, dens))
         frame_h = band_h
@@ -157,7 +165,7 @@ def main():
         sum_ms = sum(v[0] for v in per_pass.values())
         sum_bpp = sum(v[1] for v in per_pass.values())
         out = {
-            "metric": "Mpixels/s full REBLUR diff+spec pipeline", "value": round(value, 2), "unit": "Mpixels/s",
+            "metric": "Mpixels/s full %s diff+spec pipeline" % den_names[0].split("_")[0], "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16 planes)", "data": "synthetic",
             "config": {"workload": "%s: %s, %dx%d%s, steady state (accumulation saturated)" % (
@@ -170,7 +178,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of)
+                out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of, dev)
             except Exception as e:  # the baseline is a reported extra; never fail the GPU number because of it
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))

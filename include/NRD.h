@@ -22,7 +22,8 @@ namespace nrd {
 struct Instance; // opaque (== nrdhip_instance)
 
 inline const LibraryDesc* GetLibraryDesc() {
-    static const Denoiser supported[] = {Denoiser::REBLUR_DIFFUSE, Denoiser::REBLUR_SPECULAR, Denoiser::REBLUR_DIFFUSE_SPECULAR, Denoiser::SIGMA_SHADOW,
+    static const Denoiser supported[] = {Denoiser::REBLUR_DIFFUSE, Denoiser::REBLUR_SPECULAR, Denoiser::REBLUR_DIFFUSE_SPECULAR, Denoiser::RELAX_DIFFUSE,
+                                         Denoiser::RELAX_SPECULAR, Denoiser::RELAX_DIFFUSE_SPECULAR, Denoiser::SIGMA_SHADOW,
                                          Denoiser::SIGMA_SHADOW_TRANSLUCENCY, Denoiser::REFERENCE};
     static LibraryDesc desc = {};
     uint32_t v[5] = {};

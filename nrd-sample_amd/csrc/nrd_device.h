@@ -203,6 +203,21 @@ NRD_DEV Guide decode_guide(uint4 g, float range) {
     return r;
 }
 
+NRD_DEV f3 linear_to_ycocg(f3 c) {
+    float Y = c.x * 0.25f + c.y * 0.5f + c.z * 0.25f;
+    float Co = c.x * 0.5f - c.z * 0.5f;
+    float Cg = c.y * 0.5f - c.x * 0.25f - c.z * 0.25f;
+    return {Y, Co, Cg};
+}
+NRD_DEV f3 ycocg_to_linear(f3 c) {
+    float t = c.x - c.z;
+    return {fmax2(t + c.y, 0.0f), fmax2(c.x + c.z, 0.0f), fmax2(t - c.y, 0.0f)};
+}
+NRD_DEV f4 rgb_to_ycocg4(f4 v) {
+    f3 c = linear_to_ycocg({v.x, v.y, v.z});
+    return {c.x, c.y, c.z, v.w};
+}
+
 NRD_DEV float spec_magic_curve(float roughness) {
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
     return f * __builtin_sqrtf(sat(roughness));

@@ -15,6 +15,8 @@ struct ReblurParams {
     float fastHistoryClampingSigmaScale, antilagSigmaScale, antilagSensitivity;
     float responsiveRoughnessThreshold, responsiveMinAccum;
     float maxA, maxFastA, maxStab;
+    float maxASpec, maxFastASpec; // == maxA / maxFastA for REBLUR; RELAX has per-signal history caps
+    int relax;                    // 1: RELAX front half (linear RGB + world-space hitT inputs, luma-moment history, HistoryFix writes History)
     int historyFixFrameNum, historyFixStride;
     int reachPre, reachBlur, reachPost; // hard per-pass bound (pixels) on tap distance = halo rows of the pass
     uint32_t minMatDiff, minMatSpec;
@@ -24,6 +26,18 @@ struct ReblurParams {
     PlaneRef inZ, inNR, inMV, inDiff, inSpec, confD, confS, outDiff, outSpec;
     // pools
     PlaneRef guide, guidePrev, data1, data1Prev, data1Tmp, data2, hist, fast, fastPrev, stab, stabPrev, tiles, tmp1, tmp2, hitTrack;
+};
+
+// one RELAX A-trous iteration (nrd_reblur.hip k_relax_atrous)
+struct AtrousParams {
+    FrameConsts c;
+    float depthSens, histThreshold, specularVarianceBoost;
+    float phi[2], minLw[2]; // [0] diffuse, [1] specular
+    float lobeAngleFraction, roughnessFraction;
+    uint32_t minMatDiff, minMatSpec;
+    int roughnessEdgeStopping;
+    int it, last, hasDiff, hasSpec;
+    PlaneRef guide, data1, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec;
 };
 
 struct SigmaParams {
@@ -49,6 +63,7 @@ void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); /
 void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s);
 void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s);
 void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s);
+void launch_relax_atrous(const AtrousParams& p, hipStream_t s);
 
 void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s);
 void launch_sigma_smooth_tiles(const SigmaParams& p, hipStream_t s);

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
     const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
+    const bool relaxIn = VARIANT == 0 && p.relax != 0; // RELAX inputs: linear RGB + world-space hit distance
 
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         const int srcBpt = VARIANT == 0 ? 8 : RBPT;
         const int srcOff = VARIANT == 0 ? 0 : sig * 8;
         f4 center = unpack_h4(ld<uint2>(srcP, x, y, srcBpt, srcOff));
+        if (relaxIn)
+            center = rgb_to_ycocg4(center);
         float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist / pg.frustumSize);
@@ -155,7 +158,8 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
             float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
             float normalW2 = normalW * normalW;
-            float hitA = 1.0f / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
+            float hitScale = relaxIn ? 1.0f / fmax2(center.w, 1e-3f) : 1.0f; // RELAX hit distances are world units: compare relatively
+            float hitA = hitScale / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
             float hitB = -center.w * hitA;
             float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
             float roughB = -rough * roughA;
@@ -183,6 +187,8 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                 f4 sv = unpack_h4(ld<uint2>(srcP, px, py, srcBpt, srcOff));
+                if (relaxIn)
+                    sv = rgb_to_ycocg4(sv);
                 w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                 sum = fma4(sv, w, sum);
                 wsum += w;
@@ -356,6 +362,8 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * 8);
             st<uint16_t>(p.fast, x, y, LBPT, (uint16_t)0, sig * 2);
+            if (p.relax)
+                st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
         st<uint16_t>(p.data1Tmp, x, y, 2, (uint16_t)0);
         st<uint32_t>(p.data2, x, y, 4, 0u);
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     if (smbOk)
         fetchA(c, p.data1Prev, smb, prevDiffA, prevSpecA);
     prevDiffA = smbOk ? fmin2(prevDiffA + 1.0f, p.maxA) : 0.0f;
-    prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, p.maxA) : 0.0f;
+    prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, p.maxASpec) : 0.0f;
     float quality = smbOk ? smb.wsum : 0.0f;
     float outDiffA = 0.0f, outSpecA = 0.0f;
     uint32_t data2 = smbOk ? smb.bits : 0u;
@@ -394,6 +402,11 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         float fastHist = smbOk ? fetch1(c, p.fastPrev, LBPT, 0, smb) : in.x;
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), 0);
         st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), 0);
+        if (p.relax) { // second luma moment history (lives in the stabilized-luma slots)
+            float m2 = in.x * in.x;
+            float m2prev = smbOk ? fetch1(c, p.stabPrev, LBPT, 0, smb) : m2;
+            st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(m2prev, m2, nonLin)), 0);
+        }
         outDiffA = A;
     }
     if (HAS_SPEC) {
@@ -413,8 +426,10 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         f4 vmbHist = in;
         float vmbFast = in.x;
         uint32_t vmbBits = 0;
+        Footprint vmb;
+        vmb.wsum = 0.0f;
         if (historyOk && virtual_uv(c, r, hitDist, g.roughness, vu, vv)) {
-            Footprint vmb = footprint(p, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
+            vmb = footprint(p, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
             vmbBits = vmb.bits;
             if (vmb.wsum > 0.0f) {
                 float prevRough = 0.0f;
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
                 amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
                 float dA, sA;
                 fetchA(c, p.data1Prev, vmb, dA, sA);
-                Avmb = fmin2(sA + 1.0f, p.maxA);
+                Avmb = fmin2(sA + 1.0f, p.maxASpec);
                 vmbHist = fetch4(c, p.hist, RBPT, so, vmb);
                 vmbFast = fetch1(c, p.fastPrev, LBPT, lo, vmb);
             }
@@ -444,13 +459,19 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         A *= lerpf(q, 1.0f, 1.0f / (1.0f + A));
         if (p.responsiveRoughnessThreshold > 0.0f) {
             float t = smoothstep01(g.roughness / p.responsiveRoughnessThreshold);
-            A = fmin2(A, lerpf(p.responsiveMinAccum, p.maxA, t));
+            A = fmin2(A, lerpf(p.responsiveMinAccum, p.maxASpec, t));
         }
         float nonLin = 1.0f / (1.0f + A);
         f4 hist = lerp4(smbHist, vmbHist, amount);
         float fastHist = lerpf(smbFast, vmbFast, amount);
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
-        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), lo);
+        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastASpec)))), lo);
+        if (p.relax) {
+            float m2 = in.x * in.x;
+            float m2smb = smbOk ? fetch1(c, p.stabPrev, LBPT, lo, smb) : m2;
+            float m2vmb = vmb.wsum > 0.0f ? fetch1(c, p.stabPrev, LBPT, lo, vmb) : m2;
+            st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)), lo);
+        }
         outSpecA = A;
         data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8);
     }
@@ -514,10 +535,11 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
         return;
+    const PlaneRef& outP = p.relax ? p.hist : p.tmp1; // RELAX: the fixed + clamped signal IS the next frame's history
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++)
-            st<uint2>(p.tmp1, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * 8);
         st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
         return;
     }
@@ -586,9 +608,9 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             val.y *= scale;
             val.z *= scale;
             float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
-            outA[ai] = lerpf(Acur, fmin2(Acur, p.maxFastA), f);
+            outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? p.maxFastASpec : p.maxFastA), f);
         }
-        st<uint2>(p.tmp1, x, y, RBPT, pack_h4(val), sig * 8);
+        st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * 8);
     }
     st<uint16_t>(p.data1, x, y, 2, pack_data1(outA[0], outA[1]));
 }
@@ -705,6 +727,126 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     }
 }
 
+// =====================================================================================================================
+// RELAX A-trous iteration: variance-guided 3x3 at stride 2^it (Source/NRDSample.cpp:1642-1657 feeds the settings; outputs are
+// decoded by RELAX_BackEnd_UnpackRadiance, Shaders/Composition.cs.hlsl:160-161). All lanes use the same tap offsets, so the
+// gathers of a 16x4-pixel wave are 16x4-texel groups: fully coalesced at every stride; neighbouring tiles share taps in L2.
+// =====================================================================================================================
+template <bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    const FrameConsts& c = p.c;
+    int x, y, tx, ty;
+    if (!my_pixel(c, x, y, tx, ty))
+        return;
+    const int it = p.it;
+    const bool last = p.last != 0;
+    const int stride = 1 << it;
+    const int gy0 = y + c.yOff;
+    float u = ((float)x + 0.5f) * c.invW;
+    bool split = last && u < c.splitScreen;
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    if (g.sky) {
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            if (last) {
+                const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
+                const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+                st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
+            } else
+                st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+        }
+        return;
+    }
+    PixelGeo pg = pixel_geo(c, g, x, gy0, p.depthSens);
+    float A[2] = {0.0f, 0.0f};
+    if (it == 0)
+        unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        const int si = isSpec ? 1 : 0;
+        float rough = isSpec ? g.roughness : 1.0f;
+        uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
+        f4 c0 = unpack_h4(ld<uint2>(p.in, x, y, RBPT, sig * 8));
+        float var;
+        if (it == 0) {
+            float m2 = h2f(ld<uint16_t>(p.mom, x, y, LBPT, sig * 2));
+            var = fmax2(fma_(-c0.x, c0.x, m2), 0.0f);
+            if (A[si] < p.histThreshold) { // short history: 3x3 spatial estimate
+                float sy = 0.0f, sy2 = 0.0f, n = 0.0f;
+                for (int j = -1; j <= 1; j++)
+                    for (int i = -1; i <= 1; i++) {
+                        int px = x + i, py = y + j, gy = py + c.yOff;
+                        if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                            continue;
+                        if (!(absf(ld<float>(p.guide, px, py, 16, 0)) <= c.denoisingRange))
+                            continue;
+                        float Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * 8));
+                        sy += Y;
+                        sy2 = fma_(Y, Y, sy2);
+                        n += 1.0f;
+                    }
+                float inv = 1.0f / n;
+                float my = sy * inv;
+                var = fmax2(var, fmax2(fma_(-my, my, sy2 * inv), 0.0f));
+            }
+            if (isSpec)
+                var = fma_(var, p.specularVarianceBoost, var);
+        } else
+            var = c0.w;
+        float sigma = __builtin_sqrtf(var);
+        float invL = 0.3333f / fma_(p.phi[si], sigma, 1e-4f);
+        float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
+        float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+        float normalW2 = normalW * normalW;
+        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+        float roughB = -rough * roughA;
+        f3 sum = {c0.x, c0.y, c0.z};
+        float sumVar = var, wsum = 1.0f;
+#pragma unroll
+        for (int j = -1; j <= 1; j++)
+#pragma unroll
+            for (int i = -1; i <= 1; i++) {
+                if (i == 0 && j == 0)
+                    continue;
+                int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
+                if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                    continue;
+                Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
+                if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                    continue;
+                float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
+                w *= geo_weight(pg, (float)px, (float)gy, gs.z);
+                w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                if (isSpec && p.roughnessEdgeStopping)
+                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                f4 sv = unpack_h4(ld<uint2>(p.in, px, py, RBPT, sig * 8));
+                float vs = sv.w;
+                if (it == 0)
+                    vs = fmax2(fma_(-sv.x, sv.x, h2f(ld<uint16_t>(p.mom, px, py, LBPT, sig * 2))), 0.0f);
+                w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), p.minLw[si]);
+                sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
+                sumVar = fma_(vs, w * w, sumVar);
+                wsum += w;
+            }
+        float inv = 1.0f / wsum;
+        f3 o = mul3(sum, inv);
+        float ov = sumVar * inv * inv;
+        if (last) {
+            f3 rgb = ycocg_to_linear(o);
+            float hitDist = h2f(ld<uint16_t>(p.hist, x, y, RBPT, sig * 8 + 6));
+            const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
+            const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+            st<uint2>(op, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : pack_h4({rgb.x, rgb.y, rgb.z, hitDist}));
+        } else
+            st<uint2>(p.out, x, y, RBPT, pack_h4({o.x, o.y, o.z, ov}), sig * 8);
+    }
+}
+
 dim3 grid_for(const FrameConsts& c) {
     int total = c.tilesX * c.tilesY;
     int chunk = (total + 7) / 8;
@@ -739,5 +881,6 @@ void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
 void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_accumulation, ); }
 void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_history_fix, ); }
 void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_stabilization, ); }
+void launch_relax_atrous(const AtrousParams& p, hipStream_t s) { NRD_LAUNCH3(k_relax_atrous, ); }
 
 } // namespace nrdhip

@@ -120,6 +120,9 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE: d.kind = Kind::REBLUR; d.hasDiff = true; break;
         case D::REBLUR_SPECULAR: d.kind = Kind::REBLUR; d.hasSpec = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = true; break;
+        case D::RELAX_DIFFUSE: d.kind = Kind::RELAX; d.hasDiff = true; break;
+        case D::RELAX_SPECULAR: d.kind = Kind::RELAX; d.hasSpec = true; break;
+        case D::RELAX_DIFFUSE_SPECULAR: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = true; break;
         case D::SIGMA_SHADOW: d.kind = Kind::SIGMA; break;
         case D::SIGMA_SHADOW_TRANSLUCENCY: d.kind = Kind::SIGMA; d.translucency = true; break;
         case D::REFERENCE: d.kind = Kind::REFERENCE; break;
@@ -132,7 +135,7 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
 // ---- pool descriptions (indices must match the enums used by the builders below) ----------------------------------
 namespace rb { // REBLUR
 enum Perm { GUIDE_A, GUIDE_B, DATA1_A, DATA1_B, HIST, FAST_A, FAST_B, STAB_A, STAB_B };
-enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK };
+enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK, AT_A, AT_B }; // AT_*: RELAX only
 } // namespace rb
 namespace sg { // SIGMA
 enum Perm { GUIDE_A, GUIDE_B, HIST_A, HIST_B };
@@ -160,6 +163,27 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"REBLUR::Data1_Tmp", F::R16_UINT, 2, 1});
         trans.push_back({"REBLUR::Data2", F::R32_UINT, 4, 1});
         trans.push_back({"REBLUR::SpecHitDistForTracking", F::R16_SFLOAT, 2, 1});
+    } else if (d.kind == Kind::RELAX) { // same slot order as REBLUR for the shared front half; moments live in the STAB slots
+        F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
+        F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
+        uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+        perm.push_back({"RELAX::Guide_A", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"RELAX::Guide_B", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"RELAX::HistoryLength_A", F::R16_UINT, 2, 1});
+        perm.push_back({"RELAX::HistoryLength_B", F::R16_UINT, 2, 1});
+        perm.push_back({"RELAX::History", fmtRad, bRad, 1});
+        perm.push_back({"RELAX::FastHistory_A", fmtLum, bLum, 1});
+        perm.push_back({"RELAX::FastHistory_B", fmtLum, bLum, 1});
+        perm.push_back({"RELAX::Moments_A", fmtLum, bLum, 1});
+        perm.push_back({"RELAX::Moments_B", fmtLum, bLum, 1});
+        trans.push_back({"RELAX::Tiles", F::R8_UINT, 1, 16});
+        trans.push_back({"RELAX::Tmp1", fmtRad, bRad, 1});
+        trans.push_back({"RELAX::Tmp2", fmtRad, bRad, 1});
+        trans.push_back({"RELAX::HistoryLength_Tmp", F::R16_UINT, 2, 1});
+        trans.push_back({"RELAX::Data2", F::R32_UINT, 4, 1});
+        trans.push_back({"RELAX::SpecHitDistForTracking", F::R16_SFLOAT, 2, 1});
+        trans.push_back({"RELAX::Atrous_A", fmtRad, bRad, 1});
+        trans.push_back({"RELAX::Atrous_B", fmtRad, bRad, 1});
     } else if (d.kind == Kind::SIGMA) {
         perm.push_back({"SIGMA::Guide_A", F::RGBA32_UINT, 16, 1});
         perm.push_back({"SIGMA::Guide_B", F::RGBA32_UINT, 16, 1});
@@ -290,13 +314,11 @@ void build_reference(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c)
     d.dispatches.push_back(x);
 }
 
-void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
+// parameter block of the REBLUR kernels; RELAX reuses them for its front half (ClassifyTiles, PrePass, TA, HistoryFix)
+ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c, const nrd::ReblurSettings& s) {
     using RT = nrd::ResourceType;
-    const nrd::ReblurSettings& s = d.reblur;
     int cur = (int)(d.frameCounter & 1);
     uint32_t pb = d.permBase, tb = d.transBase;
-    auto P = [&](int i) { return enc_perm(pb + i); };
-    auto T = [&](int i) { return enc_trans(tb + i); };
     auto PP = [&](int i) { return I.perm[pb + i].ref(); };
     auto TP = [&](int i) { return I.trans[tb + i].ref(); };
     auto SP = [&](RT t) { return I.slots[(size_t)t].ref(); };
@@ -358,6 +380,20 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.data1Tmp = TP(rb::DATA1_TMP);
     p.data2 = TP(rb::DATA2);
     p.hitTrack = TP(rb::HITTRACK);
+    p.maxASpec = p.maxA;
+    p.maxFastASpec = p.maxFastA;
+    p.relax = 0;
+    return p;
+}
+
+void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
+    using RT = nrd::ResourceType;
+    const nrd::ReblurSettings& s = d.reblur;
+    int cur = (int)(d.frameCounter & 1);
+    uint32_t pb = d.permBase, tb = d.transBase;
+    auto P = [&](int i) { return enc_perm(pb + i); };
+    auto T = [&](int i) { return enc_trans(tb + i); };
+    ReblurParams p = make_reblur_params(I, d, c, s);
 
     float n = (float)d.nsig;
     float sp = d.hasSpec ? 2.0f : 0.0f;
@@ -426,6 +462,134 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
         }
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_stabilization(p, st); };
+        d.dispatches.push_back(x);
+    }
+}
+
+nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
+    nrd::ReblurSettings s = {};
+    s.hitDistanceParameters = {1.0f, 0.0f, 1.0f, 0.0f}; // hit distances stay in world units
+    s.maxAccumulatedFrameNum = r.diffuseMaxAccumulatedFrameNum;
+    s.maxFastAccumulatedFrameNum = r.diffuseMaxFastAccumulatedFrameNum;
+    s.historyFixFrameNum = r.historyFixFrameNum;
+    s.historyFixBasePixelStride = r.historyFixBasePixelStride;
+    s.diffusePrepassBlurRadius = r.diffusePrepassBlurRadius;
+    s.specularPrepassBlurRadius = r.specularPrepassBlurRadius;
+    s.minHitDistanceWeight = r.minHitDistanceWeight;
+    s.lobeAngleFraction = r.lobeAngleFraction;
+    s.roughnessFraction = r.roughnessFraction;
+    s.fastHistoryClampingSigmaScale = r.fastHistoryClampingSigmaScale;
+    s.minMaterialForDiffuse = r.minMaterialForDiffuse;
+    s.minMaterialForSpecular = r.minMaterialForSpecular;
+    return s;
+}
+
+// RELAX = shared front half (ClassifyTiles, PrePass, TemporalAccumulation, HistoryFix) + variance-guided A-trous iterations
+void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
+    using RT = nrd::ResourceType;
+    const nrd::RelaxSettings& r = d.relax;
+    nrd::ReblurSettings s = relax_as_reblur(r);
+    int cur = (int)(d.frameCounter & 1);
+    uint32_t pb = d.permBase, tb = d.transBase;
+    auto P = [&](int i) { return enc_perm(pb + i); };
+    auto T = [&](int i) { return enc_trans(tb + i); };
+    ReblurParams p = make_reblur_params(I, d, c, s);
+    p.relax = 1;
+    p.maxASpec = (float)std::min<uint32_t>(r.specularMaxAccumulatedFrameNum, 63);
+    p.maxFastASpec = (float)std::min<uint32_t>(r.specularMaxFastAccumulatedFrameNum, 63);
+    float n = (float)d.nsig;
+    float sp = d.hasSpec ? 2.0f : 0.0f;
+    const float GB = 16.0f;
+    {
+        Dispatch x{"RELAX::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
+        x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
+        x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
+        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"RELAX::PrePass", "nrd_reblur_prepass", (uint16_t)p.reachPre, GB + 8 * n + 8 * n + sp, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur)};
+        if (d.hasDiff)
+            x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+        if (d.hasSpec)
+            x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        x.written = {T(rb::TMP1), T(rb::HITTRACK)};
+        x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"RELAX::TemporalAccumulation", "nrd_reblur_temporal_accumulation", 0,
+                   GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + 2 * n + sp + 8 * n + 2 * n + 2 * n + 2 + 4, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)),
+                  P(rb::DATA1_A + (cur ^ 1)), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
+        x.written = {T(rb::TMP2), P(rb::FAST_A + cur), P(rb::STAB_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
+        x.launch = [p](hipStream_t st) { launch_reblur_temporal_accumulation(p, st); };
+        d.dispatches.push_back(x);
+    }
+    {
+        Dispatch x{"RELAX::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
+                   GB + 2 + 8 * n + 2 * n + 8 * n + 2, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
+        x.written = {P(rb::HIST), P(rb::DATA1_A + cur)};
+        x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
+        d.dispatches.push_back(x);
+    }
+    AtrousParams a;
+    std::memset(&a, 0, sizeof(a));
+    a.c = c;
+    a.depthSens = std::max(r.depthThreshold, 0.001f) * 4.0f;
+    a.histThreshold = (float)r.spatialVarianceEstimationHistoryThreshold;
+    a.specularVarianceBoost = r.specularVarianceBoost;
+    a.phi[0] = r.diffusePhiLuminance;
+    a.phi[1] = r.specularPhiLuminance;
+    a.minLw[0] = r.diffuseMinLuminanceWeight;
+    a.minLw[1] = r.specularMinLuminanceWeight;
+    a.lobeAngleFraction = r.lobeAngleFraction;
+    a.roughnessFraction = r.roughnessFraction;
+    a.minMatDiff = r.minMaterialForDiffuse;
+    a.minMatSpec = r.minMaterialForSpecular;
+    a.roughnessEdgeStopping = r.enableRoughnessEdgeStopping ? 1 : 0;
+    a.hasDiff = d.hasDiff;
+    a.hasSpec = d.hasSpec;
+    a.guide = p.guide;
+    a.data1 = p.data1;
+    a.hist = p.hist;
+    a.mom = p.stab;
+    a.inDiff = p.inDiff;
+    a.inSpec = p.inSpec;
+    a.outDiff = p.outDiff;
+    a.outSpec = p.outSpec;
+    int iters = (int)std::min<uint32_t>(std::max<uint32_t>(r.atrousIterationNum, 2), 8);
+    for (int it = 0; it < iters; it++) {
+        bool last = it == iters - 1;
+        a.it = it;
+        a.last = last ? 1 : 0;
+        a.in = it == 0 ? p.hist : I.trans[tb + rb::AT_A + ((it - 1) & 1)].ref();
+        a.out = I.trans[tb + rb::AT_A + (it & 1)].ref();
+        Dispatch x{it == 0 ? "RELAX::Atrous0" : (last ? "RELAX::AtrousLast" : "RELAX::Atrous"), "nrd_relax_atrous", (uint16_t)(1 << it),
+                   GB + (it == 0 ? 2 + 8 * n + 2 * n : 8 * n) + (last ? 8 * n : 0.0f) + 8 * n, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur)};
+        if (it == 0) {
+            x.read.push_back(P(rb::DATA1_A + cur));
+            x.read.push_back(P(rb::HIST));
+            x.read.push_back(P(rb::STAB_A + cur));
+        } else
+            x.read.push_back(T(rb::AT_A + ((it - 1) & 1)));
+        if (last) {
+            x.read.push_back(P(rb::HIST));
+            if (d.hasDiff) {
+                x.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
+                x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+            }
+            if (d.hasSpec) {
+                x.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
+                x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+            }
+        } else
+            x.written = {T(rb::AT_A + (it & 1))};
+        AtrousParams ap = a;
+        x.launch = [ap](hipStream_t st) { launch_relax_atrous(ap, st); };
         d.dispatches.push_back(x);
     }
 }
@@ -531,7 +695,7 @@ int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Fla
             case Kind::REFERENCE: build_reference(I, *d, c); break;
             case Kind::REBLUR: build_reblur(I, *d, c); break;
             case Kind::SIGMA: build_sigma(I, *d, c); break;
-            default: break;
+            case Kind::RELAX: build_relax(I, *d, c); break;
         }
         for (uint32_t k = 0; k < d->dispatches.size(); k++)
             out.push_back({d, k});

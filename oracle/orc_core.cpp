@@ -153,6 +153,9 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE: d.kind = Kind::REBLUR; d.hasDiff = true; break;
         case D::REBLUR_SPECULAR: d.kind = Kind::REBLUR; d.hasSpec = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = true; break;
+        case D::RELAX_DIFFUSE: d.kind = Kind::RELAX; d.hasDiff = true; break;
+        case D::RELAX_SPECULAR: d.kind = Kind::RELAX; d.hasSpec = true; break;
+        case D::RELAX_DIFFUSE_SPECULAR: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = true; break;
         case D::SIGMA_SHADOW: d.kind = Kind::SIGMA; break;
         case D::SIGMA_SHADOW_TRANSLUCENCY: d.kind = Kind::SIGMA; d.translucency = true; break;
         case D::REFERENCE: d.kind = Kind::REFERENCE; break;

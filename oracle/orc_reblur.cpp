@@ -31,6 +31,10 @@ static inline f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w
 static inline f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
 static inline f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
 static inline f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
+static inline f4 rgb_to_ycocg4(f4 v) {
+    f3 c = linear_to_ycocg({v.x, v.y, v.z});
+    return {c.x, c.y, c.z, v.w};
+}
 
 static inline void unpack_data1(uint16_t v, float& diffA, float& specA) {
     diffA = (float)(v & 0xffu) * 0.25f;
@@ -129,6 +133,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const Plane& D1 = k.perm(P_DATA1_A + k.cur);
     const Plane& HT = k.trans(T_HITTRACK);
     const float* hp = &s.hitDistanceParameters.A;
+    const bool relaxIn = k.d.kind == Kind::RELAX && variant == PRE; // RELAX inputs: linear RGB + world-space hit distance
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
@@ -161,6 +166,8 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
                 f4 center = ld_h4(*io.in[sig], x, y, io.inOff[sig]);
+                if (relaxIn)
+                    center = rgb_to_ycocg4(center);
                 float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
                 float hitDist = center.w * hitNorm;
                 float hitDistFactor = sat(hitDist / pg.frustumSize);
@@ -206,7 +213,8 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
                     float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
                     float normalW2 = normalW * normalW;
-                    float hitA = 1.0f / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
+                    float hitScale = relaxIn ? 1.0f / fmax2(center.w, 1e-3f) : 1.0f; // RELAX hit distances are world units: compare relatively
+                    float hitA = hitScale / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
                     float hitB = -center.w * hitA;
                     float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
                     float roughB = -rough * roughA;
@@ -232,6 +240,8 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         if (isSpec)
                             w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         f4 sv = ld_h4(*io.in[sig], px, py, io.inOff[sig]);
+                        if (relaxIn)
+                            sv = rgb_to_ycocg4(sv);
                         w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                         sum = fma4(sv, w, sum);
                         wsum += w;
@@ -415,8 +425,14 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
     const Plane& confD = k.slot(nrd::ResourceType::IN_DIFF_CONFIDENCE);
     const Plane& confS = k.slot(nrd::ResourceType::IN_SPEC_CONFIDENCE);
     bool historyOk = d.historyValid && !c.reset;
+    const bool relax = d.kind == Kind::RELAX;
     float maxA = (float)std::min<uint32_t>(s.maxAccumulatedFrameNum, 63);
     float maxFastA = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
+    float maxAs = relax ? (float)std::min<uint32_t>(d.relax.specularMaxAccumulatedFrameNum, 63) : maxA;
+    float maxFastAs = relax ? (float)std::min<uint32_t>(d.relax.specularMaxFastAccumulatedFrameNum, 63) : maxFastA;
+    // RELAX: second luma moment history lives in the slots REBLUR uses for the stabilized luma
+    const Plane& MOMP = k.perm(P_STAB_A + (k.cur ^ 1));
+    const Plane& MOMC = k.perm(P_STAB_A + k.cur);
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
@@ -424,6 +440,8 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 for (int sig = 0; sig < d.nsig; sig++) {
                     st_h4(OUT, x, y, {0, 0, 0, 0}, sig * 8);
                     st_h(FASTC, x, y, 0.0f, sig * 2);
+                    if (relax)
+                        st_h(MOMC, x, y, 0.0f, sig * 2);
                 }
                 st_u16(D1T, x, y, 0);
                 st_u32(D2, x, y, 0);
@@ -446,7 +464,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 fetchA(k, D1P, smb, prevDiffA, prevSpecA);
             // "+1": the stored value is the accumulation speed the previous frame USED
             prevDiffA = smbOk ? fmin2(prevDiffA + 1.0f, maxA) : 0.0f;
-            prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, maxA) : 0.0f;
+            prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, maxAs) : 0.0f;
             float quality = smbOk ? smb.wsum : 0.0f;
             float outDiffA = 0.0f, outSpecA = 0.0f;
             uint32_t data2 = smbOk ? smb.bits : 0u;
@@ -463,6 +481,11 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 float fastHist = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
                 st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
                 st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
+                if (relax) {
+                    float m2 = in.x * in.x;
+                    float m2prev = smbOk ? fetch1(k, MOMP, sig * 2, smb) : m2;
+                    st_h(MOMC, x, y, lerpf(m2prev, m2, nonLin), sig * 2);
+                }
                 outDiffA = A;
             }
             if (d.hasSpec) {
@@ -500,7 +523,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                         amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
                         float dA, sA;
                         fetchA(k, D1P, vmb, dA, sA);
-                        Avmb = fmin2(sA + 1.0f, maxA);
+                        Avmb = fmin2(sA + 1.0f, maxAs);
                         vmbHist = fetch4(k, HIST, sig * 8, vmb);
                         vmbFast = fetch1(k, FASTP, sig * 2, vmb);
                     }
@@ -517,13 +540,19 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 // responsive accumulation for very smooth surfaces
                 if (s.responsiveAccumulationSettings.roughnessThreshold > 0.0f) {
                     float t = smoothstep01(g.roughness / s.responsiveAccumulationSettings.roughnessThreshold);
-                    A = fmin2(A, lerpf((float)s.responsiveAccumulationSettings.minAccumulatedFrameNum, maxA, t));
+                    A = fmin2(A, lerpf((float)s.responsiveAccumulationSettings.minAccumulatedFrameNum, maxAs, t));
                 }
                 float nonLin = 1.0f / (1.0f + A);
                 f4 hist = lerp4(smbHist, vmbHist, amount);
                 float fastHist = lerpf(smbFast, vmbFast, amount);
                 st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
-                st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
+                st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastAs))), sig * 2);
+                if (relax) {
+                    float m2 = in.x * in.x;
+                    float m2smb = smbOk ? fetch1(k, MOMP, sig * 2, smb) : m2;
+                    float m2vmb = vmb.wsum > 0.0f ? fetch1(k, MOMP, sig * 2, vmb) : m2;
+                    st_h(MOMC, x, y, lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin), sig * 2);
+                }
                 outSpecA = A;
                 data2 |= (vmb.bits << 4) | ((uint32_t)floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8);
             }
@@ -540,11 +569,13 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
     const nrd::ReblurSettings& s = d.reblur;
     const Plane& G = k.guide();
     const Plane& IN = k.trans(T_TMP2);
-    const Plane& OUT = k.trans(T_TMP1);
+    const bool relax = d.kind == Kind::RELAX;
+    const Plane& OUT = relax ? k.perm(P_HIST) : k.trans(T_TMP1); // RELAX: the fixed + clamped signal IS the next frame's history
     const Plane& FAST = k.perm(P_FAST_A + k.cur);
     const Plane& D1T = k.trans(T_DATA1);
     const Plane& D1C = k.perm(P_DATA1_A + k.cur);
-    float maxFastA = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
+    float maxFastAd = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
+    float maxFastAs = relax ? (float)std::min<uint32_t>(d.relax.specularMaxFastAccumulatedFrameNum, 63) : maxFastAd;
     bool clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
@@ -634,7 +665,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     val.y *= scale;
                     val.z *= scale;
                     float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
-                    outA[ai] = lerpf(Acur, fmin2(Acur, maxFastA), f);
+                    outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? maxFastAs : maxFastAd), f);
                 }
                 st_h4(OUT, x, y, val, sig * 8);
             }
@@ -764,6 +795,137 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
                 st_h(STABC, x, y, Yout, sig * 2);
                 st_h4(*outP[sig], x, y, split ? ld_h4(*inP[sig], x, y) : o);
+            }
+        }
+}
+
+
+// --------------------------------------------------------------------------------------------------
+// RELAX A-trous iteration (variance-guided 3x3 at stride 2^it). Iteration 0 reads the history written by HistoryFix
+// (YCoCg + hitDist) and derives the variance from the accumulated luma moments (spatial 3x3 estimate while the history is
+// short); later iterations ping-pong {YCoCg, variance} texels; the last one converts to linear RGB and writes OUT_*.
+// Reference call sites: RelaxSettings fields Source/NRDSample.cpp:1642-1657 (atrousIterationNum, phi luminance, min luminance
+// weight, depth threshold, lobe / roughness fraction, history threshold); outputs decoded by RELAX_BackEnd_UnpackRadiance
+// Shaders/Composition.cs.hlsl:160-161.
+// --------------------------------------------------------------------------------------------------
+enum RelaxTrans { T_AT_A = T_NUM, T_AT_B };
+
+void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int it, bool last) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const nrd::RelaxSettings& s = d.relax;
+    const Plane& G = k.guide();
+    const Plane& HIST = k.perm(P_HIST);
+    const Plane& MOM = k.perm(P_STAB_A + k.cur);
+    const Plane& D1 = k.perm(P_DATA1_A + k.cur);
+    const Plane& IN = it == 0 ? HIST : k.trans(T_AT_A + ((it - 1) & 1));
+    const Plane& OUTP = k.trans(T_AT_A + (it & 1));
+    const Plane* outSlot[2] = {nullptr, nullptr};
+    const Plane* inSlot[2] = {nullptr, nullptr};
+    if (d.hasDiff) {
+        outSlot[k.sigDiff()] = &k.slot(nrd::ResourceType::OUT_DIFF_RADIANCE_HITDIST);
+        inSlot[k.sigDiff()] = &k.slot(nrd::ResourceType::IN_DIFF_RADIANCE_HITDIST);
+    }
+    if (d.hasSpec) {
+        outSlot[k.sigSpec()] = &k.slot(nrd::ResourceType::OUT_SPEC_RADIANCE_HITDIST);
+        inSlot[k.sigSpec()] = &k.slot(nrd::ResourceType::IN_SPEC_RADIANCE_HITDIST);
+    }
+    const int stride = 1 << it;
+    const float depthSens = fmax2(s.depthThreshold, 0.001f) * 4.0f;
+    const float histThreshold = (float)s.spatialVarianceEstimationHistoryThreshold;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            int gy0 = y + c.yOff;
+            float u = ((float)x + 0.5f) * c.invW;
+            bool split = last && u < c.splitScreen;
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            if (g.sky) {
+                for (int sig = 0; sig < d.nsig; sig++) {
+                    if (last)
+                        st_h4(*outSlot[sig], x, y, split ? ld_h4(*inSlot[sig], x, y) : f4{0, 0, 0, 0});
+                    else
+                        st_h4(OUTP, x, y, {0, 0, 0, 0}, sig * 8);
+                }
+                continue;
+            }
+            PixelGeo pg = pixel_geo(c, g, x, gy0, depthSens);
+            float A[2] = {0, 0};
+            if (it == 0)
+                unpack_data1(ld_u16(D1, x, y), A[0], A[1]);
+            for (int sig = 0; sig < d.nsig; sig++) {
+                bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+                float rough = isSpec ? g.roughness : 1.0f;
+                uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
+                f4 c0 = ld_h4(IN, x, y, sig * 8);
+                float var;
+                if (it == 0) {
+                    float m2 = ld_h(MOM, x, y, sig * 2);
+                    var = fmax2(fma_(-c0.x, c0.x, m2), 0.0f);
+                    if (A[isSpec ? 1 : 0] < histThreshold) { // short history: 3x3 spatial estimate
+                        float sy = 0.0f, sy2 = 0.0f, n = 0.0f;
+                        for (int j = -1; j <= 1; j++)
+                            for (int i = -1; i <= 1; i++) {
+                                int px = x + i, py = y + j, gy = py + c.yOff;
+                                if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                                    continue;
+                                if (!(absf(ld_f32(G, px, py, 0)) <= c.denoisingRange))
+                                    continue;
+                                float Y = ld_h(HIST, px, py, sig * 8);
+                                sy += Y;
+                                sy2 = fma_(Y, Y, sy2);
+                                n += 1.0f;
+                            }
+                        float inv = 1.0f / n;
+                        float my = sy * inv;
+                        var = fmax2(var, fmax2(fma_(-my, my, sy2 * inv), 0.0f));
+                    }
+                    if (isSpec)
+                        var = fma_(var, s.specularVarianceBoost, var);
+                } else
+                    var = c0.w;
+                float sigma = sqrtf(var);
+                float phi = isSpec ? s.specularPhiLuminance : s.diffusePhiLuminance;
+                float minLw = isSpec ? s.specularMinLuminanceWeight : s.diffuseMinLuminanceWeight;
+                float invL = 0.3333f / fma_(phi, sigma, 1e-4f);
+                float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
+                float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                float normalW2 = normalW * normalW;
+                float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                float roughB = -rough * roughA;
+                f3 sum = {c0.x, c0.y, c0.z};
+                float sumVar = var, wsum = 1.0f;
+                for (int j = -1; j <= 1; j++)
+                    for (int i = -1; i <= 1; i++) {
+                        if (i == 0 && j == 0)
+                            continue;
+                        int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
+                        if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                            continue;
+                        Guide gs = load_guide(G, px, py, c.denoisingRange);
+                        if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                            continue;
+                        float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
+                        w *= geo_weight(pg, (float)px, (float)gy, gs.z);
+                        w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                        if (isSpec && s.enableRoughnessEdgeStopping)
+                            w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                        f4 sv = ld_h4(IN, px, py, sig * 8);
+                        float vs = sv.w;
+                        if (it == 0)
+                            vs = fmax2(fma_(-sv.x, sv.x, ld_h(MOM, px, py, sig * 2)), 0.0f);
+                        w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), minLw);
+                        sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
+                        sumVar = fma_(vs, w * w, sumVar);
+                        wsum += w;
+                    }
+                float inv = 1.0f / wsum;
+                f3 o = mul3(sum, inv);
+                float ov = sumVar * inv * inv;
+                if (last) {
+                    f3 rgb = ycocg_to_linear(o);
+                    float hitDist = ld_h(HIST, x, y, sig * 8 + 6);
+                    st_h4(*outSlot[sig], x, y, split ? ld_h4(*inSlot[sig], x, y) : f4{rgb.x, rgb.y, rgb.z, hitDist});
+                } else
+                    st_h4(OUTP, x, y, {o.x, o.y, o.z, ov}, sig * 8);
             }
         }
 }
@@ -922,6 +1084,156 @@ void reblur_build(Instance& I, DenoiserState& d) {
             p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
         }
         p.run = temporal_stabilization;
+        d.passes.push_back(p);
+    }
+}
+
+
+// ---- RELAX = shared front half (ClassifyTiles, PrePass, TemporalAccumulation, HistoryFix) + A-trous iterations --------
+static nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
+    nrd::ReblurSettings s = {};
+    s.hitDistanceParameters = {1.0f, 0.0f, 1.0f, 0.0f}; // hit distances stay in world units
+    s.maxAccumulatedFrameNum = r.diffuseMaxAccumulatedFrameNum;
+    s.maxFastAccumulatedFrameNum = r.diffuseMaxFastAccumulatedFrameNum;
+    s.historyFixFrameNum = r.historyFixFrameNum;
+    s.historyFixBasePixelStride = r.historyFixBasePixelStride;
+    s.diffusePrepassBlurRadius = r.diffusePrepassBlurRadius;
+    s.specularPrepassBlurRadius = r.specularPrepassBlurRadius;
+    s.minHitDistanceWeight = r.minHitDistanceWeight;
+    s.lobeAngleFraction = r.lobeAngleFraction;
+    s.roughnessFraction = r.roughnessFraction;
+    s.fastHistoryClampingSigmaScale = r.fastHistoryClampingSigmaScale;
+    s.minMaterialForDiffuse = r.minMaterialForDiffuse;
+    s.minMaterialForSpecular = r.minMaterialForSpecular;
+    return s;
+}
+
+void relax_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
+    uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
+    uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
+    uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+    perm.push_back({"RELAX::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"RELAX::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"RELAX::HistoryLength_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
+    perm.push_back({"RELAX::HistoryLength_B", (uint32_t)nrd::Format::R16_UINT, 2, 1});
+    perm.push_back({"RELAX::History", fmtRad, bRad, 1});
+    perm.push_back({"RELAX::FastHistory_A", fmtLum, bLum, 1});
+    perm.push_back({"RELAX::FastHistory_B", fmtLum, bLum, 1});
+    perm.push_back({"RELAX::Moments_A", fmtLum, bLum, 1});
+    perm.push_back({"RELAX::Moments_B", fmtLum, bLum, 1});
+    trans.push_back({"RELAX::Tiles", (uint32_t)nrd::Format::R8_UINT, 1, 16});
+    trans.push_back({"RELAX::Tmp1", fmtRad, bRad, 1});
+    trans.push_back({"RELAX::Tmp2", fmtRad, bRad, 1});
+    trans.push_back({"RELAX::HistoryLength_Tmp", (uint32_t)nrd::Format::R16_UINT, 2, 1});
+    trans.push_back({"RELAX::Data2", (uint32_t)nrd::Format::R32_UINT, 4, 1});
+    trans.push_back({"RELAX::SpecHitDistForTracking", (uint32_t)nrd::Format::R16_SFLOAT, 2, 1});
+    trans.push_back({"RELAX::Atrous_A", fmtRad, bRad, 1});
+    trans.push_back({"RELAX::Atrous_B", fmtRad, bRad, 1});
+}
+
+void relax_build(Instance& I, DenoiserState& d) {
+    (void)I;
+    using RT = nrd::ResourceType;
+    d.reblur = relax_as_reblur(d.relax); // the shared passes read their parameters from here
+    int cur = (int)(d.frameCounter & 1);
+    uint32_t pb = d.permBase, tb = d.transBase;
+    auto P = [&](int i) { return enc_perm(pb + i); };
+    auto T = [&](int i) { return enc_trans(tb + i); };
+    float n = (float)d.nsig;
+    const nrd::ReblurSettings& s = d.reblur;
+    ReblurReach rr = reblur_reach(s);
+    const float GB = 16.0f;
+    float sp = d.hasSpec ? 2.0f : 0.0f;
+    {
+        Pass p;
+        p.name = "RELAX::ClassifyTiles";
+        p.kernel = "nrd_reblur_classify_tiles";
+        p.haloRows = 0;
+        p.bytesPerPixel = 4 + 4 + GB + 1.0f / 256.0f;
+        p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
+        p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
+        p.tileGrid = true;
+        p.run = classify_tiles;
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "RELAX::PrePass";
+        p.kernel = "nrd_reblur_prepass";
+        p.haloRows = (uint16_t)rr.pre;
+        p.bytesPerPixel = GB + 8 * n + 8 * n + sp;
+        p.read = {P(P_GUIDE_A + cur)};
+        if (d.hasDiff)
+            p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+        if (d.hasSpec)
+            p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        p.written = {T(T_TMP1), T(T_HITTRACK)};
+        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+            Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+            SpatialIO io = {};
+            io.reach = reblur_reach(d.reblur).pre;
+            for (int sig = 0; sig < d.nsig; sig++) {
+                bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+                io.in[sig] = &k.slot(isSpec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+                io.inOff[sig] = 0;
+                io.out[sig] = &k.trans(T_TMP1);
+                io.outOff[sig] = sig * 8;
+            }
+            spatial_filter(k, PRE, io, y0, y1);
+        };
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "RELAX::TemporalAccumulation";
+        p.kernel = "nrd_reblur_temporal_accumulation";
+        p.haloRows = 0;
+        p.bytesPerPixel = GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + 2 * n + sp + 8 * n + 2 * n + 2 * n + 2 + 4;
+        p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)),
+                  P(P_DATA1_A + (cur ^ 1)), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
+        p.written = {T(T_TMP2), P(P_FAST_A + cur), P(P_STAB_A + cur), T(T_DATA1), T(T_DATA2)};
+        p.run = temporal_accumulation;
+        d.passes.push_back(p);
+    }
+    {
+        Pass p;
+        p.name = "RELAX::HistoryFix";
+        p.kernel = "nrd_reblur_history_fix";
+        p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
+        p.bytesPerPixel = GB + 2 + 8 * n + 2 * n + 8 * n + 2;
+        p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
+        p.written = {P(P_HIST), P(P_DATA1_A + cur)};
+        p.run = history_fix;
+        d.passes.push_back(p);
+    }
+    int iters = (int)std::min<uint32_t>(std::max<uint32_t>(d.relax.atrousIterationNum, 2), 8);
+    for (int it = 0; it < iters; it++) {
+        bool last = it == iters - 1;
+        Pass p;
+        p.name = it == 0 ? "RELAX::Atrous0" : (last ? "RELAX::AtrousLast" : "RELAX::Atrous");
+        p.kernel = "nrd_relax_atrous";
+        p.haloRows = (uint16_t)(1 << it);
+        p.bytesPerPixel = GB + (it == 0 ? 2 + 8 * n + 2 * n : 8 * n) + (last ? 8 * n : 0.0f) + 8 * n;
+        p.read = {P(P_GUIDE_A + cur)};
+        if (it == 0) {
+            p.read.push_back(P(P_DATA1_A + cur));
+            p.read.push_back(P(P_HIST));
+            p.read.push_back(P(P_STAB_A + cur));
+        } else
+            p.read.push_back(T(T_AT_A + ((it - 1) & 1)));
+        if (last) {
+            p.read.push_back(P(P_HIST));
+            if (d.hasDiff) {
+                p.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
+                p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+            }
+            if (d.hasSpec) {
+                p.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
+                p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+            }
+        } else
+            p.written = {T(T_AT_A + (it & 1))};
+        p.run = [it, last](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { atrous(I, d, c, y0, y1, it, last); };
         d.passes.push_back(p);
     }
 }

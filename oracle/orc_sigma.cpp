@@ -418,8 +418,4 @@ void sigma_build(Instance&, DenoiserState& d) {
     }
 }
 
-// RELAX: not part of this milestone yet (classify() in orc_core.cpp rejects it until orc_relax.cpp lands)
-void relax_describe(DenoiserState&, std::vector<PoolPlane>&, std::vector<PoolPlane>&) {}
-void relax_build(Instance&, DenoiserState&) {}
-
 } // namespace orc

@@ -16,6 +16,7 @@ CASES = {
     "reblur_ds_sigma_reference": ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"],
     "reblur_diffuse": ["REBLUR_DIFFUSE"],
     "reblur_specular_sigma_shadow": ["REBLUR_SPECULAR", "SIGMA_SHADOW"],
+    "relax_ds": ["RELAX_DIFFUSE_SPECULAR"],
 }
 W, H, FRAMES = 64, 48, 4
 INPUT_KEYS = ["viewz", "mv", "normal_roughness", "diff", "spec", "penumbra", "translucency", "confidence", "signal",
@@ -28,6 +29,8 @@ def settings_for(api, scene, dens):
     for d in dens:
         if d.name.startswith("REBLUR"):
             s[d] = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)  # the sample's values (NRDSample.cpp:566-567)
+        elif d.name.startswith("RELAX"):
+            s[d] = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
         elif d.name.startswith("SIGMA"):
             s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
         else:

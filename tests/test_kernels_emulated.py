@@ -8,10 +8,10 @@ import util
 
 
 @pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"], ["REBLUR_DIFFUSE"],
-                                  ["REBLUR_SPECULAR", "SIGMA_SHADOW"]])
+                                  ["REBLUR_SPECULAR", "SIGMA_SHADOW"], ["RELAX_DIFFUSE_SPECULAR"], ["RELAX_DIFFUSE"], ["RELAX_SPECULAR"]])
 def test_emulated_kernels_bit_exact(pkg, api, oracle, emulated, dens):
     w, h = 72, 40  # not a multiple of 16: exercises partial tiles
-    scene = pkg.synth.Scene(w, h, dolly=0.04)
+    scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
     dd = [api.Denoiser[x] for x in dens]
     st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
     ho = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st)

@@ -276,3 +276,25 @@ def test_determinism(request, pkg, api, backend):
             hz.frame(scene.common_settings(api, fr, f, reset=(f == 0)), hz.upload(fr), st)
         runs.append(hz)
     assert util.compare_all(runs[0], runs[1], exact=True) == []
+
+
+# ---- RELAX: fixed point (linear RGB + world-space hit distance in, same out) -------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS_EMU)
+def test_relax_fixed_point(request, pkg, api, backend):
+    b = get(request, backend)
+    w, h = size_for(backend, (96, 64), (48, 32))
+    d = api.Denoiser.RELAX_DIFFUSE_SPECULAR
+    hz = pkg.harness.Harness(b, [d], w, h)
+    fr = util.flat_frame(pkg, w, h)
+    for key, rgb, hit in (("diff", (0.6, 0.5, 0.4), 1.5), ("spec", (0.3, 0.4, 0.5), 7.0)):
+        fr[key] = np.broadcast_to(np.array(rgb + (hit,), dtype=np.float16), (h, w, 4)).copy()
+    st = {d: api.RelaxSettings()}
+    for f in range(4):
+        hz.frame(util.static_common(api, w, h, f, reset=(f == 0)), hz.upload(fr), st)
+        for key, src in (("out_diff", "diff"), ("out_spec", "spec")):
+            # RGB -> YCoCg -> RGB in fp16 planes: a few ULP on the colour channels, hit distance exact to 1 ULP
+            assert util.max_ulp_f16(hz.output(key)[..., :3], fr[src][..., :3]) <= 4, (f, key)
+            assert util.max_ulp_f16(hz.output(key)[..., 3], fr[src][..., 3]) <= 1, (f, key)
+    names = [x["name"] for x in hz.nrd.dispatches([int(d)])]
+    assert names[:4] == ["RELAX::ClassifyTiles", "RELAX::PrePass", "RELAX::TemporalAccumulation", "RELAX::HistoryFix"]
+    assert len(names) == 4 + 5 and names[-1] == "RELAX::AtrousLast"  # atrousIterationNum = 5 (Source/NRDSample.cpp:1642 range 2..8)

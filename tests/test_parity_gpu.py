@@ -13,6 +13,9 @@ VARIANTS = [
     ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"],
     ["REBLUR_DIFFUSE"],
     ["REBLUR_SPECULAR", "SIGMA_SHADOW"],
+    ["RELAX_DIFFUSE_SPECULAR"],
+    ["RELAX_DIFFUSE"],
+    ["RELAX_SPECULAR"],
 ]
 
 
@@ -29,7 +32,7 @@ def report(ha, hb):
 @pytest.mark.parametrize("dens", VARIANTS)
 def test_hip_matches_oracle(pkg, api, oracle, hip, dens):
     w, h = 480, 270
-    scene = pkg.synth.Scene(w, h, dolly=0.02)
+    scene = pkg.synth.Scene(w, h, dolly=0.02, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
     dd = [api.Denoiser[x] for x in dens]
     st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
     ho = pkg.harness.Harness(oracle, dd, w, h)
@@ -49,7 +52,7 @@ def test_hip_matches_oracle(pkg, api, oracle, hip, dens):
             assert util.psnr(g, a) >= 60.0
     # permanent pool after the last frame (histories) within 1 ULP as well
     for pa, pb in zip(ho.nrd.pools[0], hg.nrd.pools[0]):
-        if pa["name"].endswith("History") and pa["name"].startswith("REBLUR"):
+        if pa["name"].endswith("::History"):
             assert util.max_ulp_f16(ho.fetch(pa["buf"]).view(np.float16), hg.fetch(pb["buf"]).view(np.float16)) <= 1
     print("bit-exact pools:", report(ho, hg) == "", report(ho, hg))
 

@@ -32,6 +32,9 @@ def default_settings(api, scene, denoisers, **reblur_kw):
             s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
         elif d == D.REFERENCE:
             s[d] = api.ReferenceSettings()
+        elif d in (D.RELAX_DIFFUSE, D.RELAX_SPECULAR, D.RELAX_DIFFUSE_SPECULAR):
+            kw = {k: v for k, v in reblur_kw.items() if k in ("minMaterialForDiffuse", "minMaterialForSpecular")}
+            s[d] = api.RelaxSettings(**kw)
     return s
 
 
