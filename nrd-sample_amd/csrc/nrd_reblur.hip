@@ -164,36 +164,39 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
             float roughB = -rough * roughA;
             const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
-#pragma unroll 2
+#pragma unroll
             for (int t = 0; t < 8; t++) {
                 float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
                 float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
                 float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
                 float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
-                if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
-                    continue;
-                int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+                // Latency: both gathers of the tap are issued UNCONDITIONALLY at a clamped (always valid) address and only
+                // then is the tap validated - one memory round trip per tap instead of three dependent ones. A rejected tap
+                // contributes nothing, exactly like an early "continue".
+                bool valid = fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H;
+                int px = (int)clampf(fpx, 0.0f, (float)(c.W - 1)), gy = (int)clampf(fpy, 0.0f, (float)(c.H - 1)), py = gy - c.yOff;
                 int ddx = px - x, ddy = gy - gy0;
-                if (ddx > reach || -ddx > reach || ddy > reach || -ddy > reach)
-                    continue;
-                if (py < 0 || py >= c.resH)
-                    continue;
-                Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
-                if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
-                    continue;
+                valid = valid && !(ddx > reach || -ddx > reach || ddy > reach || -ddy > reach) && py >= 0 && py < c.resH;
+                int cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
+                uint4 graw = ld<uint4>(p.guide, px, cpy, 16);
+                uint2 sraw = ld<uint2>(srcP, px, cpy, srcBpt, srcOff);
+                Guide gs = decode_guide(graw, c.denoisingRange);
+                // branch-free from here: a rejected tap is SELECTED out (sums untouched), which is exactly what skipping it
+                // would do, but keeps the unrolled taps in one basic block so their gathers overlap
+                valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
                 float w = g_poisson8[t][2];
                 w *= geo_weight(pg, fpx, fpy, gs.z);
                 w *= normal_weight(dot3(g.n, gs.n), normalW2);
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                f4 sv = unpack_h4(ld<uint2>(srcP, px, py, srcBpt, srcOff));
+                f4 sv = unpack_h4(sraw);
                 if (relaxIn)
                     sv = rgb_to_ycocg4(sv);
                 w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
-                sum = fma4(sv, w, sum);
-                wsum += w;
-                if (w > 0.0f)
-                    minHit = fmin2(minHit, sv.w * hitNorm);
+                f4 acc = fma4(sv, w, sum);
+                sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
+                wsum = valid ? wsum + w : wsum;
+                minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
             }
         }
         float invw = 1.0f / wsum;
@@ -263,12 +266,21 @@ NRD_DEV Footprint footprint(const ReblurParams& p, float pu, float pv, f3 NvPrev
     float planeRef = dot3(NvPrev, XvPrev);
     float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
     float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
+    // the four guide texels are fetched unconditionally at clamped addresses (one round trip), then validated
+    uint4 graw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx = f.ix + (i & 1), ty = f.iy + (i >> 1) - c.yOff;
+        tx = tx < 0 ? 0 : (tx >= c.Wprev ? c.Wprev - 1 : tx);
+        ty = ty < 0 ? 0 : (ty >= c.resH ? c.resH - 1 : ty);
+        graw[i] = ld<uint4>(p.guidePrev, tx, ty, 16);
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
         bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
         if (ok) {
-            Guide gp = decode_guide(ld<uint4>(p.guidePrev, tx, ty, 16), c.denoisingRange);
+            Guide gp = decode_guide(graw[i], c.denoisingRange);
             float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
             ok = !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
         }
@@ -279,29 +291,58 @@ NRD_DEV Footprint footprint(const ReblurParams& p, float pu, float pv, f3 NvPrev
     return f;
 }
 
+// footprint fetches: the four texels are loaded unconditionally at clamped addresses (independent loads, one round trip);
+// only taps with a non-zero weight are accumulated, so rejected texels never reach the result
+NRD_DEV void tap_xy(const FrameConsts& c, const Footprint& f, int i, int& tx, int& ty) {
+    tx = f.ix + (i & 1);
+    ty = f.iy + (i >> 1) - c.yOff;
+    tx = tx < 0 ? 0 : (tx >= c.Wprev ? c.Wprev - 1 : tx);
+    ty = ty < 0 ? 0 : (ty >= c.resH ? c.resH - 1 : ty);
+}
 NRD_DEV f4 fetch4(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
+    uint2 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx, ty;
+        tap_xy(c, f, i, tx, ty);
+        raw[i] = ld<uint2>(P, tx, ty, bpt, off);
+    }
     f4 s = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
-            s = fma4(unpack_h4(ld<uint2>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)), f.w[i], s);
+            s = fma4(unpack_h4(raw[i]), f.w[i], s);
     return mul4(s, 1.0f / f.wsum);
 }
 NRD_DEV float fetch1(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
+    uint16_t raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx, ty;
+        tap_xy(c, f, i, tx, ty);
+        raw[i] = ld<uint16_t>(P, tx, ty, bpt, off);
+    }
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
-            s = fma_(h2f(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, bpt, off)), f.w[i], s);
+            s = fma_(h2f(raw[i]), f.w[i], s);
     return s * (1.0f / f.wsum);
 }
 NRD_DEV void fetchA(const FrameConsts& c, const PlaneRef& P, const Footprint& f, float& dA, float& sA) {
+    uint16_t raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx, ty;
+        tap_xy(c, f, i, tx, ty);
+        raw[i] = ld<uint16_t>(P, tx, ty, 2);
+    }
     dA = sA = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f) {
             float a, b;
-            unpack_data1(ld<uint16_t>(P, f.ix + (i & 1), f.iy + (i >> 1) - c.yOff, 2), a, b);
+            unpack_data1(raw[i], a, b);
             dA = fma_(a, f.w[i], dA);
             sA = fma_(b, f.w[i], sA);
         }
@@ -432,12 +473,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
             vmb = footprint(p, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
             vmbBits = vmb.bits;
             if (vmb.wsum > 0.0f) {
-                float prevRough = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (vmb.w[i] > 0.0f)
-                        prevRough = fma_(h2f(ld<uint16_t>(p.guidePrev, vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff, 16, 10)), vmb.w[i], prevRough);
-                prevRough *= 1.0f / vmb.wsum;
+                float prevRough = fetch1(c, p.guidePrev, 16, 10, vmb); // roughness of the virtual footprint (guide texel bytes 10..11)
                 float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction));
                 float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
                 amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
@@ -627,11 +663,19 @@ NRD_DEV bool fetch_stab(const FrameConsts& c, const PlaneRef& P, int bpt, int of
         return false;
     int ix = (int)fx0, iy = (int)fy0;
     float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+    uint16_t raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx = ix + (i & 1), ty = iy + (i >> 1) - c.yOff;
+        tx = tx < 0 ? 0 : (tx >= c.Wprev ? c.Wprev - 1 : tx);
+        ty = ty < 0 ? 0 : (ty >= c.resH ? c.resH - 1 : ty);
+        raw[i] = ld<uint16_t>(P, tx, ty, bpt, off);
+    }
     float sum = 0.0f, wsum = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (bits & (1u << i)) {
-            sum = fma_(h2f(ld<uint16_t>(P, ix + (i & 1), iy + (i >> 1) - c.yOff, bpt, off)), bw[i], sum);
+            sum = fma_(h2f(raw[i]), bw[i], sum);
             wsum += bw[i];
         }
     if (!(wsum > 0.0f))
@@ -814,24 +858,26 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 if (i == 0 && j == 0)
                     continue;
                 int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
-                if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
-                    continue;
-                Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
-                if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
-                    continue;
+                bool valid = !(px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH);
+                int cpx = px < 0 ? 0 : (px >= c.W ? c.W - 1 : px), cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
+                uint4 graw = ld<uint4>(p.guide, cpx, cpy, 16); // all loads of the tap issued before it is validated
+                uint2 sraw = ld<uint2>(p.in, cpx, cpy, RBPT, sig * 8);
+                uint16_t mraw = it == 0 ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+                Guide gs = decode_guide(graw, c.denoisingRange);
+                valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat); // rejected taps are selected out below
                 float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
                 w *= geo_weight(pg, (float)px, (float)gy, gs.z);
                 w *= normal_weight(dot3(g.n, gs.n), normalW2);
                 if (isSpec && p.roughnessEdgeStopping)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                f4 sv = unpack_h4(ld<uint2>(p.in, px, py, RBPT, sig * 8));
+                f4 sv = unpack_h4(sraw);
                 float vs = sv.w;
                 if (it == 0)
-                    vs = fmax2(fma_(-sv.x, sv.x, h2f(ld<uint16_t>(p.mom, px, py, LBPT, sig * 2))), 0.0f);
+                    vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw)), 0.0f);
                 w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), p.minLw[si]);
-                sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
-                sumVar = fma_(vs, w * w, sumVar);
-                wsum += w;
+                sum = {valid ? fma_(sv.x, w, sum.x) : sum.x, valid ? fma_(sv.y, w, sum.y) : sum.y, valid ? fma_(sv.z, w, sum.z) : sum.z};
+                sumVar = valid ? fma_(vs, w * w, sumVar) : sumVar;
+                wsum = valid ? wsum + w : wsum;
             }
         float inv = 1.0f / wsum;
         f3 o = mul3(sum, inv);

@@ -170,22 +170,22 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
             float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
             float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
             float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
-            if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
-                continue;
-            int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
+            // loads first (clamped address), validation after: one memory round trip per tap
+            bool valid = fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H;
+            int px = (int)clampf(fpx, 0.0f, (float)(c.W - 1)), gy = (int)clampf(fpy, 0.0f, (float)(c.H - 1)), py = gy - c.yOff;
             int ddx = px - x, ddy = gy - gy0;
-            if (ddx > BLUR_REACH || -ddx > BLUR_REACH || ddy > BLUR_REACH || -ddy > BLUR_REACH)
-                continue;
-            if (py < 0 || py >= c.resH)
-                continue;
+            valid = valid && !(ddx > BLUR_REACH || -ddx > BLUR_REACH || ddy > BLUR_REACH || -ddy > BLUR_REACH) && py >= 0 && py < c.resH;
+            py = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
             float zs = ld<float>(p.guide, px, py, 16, 0);
-            if (!(absf(zs) <= c.denoisingRange))
+            uint16_t praw = ld<uint16_t>(inPen, px, py, 2);
+            uint2 sraw = PASS == 0 ? uint2{0u, 0u} : ld<uint2>(p.shadow1, px, py, 8);
+            if (!valid || !(absf(zs) <= c.denoisingRange))
                 continue;
             float ga = fma_(gax, fpx, fma_(gay, fpy, ga0));
             float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(fma_(zs, ga, geoB)));
-            float ps = h2f(ld<uint16_t>(inPen, px, py, 2));
+            float ps = h2f(praw);
             bool lits = PASS == 0 ? ps >= NRD_FP16_MAX : !(ps > 0.0f);
-            f4 sv = PASS == 0 ? input_visibility(p, px, py, ps) : unpack_h4(ld<uint2>(p.shadow1, px, py, 8));
+            f4 sv = PASS == 0 ? input_visibility(p, px, py, ps) : unpack_h4(sraw);
             sum = fma4(sv, w, sum);
             wsum += w;
             if (!lits) {

@@ -567,7 +567,8 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         a.last = last ? 1 : 0;
         a.in = it == 0 ? p.hist : I.trans[tb + rb::AT_A + ((it - 1) & 1)].ref();
         a.out = I.trans[tb + rb::AT_A + (it & 1)].ref();
-        Dispatch x{it == 0 ? "RELAX::Atrous0" : (last ? "RELAX::AtrousLast" : "RELAX::Atrous"), "nrd_relax_atrous", (uint16_t)(1 << it),
+        static const char* atrousNames[8] = {"RELAX::Atrous0", "RELAX::Atrous1", "RELAX::Atrous2", "RELAX::Atrous3", "RELAX::Atrous4", "RELAX::Atrous5", "RELAX::Atrous6", "RELAX::Atrous7"};
+        Dispatch x{atrousNames[it], "nrd_relax_atrous", (uint16_t)(1 << it),
                    GB + (it == 0 ? 2 + 8 * n + 2 * n : 8 * n) + (last ? 8 * n : 0.0f) + 8 * n, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         if (it == 0) {

@@ -1210,7 +1210,8 @@ void relax_build(Instance& I, DenoiserState& d) {
     for (int it = 0; it < iters; it++) {
         bool last = it == iters - 1;
         Pass p;
-        p.name = it == 0 ? "RELAX::Atrous0" : (last ? "RELAX::AtrousLast" : "RELAX::Atrous");
+        static const char* atrousNames[8] = {"RELAX::Atrous0", "RELAX::Atrous1", "RELAX::Atrous2", "RELAX::Atrous3", "RELAX::Atrous4", "RELAX::Atrous5", "RELAX::Atrous6", "RELAX::Atrous7"};
+        p.name = atrousNames[it];
         p.kernel = "nrd_relax_atrous";
         p.haloRows = (uint16_t)(1 << it);
         p.bytesPerPixel = GB + (it == 0 ? 2 + 8 * n + 2 * n : 8 * n) + (last ? 8 * n : 0.0f) + 8 * n;

@@ -297,4 +297,4 @@ def test_relax_fixed_point(request, pkg, api, backend):
             assert util.max_ulp_f16(hz.output(key)[..., 3], fr[src][..., 3]) <= 1, (f, key)
     names = [x["name"] for x in hz.nrd.dispatches([int(d)])]
     assert names[:4] == ["RELAX::ClassifyTiles", "RELAX::PrePass", "RELAX::TemporalAccumulation", "RELAX::HistoryFix"]
-    assert len(names) == 4 + 5 and names[-1] == "RELAX::AtrousLast"  # atrousIterationNum = 5 (Source/NRDSample.cpp:1642 range 2..8)
+    assert len(names) == 4 + 5 and names[-1] == "RELAX::Atrous4"  # atrousIterationNum = 5 (Source/NRDSample.cpp:1642 range 2..8)
