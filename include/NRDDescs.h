@@ -122,6 +122,7 @@ enum class Format : uint32_t {
     RGBA32_SFLOAT,
     R10_G10_B10_A2_UNORM,
     RGBA32_UINT, // 16-byte packed diff+spec radiance plane (2 x RGBA16F)
+    R16_UNORM,   // OCCLUSION variants: normalised hit distance (Source/NRDSample.cpp:2934-2937)
     MAX_NUM
 };
 

@@ -16,6 +16,8 @@ struct ReblurParams {
     float responsiveRoughnessThreshold, responsiveMinAccum;
     float maxA, maxFastA, maxStab;
     float maxASpec, maxFastASpec; // == maxA / maxFastA for REBLUR; RELAX has per-signal history caps
+    int occlusion;                // 1: OCCLUSION variants - IN/OUT_*_HITDIST planes hold the normalised hit distance only
+    int ioF16;                    //    ... as R16_SFLOAT (1) or R16_UNORM (0)
     int relax;                    // 1: RELAX front half (linear RGB + world-space hitT inputs, luma-moment history, HistoryFix writes History)
     int historyFixFrameNum, historyFixStride;
     int reachPre, reachBlur, reachPost; // hard per-pass bound (pixels) on tap distance = halo rows of the pass

@@ -31,6 +31,23 @@ NRD_DEV uint16_t pack_data1(float diffA, float specA) {
     return (uint16_t)(d | (s << 8));
 }
 
+// OCCLUSION variants: the signal is the normalised hit distance alone (R16_UNORM / R16F plane, Source/NRDSample.cpp:488-501);
+// internally it travels as {h, 0, 0, h} so every luma-based stage works on it unchanged
+NRD_DEV f4 load_signal(const ReblurParams& p, const PlaneRef& P, int x, int y, int bpt, int off, bool occlusion) {
+    if (!occlusion)
+        return unpack_h4(ld<uint2>(P, x, y, bpt, off));
+    uint16_t raw = ld<uint16_t>(P, x, y, 2);
+    float h = p.ioF16 ? h2f(raw) : (float)raw * (1.0f / 65535.0f);
+    return {h, 0.0f, 0.0f, h};
+}
+NRD_DEV void store_signal(const ReblurParams& p, const PlaneRef& P, int x, int y, f4 v) {
+    if (!p.occlusion) {
+        st<uint2>(P, x, y, 8, pack_h4(v));
+        return;
+    }
+    st<uint16_t>(P, x, y, 2, p.ioF16 ? f2h(v.x) : (uint16_t)__builtin_floorf(fma_(sat(v.x), 65535.0f, 0.5f)));
+}
+
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
 NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
     if (!xcd_tile(c, tx, ty))
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
     const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
     const bool relaxIn = VARIANT == 0 && p.relax != 0; // RELAX inputs: linear RGB + world-space hit distance
+    const bool occIn = VARIANT == 0 && p.occlusion != 0;
 
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
@@ -112,7 +130,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         const PlaneRef& srcP = VARIANT == 0 ? (isSpec ? p.inSpec : p.inDiff) : inP;
         const int srcBpt = VARIANT == 0 ? 8 : RBPT;
         const int srcOff = VARIANT == 0 ? 0 : sig * 8;
-        f4 center = unpack_h4(ld<uint2>(srcP, x, y, srcBpt, srcOff));
+        f4 center = load_signal(p, srcP, x, y, srcBpt, srcOff, occIn);
         if (relaxIn)
             center = rgb_to_ycocg4(center);
         float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 valid = valid && !(ddx > reach || -ddx > reach || ddy > reach || -ddy > reach) && py >= 0 && py < c.resH;
                 int cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
                 uint4 graw = ld<uint4>(p.guide, px, cpy, 16);
-                uint2 sraw = ld<uint2>(srcP, px, cpy, srcBpt, srcOff);
+                f4 sv = load_signal(p, srcP, px, cpy, srcBpt, srcOff, occIn);
                 Guide gs = decode_guide(graw, c.denoisingRange);
                 // branch-free from here: a rejected tap is SELECTED out (sums untouched), which is exactly what skipping it
                 // would do, but keeps the unrolled taps in one basic block so their gathers overlap
@@ -189,7 +207,6 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 w *= normal_weight(dot3(g.n, gs.n), normalW2);
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                f4 sv = unpack_h4(sraw);
                 if (relaxIn)
                     sv = rgb_to_ycocg4(sv);
                 w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
@@ -710,7 +727,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
             const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-            st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
+            store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : f4{0, 0, 0, 0});
             st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
         return;
@@ -767,7 +784,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         st<uint16_t>(p.stab, x, y, LBPT, f2h(Yout), sig * 2);
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-        st<uint2>(op, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : pack_h4(o));
+        store_signal(p, op, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : o);
     }
 }
 

@@ -46,6 +46,7 @@ uint32_t format_bytes(uint32_t f) {
         case Format::R8_UNORM:
         case Format::R8_UINT: return 1;
         case Format::R16_UINT:
+        case Format::R16_UNORM:
         case Format::R16_SFLOAT: return 2;
         case Format::RGBA8_UNORM:
         case Format::RG16_SFLOAT:
@@ -73,7 +74,7 @@ struct DenoiserState {
     uint32_t identifier = 0;
     nrd::Denoiser denoiser = nrd::Denoiser::MAX_NUM;
     Kind kind = Kind::REFERENCE;
-    bool hasDiff = false, hasSpec = false, translucency = false;
+    bool hasDiff = false, hasSpec = false, translucency = false, occlusion = false;
     int nsig = 0;
     uint32_t permBase = 0, permEnd = 0, transBase = 0;
     uint32_t frameCounter = 0, framesSinceReset = 0;
@@ -120,6 +121,9 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE: d.kind = Kind::REBLUR; d.hasDiff = true; break;
         case D::REBLUR_SPECULAR: d.kind = Kind::REBLUR; d.hasSpec = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = true; break;
+        case D::REBLUR_DIFFUSE_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.occlusion = true; break;
+        case D::REBLUR_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasSpec = d.occlusion = true; break;
+        case D::REBLUR_DIFFUSE_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.occlusion = true; break;
         case D::RELAX_DIFFUSE: d.kind = Kind::RELAX; d.hasDiff = true; break;
         case D::RELAX_SPECULAR: d.kind = Kind::RELAX; d.hasSpec = true; break;
         case D::RELAX_DIFFUSE_SPECULAR: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = true; break;
@@ -359,12 +363,14 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.inZ = SP(RT::IN_VIEWZ);
     p.inNR = SP(RT::IN_NORMAL_ROUGHNESS);
     p.inMV = SP(RT::IN_MV);
-    p.inDiff = SP(RT::IN_DIFF_RADIANCE_HITDIST);
-    p.inSpec = SP(RT::IN_SPEC_RADIANCE_HITDIST);
+    p.inDiff = SP(d.occlusion ? RT::IN_DIFF_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+    p.inSpec = SP(d.occlusion ? RT::IN_SPEC_HITDIST : RT::IN_SPEC_RADIANCE_HITDIST);
+    p.occlusion = d.occlusion ? 1 : 0;
+    p.ioF16 = I.slots[(size_t)(d.hasDiff ? RT::IN_DIFF_HITDIST : RT::IN_SPEC_HITDIST)].fmt == (uint32_t)nrd::Format::R16_SFLOAT ? 1 : 0;
     p.confD = SP(RT::IN_DIFF_CONFIDENCE);
     p.confS = SP(RT::IN_SPEC_CONFIDENCE);
-    p.outDiff = SP(RT::OUT_DIFF_RADIANCE_HITDIST);
-    p.outSpec = SP(RT::OUT_SPEC_RADIANCE_HITDIST);
+    p.outDiff = SP(d.occlusion ? RT::OUT_DIFF_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
+    p.outSpec = SP(d.occlusion ? RT::OUT_SPEC_HITDIST : RT::OUT_SPEC_RADIANCE_HITDIST);
     p.guide = PP(rb::GUIDE_A + cur);
     p.guidePrev = PP(rb::GUIDE_A + (cur ^ 1));
     p.data1 = PP(rb::DATA1_A + cur);
@@ -410,9 +416,9 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * n + 8 * n + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         if (d.hasDiff)
-            x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+            x.read.push_back(enc_slot(d.occlusion ? RT::IN_DIFF_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST));
         if (d.hasSpec)
-            x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+            x.read.push_back(enc_slot(d.occlusion ? RT::IN_SPEC_HITDIST : RT::IN_SPEC_RADIANCE_HITDIST));
         x.written = {T(rb::TMP1), T(rb::HITTRACK)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);
@@ -454,12 +460,12 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::DATA2), enc_slot(RT::IN_MV), P(rb::HIST), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
         x.written = {P(rb::STAB_A + cur)};
         if (d.hasDiff) {
-            x.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
-            x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+            x.written.push_back(enc_slot(d.occlusion ? RT::OUT_DIFF_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST));
+            x.read.push_back(enc_slot(d.occlusion ? RT::IN_DIFF_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST));
         }
         if (d.hasSpec) {
-            x.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
-            x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+            x.written.push_back(enc_slot(d.occlusion ? RT::OUT_SPEC_HITDIST : RT::OUT_SPEC_RADIANCE_HITDIST));
+            x.read.push_back(enc_slot(d.occlusion ? RT::IN_SPEC_HITDIST : RT::IN_SPEC_RADIANCE_HITDIST));
         }
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_stabilization(p, st); };
         d.dispatches.push_back(x);

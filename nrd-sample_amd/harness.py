@@ -20,12 +20,16 @@ INPUT_SLOTS = {
     RT.IN_PENUMBRA: ("penumbra", F.R16_SFLOAT),
     RT.IN_TRANSLUCENCY: ("translucency", F.RGBA8_UNORM),
     RT.IN_SIGNAL: ("signal", F.RGBA16_SFLOAT),
+    RT.IN_DIFF_HITDIST: ("diff_hitdist", F.R16_UNORM),  # OCCLUSION variants (Source/NRDSample.cpp:488-501)
+    RT.IN_SPEC_HITDIST: ("spec_hitdist", F.R16_UNORM),
 }
 OUTPUT_SLOTS = {
     RT.OUT_DIFF_RADIANCE_HITDIST: ("out_diff", F.RGBA16_SFLOAT, 8),
     RT.OUT_SPEC_RADIANCE_HITDIST: ("out_spec", F.RGBA16_SFLOAT, 8),
     RT.OUT_SHADOW_TRANSLUCENCY: ("out_shadow", F.RGBA8_UNORM, 4),
     RT.OUT_VALIDATION: ("out_validation", F.RGBA8_UNORM, 4),
+    RT.OUT_DIFF_HITDIST: ("out_diff_hitdist", F.R16_UNORM, 2),
+    RT.OUT_SPEC_HITDIST: ("out_spec_hitdist", F.R16_UNORM, 2),
 }
 
 

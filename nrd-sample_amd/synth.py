@@ -291,6 +291,11 @@ class Scene:
         s4 = torch.where(hit[..., None], s4, torch.zeros_like(s4))
         out["diff"] = d4.to(torch.float16)
         out["spec"] = s4.to(torch.float16)
+        if not self.relax:  # OCCLUSION variants take the normalised hit distance alone, R16_UNORM
+            for key, src in (("diff_hitdist", d4), ("spec_hitdist", s4)):
+                q = torch.floor(torch.clamp(src[..., 3], 0, 1) * 65535 + 0.5).to(torch.int32)  # 0..65535 (sky = 0)
+                # stored as a 16-bit pattern: int16 reinterpretation keeps the bits on both backends
+                out[key] = torch.where(q >= 32768, q - 65536, q).to(torch.int16)
         pen = torch.where(lit, torch.full_like(ts, FP16_MAX), torch.clamp(torch.where(torch.isfinite(ts), ts, torch.zeros_like(ts)) * self.tan_sun, max=1000.0))
         pen = torch.where(ndl > 0, pen, torch.zeros_like(pen))  # back-facing: fully shadowed at distance 0
         pen = torch.where(hit, pen, torch.full_like(pen, FP16_MAX))
@@ -309,6 +314,9 @@ class Scene:
         out["clean_diff"] = sky_irr.to(torch.float32)
         if dev == "cpu":
             out = {k: (x.numpy().view(np.uint32) if k == "normal_roughness" else x.numpy()) for k, x in out.items()}
+            for k in ("diff_hitdist", "spec_hitdist"):
+                if k in out:
+                    out[k] = out[k].view(np.uint16)
         out["world_to_view"], out["world_to_view_prev"] = w2v, w2v_prev
         out["view_to_clip"] = self.proj
         return out

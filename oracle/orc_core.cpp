@@ -153,6 +153,9 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE: d.kind = Kind::REBLUR; d.hasDiff = true; break;
         case D::REBLUR_SPECULAR: d.kind = Kind::REBLUR; d.hasSpec = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = true; break;
+        case D::REBLUR_DIFFUSE_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.occlusion = true; break;
+        case D::REBLUR_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasSpec = d.occlusion = true; break;
+        case D::REBLUR_DIFFUSE_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.occlusion = true; break;
         case D::RELAX_DIFFUSE: d.kind = Kind::RELAX; d.hasDiff = true; break;
         case D::RELAX_SPECULAR: d.kind = Kind::RELAX; d.hasSpec = true; break;
         case D::RELAX_DIFFUSE_SPECULAR: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = true; break;

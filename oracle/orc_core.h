@@ -27,6 +27,7 @@ static inline uint32_t format_bytes(uint32_t f) {
         case Format::R8_UNORM:
         case Format::R8_UINT: return 1;
         case Format::R16_UINT:
+        case Format::R16_UNORM:
         case Format::R16_SFLOAT: return 2;
         case Format::RGBA8_UNORM:
         case Format::RG16_SFLOAT:

@@ -31,6 +31,32 @@ static inline f4 add4(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w
 static inline f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
 static inline f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
 static inline f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
+// OCCLUSION variants: the signal is the normalised hit distance alone (R16_UNORM or R16F plane); internally it travels as
+// {h, 0, 0, h} so every luma-based stage works on it unchanged (Source/NRDSample.cpp:488-501 binds IN/OUT_*_HITDIST)
+static inline f4 load_signal(const Plane& P, int x, int y, int off, bool occlusion) {
+    if (!occlusion)
+        return ld_h4(P, x, y, off);
+    float h = P.fmt == (uint32_t)nrd::Format::R16_SFLOAT ? ld_h(P, x, y) : (float)ld_u16(P, x, y) * (1.0f / 65535.0f);
+    return {h, 0.0f, 0.0f, h};
+}
+static inline void store_signal(const Plane& P, int x, int y, f4 v, bool occlusion) {
+    if (!occlusion) {
+        st_h4(P, x, y, v);
+        return;
+    }
+    if (P.fmt == (uint32_t)nrd::Format::R16_SFLOAT)
+        st_h(P, x, y, v.x);
+    else
+        st_u16(P, x, y, (uint16_t)floorf(fma_(sat(v.x), 65535.0f, 0.5f)));
+}
+static inline nrd::ResourceType in_slot(const DenoiserState& d, bool spec) {
+    using RT = nrd::ResourceType;
+    return d.occlusion ? (spec ? RT::IN_SPEC_HITDIST : RT::IN_DIFF_HITDIST) : (spec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+}
+static inline nrd::ResourceType out_slot(const DenoiserState& d, bool spec) {
+    using RT = nrd::ResourceType;
+    return d.occlusion ? (spec ? RT::OUT_SPEC_HITDIST : RT::OUT_DIFF_HITDIST) : (spec ? RT::OUT_SPEC_RADIANCE_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
+}
 static inline f4 rgb_to_ycocg4(f4 v) {
     f3 c = linear_to_ycocg({v.x, v.y, v.z});
     return {c.x, c.y, c.z, v.w};
@@ -134,6 +160,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const Plane& HT = k.trans(T_HITTRACK);
     const float* hp = &s.hitDistanceParameters.A;
     const bool relaxIn = k.d.kind == Kind::RELAX && variant == PRE; // RELAX inputs: linear RGB + world-space hit distance
+    const bool occIn = k.d.occlusion && variant == PRE;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
@@ -165,7 +192,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 bool isSpec = (sig == k.sigSpec()) && k.d.hasSpec;
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
-                f4 center = ld_h4(*io.in[sig], x, y, io.inOff[sig]);
+                f4 center = load_signal(*io.in[sig], x, y, io.inOff[sig], occIn);
                 if (relaxIn)
                     center = rgb_to_ycocg4(center);
                 float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
@@ -239,7 +266,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         w *= normal_weight(dot3(g.n, gs.n), normalW2);
                         if (isSpec)
                             w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                        f4 sv = ld_h4(*io.in[sig], px, py, io.inOff[sig]);
+                        f4 sv = load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
                         if (relaxIn)
                             sv = rgb_to_ycocg4(sv);
                         w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
@@ -690,12 +717,12 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
     const Plane* outP[2] = {nullptr, nullptr};
     const Plane* inP[2] = {nullptr, nullptr};
     if (d.hasDiff) {
-        outP[k.sigDiff()] = &k.slot(nrd::ResourceType::OUT_DIFF_RADIANCE_HITDIST);
-        inP[k.sigDiff()] = &k.slot(nrd::ResourceType::IN_DIFF_RADIANCE_HITDIST);
+        outP[k.sigDiff()] = &k.slot(out_slot(d, false));
+        inP[k.sigDiff()] = &k.slot(in_slot(d, false));
     }
     if (d.hasSpec) {
-        outP[k.sigSpec()] = &k.slot(nrd::ResourceType::OUT_SPEC_RADIANCE_HITDIST);
-        inP[k.sigSpec()] = &k.slot(nrd::ResourceType::IN_SPEC_RADIANCE_HITDIST);
+        outP[k.sigSpec()] = &k.slot(out_slot(d, true));
+        inP[k.sigSpec()] = &k.slot(in_slot(d, true));
     }
     bool historyOk = d.historyValid && !c.reset;
     float maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
@@ -707,7 +734,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
-                    st_h4(*outP[sig], x, y, split ? ld_h4(*inP[sig], x, y) : f4{0, 0, 0, 0});
+                    store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, d.occlusion) : f4{0, 0, 0, 0}, d.occlusion);
                     st_h(STABC, x, y, 0.0f, sig * 2);
                 }
                 continue;
@@ -794,7 +821,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 float scale = (Yout + 1e-6f) / (Y + 1e-6f);
                 f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
                 st_h(STABC, x, y, Yout, sig * 2);
-                st_h4(*outP[sig], x, y, split ? ld_h4(*inP[sig], x, y) : o);
+                store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, d.occlusion) : o, d.occlusion);
             }
         }
 }
@@ -984,9 +1011,9 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.bytesPerPixel = GB + 8 * n + 8 * n + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
         if (d.hasDiff)
-            p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+            p.read.push_back(enc_slot(in_slot(d, false)));
         if (d.hasSpec)
-            p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+            p.read.push_back(enc_slot(in_slot(d, true)));
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
@@ -994,7 +1021,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                io.in[sig] = &k.slot(isSpec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+                io.in[sig] = &k.slot(in_slot(d, isSpec));
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
                 io.outOff[sig] = sig * 8;
@@ -1076,12 +1103,12 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2), enc_slot(RT::IN_MV), P(P_HIST), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {P(P_STAB_A + cur)};
         if (d.hasDiff) {
-            p.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
-            p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+            p.written.push_back(enc_slot(out_slot(d, false)));
+            p.read.push_back(enc_slot(in_slot(d, false)));
         }
         if (d.hasSpec) {
-            p.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
-            p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+            p.written.push_back(enc_slot(out_slot(d, true)));
+            p.read.push_back(enc_slot(in_slot(d, true)));
         }
         p.run = temporal_stabilization;
         d.passes.push_back(p);

@@ -298,3 +298,30 @@ def test_relax_fixed_point(request, pkg, api, backend):
     names = [x["name"] for x in hz.nrd.dispatches([int(d)])]
     assert names[:4] == ["RELAX::ClassifyTiles", "RELAX::PrePass", "RELAX::TemporalAccumulation", "RELAX::HistoryFix"]
     assert len(names) == 4 + 5 and names[-1] == "RELAX::Atrous4"  # atrousIterationNum = 5 (Source/NRDSample.cpp:1642 range 2..8)
+
+
+# ---- OCCLUSION variants: the normalised hit distance alone, R16_UNORM in / out (Source/NRDSample.cpp:488-501, :2934-2937) ----
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_occlusion_fixed_point_and_denoising(request, pkg, api, backend):
+    b = get(request, backend)
+    w, h = 96, 64
+    d = api.Denoiser.REBLUR_DIFFUSE_SPECULAR_OCCLUSION
+    hz = pkg.harness.Harness(b, [d], w, h)
+    fr = util.flat_frame(pkg, w, h)
+    fr["diff_hitdist"] = np.full((h, w), 40000, dtype=np.uint16)
+    fr["spec_hitdist"] = np.full((h, w), 12345, dtype=np.uint16)
+    st = {d: api.ReblurSettings()}
+    for f in range(3):
+        hz.frame(util.static_common(api, w, h, f, reset=(f == 0)), hz.upload(fr), st)
+        for key, src in (("out_diff_hitdist", "diff_hitdist"), ("out_spec_hitdist", "spec_hitdist")):
+            out = hz.fetch(hz.outputs[key]).view(np.uint16).reshape(h, w).astype(np.int32)
+            assert np.abs(out - fr[src].astype(np.int32)).max() <= 32, (f, key)  # internal planes are fp16: 1 ULP = 32 LSB
+    # noisy AO gets denoised, mean preserved
+    hz = pkg.harness.Harness(b, [d], w, h)
+    rng = np.random.default_rng(3)
+    for f in range(8):
+        fr["diff_hitdist"] = np.clip(rng.normal(30000, 9000, (h, w)), 0, 65535).astype(np.uint16)
+        fr["spec_hitdist"] = fr["diff_hitdist"]
+        hz.frame(util.static_common(api, w, h, f, reset=(f == 0)), hz.upload(fr), st)
+    out = hz.fetch(hz.outputs["out_diff_hitdist"]).view(np.uint16).reshape(h, w).astype(np.float64)
+    assert abs(out[8:-8, 8:-8].mean() / 30000 - 1) < 0.03 and out[8:-8, 8:-8].std() < 0.25 * 9000

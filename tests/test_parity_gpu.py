@@ -16,6 +16,8 @@ VARIANTS = [
     ["RELAX_DIFFUSE_SPECULAR"],
     ["RELAX_DIFFUSE"],
     ["RELAX_SPECULAR"],
+    ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"],
+    ["REBLUR_DIFFUSE_OCCLUSION", "REBLUR_SPECULAR_OCCLUSION"],
 ]
 
 

@@ -26,7 +26,7 @@ def default_settings(api, scene, denoisers, **reblur_kw):
     D = api.Denoiser
     s = {}
     for d in denoisers:
-        if d in (D.REBLUR_DIFFUSE, D.REBLUR_SPECULAR, D.REBLUR_DIFFUSE_SPECULAR):
+        if d.name.startswith("REBLUR"):
             s[d] = api.ReblurSettings(**reblur_kw)
         elif d in (D.SIGMA_SHADOW, D.SIGMA_SHADOW_TRANSLUCENCY):
             s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
@@ -67,6 +67,10 @@ def compare_all(ha, hb, exact=True, ulp=1):
             u = max_ulp_f16(a.view(np.float16), b.view(np.float16))
             if u > ulp:
                 bad.append((key, "%d ulp" % u))
+    for key in ("out_diff_hitdist", "out_spec_hitdist"):  # R16_UNORM outputs of the OCCLUSION variants
+        a, b = ha.fetch(ha.outputs[key]).view(np.uint16).astype(np.int32), hb.fetch(hb.outputs[key]).view(np.uint16).astype(np.int32)
+        if (exact and not np.array_equal(a, b)) or np.abs(a - b).max() > 16:  # 1 ULP fp16 at 1.0 = 2^-11 = 32 LSB of unorm16
+            bad.append((key, int(np.abs(a - b).max())))
     a, b = ha.fetch(ha.outputs["out_shadow"]).astype(np.int32), hb.fetch(hb.outputs["out_shadow"]).astype(np.int32)
     if (exact and not np.array_equal(a, b)) or np.abs(a - b).max() > 1:
         bad.append(("out_shadow", int(np.abs(a - b).max())))
