@@ -32,6 +32,8 @@ WORKLOADS = {
     "reblur_ds_sigma_1440p": (2560, 1440, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY"]),
     "reblur_ds_1080p": (1920, 1080, ["REBLUR_DIFFUSE_SPECULAR"]),
     "relax_ds_4k": (3840, 2160, ["RELAX_DIFFUSE_SPECULAR"]),
+    "relax_ds_sh_4k": (3840, 2160, ["RELAX_DIFFUSE_SPECULAR_SH"]),  # BASELINE.json configs[3]
+    "reblur_ds_sh_4k": (3840, 2160, ["REBLUR_DIFFUSE_SPECULAR_SH"]),
 }
 
 

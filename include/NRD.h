@@ -22,9 +22,13 @@ namespace nrd {
 struct Instance; // opaque (== nrdhip_instance)
 
 inline const LibraryDesc* GetLibraryDesc() {
-    static const Denoiser supported[] = {Denoiser::REBLUR_DIFFUSE, Denoiser::REBLUR_SPECULAR, Denoiser::REBLUR_DIFFUSE_SPECULAR, Denoiser::RELAX_DIFFUSE,
-                                         Denoiser::RELAX_SPECULAR, Denoiser::RELAX_DIFFUSE_SPECULAR, Denoiser::SIGMA_SHADOW,
-                                         Denoiser::SIGMA_SHADOW_TRANSLUCENCY, Denoiser::REFERENCE};
+    // every enumerator except REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION (creation returns Result::UNSUPPORTED for it)
+    static const Denoiser supported[] = {Denoiser::REBLUR_DIFFUSE, Denoiser::REBLUR_DIFFUSE_OCCLUSION, Denoiser::REBLUR_DIFFUSE_SH,
+                                         Denoiser::REBLUR_SPECULAR, Denoiser::REBLUR_SPECULAR_OCCLUSION, Denoiser::REBLUR_SPECULAR_SH,
+                                         Denoiser::REBLUR_DIFFUSE_SPECULAR, Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION, Denoiser::REBLUR_DIFFUSE_SPECULAR_SH,
+                                         Denoiser::RELAX_DIFFUSE, Denoiser::RELAX_DIFFUSE_SH, Denoiser::RELAX_SPECULAR, Denoiser::RELAX_SPECULAR_SH,
+                                         Denoiser::RELAX_DIFFUSE_SPECULAR, Denoiser::RELAX_DIFFUSE_SPECULAR_SH,
+                                         Denoiser::SIGMA_SHADOW, Denoiser::SIGMA_SHADOW_TRANSLUCENCY, Denoiser::REFERENCE};
     static LibraryDesc desc = {};
     uint32_t v[5] = {};
     nrdhip_library_desc(v);

@@ -18,6 +18,7 @@ struct ReblurParams {
     float maxASpec, maxFastASpec; // == maxA / maxFastA for REBLUR; RELAX has per-signal history caps
     int occlusion;                // 1: OCCLUSION variants - IN/OUT_*_HITDIST planes hold the normalised hit distance only
     int ioF16;                    //    ... as R16_SFLOAT (1) or R16_UNORM (0)
+    int sh;                       // 1: SH variants - every signal carries a second texel (SH1) filtered with the weights of SH0
     int relax;                    // 1: RELAX front half (linear RGB + world-space hitT inputs, luma-moment history, HistoryFix writes History)
     int historyFixFrameNum, historyFixStride;
     int reachPre, reachBlur, reachPost; // hard per-pass bound (pixels) on tap distance = halo rows of the pass
@@ -26,6 +27,7 @@ struct ReblurParams {
     int hasDiff, hasSpec;
     // resource slots
     PlaneRef inZ, inNR, inMV, inDiff, inSpec, confD, confS, outDiff, outSpec;
+    PlaneRef inDiff1, inSpec1, outDiff1, outSpec1; // SH mode: IN/OUT_*_SH1
     // pools
     PlaneRef guide, guidePrev, data1, data1Prev, data1Tmp, data2, hist, fast, fastPrev, stab, stabPrev, tiles, tmp1, tmp2, hitTrack;
 };
@@ -38,8 +40,8 @@ struct AtrousParams {
     float lobeAngleFraction, roughnessFraction;
     uint32_t minMatDiff, minMatSpec;
     int roughnessEdgeStopping;
-    int it, last, hasDiff, hasSpec;
-    PlaneRef guide, data1, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec;
+    int it, last, hasDiff, hasSpec, sh;
+    PlaneRef guide, data1, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec, inDiff1, inSpec1, outDiff1, outSpec1;
 };
 
 struct SigmaParams {

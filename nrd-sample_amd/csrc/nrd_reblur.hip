@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
 template <int VARIANT, bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    constexpr int RBPT = 8 * NSIG; // bytes per texel of the internal radiance planes
+    const int sb = p.sh ? 16 : 8;  // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    const int RBPT = sb * NSIG;    // bytes per texel of the internal radiance planes
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
@@ -98,8 +99,11 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
 
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
-        for (int sig = 0; sig < NSIG; sig++)
-            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+        for (int sig = 0; sig < NSIG; sig++) {
+            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+            if (p.sh)
+                st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
+        }
         if (VARIANT == 0 && HAS_SPEC)
             st<uint16_t>(p.hitTrack, x, y, 2, (uint16_t)0);
         return;
@@ -129,10 +133,14 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
         const PlaneRef& srcP = VARIANT == 0 ? (isSpec ? p.inSpec : p.inDiff) : inP;
         const int srcBpt = VARIANT == 0 ? 8 : RBPT;
-        const int srcOff = VARIANT == 0 ? 0 : sig * 8;
+        const int srcOff = VARIANT == 0 ? 0 : sig * sb;
         f4 center = load_signal(p, srcP, x, y, srcBpt, srcOff, occIn);
         if (relaxIn)
             center = rgb_to_ycocg4(center);
+        // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
+        const PlaneRef& src1P = VARIANT == 0 ? (isSpec ? p.inSpec1 : p.inDiff1) : inP;
+        const int src1Off = VARIANT == 0 ? 0 : srcOff + 8;
+        f4 sum1 = p.sh ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
         float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist / pg.frustumSize);
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 int cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
                 uint4 graw = ld<uint4>(p.guide, px, cpy, 16);
                 f4 sv = load_signal(p, srcP, px, cpy, srcBpt, srcOff, occIn);
+                f4 sv1 = p.sh ? unpack_h4(ld<uint2>(src1P, px, cpy, srcBpt, src1Off)) : f4{0, 0, 0, 0};
                 Guide gs = decode_guide(graw, c.denoisingRange);
                 // branch-free from here: a rejected tap is SELECTED out (sums untouched), which is exactly what skipping it
                 // would do, but keeps the unrolled taps in one basic block so their gathers overlap
@@ -212,12 +221,18 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                 f4 acc = fma4(sv, w, sum);
                 sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
+                if (p.sh) {
+                    f4 acc1 = fma4(sv1, w, sum1);
+                    sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                }
                 wsum = valid ? wsum + w : wsum;
                 minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
             }
         }
         float invw = 1.0f / wsum;
-        st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, invw)), sig * 8);
+        st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, invw)), sig * sb);
+        if (p.sh)
+            st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum1, invw)), sig * sb + 8);
         if (VARIANT == 0 && isSpec)
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit));
     }
@@ -409,7 +424,9 @@ NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    const int RBPT = sb * NSIG;
+    constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
@@ -418,7 +435,9 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
-            st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+            st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+            if (p.sh)
+                st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
             st<uint16_t>(p.fast, x, y, LBPT, (uint16_t)0, sig * 2);
             if (p.relax)
                 st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
@@ -459,6 +478,11 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         f4 hist = smbOk ? fetch4(c, p.hist, RBPT, 0, smb) : in;
         float fastHist = smbOk ? fetch1(c, p.fastPrev, LBPT, 0, smb) : in.x;
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), 0);
+        if (p.sh) { // SH1 follows SH0: same footprint, same blend factor
+            f4 in1 = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, 8));
+            f4 hist1 = smbOk ? fetch4(c, p.hist, RBPT, 8, smb) : in1;
+            st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist1, in1, nonLin)), 8);
+        }
         st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), 0);
         if (p.relax) { // second luma moment history (lives in the stabilized-luma slots)
             float m2 = in.x * in.x;
@@ -468,7 +492,8 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         outDiffA = A;
     }
     if (HAS_SPEC) {
-        constexpr int so = SIG_SPEC * 8, lo = SIG_SPEC * 2;
+        const int so = SIG_SPEC * sb;
+        constexpr int lo = SIG_SPEC * 2;
         f4 in = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, so));
         float hitDist = h2f(ld<uint16_t>(p.hitTrack, x, y, 2));
         f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
@@ -518,6 +543,12 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         f4 hist = lerp4(smbHist, vmbHist, amount);
         float fastHist = lerpf(smbFast, vmbFast, amount);
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
+        if (p.sh) {
+            f4 in1 = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, so + 8));
+            f4 smb1 = smbOk ? fetch4(c, p.hist, RBPT, so + 8, smb) : in1;
+            f4 vmb1 = vmb.wsum > 0.0f ? fetch4(c, p.hist, RBPT, so + 8, vmb) : in1;
+            st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin)), so + 8);
+        }
         st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastASpec)))), lo);
         if (p.relax) {
             float m2 = in.x * in.x;
@@ -573,7 +604,9 @@ NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, float& 
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    const int RBPT = sb * NSIG;
+    constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     __shared__ float tile[NSIG][400];
     const FrameConsts& c = p.c;
@@ -591,8 +624,11 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     const PlaneRef& outP = p.relax ? p.hist : p.tmp1; // RELAX: the fixed + clamped signal IS the next frame's history
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
-        for (int sig = 0; sig < NSIG; sig++)
-            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+        for (int sig = 0; sig < NSIG; sig++) {
+            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+            if (p.sh)
+                st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
+        }
         st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
         return;
     }
@@ -608,7 +644,8 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         const int ai = isSpec ? 1 : 0;
         float rough = isSpec ? g.roughness : 1.0f;
         uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
-        f4 val = unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * 8));
+        f4 val = unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb));
+        f4 val1 = p.sh ? unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb + 8)) : f4{0, 0, 0, 0};
         float Acur = A[ai];
         if (Acur < (float)p.historyFixFrameNum && p.historyFixFrameNum > 0) {
             float normA = sat(Acur / (float)p.historyFixFrameNum);
@@ -624,6 +661,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                 float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
                 float roughB = -rough * roughA;
                 f4 sum = mul4(val, 1.0f + Acur);
+                f4 sum1 = mul4(val1, 1.0f + Acur);
                 float wsum = 1.0f + Acur;
                 for (int j = -2; j <= 2; j++)
                     for (int i = -2; i <= 2; i++) {
@@ -643,10 +681,13 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                         float tA[2];
                         unpack_data1(ld<uint16_t>(p.data1Tmp, px, py, 2), tA[0], tA[1]);
                         w *= 1.0f + tA[ai];
-                        sum = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * 8)), w, sum);
+                        sum = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * sb)), w, sum);
+                        if (p.sh)
+                            sum1 = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * sb + 8)), w, sum1);
                         wsum += w;
                     }
                 val = mul4(sum, 1.0f / wsum);
+                val1 = mul4(sum1, 1.0f / wsum);
             }
         }
         if (p.clampEnabled) {
@@ -660,10 +701,15 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             val.x = Yc;
             val.y *= scale;
             val.z *= scale;
+            val1.x *= scale;
+            val1.y *= scale;
+            val1.z *= scale;
             float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
             outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? p.maxFastASpec : p.maxFastA), f);
         }
-        st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * 8);
+        st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * sb);
+        if (p.sh)
+            st<uint2>(outP, x, y, RBPT, pack_h4(val1), sig * sb + 8);
     }
     st<uint16_t>(p.data1, x, y, 2, pack_data1(outA[0], outA[1]));
 }
@@ -704,7 +750,9 @@ NRD_DEV bool fetch_stab(const FrameConsts& c, const PlaneRef& P, int bpt, int of
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    const int RBPT = sb * NSIG;
+    constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     __shared__ float tile[NSIG][400];
     const FrameConsts& c = p.c;
@@ -712,7 +760,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     if (!xcd_tile(c, tx, ty))
         return;
     for (int sig = 0; sig < NSIG; sig++)
-        stage_luma_tile(c, p.guide, tx, ty, tile[sig], [&](int px, int py) { return h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * 8)); });
+        stage_luma_tile(c, p.guide, tx, ty, tile[sig], [&](int px, int py) { return h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb)); });
     __syncthreads();
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
@@ -728,6 +776,8 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
             store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : f4{0, 0, 0, 0});
+            if (p.sh)
+                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
             st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
         return;
@@ -741,7 +791,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-        f4 cur = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * 8));
+        f4 cur = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * sb));
         float m1, m2;
         moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, m1, m2);
         float sigma = __builtin_sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f));
@@ -785,6 +835,11 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
         store_signal(p, op, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : o);
+        if (p.sh) {
+            f4 c1 = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * sb + 8));
+            f4 o1 = {c1.x * scale, c1.y * scale, c1.z * scale, c1.w};
+            st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : pack_h4(o1));
+        }
     }
 }
 
@@ -796,7 +851,9 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    constexpr int RBPT = 8 * NSIG, LBPT = 2 * NSIG;
+    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    const int RBPT = sb * NSIG;
+    constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
@@ -817,8 +874,13 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
                 const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
                 st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
-            } else
-                st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * 8);
+                if (p.sh)
+                    st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
+            } else {
+                st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+                if (p.sh)
+                    st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
+            }
         }
         return;
     }
@@ -832,7 +894,8 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         const int si = isSpec ? 1 : 0;
         float rough = isSpec ? g.roughness : 1.0f;
         uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
-        f4 c0 = unpack_h4(ld<uint2>(p.in, x, y, RBPT, sig * 8));
+        f4 c0 = unpack_h4(ld<uint2>(p.in, x, y, RBPT, sig * sb));
+        f4 sum1 = p.sh ? unpack_h4(ld<uint2>(p.in, x, y, RBPT, sig * sb + 8)) : f4{0, 0, 0, 0};
         float var;
         if (it == 0) {
             float m2 = h2f(ld<uint16_t>(p.mom, x, y, LBPT, sig * 2));
@@ -846,7 +909,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                             continue;
                         if (!(absf(ld<float>(p.guide, px, py, 16, 0)) <= c.denoisingRange))
                             continue;
-                        float Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * 8));
+                        float Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb));
                         sy += Y;
                         sy2 = fma_(Y, Y, sy2);
                         n += 1.0f;
@@ -878,7 +941,8 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 bool valid = !(px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH);
                 int cpx = px < 0 ? 0 : (px >= c.W ? c.W - 1 : px), cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
                 uint4 graw = ld<uint4>(p.guide, cpx, cpy, 16); // all loads of the tap issued before it is validated
-                uint2 sraw = ld<uint2>(p.in, cpx, cpy, RBPT, sig * 8);
+                uint2 sraw = ld<uint2>(p.in, cpx, cpy, RBPT, sig * sb);
+                uint2 sraw1 = p.sh ? ld<uint2>(p.in, cpx, cpy, RBPT, sig * sb + 8) : uint2{0u, 0u};
                 uint16_t mraw = it == 0 ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
                 Guide gs = decode_guide(graw, c.denoisingRange);
                 valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat); // rejected taps are selected out below
@@ -893,6 +957,10 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                     vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw)), 0.0f);
                 w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), p.minLw[si]);
                 sum = {valid ? fma_(sv.x, w, sum.x) : sum.x, valid ? fma_(sv.y, w, sum.y) : sum.y, valid ? fma_(sv.z, w, sum.z) : sum.z};
+                if (p.sh) {
+                    f4 acc1 = fma4(unpack_h4(sraw1), w, sum1);
+                    sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                }
                 sumVar = valid ? fma_(vs, w * w, sumVar) : sumVar;
                 wsum = valid ? wsum + w : wsum;
             }
@@ -901,12 +969,17 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         float ov = sumVar * inv * inv;
         if (last) {
             f3 rgb = ycocg_to_linear(o);
-            float hitDist = h2f(ld<uint16_t>(p.hist, x, y, RBPT, sig * 8 + 6));
+            float hitDist = h2f(ld<uint16_t>(p.hist, x, y, RBPT, sig * sb + 6));
             const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
             st<uint2>(op, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : pack_h4({rgb.x, rgb.y, rgb.z, hitDist}));
-        } else
-            st<uint2>(p.out, x, y, RBPT, pack_h4({o.x, o.y, o.z, ov}), sig * 8);
+            if (p.sh)
+                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : pack_h4(mul4(sum1, inv)));
+        } else {
+            st<uint2>(p.out, x, y, RBPT, pack_h4({o.x, o.y, o.z, ov}), sig * sb);
+            if (p.sh)
+                st<uint2>(p.out, x, y, RBPT, pack_h4(mul4(sum1, inv)), sig * sb + 8);
+        }
     }
 }
 

@@ -74,7 +74,7 @@ struct DenoiserState {
     uint32_t identifier = 0;
     nrd::Denoiser denoiser = nrd::Denoiser::MAX_NUM;
     Kind kind = Kind::REFERENCE;
-    bool hasDiff = false, hasSpec = false, translucency = false, occlusion = false;
+    bool hasDiff = false, hasSpec = false, translucency = false, occlusion = false, sh = false;
     int nsig = 0;
     uint32_t permBase = 0, permEnd = 0, transBase = 0;
     uint32_t frameCounter = 0, framesSinceReset = 0;
@@ -124,6 +124,12 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.occlusion = true; break;
         case D::REBLUR_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasSpec = d.occlusion = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.occlusion = true; break;
+        case D::REBLUR_DIFFUSE_SH: d.kind = Kind::REBLUR; d.hasDiff = d.sh = true; break;
+        case D::REBLUR_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasSpec = d.sh = true; break;
+        case D::REBLUR_DIFFUSE_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.sh = true; break;
+        case D::RELAX_DIFFUSE_SH: d.kind = Kind::RELAX; d.hasDiff = d.sh = true; break;
+        case D::RELAX_SPECULAR_SH: d.kind = Kind::RELAX; d.hasSpec = d.sh = true; break;
+        case D::RELAX_DIFFUSE_SPECULAR_SH: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = d.sh = true; break;
         case D::RELAX_DIFFUSE: d.kind = Kind::RELAX; d.hasDiff = true; break;
         case D::RELAX_SPECULAR: d.kind = Kind::RELAX; d.hasSpec = true; break;
         case D::RELAX_DIFFUSE_SPECULAR: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = true; break;
@@ -151,7 +157,7 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
     if (d.kind == Kind::REBLUR) {
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
-        uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+        uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig; // SH mode: SH0 + SH1 texels per signal
         perm.push_back({"REBLUR::Guide_A", F::RGBA32_UINT, 16, 1});
         perm.push_back({"REBLUR::Guide_B", F::RGBA32_UINT, 16, 1});
         perm.push_back({"REBLUR::Data1_A", F::R16_UINT, 2, 1});
@@ -170,7 +176,7 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
     } else if (d.kind == Kind::RELAX) { // same slot order as REBLUR for the shared front half; moments live in the STAB slots
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
-        uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+        uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig; // SH mode: SH0 + SH1 texels per signal
         perm.push_back({"RELAX::Guide_A", F::RGBA32_UINT, 16, 1});
         perm.push_back({"RELAX::Guide_B", F::RGBA32_UINT, 16, 1});
         perm.push_back({"RELAX::HistoryLength_A", F::R16_UINT, 2, 1});
@@ -318,6 +324,30 @@ void build_reference(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c)
     d.dispatches.push_back(x);
 }
 
+nrd::ResourceType in_slot(const DenoiserState& d, bool spec) {
+    using RT = nrd::ResourceType;
+    if (d.sh)
+        return spec ? RT::IN_SPEC_SH0 : RT::IN_DIFF_SH0;
+    return d.occlusion ? (spec ? RT::IN_SPEC_HITDIST : RT::IN_DIFF_HITDIST) : (spec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+}
+nrd::ResourceType out_slot(const DenoiserState& d, bool spec) {
+    using RT = nrd::ResourceType;
+    if (d.sh)
+        return spec ? RT::OUT_SPEC_SH0 : RT::OUT_DIFF_SH0;
+    return d.occlusion ? (spec ? RT::OUT_SPEC_HITDIST : RT::OUT_DIFF_HITDIST) : (spec ? RT::OUT_SPEC_RADIANCE_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
+}
+// appends the signal slots (SH0 [+ SH1]) of the active signals to a dispatch's read / written list
+void push_signal_slots(const DenoiserState& d, std::vector<uint32_t>& list, bool outputs) {
+    using RT = nrd::ResourceType;
+    for (int spec = 0; spec < 2; spec++) {
+        if (spec ? !d.hasSpec : !d.hasDiff)
+            continue;
+        list.push_back(enc_slot(outputs ? out_slot(d, spec != 0) : in_slot(d, spec != 0)));
+        if (d.sh)
+            list.push_back(enc_slot(outputs ? (spec ? RT::OUT_SPEC_SH1 : RT::OUT_DIFF_SH1) : (spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1)));
+    }
+}
+
 // parameter block of the REBLUR kernels; RELAX reuses them for its front half (ClassifyTiles, PrePass, TA, HistoryFix)
 ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c, const nrd::ReblurSettings& s) {
     using RT = nrd::ResourceType;
@@ -363,14 +393,19 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.inZ = SP(RT::IN_VIEWZ);
     p.inNR = SP(RT::IN_NORMAL_ROUGHNESS);
     p.inMV = SP(RT::IN_MV);
-    p.inDiff = SP(d.occlusion ? RT::IN_DIFF_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
-    p.inSpec = SP(d.occlusion ? RT::IN_SPEC_HITDIST : RT::IN_SPEC_RADIANCE_HITDIST);
+    p.inDiff = SP(in_slot(d, false));
+    p.inSpec = SP(in_slot(d, true));
+    p.inDiff1 = SP(RT::IN_DIFF_SH1);
+    p.inSpec1 = SP(RT::IN_SPEC_SH1);
+    p.outDiff1 = SP(RT::OUT_DIFF_SH1);
+    p.outSpec1 = SP(RT::OUT_SPEC_SH1);
+    p.sh = d.sh ? 1 : 0;
     p.occlusion = d.occlusion ? 1 : 0;
-    p.ioF16 = I.slots[(size_t)(d.hasDiff ? RT::IN_DIFF_HITDIST : RT::IN_SPEC_HITDIST)].fmt == (uint32_t)nrd::Format::R16_SFLOAT ? 1 : 0;
+    p.ioF16 = I.slots[(size_t)in_slot(d, !d.hasDiff)].fmt == (uint32_t)nrd::Format::R16_SFLOAT ? 1 : 0;
     p.confD = SP(RT::IN_DIFF_CONFIDENCE);
     p.confS = SP(RT::IN_SPEC_CONFIDENCE);
-    p.outDiff = SP(d.occlusion ? RT::OUT_DIFF_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
-    p.outSpec = SP(d.occlusion ? RT::OUT_SPEC_HITDIST : RT::OUT_SPEC_RADIANCE_HITDIST);
+    p.outDiff = SP(out_slot(d, false));
+    p.outSpec = SP(out_slot(d, true));
     p.guide = PP(rb::GUIDE_A + cur);
     p.guidePrev = PP(rb::GUIDE_A + (cur ^ 1));
     p.data1 = PP(rb::DATA1_A + cur);
@@ -402,6 +437,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     ReblurParams p = make_reblur_params(I, d, c, s);
 
     float n = (float)d.nsig;
+    float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     float sp = d.hasSpec ? 2.0f : 0.0f;
     uint16_t blurHalo = (uint16_t)p.reachBlur, postHalo = (uint16_t)p.reachPost, preHalo = (uint16_t)p.reachPre;
     const float GB = 16.0f; // guide texel bytes
@@ -413,19 +449,16 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * n + 8 * n + sp, {}, {}, nullptr};
+        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * nr + 8 * nr + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
-        if (d.hasDiff)
-            x.read.push_back(enc_slot(d.occlusion ? RT::IN_DIFF_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST));
-        if (d.hasSpec)
-            x.read.push_back(enc_slot(d.occlusion ? RT::IN_SPEC_HITDIST : RT::IN_SPEC_RADIANCE_HITDIST));
+        push_signal_slots(d, x.read, false);
         x.written = {T(rb::TMP1), T(rb::HITTRACK)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);
     }
     {
         Dispatch x{"REBLUR::TemporalAccumulation", "nrd_reblur_temporal_accumulation", 0,
-                   GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + sp + 8 * n + 2 * n + 2 + 4, {}, {}, nullptr};
+                   GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + sp + 8 * nr + 2 * n + 2 + 4, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST),
                   P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1)), T(rb::HITTRACK)};
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
@@ -434,21 +467,21 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"REBLUR::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
-                   GB + 2 + 8 * n + 2 * n + 8 * n + 2, {}, {}, nullptr};
+                   GB + 2 + 8 * nr + 2 * n + 8 * nr + 2, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
         x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, GB + 2 + 8 * n + 8 * n, {}, {}, nullptr};
+        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
         x.written = {T(rb::TMP2)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 1, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, GB + 2 + 8 * n + 8 * n, {}, {}, nullptr};
+        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
         x.written = {P(rb::HIST)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 2, st); };
@@ -456,17 +489,11 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"REBLUR::TemporalStabilization", "nrd_reblur_temporal_stabilization", 2,
-                   GB + 2 + 4 + 8 + 8 * n + 2 * n + sp + 8 * n + 2 * n, {}, {}, nullptr};
+                   GB + 2 + 4 + 8 + 8 * nr + 2 * n + sp + 8 * nr + 2 * n, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::DATA2), enc_slot(RT::IN_MV), P(rb::HIST), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
         x.written = {P(rb::STAB_A + cur)};
-        if (d.hasDiff) {
-            x.written.push_back(enc_slot(d.occlusion ? RT::OUT_DIFF_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST));
-            x.read.push_back(enc_slot(d.occlusion ? RT::IN_DIFF_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST));
-        }
-        if (d.hasSpec) {
-            x.written.push_back(enc_slot(d.occlusion ? RT::OUT_SPEC_HITDIST : RT::OUT_SPEC_RADIANCE_HITDIST));
-            x.read.push_back(enc_slot(d.occlusion ? RT::IN_SPEC_HITDIST : RT::IN_SPEC_RADIANCE_HITDIST));
-        }
+        push_signal_slots(d, x.written, true);
+        push_signal_slots(d, x.read, false);
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_stabilization(p, st); };
         d.dispatches.push_back(x);
     }
@@ -504,6 +531,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.maxASpec = (float)std::min<uint32_t>(r.specularMaxAccumulatedFrameNum, 63);
     p.maxFastASpec = (float)std::min<uint32_t>(r.specularMaxFastAccumulatedFrameNum, 63);
     float n = (float)d.nsig;
+    float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     float sp = d.hasSpec ? 2.0f : 0.0f;
     const float GB = 16.0f;
     {
@@ -514,19 +542,16 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"RELAX::PrePass", "nrd_reblur_prepass", (uint16_t)p.reachPre, GB + 8 * n + 8 * n + sp, {}, {}, nullptr};
+        Dispatch x{"RELAX::PrePass", "nrd_reblur_prepass", (uint16_t)p.reachPre, GB + 8 * nr + 8 * nr + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
-        if (d.hasDiff)
-            x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
-        if (d.hasSpec)
-            x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        push_signal_slots(d, x.read, false);
         x.written = {T(rb::TMP1), T(rb::HITTRACK)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);
     }
     {
         Dispatch x{"RELAX::TemporalAccumulation", "nrd_reblur_temporal_accumulation", 0,
-                   GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + 2 * n + sp + 8 * n + 2 * n + 2 * n + 2 + 4, {}, {}, nullptr};
+                   GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + 2 * n + sp + 8 * nr + 2 * n + 2 * n + 2 + 4, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)),
                   P(rb::DATA1_A + (cur ^ 1)), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), P(rb::STAB_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
@@ -535,7 +560,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"RELAX::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
-                   GB + 2 + 8 * n + 2 * n + 8 * n + 2, {}, {}, nullptr};
+                   GB + 2 + 8 * nr + 2 * n + 8 * nr + 2, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
         x.written = {P(rb::HIST), P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
@@ -558,6 +583,11 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     a.roughnessEdgeStopping = r.enableRoughnessEdgeStopping ? 1 : 0;
     a.hasDiff = d.hasDiff;
     a.hasSpec = d.hasSpec;
+    a.sh = d.sh ? 1 : 0;
+    a.inDiff1 = p.inDiff1;
+    a.inSpec1 = p.inSpec1;
+    a.outDiff1 = p.outDiff1;
+    a.outSpec1 = p.outSpec1;
     a.guide = p.guide;
     a.data1 = p.data1;
     a.hist = p.hist;
@@ -575,7 +605,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         a.out = I.trans[tb + rb::AT_A + (it & 1)].ref();
         static const char* atrousNames[8] = {"RELAX::Atrous0", "RELAX::Atrous1", "RELAX::Atrous2", "RELAX::Atrous3", "RELAX::Atrous4", "RELAX::Atrous5", "RELAX::Atrous6", "RELAX::Atrous7"};
         Dispatch x{atrousNames[it], "nrd_relax_atrous", (uint16_t)(1 << it),
-                   GB + (it == 0 ? 2 + 8 * n + 2 * n : 8 * n) + (last ? 8 * n : 0.0f) + 8 * n, {}, {}, nullptr};
+                   GB + (it == 0 ? 2 + 8 * nr + 2 * n : 8 * nr) + (last ? 8 * nr : 0.0f) + 8 * nr, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         if (it == 0) {
             x.read.push_back(P(rb::DATA1_A + cur));
@@ -585,14 +615,8 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             x.read.push_back(T(rb::AT_A + ((it - 1) & 1)));
         if (last) {
             x.read.push_back(P(rb::HIST));
-            if (d.hasDiff) {
-                x.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
-                x.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
-            }
-            if (d.hasSpec) {
-                x.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
-                x.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
-            }
+            push_signal_slots(d, x.written, true);
+            push_signal_slots(d, x.read, false);
         } else
             x.written = {T(rb::AT_A + (it & 1))};
         AtrousParams ap = a;

@@ -22,6 +22,11 @@ INPUT_SLOTS = {
     RT.IN_SIGNAL: ("signal", F.RGBA16_SFLOAT),
     RT.IN_DIFF_HITDIST: ("diff_hitdist", F.R16_UNORM),  # OCCLUSION variants (Source/NRDSample.cpp:488-501)
     RT.IN_SPEC_HITDIST: ("spec_hitdist", F.R16_UNORM),
+    # SH variants: SH0 shares the radiance texture, SH1 is a second one (Source/NRDSample.cpp:464-476)
+    RT.IN_DIFF_SH0: ("diff", F.RGBA16_SFLOAT),
+    RT.IN_DIFF_SH1: ("diff_sh1", F.RGBA16_SFLOAT),
+    RT.IN_SPEC_SH0: ("spec", F.RGBA16_SFLOAT),
+    RT.IN_SPEC_SH1: ("spec_sh1", F.RGBA16_SFLOAT),
 }
 OUTPUT_SLOTS = {
     RT.OUT_DIFF_RADIANCE_HITDIST: ("out_diff", F.RGBA16_SFLOAT, 8),
@@ -30,6 +35,10 @@ OUTPUT_SLOTS = {
     RT.OUT_VALIDATION: ("out_validation", F.RGBA8_UNORM, 4),
     RT.OUT_DIFF_HITDIST: ("out_diff_hitdist", F.R16_UNORM, 2),
     RT.OUT_SPEC_HITDIST: ("out_spec_hitdist", F.R16_UNORM, 2),
+    RT.OUT_DIFF_SH0: ("out_diff", F.RGBA16_SFLOAT, 8),
+    RT.OUT_DIFF_SH1: ("out_diff_sh1", F.RGBA16_SFLOAT, 8),
+    RT.OUT_SPEC_SH0: ("out_spec", F.RGBA16_SFLOAT, 8),
+    RT.OUT_SPEC_SH1: ("out_spec_sh1", F.RGBA16_SFLOAT, 8),
 }
 
 
@@ -50,7 +59,8 @@ class Harness:
         self.denoisers = list(denoisers)
         self.outputs = {}
         for slot, (key, fmt, bpt) in OUTPUT_SLOTS.items():
-            self.outputs[key] = self._zeros(height, width * bpt)
+            if key not in self.outputs:  # SH0 outputs share the plain radiance output planes, like the sample's textures
+                self.outputs[key] = self._zeros(height, width * bpt)
         self.resident = {}
 
     def _zeros(self, rows, rowbytes):

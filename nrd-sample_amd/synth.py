@@ -291,6 +291,14 @@ class Scene:
         s4 = torch.where(hit[..., None], s4, torch.zeros_like(s4))
         out["diff"] = d4.to(torch.float16)
         out["spec"] = s4.to(torch.float16)
+        # SH variants (REBLUR_/RELAX_FrontEnd_PackSh, Shaders/TraceOpaque.cs.hlsl:738-752): SH1 = incoming direction weighted by
+        # the luminance of the sample (diffuse: around the normal, specular: around the reflection vector)
+        def sh1(direction, rad):
+            lum = 0.2126 * rad[..., 0:1] + 0.7152 * rad[..., 1:2] + 0.0722 * rad[..., 2:3]
+            v = torch.cat([direction * lum, torch.zeros_like(lum)], -1)
+            return torch.where(hit[..., None], v, torch.zeros_like(v)).to(torch.float16)
+        out["diff_sh1"] = sh1(n, diff)
+        out["spec_sh1"] = sh1(refl, spec)
         if not self.relax:  # OCCLUSION variants take the normalised hit distance alone, R16_UNORM
             for key, src in (("diff_hitdist", d4), ("spec_hitdist", s4)):
                 q = torch.floor(torch.clamp(src[..., 3], 0, 1) * 65535 + 0.5).to(torch.int32)  # 0..65535 (sky = 0)

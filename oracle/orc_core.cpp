@@ -156,6 +156,12 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.occlusion = true; break;
         case D::REBLUR_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasSpec = d.occlusion = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.occlusion = true; break;
+        case D::REBLUR_DIFFUSE_SH: d.kind = Kind::REBLUR; d.hasDiff = d.sh = true; break;
+        case D::REBLUR_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasSpec = d.sh = true; break;
+        case D::REBLUR_DIFFUSE_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.sh = true; break;
+        case D::RELAX_DIFFUSE_SH: d.kind = Kind::RELAX; d.hasDiff = d.sh = true; break;
+        case D::RELAX_SPECULAR_SH: d.kind = Kind::RELAX; d.hasSpec = d.sh = true; break;
+        case D::RELAX_DIFFUSE_SPECULAR_SH: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = d.sh = true; break;
         case D::RELAX_DIFFUSE: d.kind = Kind::RELAX; d.hasDiff = true; break;
         case D::RELAX_SPECULAR: d.kind = Kind::RELAX; d.hasSpec = true; break;
         case D::RELAX_DIFFUSE_SPECULAR: d.kind = Kind::RELAX; d.hasDiff = d.hasSpec = true; break;

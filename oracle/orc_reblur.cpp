@@ -51,10 +51,16 @@ static inline void store_signal(const Plane& P, int x, int y, f4 v, bool occlusi
 }
 static inline nrd::ResourceType in_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
+    if (d.sh)
+        return spec ? RT::IN_SPEC_SH0 : RT::IN_DIFF_SH0;
     return d.occlusion ? (spec ? RT::IN_SPEC_HITDIST : RT::IN_DIFF_HITDIST) : (spec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
 }
+static inline nrd::ResourceType in1_slot(bool spec) { return spec ? nrd::ResourceType::IN_SPEC_SH1 : nrd::ResourceType::IN_DIFF_SH1; }
+static inline nrd::ResourceType out1_slot(bool spec) { return spec ? nrd::ResourceType::OUT_SPEC_SH1 : nrd::ResourceType::OUT_DIFF_SH1; }
 static inline nrd::ResourceType out_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
+    if (d.sh)
+        return spec ? RT::OUT_SPEC_SH0 : RT::OUT_DIFF_SH0;
     return d.occlusion ? (spec ? RT::OUT_SPEC_HITDIST : RT::OUT_DIFF_HITDIST) : (spec ? RT::OUT_SPEC_RADIANCE_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
 }
 static inline f4 rgb_to_ycocg4(f4 v) {
@@ -91,6 +97,8 @@ struct Ctx {
 // --------------------------------------------------------------------------------------------------
 void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int ty1) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
     const Plane& inZ = k.slot(nrd::ResourceType::IN_VIEWZ);
     const Plane& inNR = k.slot(nrd::ResourceType::IN_NORMAL_ROUGHNESS);
     const Plane& G = k.guide();
@@ -150,7 +158,15 @@ struct SpatialIO {
     const Plane* out[2];
     int outOff[2];
     int reach; // taps farther than this many pixels (rows or columns) from the centre are rejected
+    const Plane* in1[2]; // SH mode, PrePass only: the separate IN_*_SH1 planes (internal planes keep SH1 at +8 in the texel)
 };
+
+// SH mode (REBLUR_*_SH / RELAX_*_SH, Source/NRDSample.cpp:464-476): every signal carries a second texel (SH1, the
+// direction-weighted first-order band, Shaders/TraceOpaque.cs.hlsl:738-752) that is filtered with EXACTLY the weights of
+// SH0; luma rescales (history clamping, stabilization) scale SH1.xyz by the same factor.
+static inline f4 load_sh1(const SpatialIO& io, int sig, int x, int y, bool pre) {
+    return pre ? ld_h4(*io.in1[sig], x, y, 0) : ld_h4(*io.in[sig], x, y, io.inOff[sig] + 8);
+}
 
 void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1) {
     const Consts& c = k.c;
@@ -161,12 +177,16 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const float* hp = &s.hitDistanceParameters.A;
     const bool relaxIn = k.d.kind == Kind::RELAX && variant == PRE; // RELAX inputs: linear RGB + world-space hit distance
     const bool occIn = k.d.occlusion && variant == PRE;
+    const bool sh = k.d.sh;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
-                for (int sig = 0; sig < k.d.nsig; sig++)
+                for (int sig = 0; sig < k.d.nsig; sig++) {
                     st_h4(*io.out[sig], x, y, {0, 0, 0, 0}, io.outOff[sig]);
+                    if (sh)
+                        st_h4(*io.out[sig], x, y, {0, 0, 0, 0}, io.outOff[sig] + 8);
+                }
                 if (variant == PRE && k.d.hasSpec)
                     st_h(HT, x, y, 0.0f);
                 continue;
@@ -195,6 +215,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 f4 center = load_signal(*io.in[sig], x, y, io.inOff[sig], occIn);
                 if (relaxIn)
                     center = rgb_to_ycocg4(center);
+                f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
                 float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
                 float hitDist = center.w * hitNorm;
                 float hitDistFactor = sat(hitDist / pg.frustumSize);
@@ -271,6 +292,8 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                             sv = rgb_to_ycocg4(sv);
                         w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                         sum = fma4(sv, w, sum);
+                        if (sh)
+                            sum1 = fma4(load_sh1(io, sig, px, py, variant == PRE), w, sum1);
                         wsum += w;
                         if (w > 0.0f)
                             minHit = fmin2(minHit, sv.w * hitNorm);
@@ -278,6 +301,8 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 }
                 float invw = 1.0f / wsum;
                 st_h4(*io.out[sig], x, y, mul4(sum, invw), io.outOff[sig]);
+                if (sh)
+                    st_h4(*io.out[sig], x, y, mul4(sum1, invw), io.outOff[sig] + 8);
                 if (variant == PRE && isSpec)
                     st_h(HT, x, y, minHit);
             }
@@ -437,6 +462,8 @@ static inline float spec_accum_limit(float roughness, float NoV, float parallaxP
 // --------------------------------------------------------------------------------------------------
 void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
     const nrd::ReblurSettings& s = d.reblur;
     const Plane& G = k.guide();
     const Plane& MV = k.slot(nrd::ResourceType::IN_MV);
@@ -465,7 +492,9 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
-                    st_h4(OUT, x, y, {0, 0, 0, 0}, sig * 8);
+                    st_h4(OUT, x, y, {0, 0, 0, 0}, sig * sb);
+                    if (d.sh)
+                        st_h4(OUT, x, y, {0, 0, 0, 0}, sig * sb + 8);
                     st_h(FASTC, x, y, 0.0f, sig * 2);
                     if (relax)
                         st_h(MOMC, x, y, 0.0f, sig * 2);
@@ -498,15 +527,20 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
 
             if (d.hasDiff) {
                 int sig = k.sigDiff();
-                f4 in = ld_h4(IN, x, y, sig * 8);
+                f4 in = ld_h4(IN, x, y, sig * sb);
                 float A = prevDiffA;
                 if (c.confAvail)
                     A *= sample_confidence(confD, u, v);
                 A *= lerpf(quality, 1.0f, 1.0f / (1.0f + A));
                 float nonLin = 1.0f / (1.0f + A);
-                f4 hist = smbOk ? fetch4(k, HIST, sig * 8, smb) : in;
+                f4 hist = smbOk ? fetch4(k, HIST, sig * sb, smb) : in;
                 float fastHist = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
-                st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
+                st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * sb);
+                if (d.sh) { // SH1 follows SH0: same footprint, same blend factor
+                    f4 in1 = ld_h4(IN, x, y, sig * sb + 8);
+                    f4 hist1 = smbOk ? fetch4(k, HIST, sig * sb + 8, smb) : in1;
+                    st_h4(OUT, x, y, lerp4(hist1, in1, nonLin), sig * sb + 8);
+                }
                 st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
                 if (relax) {
                     float m2 = in.x * in.x;
@@ -517,7 +551,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
             }
             if (d.hasSpec) {
                 int sig = k.sigSpec();
-                f4 in = ld_h4(IN, x, y, sig * 8);
+                f4 in = ld_h4(IN, x, y, sig * sb);
                 float hitDist = ld_h(HT, x, y);
                 // parallax (pixels) of the point seen from the previous camera position
                 f3 Xpar = sub3(r.XwPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
@@ -551,11 +585,11 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                         float dA, sA;
                         fetchA(k, D1P, vmb, dA, sA);
                         Avmb = fmin2(sA + 1.0f, maxAs);
-                        vmbHist = fetch4(k, HIST, sig * 8, vmb);
+                        vmbHist = fetch4(k, HIST, sig * sb, vmb);
                         vmbFast = fetch1(k, FASTP, sig * 2, vmb);
                     }
                 }
-                f4 smbHist = smbOk ? fetch4(k, HIST, sig * 8, smb) : in;
+                f4 smbHist = smbOk ? fetch4(k, HIST, sig * sb, smb) : in;
                 float smbFast = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
                 if (!smbOk)
                     Asmb = 0.0f;
@@ -572,7 +606,13 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 float nonLin = 1.0f / (1.0f + A);
                 f4 hist = lerp4(smbHist, vmbHist, amount);
                 float fastHist = lerpf(smbFast, vmbFast, amount);
-                st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * 8);
+                st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * sb);
+                if (d.sh) {
+                    f4 in1 = ld_h4(IN, x, y, sig * sb + 8);
+                    f4 smb1 = smbOk ? fetch4(k, HIST, sig * sb + 8, smb) : in1;
+                    f4 vmb1 = vmb.wsum > 0.0f ? fetch4(k, HIST, sig * sb + 8, vmb) : in1;
+                    st_h4(OUT, x, y, lerp4(lerp4(smb1, vmb1, amount), in1, nonLin), sig * sb + 8);
+                }
                 st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastAs))), sig * 2);
                 if (relax) {
                     float m2 = in.x * in.x;
@@ -593,6 +633,8 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
 // --------------------------------------------------------------------------------------------------
 void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
     const nrd::ReblurSettings& s = d.reblur;
     const Plane& G = k.guide();
     const Plane& IN = k.trans(T_TMP2);
@@ -608,8 +650,11 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
-                for (int sig = 0; sig < d.nsig; sig++)
-                    st_h4(OUT, x, y, {0, 0, 0, 0}, sig * 8);
+                for (int sig = 0; sig < d.nsig; sig++) {
+                    st_h4(OUT, x, y, {0, 0, 0, 0}, sig * sb);
+                    if (d.sh)
+                        st_h4(OUT, x, y, {0, 0, 0, 0}, sig * sb + 8);
+                }
                 st_u16(D1C, x, y, 0);
                 continue;
             }
@@ -624,7 +669,8 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                 int ai = isSpec ? 1 : 0;
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
-                f4 val = ld_h4(IN, x, y, sig * 8);
+                f4 val = ld_h4(IN, x, y, sig * sb);
+                f4 val1 = d.sh ? ld_h4(IN, x, y, sig * sb + 8) : f4{0, 0, 0, 0};
                 float Acur = A[ai];
                 // ---- history reconstruction
                 if (Acur < (float)s.historyFixFrameNum && s.historyFixFrameNum > 0) {
@@ -641,6 +687,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                         float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
                         float roughB = -rough * roughA;
                         f4 sum = mul4(val, 1.0f + Acur);
+                        f4 sum1 = mul4(val1, 1.0f + Acur);
                         float wsum = 1.0f + Acur;
                         for (int j = -2; j <= 2; j++)
                             for (int i = -2; i <= 2; i++) {
@@ -660,10 +707,13 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                 float tA[2];
                                 unpack_data1(ld_u16(D1T, px, py), tA[0], tA[1]);
                                 w *= 1.0f + tA[ai];
-                                sum = fma4(ld_h4(IN, px, py, sig * 8), w, sum);
+                                sum = fma4(ld_h4(IN, px, py, sig * sb), w, sum);
+                                if (d.sh)
+                                    sum1 = fma4(ld_h4(IN, px, py, sig * sb + 8), w, sum1);
                                 wsum += w;
                             }
                         val = mul4(sum, 1.0f / wsum);
+                        val1 = mul4(sum1, 1.0f / wsum);
                     }
                 }
                 // ---- fast history clamping (5x5 moments of the fast luma history)
@@ -691,10 +741,15 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     val.x = Yc;
                     val.y *= scale;
                     val.z *= scale;
+                    val1.x *= scale;
+                    val1.y *= scale;
+                    val1.z *= scale;
                     float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
                     outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? maxFastAs : maxFastAd), f);
                 }
-                st_h4(OUT, x, y, val, sig * 8);
+                st_h4(OUT, x, y, val, sig * sb);
+                if (d.sh)
+                    st_h4(OUT, x, y, val1, sig * sb + 8);
             }
             st_u16(D1C, x, y, pack_data1(outA[0], outA[1]));
         }
@@ -705,6 +760,8 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
 // --------------------------------------------------------------------------------------------------
 void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
     const nrd::ReblurSettings& s = d.reblur;
     const Plane& G = k.guide();
     const Plane& MV = k.slot(nrd::ResourceType::IN_MV);
@@ -716,13 +773,19 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
     const Plane& HT = k.trans(T_HITTRACK);
     const Plane* outP[2] = {nullptr, nullptr};
     const Plane* inP[2] = {nullptr, nullptr};
+    const Plane* out1P[2] = {nullptr, nullptr};
+    const Plane* in1P[2] = {nullptr, nullptr};
     if (d.hasDiff) {
         outP[k.sigDiff()] = &k.slot(out_slot(d, false));
         inP[k.sigDiff()] = &k.slot(in_slot(d, false));
+        out1P[k.sigDiff()] = &k.slot(out1_slot(false));
+        in1P[k.sigDiff()] = &k.slot(in1_slot(false));
     }
     if (d.hasSpec) {
         outP[k.sigSpec()] = &k.slot(out_slot(d, true));
         inP[k.sigSpec()] = &k.slot(in_slot(d, true));
+        out1P[k.sigSpec()] = &k.slot(out1_slot(true));
+        in1P[k.sigSpec()] = &k.slot(in1_slot(true));
     }
     bool historyOk = d.historyValid && !c.reset;
     float maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
@@ -735,6 +798,8 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
                     store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, d.occlusion) : f4{0, 0, 0, 0}, d.occlusion);
+                    if (d.sh)
+                        st_h4(*out1P[sig], x, y, split ? ld_h4(*in1P[sig], x, y) : f4{0, 0, 0, 0});
                     st_h(STABC, x, y, 0.0f, sig * 2);
                 }
                 continue;
@@ -746,7 +811,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             unpack_data1(ld_u16(D1, x, y), A[0], A[1]);
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                f4 cur = ld_h4(HIST, x, y, sig * 8);
+                f4 cur = ld_h4(HIST, x, y, sig * sb);
                 // 5x5 local luma moments
                 float m1 = 0.0f, m2 = 0.0f;
                 for (int j = -2; j <= 2; j++)
@@ -756,7 +821,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                         if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
                             float zt = ld_f32(G, px, py, 0);
                             if (absf(zt) <= c.denoisingRange)
-                                f = ld_h(HIST, px, py, sig * 8);
+                                f = ld_h(HIST, px, py, sig * sb);
                         }
                         m1 += f;
                         m2 = fma_(f, f, m2);
@@ -822,6 +887,10 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
                 st_h(STABC, x, y, Yout, sig * 2);
                 store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, d.occlusion) : o, d.occlusion);
+                if (d.sh) {
+                    f4 c1 = ld_h4(HIST, x, y, sig * sb + 8);
+                    st_h4(*out1P[sig], x, y, split ? ld_h4(*in1P[sig], x, y) : f4{c1.x * scale, c1.y * scale, c1.z * scale, c1.w});
+                }
             }
         }
 }
@@ -839,6 +908,8 @@ enum RelaxTrans { T_AT_A = T_NUM, T_AT_B };
 
 void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int it, bool last) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
     const nrd::RelaxSettings& s = d.relax;
     const Plane& G = k.guide();
     const Plane& HIST = k.perm(P_HIST);
@@ -848,13 +919,19 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
     const Plane& OUTP = k.trans(T_AT_A + (it & 1));
     const Plane* outSlot[2] = {nullptr, nullptr};
     const Plane* inSlot[2] = {nullptr, nullptr};
+    const Plane* out1Slot[2] = {nullptr, nullptr};
+    const Plane* in1Slot[2] = {nullptr, nullptr};
     if (d.hasDiff) {
-        outSlot[k.sigDiff()] = &k.slot(nrd::ResourceType::OUT_DIFF_RADIANCE_HITDIST);
-        inSlot[k.sigDiff()] = &k.slot(nrd::ResourceType::IN_DIFF_RADIANCE_HITDIST);
+        outSlot[k.sigDiff()] = &k.slot(out_slot(d, false));
+        inSlot[k.sigDiff()] = &k.slot(in_slot(d, false));
+        out1Slot[k.sigDiff()] = &k.slot(out1_slot(false));
+        in1Slot[k.sigDiff()] = &k.slot(in1_slot(false));
     }
     if (d.hasSpec) {
-        outSlot[k.sigSpec()] = &k.slot(nrd::ResourceType::OUT_SPEC_RADIANCE_HITDIST);
-        inSlot[k.sigSpec()] = &k.slot(nrd::ResourceType::IN_SPEC_RADIANCE_HITDIST);
+        outSlot[k.sigSpec()] = &k.slot(out_slot(d, true));
+        inSlot[k.sigSpec()] = &k.slot(in_slot(d, true));
+        out1Slot[k.sigSpec()] = &k.slot(out1_slot(true));
+        in1Slot[k.sigSpec()] = &k.slot(in1_slot(true));
     }
     const int stride = 1 << it;
     const float depthSens = fmax2(s.depthThreshold, 0.001f) * 4.0f;
@@ -867,10 +944,15 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
-                    if (last)
+                    if (last) {
                         st_h4(*outSlot[sig], x, y, split ? ld_h4(*inSlot[sig], x, y) : f4{0, 0, 0, 0});
-                    else
-                        st_h4(OUTP, x, y, {0, 0, 0, 0}, sig * 8);
+                        if (d.sh)
+                            st_h4(*out1Slot[sig], x, y, split ? ld_h4(*in1Slot[sig], x, y) : f4{0, 0, 0, 0});
+                    } else {
+                        st_h4(OUTP, x, y, {0, 0, 0, 0}, sig * sb);
+                        if (d.sh)
+                            st_h4(OUTP, x, y, {0, 0, 0, 0}, sig * sb + 8);
+                    }
                 }
                 continue;
             }
@@ -882,7 +964,8 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
-                f4 c0 = ld_h4(IN, x, y, sig * 8);
+                f4 c0 = ld_h4(IN, x, y, sig * sb);
+                f4 sum1 = d.sh ? ld_h4(IN, x, y, sig * sb + 8) : f4{0, 0, 0, 0};
                 float var;
                 if (it == 0) {
                     float m2 = ld_h(MOM, x, y, sig * 2);
@@ -896,7 +979,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                                     continue;
                                 if (!(absf(ld_f32(G, px, py, 0)) <= c.denoisingRange))
                                     continue;
-                                float Y = ld_h(HIST, px, py, sig * 8);
+                                float Y = ld_h(HIST, px, py, sig * sb);
                                 sy += Y;
                                 sy2 = fma_(Y, Y, sy2);
                                 n += 1.0f;
@@ -935,12 +1018,14 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         w *= normal_weight(dot3(g.n, gs.n), normalW2);
                         if (isSpec && s.enableRoughnessEdgeStopping)
                             w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                        f4 sv = ld_h4(IN, px, py, sig * 8);
+                        f4 sv = ld_h4(IN, px, py, sig * sb);
                         float vs = sv.w;
                         if (it == 0)
                             vs = fmax2(fma_(-sv.x, sv.x, ld_h(MOM, px, py, sig * 2)), 0.0f);
                         w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), minLw);
                         sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
+                        if (d.sh)
+                            sum1 = fma4(ld_h4(IN, px, py, sig * sb + 8), w, sum1);
                         sumVar = fma_(vs, w * w, sumVar);
                         wsum += w;
                     }
@@ -949,10 +1034,15 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 float ov = sumVar * inv * inv;
                 if (last) {
                     f3 rgb = ycocg_to_linear(o);
-                    float hitDist = ld_h(HIST, x, y, sig * 8 + 6);
+                    float hitDist = ld_h(HIST, x, y, sig * sb + 6);
                     st_h4(*outSlot[sig], x, y, split ? ld_h4(*inSlot[sig], x, y) : f4{rgb.x, rgb.y, rgb.z, hitDist});
-                } else
-                    st_h4(OUTP, x, y, {o.x, o.y, o.z, ov}, sig * 8);
+                    if (d.sh)
+                        st_h4(*out1Slot[sig], x, y, split ? ld_h4(*in1Slot[sig], x, y) : mul4(sum1, inv));
+                } else {
+                    st_h4(OUTP, x, y, {o.x, o.y, o.z, ov}, sig * sb);
+                    if (d.sh)
+                        st_h4(OUTP, x, y, mul4(sum1, inv), sig * sb + 8);
+                }
             }
         }
 }
@@ -962,7 +1052,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
 void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
     uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
     uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
-    uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+    uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig; // SH mode: SH0 + SH1 texels per signal
     perm.push_back({"REBLUR::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
     perm.push_back({"REBLUR::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
     perm.push_back({"REBLUR::Data1_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
@@ -988,6 +1078,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
     auto P = [&](int i) { return enc_perm(pb + i); };
     auto T = [&](int i) { return enc_trans(tb + i); };
     float n = (float)d.nsig;
+    float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     const nrd::ReblurSettings& s = d.reblur;
     ReblurReach rr = reblur_reach(s);
     const float GB = 16.0f; // guide texel bytes
@@ -1008,23 +1099,32 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PrePass";
         p.kernel = "nrd_reblur_prepass";
         p.haloRows = (uint16_t)rr.pre;
-        p.bytesPerPixel = GB + 8 * n + 8 * n + (d.hasSpec ? 2 : 0);
+        p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
-        if (d.hasDiff)
+        if (d.hasDiff) {
             p.read.push_back(enc_slot(in_slot(d, false)));
-        if (d.hasSpec)
+            if (d.sh)
+                p.read.push_back(enc_slot(in1_slot(false)));
+        }
+        if (d.hasSpec) {
             p.read.push_back(enc_slot(in_slot(d, true)));
+            if (d.sh)
+                p.read.push_back(enc_slot(in1_slot(true)));
+        }
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
                 io.in[sig] = &k.slot(in_slot(d, isSpec));
+                io.in1[sig] = d.sh ? &k.slot(in1_slot(isSpec)) : nullptr;
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
-                io.outOff[sig] = sig * 8;
+                io.outOff[sig] = sig * sb;
             }
             spatial_filter(k, PRE, io, y0, y1);
         };
@@ -1035,7 +1135,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::TemporalAccumulation";
         p.kernel = "nrd_reblur_temporal_accumulation";
         p.haloRows = 0; // previous-frame planes are read at motion-displaced rows: the tiler adds its motion margin
-        p.bytesPerPixel = GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n + 2 + 4;
+        p.bytesPerPixel = GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + (d.hasSpec ? 2 : 0) + 8 * nr + 2 * n + 2 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
         p.run = temporal_accumulation;
@@ -1046,7 +1146,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::HistoryFix";
         p.kernel = "nrd_reblur_history_fix";
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
-        p.bytesPerPixel = GB + 2 + 8 * n + 2 * n + 8 * n + 2;
+        p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + 8 * nr + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
         p.written = {T(T_TMP1), P(P_DATA1_A + cur)};
         p.run = history_fix;
@@ -1057,17 +1157,19 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::Blur";
         p.kernel = "nrd_reblur_blur";
         p.haloRows = (uint16_t)rr.blur;
-        p.bytesPerPixel = GB + 2 + 8 * n + 8 * n;
+        p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
         p.written = {T(T_TMP2)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).blur;
             for (int sig = 0; sig < d.nsig; sig++) {
                 io.in[sig] = &k.trans(T_TMP1);
                 io.out[sig] = &k.trans(T_TMP2);
-                io.inOff[sig] = io.outOff[sig] = sig * 8;
+                io.inOff[sig] = io.outOff[sig] = sig * sb;
             }
             spatial_filter(k, BLUR, io, y0, y1);
         };
@@ -1078,17 +1180,19 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PostBlur";
         p.kernel = "nrd_reblur_post_blur";
         p.haloRows = (uint16_t)rr.post;
-        p.bytesPerPixel = GB + 2 + 8 * n + 8 * n;
+        p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
         p.written = {P(P_HIST)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).post;
             for (int sig = 0; sig < d.nsig; sig++) {
                 io.in[sig] = &k.trans(T_TMP2);
                 io.out[sig] = &k.perm(P_HIST);
-                io.inOff[sig] = io.outOff[sig] = sig * 8;
+                io.inOff[sig] = io.outOff[sig] = sig * sb;
             }
             spatial_filter(k, POST, io, y0, y1);
         };
@@ -1099,16 +1203,24 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::TemporalStabilization";
         p.kernel = "nrd_reblur_temporal_stabilization";
         p.haloRows = 2;
-        p.bytesPerPixel = GB + 2 + 4 + 8 + 8 * n + 2 * n + (d.hasSpec ? 2 : 0) + 8 * n + 2 * n;
+        p.bytesPerPixel = GB + 2 + 4 + 8 + 8 * nr + 2 * n + (d.hasSpec ? 2 : 0) + 8 * nr + 2 * n;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2), enc_slot(RT::IN_MV), P(P_HIST), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {P(P_STAB_A + cur)};
         if (d.hasDiff) {
             p.written.push_back(enc_slot(out_slot(d, false)));
+            if (d.sh)
+                p.written.push_back(enc_slot(out1_slot(false)));
             p.read.push_back(enc_slot(in_slot(d, false)));
+            if (d.sh)
+                p.read.push_back(enc_slot(in1_slot(false)));
         }
         if (d.hasSpec) {
             p.written.push_back(enc_slot(out_slot(d, true)));
+            if (d.sh)
+                p.written.push_back(enc_slot(out1_slot(true)));
             p.read.push_back(enc_slot(in_slot(d, true)));
+            if (d.sh)
+                p.read.push_back(enc_slot(in1_slot(true)));
         }
         p.run = temporal_stabilization;
         d.passes.push_back(p);
@@ -1138,7 +1250,7 @@ static nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
 void relax_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
     uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
     uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
-    uint32_t bRad = 8u * d.nsig, bLum = 2u * d.nsig;
+    uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig;
     perm.push_back({"RELAX::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
     perm.push_back({"RELAX::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
     perm.push_back({"RELAX::HistoryLength_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
@@ -1167,6 +1279,7 @@ void relax_build(Instance& I, DenoiserState& d) {
     auto P = [&](int i) { return enc_perm(pb + i); };
     auto T = [&](int i) { return enc_trans(tb + i); };
     float n = (float)d.nsig;
+    float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     const nrd::ReblurSettings& s = d.reblur;
     ReblurReach rr = reblur_reach(s);
     const float GB = 16.0f;
@@ -1188,23 +1301,32 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.name = "RELAX::PrePass";
         p.kernel = "nrd_reblur_prepass";
         p.haloRows = (uint16_t)rr.pre;
-        p.bytesPerPixel = GB + 8 * n + 8 * n + sp;
+        p.bytesPerPixel = GB + 8 * nr + 8 * nr + sp;
         p.read = {P(P_GUIDE_A + cur)};
-        if (d.hasDiff)
-            p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
-        if (d.hasSpec)
-            p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+        if (d.hasDiff) {
+            p.read.push_back(enc_slot(in_slot(d, false)));
+            if (d.sh)
+                p.read.push_back(enc_slot(in1_slot(false)));
+        }
+        if (d.hasSpec) {
+            p.read.push_back(enc_slot(in_slot(d, true)));
+            if (d.sh)
+                p.read.push_back(enc_slot(in1_slot(true)));
+        }
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                io.in[sig] = &k.slot(isSpec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
+                io.in[sig] = &k.slot(in_slot(d, isSpec));
+                io.in1[sig] = d.sh ? &k.slot(in1_slot(isSpec)) : nullptr;
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
-                io.outOff[sig] = sig * 8;
+                io.outOff[sig] = sig * sb;
             }
             spatial_filter(k, PRE, io, y0, y1);
         };
@@ -1215,7 +1337,7 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.name = "RELAX::TemporalAccumulation";
         p.kernel = "nrd_reblur_temporal_accumulation";
         p.haloRows = 0;
-        p.bytesPerPixel = GB + 8 + GB + 2 + 8 * n + 8 * n + 2 * n + 2 * n + sp + 8 * n + 2 * n + 2 * n + 2 + 4;
+        p.bytesPerPixel = GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + 2 * n + sp + 8 * nr + 2 * n + 2 * n + 2 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)),
                   P(P_DATA1_A + (cur ^ 1)), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {T(T_TMP2), P(P_FAST_A + cur), P(P_STAB_A + cur), T(T_DATA1), T(T_DATA2)};
@@ -1227,7 +1349,7 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.name = "RELAX::HistoryFix";
         p.kernel = "nrd_reblur_history_fix";
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
-        p.bytesPerPixel = GB + 2 + 8 * n + 2 * n + 8 * n + 2;
+        p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + 8 * nr + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
         p.written = {P(P_HIST), P(P_DATA1_A + cur)};
         p.run = history_fix;
@@ -1241,7 +1363,7 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.name = atrousNames[it];
         p.kernel = "nrd_relax_atrous";
         p.haloRows = (uint16_t)(1 << it);
-        p.bytesPerPixel = GB + (it == 0 ? 2 + 8 * n + 2 * n : 8 * n) + (last ? 8 * n : 0.0f) + 8 * n;
+        p.bytesPerPixel = GB + (it == 0 ? 2 + 8 * nr + 2 * n : 8 * nr) + (last ? 8 * nr : 0.0f) + 8 * nr;
         p.read = {P(P_GUIDE_A + cur)};
         if (it == 0) {
             p.read.push_back(P(P_DATA1_A + cur));
@@ -1252,12 +1374,20 @@ void relax_build(Instance& I, DenoiserState& d) {
         if (last) {
             p.read.push_back(P(P_HIST));
             if (d.hasDiff) {
-                p.written.push_back(enc_slot(RT::OUT_DIFF_RADIANCE_HITDIST));
-                p.read.push_back(enc_slot(RT::IN_DIFF_RADIANCE_HITDIST));
+                p.written.push_back(enc_slot(out_slot(d, false)));
+                p.read.push_back(enc_slot(in_slot(d, false)));
+                if (d.sh) {
+                    p.written.push_back(enc_slot(out1_slot(false)));
+                    p.read.push_back(enc_slot(in1_slot(false)));
+                }
             }
             if (d.hasSpec) {
-                p.written.push_back(enc_slot(RT::OUT_SPEC_RADIANCE_HITDIST));
-                p.read.push_back(enc_slot(RT::IN_SPEC_RADIANCE_HITDIST));
+                p.written.push_back(enc_slot(out_slot(d, true)));
+                p.read.push_back(enc_slot(in_slot(d, true)));
+                if (d.sh) {
+                    p.written.push_back(enc_slot(out1_slot(true)));
+                    p.read.push_back(enc_slot(in1_slot(true)));
+                }
             }
         } else
             p.written = {T(T_AT_A + (it & 1))};

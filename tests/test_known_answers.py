@@ -325,3 +325,33 @@ def test_occlusion_fixed_point_and_denoising(request, pkg, api, backend):
         hz.frame(util.static_common(api, w, h, f, reset=(f == 0)), hz.upload(fr), st)
     out = hz.fetch(hz.outputs["out_diff_hitdist"]).view(np.uint16).reshape(h, w).astype(np.float64)
     assert abs(out[8:-8, 8:-8].mean() / 30000 - 1) < 0.03 and out[8:-8, 8:-8].std() < 0.25 * 9000
+
+
+# ---- SH variants: SH1 is filtered with exactly the weights of SH0 (Source/NRDSample.cpp:464-476) ---------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("den", ["REBLUR_DIFFUSE_SPECULAR_SH", "RELAX_DIFFUSE_SPECULAR_SH"])
+def test_sh_fixed_point_and_linearity(request, pkg, api, backend, den):
+    b = get(request, backend)
+    w, h = 96, 64
+    d = api.Denoiser[den]
+    relax = den.startswith("RELAX")
+    st = {d: api.RelaxSettings() if relax else api.ReblurSettings()}
+    fr = util.flat_frame(pkg, w, h, rng=np.random.default_rng(9))
+    if relax:
+        for key, hit in (("diff", 1.5), ("spec", 7.0)):
+            fr[key][..., 3] = hit
+    # SH1 proportional to SH0's first three channels: since both see the same weights, the output keeps the proportion
+    k = 0.5
+    fr["diff_sh1"] = (fr["diff"].astype(np.float32) * k).astype(np.float16)
+    fr["spec_sh1"] = (fr["spec"].astype(np.float32) * k).astype(np.float16)
+    hz = pkg.harness.Harness(b, [d], w, h)
+    for f in range(3):
+        hz.frame(util.static_common(api, w, h, f, reset=(f == 0)), hz.upload(fr), st)
+    if not relax:  # REBLUR keeps YCoCg in SH0, so SH1 = k * SH0 must survive every pass (up to fp16 rounding of both planes)
+        for a, b1 in (("out_diff", "out_diff_sh1"), ("out_spec", "out_spec_sh1")):
+            sh0 = hz.output(a).astype(np.float32)[8:-8, 8:-8, 0]
+            sh1 = hz.output(b1).astype(np.float32)[8:-8, 8:-8, 0]
+            assert np.abs(sh1 / np.maximum(sh0, 1e-3) - k).max() < 0.01
+    else:  # RELAX outputs linear RGB in SH0 while SH1 stays in its own space: just require a denoised, finite SH1
+        sh1 = hz.output("out_diff_sh1").astype(np.float32)
+        assert np.isfinite(sh1).all() and sh1[8:-8, 8:-8, 0].std() < 0.5 * fr["diff_sh1"].astype(np.float32)[8:-8, 8:-8, 0].std()

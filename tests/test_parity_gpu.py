@@ -18,6 +18,10 @@ VARIANTS = [
     ["RELAX_SPECULAR"],
     ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"],
     ["REBLUR_DIFFUSE_OCCLUSION", "REBLUR_SPECULAR_OCCLUSION"],
+    ["REBLUR_DIFFUSE_SPECULAR_SH"],
+    ["REBLUR_DIFFUSE_SH", "REBLUR_SPECULAR_SH"],
+    ["RELAX_DIFFUSE_SPECULAR_SH"],
+    ["RELAX_DIFFUSE_SH", "RELAX_SPECULAR_SH"],
 ]
 
 

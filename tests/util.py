@@ -32,7 +32,7 @@ def default_settings(api, scene, denoisers, **reblur_kw):
             s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
         elif d == D.REFERENCE:
             s[d] = api.ReferenceSettings()
-        elif d in (D.RELAX_DIFFUSE, D.RELAX_SPECULAR, D.RELAX_DIFFUSE_SPECULAR):
+        elif d.name.startswith("RELAX"):
             kw = {k: v for k, v in reblur_kw.items() if k in ("minMaterialForDiffuse", "minMaterialForSpecular")}
             s[d] = api.RelaxSettings(**kw)
     return s
@@ -58,7 +58,7 @@ def run_frames(api, harness_mod, backend, scene, denoisers, nframes, settings=No
 def compare_all(ha, hb, exact=True, ulp=1):
     """compare outputs and every pool plane of two harnesses; returns list of (name, detail) mismatches"""
     bad = []
-    for key in ("out_diff", "out_spec"):
+    for key in ("out_diff", "out_spec", "out_diff_sh1", "out_spec_sh1"):
         a, b = ha.fetch(ha.outputs[key]), hb.fetch(hb.outputs[key])
         if exact:
             if not np.array_equal(a, b):
