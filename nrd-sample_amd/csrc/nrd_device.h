@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #define NRD_DEV static __device__ __forceinline__
+#define NRD_HD static __host__ __device__ __forceinline__
 
 namespace nrdhip {
 
@@ -58,7 +59,7 @@ struct f4 {
     float x, y, z, w;
 };
 
-NRD_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+NRD_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 NRD_DEV float fmin2(float a, float b) { return a < b ? a : b; }
 NRD_DEV float fmax2(float a, float b) { return a > b ? a : b; }
 NRD_DEV float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
@@ -69,6 +70,8 @@ NRD_DEV float smoothstep01(float x) {
     return x * x * (3.0f - 2.0f * x);
 }
 NRD_DEV float absf(float x) { return x < 0.0f ? -x : x; }
+NRD_DEV int imin(int a, int b) { return a < b ? a : b; }
+NRD_DEV int imax(int a, int b) { return a > b ? a : b; }
 
 NRD_DEV f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 NRD_DEV f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -239,7 +242,7 @@ NRD_DEV float spec_dominant_factor(float roughness) {
     return s * (__builtin_sqrtf(s) + roughness);
 }
 
-NRD_DEV uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
+NRD_HD uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
     uint32_t h = (x * 73856093u) ^ (y * 19349663u) ^ (frame * 83492791u) ^ (salt * 2654435761u);
     h ^= h >> 13;
     h *= 0x5bd1e995u;
@@ -294,20 +297,38 @@ NRD_DEV float geo_weight(const PixelGeo& p, float px, float gy, float zs) {
 }
 
 // ---- plane access ------------------------------------------------------------------------------------------------
+// Texel addressing: every plane is < 4 GiB (8K x 32 B = 1 GiB), so the byte offset is a 32-bit quantity built with one
+// 24-bit multiply-add (rows < 2^24, pitch < 2^24) and the access becomes "global_load vdst, voffset, sbase" - no 64-bit
+// (quarter-rate) address arithmetic per tap.
+NRD_DEV uint32_t texel_offset(const PlaneRef& P, int x, int y, int bpt, int off) {
+    return __umul24((uint32_t)y, P.pitch) + (uint32_t)x * (uint32_t)bpt + (uint32_t)off;
+}
 template <typename T>
 NRD_DEV T ld(const PlaneRef& P, int x, int y, int bpt, int off = 0) {
-    return *reinterpret_cast<const T*>(P.p + (size_t)y * P.pitch + (size_t)x * bpt + off);
+    return *reinterpret_cast<const T*>(P.p + texel_offset(P, x, y, bpt, off));
 }
 template <typename T>
 NRD_DEV void st(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
-    *reinterpret_cast<T*>(P.p + (size_t)y * P.pitch + (size_t)x * bpt + off) = v;
+    *reinterpret_cast<T*>(P.p + texel_offset(P, x, y, bpt, off)) = v;
 }
 
 // 8-tap Poisson disk + weight (same frozen table as the oracle)
-__device__ static const float g_poisson8[8][3] = {
-    {-0.4706069f, -0.4427112f, 0.7592f}, {-0.9057375f, 0.3003471f, 0.5483f}, {-0.3487388f, 0.4037880f, 0.8287f},
-    {0.1023042f, 0.6439373f, 0.7554f},   {0.5699277f, 0.3513750f, 0.7439f},  {0.2939128f, -0.1131226f, 0.9366f},
-    {0.7836658f, -0.4208784f, 0.5932f},  {0.1564120f, -0.8198990f, 0.6314f}};
+#define NRD_POISSON8_TABLE                                                                                          \
+    {{-0.4706069f, -0.4427112f, 0.7592f}, {-0.9057375f, 0.3003471f, 0.5483f}, {-0.3487388f, 0.4037880f, 0.8287f},    \
+     {0.1023042f, 0.6439373f, 0.7554f},   {0.5699277f, 0.3513750f, 0.7439f},  {0.2939128f, -0.1131226f, 0.9366f},    \
+     {0.7836658f, -0.4208784f, 0.5932f},  {0.1564120f, -0.8198990f, 0.6314f}}
+__device__ static const float g_poisson8[8][3] = NRD_POISSON8_TABLE;
+
+// Passes that rotate the disk once per FRAME (all lanes share the rotation) get their 8 rotated offsets from the host in the
+// kernel arguments (SGPRs) - the same two roundings per coordinate the per-pixel path performs, done once instead of per tap.
+NRD_HD void rotate_taps(const float (*rot)[2], uint32_t frameIndex, uint32_t salt, const float (*disk)[3], float (*out)[2]) {
+    uint32_t h = hash_px(0u, 0u, frameIndex, salt);
+    float rc = rot[h & 63u][0], rs = rot[h & 63u][1];
+    for (int t = 0; t < 8; t++) {
+        out[t][0] = fma_(disk[t][0], rc, -(disk[t][1] * rs));
+        out[t][1] = fma_(disk[t][0], rs, disk[t][1] * rc);
+    }
+}
 
 // XCD-aware tile assignment: the dispatcher round-robins consecutive workgroups over the 8 XCDs, so give each XCD a
 // contiguous run of tiles (row-major) - stencil/gather overlap between neighbouring tiles then stays in ONE XCD's L2.

@@ -22,6 +22,7 @@ struct ReblurParams {
     int relax;                    // 1: RELAX front half (linear RGB + world-space hitT inputs, luma-moment history, HistoryFix writes History)
     int historyFixFrameNum, historyFixStride;
     int reachPre, reachBlur, reachPost; // hard per-pass bound (pixels) on tap distance = halo rows of the pass
+    float tapsPre[8][2], tapsPost[8][2]; // Poisson disk rotated for this frame (PrePass / PostBlur rotate per frame)
     uint32_t minMatDiff, minMatSpec;
     int clampEnabled;
     int hasDiff, hasSpec;

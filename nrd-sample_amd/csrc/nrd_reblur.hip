@@ -81,11 +81,14 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
 // =====================================================================================================================
 // Spatial filter: PrePass (VARIANT 0), Blur (1), PostBlur (2)
 // =====================================================================================================================
-template <int VARIANT, bool HAS_DIFF, bool HAS_SPEC>
+// MODE: 0 = REBLUR radiance, 1 = RELAX radiance, 2 = OCCLUSION (hit distance only), 3 = REBLUR SH, 4 = RELAX SH (compile-time so
+// the unrolled tap loop stays one basic block)
+template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    const int sb = p.sh ? 16 : 8;  // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    const int RBPT = sb * NSIG;    // bytes per texel of the internal radiance planes
+    constexpr bool SH = MODE == 3 || MODE == 4;
+    constexpr int sb = SH ? 16 : 8;   // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    constexpr int RBPT = sb * NSIG;  // bytes per texel of the internal radiance planes
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
     const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
-    const bool relaxIn = VARIANT == 0 && p.relax != 0; // RELAX inputs: linear RGB + world-space hit distance
-    const bool occIn = VARIANT == 0 && p.occlusion != 0;
+    constexpr bool relaxIn = VARIANT == 0 && (MODE == 1 || MODE == 4); // RELAX inputs: linear RGB + world-space hit distance
+    constexpr bool occIn = VARIANT == 0 && MODE == 2;
 
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-            if (p.sh)
+            if (SH)
                 st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
         }
         if (VARIANT == 0 && HAS_SPEC)
@@ -125,6 +128,11 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)
         unpack_data1(ld<uint16_t>(p.data1, x, y, 2), diffA, specA);
+    // tap window (global pixel coordinates): within `reach` of the centre, inside the frame and inside the held rows
+    const int loX = imax(x - reach, 0), hiX = imin(x + reach, c.W - 1);
+    const int loY = imax(gy0 - reach, imax(c.yOff, 0)), hiY = imin(gy0 + reach, imin(c.yOff + c.resH, c.H) - 1);
+    const uint32_t spanX = (uint32_t)(hiX - loX), spanY = (uint32_t)(hiY - loY);
+    const float loXf = (float)(loX - 1), hiXf = (float)(hiX + 1), loYf = (float)(loY - 1), hiYf = (float)(hiY + 1);
 
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         float rough = isSpec ? g.roughness : 1.0f;
         uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
         const PlaneRef& srcP = VARIANT == 0 ? (isSpec ? p.inSpec : p.inDiff) : inP;
-        const int srcBpt = VARIANT == 0 ? 8 : RBPT;
+        constexpr int srcBpt = VARIANT == 0 ? 8 : RBPT;
         const int srcOff = VARIANT == 0 ? 0 : sig * sb;
         f4 center = load_signal(p, srcP, x, y, srcBpt, srcOff, occIn);
         if (relaxIn)
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
         const PlaneRef& src1P = VARIANT == 0 ? (isSpec ? p.inSpec1 : p.inDiff1) : inP;
         const int src1Off = VARIANT == 0 ? 0 : srcOff + 8;
-        f4 sum1 = p.sh ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
+        f4 sum1 = SH ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
         float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist / pg.frustumSize);
@@ -192,21 +200,26 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
 #pragma unroll
             for (int t = 0; t < 8; t++) {
-                float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
-                float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                float ox, oy;
+                if (PER_PIXEL) {
+                    ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+                    oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                } else {
+                    ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
+                    oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
+                }
                 float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
                 float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
                 // Latency: both gathers of the tap are issued UNCONDITIONALLY at a clamped (always valid) address and only
                 // then is the tap validated - one memory round trip per tap instead of three dependent ones. A rejected tap
-                // contributes nothing, exactly like an early "continue".
-                bool valid = fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H;
-                int px = (int)clampf(fpx, 0.0f, (float)(c.W - 1)), gy = (int)clampf(fpy, 0.0f, (float)(c.H - 1)), py = gy - c.yOff;
-                int ddx = px - x, ddy = gy - gy0;
-                valid = valid && !(ddx > reach || -ddx > reach || ddy > reach || -ddy > reach) && py >= 0 && py < c.resH;
-                int cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
+                // contributes nothing, exactly like an early "continue". The tap window [lo, hi] folds the frame bounds, the
+                // rows this instance holds and the hard reach of the pass into one range test per axis.
+                int ipx = (int)__builtin_amdgcn_fmed3f(fpx, loXf, hiXf), ipy = (int)__builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
+                bool valid = ((uint32_t)(ipx - loX) <= spanX) & ((uint32_t)(ipy - loY) <= spanY);
+                int px = imin(imax(ipx, loX), hiX), cpy = imin(imax(ipy, loY), hiY) - c.yOff;
                 uint4 graw = ld<uint4>(p.guide, px, cpy, 16);
                 f4 sv = load_signal(p, srcP, px, cpy, srcBpt, srcOff, occIn);
-                f4 sv1 = p.sh ? unpack_h4(ld<uint2>(src1P, px, cpy, srcBpt, src1Off)) : f4{0, 0, 0, 0};
+                f4 sv1 = SH ? unpack_h4(ld<uint2>(src1P, px, cpy, srcBpt, src1Off)) : f4{0, 0, 0, 0};
                 Guide gs = decode_guide(graw, c.denoisingRange);
                 // branch-free from here: a rejected tap is SELECTED out (sums untouched), which is exactly what skipping it
                 // would do, but keeps the unrolled taps in one basic block so their gathers overlap
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                 f4 acc = fma4(sv, w, sum);
                 sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
-                if (p.sh) {
+                if (SH) {
                     f4 acc1 = fma4(sv1, w, sum1);
                     sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
                 }
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         }
         float invw = 1.0f / wsum;
         st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, invw)), sig * sb);
-        if (p.sh)
+        if (SH)
             st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum1, invw)), sig * sb + 8);
         if (VARIANT == 0 && isSpec)
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit));
@@ -848,11 +861,30 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
 // decoded by RELAX_BackEnd_UnpackRadiance, Shaders/Composition.cs.hlsl:160-161). All lanes use the same tap offsets, so the
 // gathers of a 16x4-pixel wave are 16x4-texel groups: fully coalesced at every stride; neighbouring tiles share taps in L2.
 // =====================================================================================================================
-template <bool HAS_DIFF, bool HAS_SPEC>
+// whole radiance texel (8 / 16 / 32 bytes: one or two signals, SH0 [+ SH1]) in as few loads as its size allows
+template <int BYTES>
+NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) {
+    if constexpr (BYTES == 8) {
+        t[0] = ld<uint2>(P, x, y, 8);
+    } else {
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; k++) {
+            uint4 v = ld<uint4>(P, x, y, BYTES, k * 16);
+            t[2 * k] = uint2{v.x, v.y};
+            t[2 * k + 1] = uint2{v.z, v.w};
+        }
+    }
+}
+
+// FIRST: iteration 0 (variance from the luminance moments, 3x3 spatial estimate for short histories). The 3x3 taps of the
+// signals share their positions, so the tap loop is the OUTER loop: one guide gather + decode + plane/normal terms per tap
+// serve both signals (each signal still sees exactly the operation sequence of the oracle).
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool FIRST>
 __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    const int RBPT = sb * NSIG;
+    constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    constexpr int RBPT = sb * NSIG;
+    constexpr int SW = sb / 8; // uint2 words per signal
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
@@ -874,11 +906,11 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
                 const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
                 st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
-                if (p.sh)
+                if (SH)
                     st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
             } else {
                 st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-                if (p.sh)
+                if (SH)
                     st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
             }
         }
@@ -886,20 +918,28 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     }
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.depthSens);
     float A[2] = {0.0f, 0.0f};
-    if (it == 0)
+    if (FIRST)
         unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.in, x, y, ctex);
+    f4 c0[NSIG], sum1[NSIG];
+    f3 sum[NSIG];
+    float sumVar[NSIG], wsum[NSIG], invL[NSIG], normalW2[NSIG], minLw[NSIG];
+    uint32_t minMat[NSIG];
+    float roughA = 0.0f, roughB = 0.0f;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         const int si = isSpec ? 1 : 0;
         float rough = isSpec ? g.roughness : 1.0f;
-        uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
-        f4 c0 = unpack_h4(ld<uint2>(p.in, x, y, RBPT, sig * sb));
-        f4 sum1 = p.sh ? unpack_h4(ld<uint2>(p.in, x, y, RBPT, sig * sb + 8)) : f4{0, 0, 0, 0};
+        minMat[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
+        minLw[sig] = p.minLw[si];
+        c0[sig] = unpack_h4(ctex[sig * SW]);
+        sum1[sig] = SH ? unpack_h4(ctex[sig * SW + (SH ? 1 : 0)]) : f4{0, 0, 0, 0};
         float var;
-        if (it == 0) {
+        if (FIRST) {
             float m2 = h2f(ld<uint16_t>(p.mom, x, y, LBPT, sig * 2));
-            var = fmax2(fma_(-c0.x, c0.x, m2), 0.0f);
+            var = fmax2(fma_(-c0[sig].x, c0[sig].x, m2), 0.0f);
             if (A[si] < p.histThreshold) { // short history: 3x3 spatial estimate
                 float sy = 0.0f, sy2 = 0.0f, n = 0.0f;
                 for (int j = -1; j <= 1; j++)
@@ -921,64 +961,86 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
             if (isSpec)
                 var = fma_(var, p.specularVarianceBoost, var);
         } else
-            var = c0.w;
+            var = c0[sig].w;
         float sigma = __builtin_sqrtf(var);
-        float invL = 0.3333f / fma_(p.phi[si], sigma, 1e-4f);
+        invL[sig] = 0.3333f / fma_(p.phi[si], sigma, 1e-4f);
         float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
         float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
-        float normalW2 = normalW * normalW;
-        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
-        float roughB = -rough * roughA;
-        f3 sum = {c0.x, c0.y, c0.z};
-        float sumVar = var, wsum = 1.0f;
+        normalW2[sig] = normalW * normalW;
+        if (isSpec) {
+            roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+            roughB = -rough * roughA;
+        }
+        sum[sig] = {c0[sig].x, c0[sig].y, c0[sig].z};
+        sumVar[sig] = var;
+        wsum[sig] = 1.0f;
+    }
+    // rows / columns a tap may land on: inside the frame and inside the rows this instance holds
+    const int loY = imax(0, -c.yOff), hiY = imin(c.resH, c.H - c.yOff) - 1;
+    const bool roughStop = p.roughnessEdgeStopping != 0;
 #pragma unroll
-        for (int j = -1; j <= 1; j++)
+    for (int j = -1; j <= 1; j++)
 #pragma unroll
-            for (int i = -1; i <= 1; i++) {
-                if (i == 0 && j == 0)
-                    continue;
-                int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
-                bool valid = !(px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH);
-                int cpx = px < 0 ? 0 : (px >= c.W ? c.W - 1 : px), cpy = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
-                uint4 graw = ld<uint4>(p.guide, cpx, cpy, 16); // all loads of the tap issued before it is validated
-                uint2 sraw = ld<uint2>(p.in, cpx, cpy, RBPT, sig * sb);
-                uint2 sraw1 = p.sh ? ld<uint2>(p.in, cpx, cpy, RBPT, sig * sb + 8) : uint2{0u, 0u};
-                uint16_t mraw = it == 0 ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
-                Guide gs = decode_guide(graw, c.denoisingRange);
-                valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat); // rejected taps are selected out below
+        for (int i = -1; i <= 1; i++) {
+            if (i == 0 && j == 0)
+                continue;
+            int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
+            bool inside = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+            int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
+            uint4 graw = ld<uint4>(p.guide, cpx, cpy, 16); // all loads of the tap issued before it is validated
+            uint2 stex[RBPT / 8];
+            load_texel<RBPT>(p.in, cpx, cpy, stex);
+            uint16_t mraw[NSIG];
+#pragma unroll
+            for (int sig = 0; sig < NSIG; sig++)
+                mraw[sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+            Guide gs = decode_guide(graw, c.denoisingRange);
+            float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
+            float nDot = dot3(g.n, gs.n);
+#pragma unroll
+            for (int sig = 0; sig < NSIG; sig++) {
+                const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+                bool valid = inside && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
                 float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
-                w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                if (isSpec && p.roughnessEdgeStopping)
-                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                f4 sv = unpack_h4(sraw);
-                float vs = sv.w;
-                if (it == 0)
-                    vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw)), 0.0f);
-                w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), p.minLw[si]);
-                sum = {valid ? fma_(sv.x, w, sum.x) : sum.x, valid ? fma_(sv.y, w, sum.y) : sum.y, valid ? fma_(sv.z, w, sum.z) : sum.z};
-                if (p.sh) {
-                    f4 acc1 = fma4(unpack_h4(sraw1), w, sum1);
-                    sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                w *= geoW;
+                w *= normal_weight(nDot, normalW2[sig]);
+                if (isSpec) {
+                    float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                    w *= roughStop ? rw : 1.0f;
                 }
-                sumVar = valid ? fma_(vs, w * w, sumVar) : sumVar;
-                wsum = valid ? wsum + w : wsum;
+                f4 sv = unpack_h4(stex[sig * SW]);
+                float vs = sv.w;
+                if (FIRST)
+                    vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[sig])), 0.0f);
+                w *= fmax2(exp_weight(absf(sv.x - c0[sig].x) * invL[sig]), minLw[sig]);
+                sum[sig] = {valid ? fma_(sv.x, w, sum[sig].x) : sum[sig].x, valid ? fma_(sv.y, w, sum[sig].y) : sum[sig].y,
+                            valid ? fma_(sv.z, w, sum[sig].z) : sum[sig].z};
+                if (SH) {
+                    f4 acc1 = fma4(unpack_h4(stex[sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
+                    sum1[sig] = {valid ? acc1.x : sum1[sig].x, valid ? acc1.y : sum1[sig].y, valid ? acc1.z : sum1[sig].z, valid ? acc1.w : sum1[sig].w};
+                }
+                sumVar[sig] = valid ? fma_(vs, w * w, sumVar[sig]) : sumVar[sig];
+                wsum[sig] = valid ? wsum[sig] + w : wsum[sig];
             }
-        float inv = 1.0f / wsum;
-        f3 o = mul3(sum, inv);
-        float ov = sumVar * inv * inv;
+        }
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        float inv = 1.0f / wsum[sig];
+        f3 o = mul3(sum[sig], inv);
+        float ov = sumVar[sig] * inv * inv;
         if (last) {
             f3 rgb = ycocg_to_linear(o);
             float hitDist = h2f(ld<uint16_t>(p.hist, x, y, RBPT, sig * sb + 6));
             const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
             st<uint2>(op, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : pack_h4({rgb.x, rgb.y, rgb.z, hitDist}));
-            if (p.sh)
-                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : pack_h4(mul4(sum1, inv)));
+            if (SH)
+                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : pack_h4(mul4(sum1[sig], inv)));
         } else {
             st<uint2>(p.out, x, y, RBPT, pack_h4({o.x, o.y, o.z, ov}), sig * sb);
-            if (p.sh)
-                st<uint2>(p.out, x, y, RBPT, pack_h4(mul4(sum1, inv)), sig * sb + 8);
+            if (SH)
+                st<uint2>(p.out, x, y, RBPT, pack_h4(mul4(sum1[sig], inv)), sig * sb + 8);
         }
     }
 }
@@ -1001,22 +1063,61 @@ dim3 grid_for(const FrameConsts& c) {
             hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
     } while (0)
 
+// same, flags AFTER the signal pair
+#define NRD_LAUNCH4(KERNEL, ...)                                                                                 \
+    do {                                                                                                          \
+        if (p.hasDiff && p.hasSpec)                                                                               \
+            hipLaunchKernelGGL((KERNEL<true, true, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
+        else if (p.hasDiff)                                                                                       \
+            hipLaunchKernelGGL((KERNEL<true, false, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);      \
+        else                                                                                                      \
+            hipLaunchKernelGGL((KERNEL<false, true, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);      \
+    } while (0)
+
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }
 
 void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
-    if (variant == 0)
-        NRD_LAUNCH3(k_spatial, 0, );
-    else if (variant == 1)
-        NRD_LAUNCH3(k_spatial, 1, );
-    else
-        NRD_LAUNCH3(k_spatial, 2, );
+    // PrePass decodes the denoiser's input convention (MODE 0..4); Blur / PostBlur only differ by the SH texel
+    int mode = p.sh ? (p.relax ? 4 : 3) : (p.relax ? 1 : (p.occlusion ? 2 : 0));
+    if (variant == 0) {
+        switch (mode) {
+        case 0: NRD_LAUNCH3(k_spatial, 0, 0, ); break;
+        case 1: NRD_LAUNCH3(k_spatial, 0, 1, ); break;
+        case 2: NRD_LAUNCH3(k_spatial, 0, 2, ); break;
+        case 3: NRD_LAUNCH3(k_spatial, 0, 3, ); break;
+        default: NRD_LAUNCH3(k_spatial, 0, 4, ); break;
+        }
+    } else if (variant == 1) {
+        if (p.sh)
+            NRD_LAUNCH3(k_spatial, 1, 3, );
+        else
+            NRD_LAUNCH3(k_spatial, 1, 0, );
+    } else {
+        if (p.sh)
+            NRD_LAUNCH3(k_spatial, 2, 3, );
+        else
+            NRD_LAUNCH3(k_spatial, 2, 0, );
+    }
 }
 
 void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_accumulation, ); }
 void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_history_fix, ); }
 void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_stabilization, ); }
-void launch_relax_atrous(const AtrousParams& p, hipStream_t s) { NRD_LAUNCH3(k_relax_atrous, ); }
+void launch_relax_atrous(const AtrousParams& p, hipStream_t s) {
+    bool first = p.it == 0;
+    if (p.sh) {
+        if (first)
+            NRD_LAUNCH4(k_relax_atrous, true, true);
+        else
+            NRD_LAUNCH4(k_relax_atrous, true, false);
+    } else {
+        if (first)
+            NRD_LAUNCH4(k_relax_atrous, false, true);
+        else
+            NRD_LAUNCH4(k_relax_atrous, false, false);
+    }
+}
 
 } // namespace nrdhip

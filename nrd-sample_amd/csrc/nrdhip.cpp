@@ -385,6 +385,9 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.reachPre = (int)(std::max(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) * 1.1f) + 3;
     p.reachBlur = (int)((s.maxBlurRadius + s.minBlurRadius) * 1.1f) + 3;
     p.reachPost = (int)((s.maxBlurRadius + s.minBlurRadius) * 2.2f) + 3;
+    static const float disk[8][3] = NRD_POISSON8_TABLE;
+    rotate_taps(c.rot, c.frameIndex, 1u, disk, p.tapsPre);  // salt = VARIANT + 1 (nrd_reblur.hip k_spatial)
+    rotate_taps(c.rot, c.frameIndex, 3u, disk, p.tapsPost);
     p.minMatDiff = s.minMaterialForDiffuse;
     p.minMatSpec = s.minMaterialForSpecular;
     p.clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum ? 1 : 0;

@@ -120,6 +120,17 @@ inline void sync() {
 
 // NOTE: the emulated barrier requires every thread of the block to reach every barrier (true for the product kernels:
 // block-uniform early exits happen before the first barrier, per-thread exits after the last one).
+inline unsigned int __umul24(unsigned int a, unsigned int b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+// v_med3_f32: a NaN operand yields the minimum of the others
+inline float hipemu_fmed3f(float a, float b, float c) {
+    if (a != a) return b < c ? b : c;
+    if (b != b) return a < c ? a : c;
+    if (c != c) return a < b ? a : b;
+    float lo = a < b ? a : b, hi = a < b ? b : a;
+    float m = hi < c ? hi : c; // min(max(a, b), c)
+    return lo > m ? lo : m;    // max(min(a, b), .)
+}
+#define __builtin_amdgcn_fmed3f hipemu_fmed3f
 inline void __syncthreads() { hipemu::sync(); }
 inline int __syncthreads_or(int v) {
     hipemu::sync();
