@@ -48,6 +48,21 @@ NRD_DEV void store_signal(const ReblurParams& p, const PlaneRef& P, int x, int y
     st<uint16_t>(P, x, y, 2, p.ioF16 ? f2h(v.x) : (uint16_t)__builtin_floorf(fma_(sat(v.x), 65535.0f, 0.5f)));
 }
 
+// whole radiance texel (8 / 16 / 32 bytes: one or two signals, SH0 [+ SH1]) in as few loads as its size allows
+template <int BYTES>
+NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) {
+    if constexpr (BYTES == 8) {
+        t[0] = ld<uint2>(P, x, y, 8);
+    } else {
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; k++) {
+            uint4 v = ld<uint4>(P, x, y, BYTES, k * 16);
+            t[2 * k] = uint2{v.x, v.y};
+            t[2 * k + 1] = uint2{v.z, v.w};
+        }
+    }
+}
+
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
 NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
     if (!xcd_tile(c, tx, ty))
@@ -434,11 +449,116 @@ NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
 // =====================================================================================================================
 // K3 TemporalAccumulation
 // =====================================================================================================================
-template <bool HAS_DIFF, bool HAS_SPEC>
+// Everything TemporalAccumulation needs from ONE bilinear footprint of the previous frame, fetched in one go: the four texel
+// positions depend only on the reprojected uv, so guides, accumulation speeds, radiance history and luma histories of all
+// signals are gathered unconditionally (clamped addresses) BEFORE any of them is validated - the surface-motion and the
+// virtual-motion footprints together are one memory round trip instead of a chain of dependent ones.
+template <int RBPT, int LBPT, bool RELAX>
+struct FootRaw {
+    uint4 g[4];
+    uint16_t a[4];
+    uint2 t[4][RBPT / 8];
+    uint32_t f[4]; // fast luma history texel: LBPT bytes = one fp16 per signal
+    uint32_t m[4]; // RELAX: second luma moment history
+};
+NRD_DEV uint32_t load_luma(const PlaneRef& P, int x, int y, int lbpt) { return lbpt == 4 ? ld<uint32_t>(P, x, y, 4) : (uint32_t)ld<uint16_t>(P, x, y, 2); }
+
+struct FootPos {
+    int ix, iy;
+    float fx, fy;
+    bool sane;
+};
+NRD_DEV FootPos foot_pos(const FrameConsts& c, float pu, float pv) {
+    FootPos f;
+    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
+    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    f.fx = px - fx0;
+    f.fy = py - fy0;
+    f.sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+    f.ix = f.sane ? (int)fx0 : -4;
+    f.iy = f.sane ? (int)fy0 : -4;
+    return f;
+}
+template <int RBPT, int LBPT, bool RELAX>
+NRD_DEV void load_foot(const ReblurParams& p, const FootPos& fp, FootRaw<RBPT, LBPT, RELAX>& r) {
+    const FrameConsts& c = p.c;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx = imin(imax(fp.ix + (i & 1), 0), c.Wprev - 1), ty = imin(imax(fp.iy + (i >> 1) - c.yOff, 0), c.resH - 1);
+        r.g[i] = ld<uint4>(p.guidePrev, tx, ty, 16);
+        r.a[i] = ld<uint16_t>(p.data1Prev, tx, ty, 2);
+        load_texel<RBPT>(p.hist, tx, ty, r.t[i]);
+        r.f[i] = load_luma(p.fastPrev, tx, ty, LBPT);
+        r.m[i] = RELAX ? load_luma(p.stabPrev, tx, ty, LBPT) : 0u;
+    }
+}
+// validation of the four texels (same tests, same order as footprint())
+NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const uint4 (&graw)[4], f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
+    Footprint f;
+    f.ix = fp.ix;
+    f.iy = fp.iy;
+    float fx = fp.fx, fy = fp.fy;
+    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+    f.wsum = 0.0f;
+    f.bits = 0;
+    float planeRef = dot3(NvPrev, XvPrev);
+    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+    float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
+        bool ok = fp.sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
+        Guide gp = decode_guide(graw[i], c.denoisingRange);
+        float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+        ok = ok && !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
+        f.w[i] = ok ? bw[i] : 0.0f;
+        f.wsum += f.w[i];
+        f.bits |= ok ? (1u << i) : 0u;
+    }
+    return f;
+}
+// weighted texel blends of an already fetched footprint (identical arithmetic to fetch4 / fetch1 / fetchA)
+template <int WORDS>
+NRD_DEV f4 blend4(const Footprint& f, const uint2 (&t)[4][WORDS], int word) {
+    f4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f4 acc = fma4(unpack_h4(t[i][word]), f.w[i], s);
+        bool on = f.w[i] > 0.0f;
+        s = {on ? acc.x : s.x, on ? acc.y : s.y, on ? acc.z : s.z, on ? acc.w : s.w};
+    }
+    return mul4(s, 1.0f / f.wsum);
+}
+NRD_DEV float blend1(const Footprint& f, const uint32_t (&r)[4], int half) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float acc = fma_(h2f((uint16_t)(r[i] >> (16 * half))), f.w[i], s);
+        s = f.w[i] > 0.0f ? acc : s;
+    }
+    return s * (1.0f / f.wsum);
+}
+NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, float& sA) {
+    dA = sA = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float a, b;
+        unpack_data1(raw[i], a, b);
+        bool on = f.w[i] > 0.0f;
+        dA = on ? fma_(a, f.w[i], dA) : dA;
+        sA = on ? fma_(b, f.w[i], sA) : sA;
+    }
+    float inv = 1.0f / f.wsum;
+    dA *= inv;
+    sA *= inv;
+}
+
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
 __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    const int RBPT = sb * NSIG;
+    constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    constexpr int RBPT = sb * NSIG;
+    constexpr int SW = sb / 8, S1 = SH ? 1 : 0; // uint2 words per signal; word of the SH1 texel
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
@@ -449,32 +569,53 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-            if (p.sh)
+            if (SH)
                 st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
             st<uint16_t>(p.fast, x, y, LBPT, (uint16_t)0, sig * 2);
-            if (p.relax)
+            if (RELAX)
                 st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
         st<uint16_t>(p.data1Tmp, x, y, 2, (uint16_t)0);
         st<uint32_t>(p.data2, x, y, 4, 0u);
         return;
     }
+    // ---- centre loads
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.tmp1, x, y, ctex);
+    f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
+    float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
+    float confD = (HAS_DIFF && c.confAvail) ? sample_confidence(p.confD, u, v) : 1.0f;
+    float confS = (HAS_SPEC && c.confAvail) ? sample_confidence(p.confS, u, v) : 1.0f;
     f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
     f3 Nv = rot3(c.w2v, g.n);
     f3 V = mul3(normalize3(Xv), -1.0f);
     float NoV = absf(dot3(Nv, V));
-    Reproj r = reproject(c, Xv, u, v, unpack_h4(ld<uint2>(p.inMV, x, y, 8)));
+    Reproj r = reproject(c, Xv, u, v, mvRaw);
     f3 NvPrev = rot3(c.w2vPrev, g.n);
     float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(r.zPrev);
     uint32_t minMatAny = p.minMatDiff < p.minMatSpec ? p.minMatDiff : p.minMatSpec;
     const bool historyOk = c.historyOk != 0;
-    Footprint smb = footprint(p, r.su, r.sv, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
+    // ---- both footprints: positions, then ALL their gathers, then validation
+    FootPos spos = foot_pos(c, r.su, r.sv);
+    FootRaw<RBPT, LBPT, RELAX> sraw, vraw;
+    load_foot(p, spos, sraw);
+    float vu = -10.0f, vv = -10.0f;
+    bool vOk = false;
+    if (HAS_SPEC) {
+        float tu, tv;
+        vOk = virtual_uv(c, r, hitDist, g.roughness, tu, tv) && historyOk;
+        vu = vOk ? tu : -10.0f; // an unusable virtual position lands outside: no texel validates (bits 0, weight 0)
+        vv = vOk ? tv : -10.0f;
+    }
+    FootPos vpos = foot_pos(c, vu, vv);
+    if (HAS_SPEC)
+        load_foot(p, vpos, vraw);
+    Footprint smb = foot_weights(c, spos, sraw.g, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
     bool smbOk = historyOk && smb.wsum > 0.0f;
-    float prevDiffA = 0.0f, prevSpecA = 0.0f;
-    if (smbOk)
-        fetchA(c, p.data1Prev, smb, prevDiffA, prevSpecA);
+    float prevDiffA, prevSpecA;
+    blendA(smb, sraw.a, prevDiffA, prevSpecA);
     prevDiffA = smbOk ? fmin2(prevDiffA + 1.0f, p.maxA) : 0.0f;
     prevSpecA = smbOk ? fmin2(prevSpecA + 1.0f, p.maxASpec) : 0.0f;
     float quality = smbOk ? smb.wsum : 0.0f;
@@ -482,33 +623,31 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     uint32_t data2 = smbOk ? smb.bits : 0u;
 
     if (HAS_DIFF) {
-        f4 in = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, 0));
+        f4 in = unpack_h4(ctex[0]);
         float A = prevDiffA;
-        if (c.confAvail)
-            A *= sample_confidence(p.confD, u, v);
+        A *= confD;
         A *= lerpf(quality, 1.0f, 1.0f / (1.0f + A));
         float nonLin = 1.0f / (1.0f + A);
-        f4 hist = smbOk ? fetch4(c, p.hist, RBPT, 0, smb) : in;
-        float fastHist = smbOk ? fetch1(c, p.fastPrev, LBPT, 0, smb) : in.x;
+        f4 hist = smbOk ? blend4(smb, sraw.t, 0) : in;
+        float fastHist = smbOk ? blend1(smb, sraw.f, 0) : in.x;
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), 0);
-        if (p.sh) { // SH1 follows SH0: same footprint, same blend factor
-            f4 in1 = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, 8));
-            f4 hist1 = smbOk ? fetch4(c, p.hist, RBPT, 8, smb) : in1;
+        if (SH) { // SH1 follows SH0: same footprint, same blend factor
+            f4 in1 = unpack_h4(ctex[S1]);
+            f4 hist1 = smbOk ? blend4(smb, sraw.t, S1) : in1;
             st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist1, in1, nonLin)), 8);
         }
         st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), 0);
-        if (p.relax) { // second luma moment history (lives in the stabilized-luma slots)
+        if (RELAX) { // second luma moment history (lives in the stabilized-luma slots)
             float m2 = in.x * in.x;
-            float m2prev = smbOk ? fetch1(c, p.stabPrev, LBPT, 0, smb) : m2;
+            float m2prev = smbOk ? blend1(smb, sraw.m, 0) : m2;
             st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(m2prev, m2, nonLin)), 0);
         }
         outDiffA = A;
     }
     if (HAS_SPEC) {
-        const int so = SIG_SPEC * sb;
+        constexpr int so = SIG_SPEC * sb, sw = SIG_SPEC * SW;
         constexpr int lo = SIG_SPEC * 2;
-        f4 in = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, so));
-        float hitDist = h2f(ld<uint16_t>(p.hitTrack, x, y, 2));
+        f4 in = unpack_h4(ctex[sw]);
         f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
         f3 XparV = rot3(c.w2v, sub3(r.XwPrev, cd));
         float pu, pv, parallax = 0.0f;
@@ -517,35 +656,26 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
             parallax = __builtin_sqrtf(fma_(dx, dx, dy * dy));
         }
         float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
-        float vu, vv;
-        float amount = 0.0f, Avmb = 0.0f;
-        f4 vmbHist = in;
-        float vmbFast = in.x;
-        uint32_t vmbBits = 0;
-        Footprint vmb;
-        vmb.wsum = 0.0f;
-        if (historyOk && virtual_uv(c, r, hitDist, g.roughness, vu, vv)) {
-            vmb = footprint(p, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
-            vmbBits = vmb.bits;
-            if (vmb.wsum > 0.0f) {
-                float prevRough = fetch1(c, p.guidePrev, 16, 10, vmb); // roughness of the virtual footprint (guide texel bytes 10..11)
-                float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction));
-                float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
-                amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
-                float dA, sA;
-                fetchA(c, p.data1Prev, vmb, dA, sA);
-                Avmb = fmin2(sA + 1.0f, p.maxASpec);
-                vmbHist = fetch4(c, p.hist, RBPT, so, vmb);
-                vmbFast = fetch1(c, p.fastPrev, LBPT, lo, vmb);
-            }
-        }
-        f4 smbHist = smbOk ? fetch4(c, p.hist, RBPT, so, smb) : in;
-        float smbFast = smbOk ? fetch1(c, p.fastPrev, LBPT, lo, smb) : in.x;
+        Footprint vmb = foot_weights(c, vpos, vraw.g, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
+        uint32_t vmbBits = vmb.bits;
+        bool vmbOk = vmb.wsum > 0.0f;
+        // roughness of the virtual footprint: guide texel bytes 10..11 = upper half of .z
+        uint32_t rr[4] = {vraw.g[0].z, vraw.g[1].z, vraw.g[2].z, vraw.g[3].z};
+        float prevRough = blend1(vmb, rr, 1);
+        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction));
+        float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
+        float amount = vmbOk ? spec_dominant_factor(g.roughness) * vmb.wsum * rconf : 0.0f;
+        float dA, sA;
+        blendA(vmb, vraw.a, dA, sA);
+        float Avmb = vmbOk ? fmin2(sA + 1.0f, p.maxASpec) : 0.0f;
+        f4 vmbHist = vmbOk ? blend4(vmb, vraw.t, sw) : in;
+        float vmbFast = vmbOk ? blend1(vmb, vraw.f, SIG_SPEC) : in.x;
+        f4 smbHist = smbOk ? blend4(smb, sraw.t, sw) : in;
+        float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : in.x;
         if (!smbOk)
             Asmb = 0.0f;
         float A = lerpf(Asmb, Avmb, amount);
-        if (c.confAvail)
-            A *= sample_confidence(p.confS, u, v);
+        A *= confS;
         float q = lerpf(quality, 1.0f, amount);
         A *= lerpf(q, 1.0f, 1.0f / (1.0f + A));
         if (p.responsiveRoughnessThreshold > 0.0f) {
@@ -556,17 +686,17 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         f4 hist = lerp4(smbHist, vmbHist, amount);
         float fastHist = lerpf(smbFast, vmbFast, amount);
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
-        if (p.sh) {
-            f4 in1 = unpack_h4(ld<uint2>(p.tmp1, x, y, RBPT, so + 8));
-            f4 smb1 = smbOk ? fetch4(c, p.hist, RBPT, so + 8, smb) : in1;
-            f4 vmb1 = vmb.wsum > 0.0f ? fetch4(c, p.hist, RBPT, so + 8, vmb) : in1;
+        if (SH) {
+            f4 in1 = unpack_h4(ctex[sw + S1]);
+            f4 smb1 = smbOk ? blend4(smb, sraw.t, sw + S1) : in1;
+            f4 vmb1 = vmbOk ? blend4(vmb, vraw.t, sw + S1) : in1;
             st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin)), so + 8);
         }
         st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastASpec)))), lo);
-        if (p.relax) {
+        if (RELAX) {
             float m2 = in.x * in.x;
-            float m2smb = smbOk ? fetch1(c, p.stabPrev, LBPT, lo, smb) : m2;
-            float m2vmb = vmb.wsum > 0.0f ? fetch1(c, p.stabPrev, LBPT, lo, vmb) : m2;
+            float m2smb = smbOk ? blend1(smb, sraw.m, SIG_SPEC) : m2;
+            float m2vmb = vmbOk ? blend1(vmb, vraw.m, SIG_SPEC) : m2;
             st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)), lo);
         }
         outSpecA = A;
@@ -579,22 +709,6 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
 // =====================================================================================================================
 // 5x5 luma tile in LDS: 20x20 floats, NaN marks "sky / outside" (the consumer substitutes its own centre value)
 // =====================================================================================================================
-template <typename Fetch>
-NRD_DEV void stage_luma_tile(const FrameConsts& c, const PlaneRef& guide, int tx, int ty, float* tile, Fetch fetch) {
-    int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-    for (int i = tid; i < 400; i += 256) {
-        int lx = i % 20, ly = i / 20;
-        int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
-        float val = u2f(0x7fc00000u);
-        if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
-            float zt = ld<float>(guide, px, py, 16, 0);
-            if (absf(zt) <= c.denoisingRange)
-                val = fetch(px, py);
-        }
-        tile[i] = val;
-    }
-}
-
 NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, float& m1, float& m2) {
     m1 = 0.0f;
     m2 = 0.0f;
@@ -614,11 +728,11 @@ NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, float& 
 // =====================================================================================================================
 // K4 HistoryFix
 // =====================================================================================================================
-template <bool HAS_DIFF, bool HAS_SPEC>
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH>
 __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    const int RBPT = sb * NSIG;
+    constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    constexpr int RBPT = sb * NSIG;
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     __shared__ float tile[NSIG][400];
@@ -627,8 +741,20 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     if (!xcd_tile(c, tx, ty))
         return;
     if (p.clampEnabled) {
-        for (int sig = 0; sig < NSIG; sig++)
-            stage_luma_tile(c, p.guide, tx, ty, tile[sig], [&](int px, int py) { return h2f(ld<uint16_t>(p.fast, px, py, LBPT, sig * 2)); });
+        // 20x20 fast-luma tiles of all signals in one sweep (depth + one luma texel per position, clamped unconditional loads)
+        int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+        for (int i = tid; i < 400; i += 256) {
+            int lx = i % 20, ly = i / 20;
+            int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
+            bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
+            int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
+            float zt = ld<float>(p.guide, cx, cy, 16, 0);
+            uint32_t l = load_luma(p.fast, cx, cy, LBPT);
+            bool ok = inside && absf(zt) <= c.denoisingRange;
+#pragma unroll
+            for (int sig = 0; sig < NSIG; sig++)
+                tile[sig][i] = ok ? h2f((uint16_t)(l >> (16 * sig))) : u2f(0x7fc00000u);
+        }
         __syncthreads();
     }
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
@@ -639,7 +765,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-            if (p.sh)
+            if (SH)
                 st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
         }
         st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
@@ -658,7 +784,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         float rough = isSpec ? g.roughness : 1.0f;
         uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
         f4 val = unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb));
-        f4 val1 = p.sh ? unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb + 8)) : f4{0, 0, 0, 0};
+        f4 val1 = SH ? unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb + 8)) : f4{0, 0, 0, 0};
         float Acur = A[ai];
         if (Acur < (float)p.historyFixFrameNum && p.historyFixFrameNum > 0) {
             float normA = sat(Acur / (float)p.historyFixFrameNum);
@@ -695,7 +821,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                         unpack_data1(ld<uint16_t>(p.data1Tmp, px, py, 2), tA[0], tA[1]);
                         w *= 1.0f + tA[ai];
                         sum = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * sb)), w, sum);
-                        if (p.sh)
+                        if (SH)
                             sum1 = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * sb + 8)), w, sum1);
                         wsum += w;
                     }
@@ -721,7 +847,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? p.maxFastASpec : p.maxFastA), f);
         }
         st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * sb);
-        if (p.sh)
+        if (SH)
             st<uint2>(outP, x, y, RBPT, pack_h4(val1), sig * sb + 8);
     }
     st<uint16_t>(p.data1, x, y, 2, pack_data1(outA[0], outA[1]));
@@ -730,41 +856,37 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
 // =====================================================================================================================
 // K7 TemporalStabilization (+ split screen)
 // =====================================================================================================================
-NRD_DEV bool fetch_stab(const FrameConsts& c, const PlaneRef& P, int bpt, int off, float pu, float pv, uint32_t bits, float& out) {
-    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
-    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-    float fx = px - fx0, fy = py - fy0;
-    bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
-    if (!sane)
-        return false;
-    int ix = (int)fx0, iy = (int)fy0;
-    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
-    uint16_t raw[4];
+// stabilized-luma history of one footprint: the four texels (all signals) are fetched up front, then blended with the
+// validity bits TemporalAccumulation recorded for that footprint
+NRD_DEV void load_stab(const ReblurParams& p, const FootPos& fp, int lbpt, uint32_t (&raw)[4]) {
+    const FrameConsts& c = p.c;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        int tx = ix + (i & 1), ty = iy + (i >> 1) - c.yOff;
-        tx = tx < 0 ? 0 : (tx >= c.Wprev ? c.Wprev - 1 : tx);
-        ty = ty < 0 ? 0 : (ty >= c.resH ? c.resH - 1 : ty);
-        raw[i] = ld<uint16_t>(P, tx, ty, bpt, off);
+        int tx = imin(imax(fp.ix + (i & 1), 0), c.Wprev - 1), ty = imin(imax(fp.iy + (i >> 1) - c.yOff, 0), c.resH - 1);
+        raw[i] = load_luma(p.stabPrev, tx, ty, lbpt);
     }
+}
+NRD_DEV bool blend_stab(const FootPos& fp, const uint32_t (&raw)[4], int half, uint32_t bits, float& out) {
+    float fx = fp.fx, fy = fp.fy;
+    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
     float sum = 0.0f, wsum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (bits & (1u << i)) {
-            sum = fma_(h2f(raw[i]), bw[i], sum);
-            wsum += bw[i];
-        }
-    if (!(wsum > 0.0f))
-        return false;
+    for (int i = 0; i < 4; i++) {
+        bool on = (bits & (1u << i)) != 0u;
+        float acc = fma_(h2f((uint16_t)(raw[i] >> (16 * half))), bw[i], sum);
+        sum = on ? acc : sum;
+        wsum = on ? wsum + bw[i] : wsum;
+    }
     out = sum * (1.0f / wsum);
-    return true;
+    return fp.sane && wsum > 0.0f;
 }
 
-template <bool HAS_DIFF, bool HAS_SPEC>
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH>
 __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
-    const int sb = p.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    const int RBPT = sb * NSIG;
+    constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+    constexpr int RBPT = sb * NSIG;
+    constexpr int SW = sb / 8, S1 = SH ? 1 : 0;
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     __shared__ float tile[NSIG][400];
@@ -772,8 +894,24 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
-    for (int sig = 0; sig < NSIG; sig++)
-        stage_luma_tile(c, p.guide, tx, ty, tile[sig], [&](int px, int py) { return h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb)); });
+    // 20x20 luma tiles of all signals in one sweep: guide depth + whole radiance texel per position, fetched unconditionally
+    // at clamped coordinates (NaN marks "sky / outside")
+    {
+        int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+        for (int i = tid; i < 400; i += 256) {
+            int lx = i % 20, ly = i / 20;
+            int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
+            bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
+            int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
+            float zt = ld<float>(p.guide, cx, cy, 16, 0);
+            uint2 t[RBPT / 8];
+            load_texel<RBPT>(p.hist, cx, cy, t);
+            bool ok = inside && absf(zt) <= c.denoisingRange;
+#pragma unroll
+            for (int sig = 0; sig < NSIG; sig++)
+                tile[sig][i] = ok ? h2f((uint16_t)t[sig * SW].x) : u2f(0x7fc00000u);
+        }
+    }
     __syncthreads();
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
@@ -789,50 +927,48 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
             store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : f4{0, 0, 0, 0});
-            if (p.sh)
+            if (SH)
                 st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
             st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
         return;
     }
-    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
-    Reproj r = reproject(c, Xv, u, v, unpack_h4(ld<uint2>(p.inMV, x, y, 8)));
+    // ---- centre loads, then both history footprints in one round trip
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.hist, x, y, ctex);
+    f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
     uint32_t data2 = ld<uint32_t>(p.data2, x, y, 4);
     float A[2];
     unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
+    float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
+    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
+    Reproj r = reproject(c, Xv, u, v, mvRaw);
     const bool historyOk = c.historyOk != 0;
+    float amount = (float)((data2 >> 8) & 255u) * (1.0f / 255.0f);
+    FootPos spos = foot_pos(c, r.su, r.sv);
+    uint32_t sraw[4], vraw[4] = {0u, 0u, 0u, 0u};
+    load_stab(p, spos, LBPT, sraw);
+    FootPos vpos = spos;
+    if (HAS_SPEC) {
+        float tu, tv;
+        bool vOk = virtual_uv(c, r, hitDist, g.roughness, tu, tv) && amount > 0.0f;
+        vpos = foot_pos(c, vOk ? tu : -10.0f, vOk ? tv : -10.0f); // unusable virtual position: lands outside, never validates
+        load_stab(p, vpos, LBPT, vraw);
+    }
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-        f4 cur = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * sb));
+        f4 cur = unpack_h4(ctex[sig * SW]);
         float m1, m2;
         moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, m1, m2);
         float sigma = __builtin_sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f));
-        float Yhist = cur.x;
-        bool have = false;
-        if (historyOk) {
-            float smbY = 0.0f;
-            bool smbOk = fetch_stab(c, p.stabPrev, LBPT, sig * 2, r.su, r.sv, data2 & 15u, smbY);
-            if (isSpec) {
-                float amount = (float)((data2 >> 8) & 255u) * (1.0f / 255.0f);
-                float vu, vv, vmbY = 0.0f;
-                bool vmbOk = amount > 0.0f && virtual_uv(c, r, h2f(ld<uint16_t>(p.hitTrack, x, y, 2)), g.roughness, vu, vv) &&
-                             fetch_stab(c, p.stabPrev, LBPT, sig * 2, vu, vv, (data2 >> 4) & 15u, vmbY);
-                if (smbOk && vmbOk) {
-                    Yhist = lerpf(smbY, vmbY, amount);
-                    have = true;
-                } else if (smbOk) {
-                    Yhist = smbY;
-                    have = true;
-                } else if (vmbOk) {
-                    Yhist = vmbY;
-                    have = true;
-                }
-            } else if (smbOk) {
-                Yhist = smbY;
-                have = true;
-            }
-        }
+        float smbY, vmbY = 0.0f;
+        bool smbOk = blend_stab(spos, sraw, sig, data2 & 15u, smbY) && historyOk;
+        bool vmbOk = false;
+        if (isSpec)
+            vmbOk = blend_stab(vpos, vraw, sig, (data2 >> 4) & 15u, vmbY) && historyOk;
+        float Yhist = (smbOk && vmbOk) ? lerpf(smbY, vmbY, amount) : (smbOk ? smbY : (vmbOk ? vmbY : cur.x));
+        bool have = smbOk || vmbOk;
         float Acur = A[isSpec ? 1 : 0];
         float Y = cur.x;
         float band = sigma * p.antilagSigmaScale;
@@ -848,8 +984,8 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
         store_signal(p, op, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : o);
-        if (p.sh) {
-            f4 c1 = unpack_h4(ld<uint2>(p.hist, x, y, RBPT, sig * sb + 8));
+        if (SH) {
+            f4 c1 = unpack_h4(ctex[sig * SW + S1]);
             f4 o1 = {c1.x * scale, c1.y * scale, c1.z * scale, c1.w};
             st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : pack_h4(o1));
         }
@@ -861,21 +997,6 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
 // decoded by RELAX_BackEnd_UnpackRadiance, Shaders/Composition.cs.hlsl:160-161). All lanes use the same tap offsets, so the
 // gathers of a 16x4-pixel wave are 16x4-texel groups: fully coalesced at every stride; neighbouring tiles share taps in L2.
 // =====================================================================================================================
-// whole radiance texel (8 / 16 / 32 bytes: one or two signals, SH0 [+ SH1]) in as few loads as its size allows
-template <int BYTES>
-NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) {
-    if constexpr (BYTES == 8) {
-        t[0] = ld<uint2>(P, x, y, 8);
-    } else {
-#pragma unroll
-        for (int k = 0; k < BYTES / 16; k++) {
-            uint4 v = ld<uint4>(P, x, y, BYTES, k * 16);
-            t[2 * k] = uint2{v.x, v.y};
-            t[2 * k + 1] = uint2{v.z, v.w};
-        }
-    }
-}
-
 // FIRST: iteration 0 (variance from the luminance moments, 3x3 spatial estimate for short histories). The 3x3 taps of the
 // signals share their positions, so the tap loop is the OUTER loop: one guide gather + decode + plane/normal terms per tap
 // serve both signals (each signal still sees exactly the operation sequence of the oracle).
@@ -1102,9 +1223,31 @@ void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
     }
 }
 
-void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_accumulation, ); }
-void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_history_fix, ); }
-void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_temporal_stabilization, ); }
+void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) {
+    if (p.sh) {
+        if (p.relax)
+            NRD_LAUNCH4(k_temporal_accumulation, true, true);
+        else
+            NRD_LAUNCH4(k_temporal_accumulation, true, false);
+    } else {
+        if (p.relax)
+            NRD_LAUNCH4(k_temporal_accumulation, false, true);
+        else
+            NRD_LAUNCH4(k_temporal_accumulation, false, false);
+    }
+}
+void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s) {
+    if (p.sh)
+        NRD_LAUNCH4(k_history_fix, true);
+    else
+        NRD_LAUNCH4(k_history_fix, false);
+}
+void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s) {
+    if (p.sh)
+        NRD_LAUNCH4(k_temporal_stabilization, true);
+    else
+        NRD_LAUNCH4(k_temporal_stabilization, false);
+}
 void launch_relax_atrous(const AtrousParams& p, hipStream_t s) {
     bool first = p.it == 0;
     if (p.sh) {
