@@ -174,7 +174,7 @@ def main():
                 args.workload, "+".join(den_names), w, frame_h, "" if world == 1 else " row-tiled %d x %d rows, RCCL halo exchange" % (world, band_h)),
                 "unique_input_frames": args.unique_frames, "algorithmic_bytes_per_pixel": round(sum_bpp, 2)},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom_name),
                          "pipeline_frac": round(sum_bpp * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "passes_ms": {k: round(v[0], 4) for k, v in per_pass.items()},
         }
@@ -264,6 +264,32 @@ class SingleRunner:
                 t, n, _ = acc.get(name, (0.0, 0, bpp))
                 acc[name] = (t + a.elapsed_time(b), n + 1, bpp)
         return {k: (t / n, bpp) for k, (t, n, bpp) in acc.items()}
+
+
+# pass name -> prefix of the kernel name in the rocprofv3 counter tables (tools/summarize_profiles.py)
+PASS_KERNEL = {
+    "REBLUR::ClassifyTiles": "k_classify_tiles", "REBLUR::PrePass": "k_spatial<0", "REBLUR::Blur": "k_spatial<1",
+    "REBLUR::PostBlur": "k_spatial<2", "REBLUR::TemporalAccumulation": "k_temporal_accumulation",
+    "REBLUR::HistoryFix": "k_history_fix", "REBLUR::TemporalStabilization": "k_temporal_stabilization",
+}
+
+
+def measured_traffic(workload, pass_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the gfx950 correction of
+    MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc runs, tools/profile_gpu.sh); None if that workload / kernel
+    has no committed counter table - a live bench run cannot collect counters itself."""
+    import glob
+    import json
+
+    prefix = PASS_KERNEL.get(pass_name)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_%s.json" % workload)))
+    if not prefix or not files:
+        return None
+    table = json.load(open(files[-1]))
+    for k, v in table.items():
+        if k.startswith(prefix):
+            return round(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return None
 
 
 if __name__ == "__main__":
