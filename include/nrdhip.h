@@ -119,10 +119,60 @@ NRDHIP_API int nrdhip_library_desc(uint32_t out[5]);
 NRDHIP_API const char* nrdhip_denoiser_string(uint32_t denoiser);
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 CommonSettings, 1 ReblurSettings, 2 RelaxSettings, 3 SigmaSettings, 4 ReferenceSettings,
- * 5 nrdhip_create_desc, 6 nrdhip_plane_info, 7 nrdhip_dispatch_info */
+ * 5 nrdhip_create_desc, 6 nrdhip_plane_info, 7 nrdhip_dispatch_info, 8 nrdhip_confidence_blur_desc, 9 nrdhip_unpack_desc */
 NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which);
 /* last error text of the instance (or of creation when inst == NULL) */
 NRDHIP_API const char* nrdhip_last_error(nrdhip_instance* inst);
+
+/* ===================================================================================================================
+ * Sample-side passes either side of the denoiser (SURVEY.md 8f "next" rows). Stand-alone: no instance, caller-owned
+ * planes, work enqueued on `hip_stream`.
+ * =================================================================================================================== */
+
+/* History-confidence producer = the sample's "History confidence - Blur" loop: 5 dispatches of
+ * Shaders/ConfidenceBlur.cs.hlsl:33-106 with step = 1..5, ping -> pong -> ping ... (Source/NRDSample.cpp:3999-4026);
+ * the 5th lands in `pong`, the texture the sample binds to IN_DIFF_CONFIDENCE / IN_SPEC_CONFIDENCE (:457, :462).
+ * Texel = RGBA16_SFLOAT {gradient, octahedral view normal xy, viewZ * FP16_VIEWZ_SCALE} (Shaders/SharcUpdate.cs.hlsl:249). */
+typedef struct nrdhip_confidence_blur_desc {
+    void* ping;               /* Gradient_Ping: input of the first pass (overwritten by the even passes) */
+    void* pong;               /* Gradient_Pong: result */
+    uint32_t pitch_bytes;     /* row pitch of both */
+    uint16_t width, height;   /* Sample::GetSharcDims() (Source/NRDSample.cpp:596-598) */
+    float camera_frustum[4];  /* gCameraFrustum (:3708) */
+    float inv_size[2];        /* gInvSharcRenderSize (:3724) */
+    float rect_width;         /* gRectSize.x */
+    float unproject;          /* gUnproject (:3738) */
+    float ortho_mode;         /* gOrthoMode */
+    uint32_t frame_index;     /* gFrameIndex */
+    uint32_t max_accumulated_frame_num; /* gMaxAccumulatedFrameNum (:3747) */
+    uint32_t relax;           /* gDenoiserType == DENOISER_RELAX */
+    uint32_t first_pass;      /* 0-based; 0 */
+    uint32_t passes_num;      /* 5 (the sample's loop); sub-ranges allow per-pass timing */
+} nrdhip_confidence_blur_desc;
+NRDHIP_API int nrdhip_confidence_blur(const nrdhip_confidence_blur_desc* desc, void* hip_stream);
+
+/* Back-end consumer = the NRD-facing part of Shaders/Composition.cs.hlsl:57-64 (shadow), :74-175 (diffuse / specular):
+ * decodes OUT_* planes into linear radiance {rgb, normalised hit distance} and shadow {x, yzw}. */
+enum { NRDHIP_UNPACK_NORMAL = 0, NRDHIP_UNPACK_OCCLUSION = 1, NRDHIP_UNPACK_SH = 2 };
+typedef struct nrdhip_unpack_desc {
+    uint16_t width, height;
+    uint32_t mode;            /* NRDHIP_UNPACK_* (NRD_MODE of Shaders/Shared.hlsli) */
+    uint32_t relax;           /* RELAX_BackEnd_* instead of REBLUR_BackEnd_* (Composition.cs.hlsl:160-166, 177-181) */
+    uint32_t resolve;         /* SH mode: 1 = resolve against the G-buffer normal (gResolve), 0 = NRD_SG_ExtractColor */
+    const void* diff; uint32_t diff_pitch;         /* OUT_DIFF_RADIANCE_HITDIST | OUT_DIFF_SH0 (RGBA16F) | OUT_DIFF_HITDIST (R16_UNORM); NULL = none */
+    const void* spec; uint32_t spec_pitch;
+    const void* diff_sh1; uint32_t diff_sh1_pitch; /* SH mode: OUT_DIFF_SH1 / OUT_SPEC_SH1 */
+    const void* spec_sh1; uint32_t spec_sh1_pitch;
+    const void* normal_roughness; uint32_t normal_roughness_pitch; /* IN_NORMAL_ROUGHNESS (R10G10B10A2), SH resolve only */
+    const void* shadow; uint32_t shadow_pitch; uint32_t shadow_bytes_per_texel; /* OUT_SHADOW_TRANSLUCENCY RGBA8 (4) or R8 (1) */
+    void* out_diff; uint32_t out_diff_pitch;       /* RGBA16F {linear rgb, hit distance term}; NULL = skip */
+    void* out_spec; uint32_t out_spec_pitch;
+    void* out_shadow; uint32_t out_shadow_pitch;   /* RGBA16F SIGMA_BackEnd_UnpackShadow result */
+    float view_to_world[9];   /* SH resolve: rotation part of gViewToWorld (row-major 3x3) */
+    float camera_frustum[4];
+    float inv_rect_size[2];
+} nrdhip_unpack_desc;
+NRDHIP_API int nrdhip_backend_unpack(const nrdhip_unpack_desc* desc, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -311,6 +311,26 @@ class DispatchInfo(C.Structure):
                 ("read_num", _u32), ("read", _u32 * 24), ("algorithmic_bytes_per_pixel", _f)]
 
 
+class ConfidenceBlurDesc(C.Structure):
+    """nrdhip_confidence_blur_desc (Shaders/ConfidenceBlur.cs.hlsl, Source/NRDSample.cpp:3999-4026)"""
+    _fields_ = [("ping", C.c_void_p), ("pong", C.c_void_p), ("pitch_bytes", _u32), ("width", _u16), ("height", _u16),
+                ("camera_frustum", _f * 4), ("inv_size", _f * 2), ("rect_width", _f), ("unproject", _f), ("ortho_mode", _f),
+                ("frame_index", _u32), ("max_accumulated_frame_num", _u32), ("relax", _u32), ("first_pass", _u32), ("passes_num", _u32)]
+
+
+class UnpackDesc(C.Structure):
+    """nrdhip_unpack_desc (NRD-facing part of Shaders/Composition.cs.hlsl:57-64, 74-175)"""
+    _fields_ = [("width", _u16), ("height", _u16), ("mode", _u32), ("relax", _u32), ("resolve", _u32),
+                ("diff", C.c_void_p), ("diff_pitch", _u32), ("spec", C.c_void_p), ("spec_pitch", _u32),
+                ("diff_sh1", C.c_void_p), ("diff_sh1_pitch", _u32), ("spec_sh1", C.c_void_p), ("spec_sh1_pitch", _u32),
+                ("normal_roughness", C.c_void_p), ("normal_roughness_pitch", _u32),
+                ("shadow", C.c_void_p), ("shadow_pitch", _u32), ("shadow_bytes_per_texel", _u32),
+                ("out_diff", C.c_void_p), ("out_diff_pitch", _u32), ("out_spec", C.c_void_p), ("out_spec_pitch", _u32),
+                ("out_shadow", C.c_void_p), ("out_shadow_pitch", _u32),
+                ("view_to_world", _f * 9), ("camera_frustum", _f * 4), ("inv_rect_size", _f * 2)]
+
+
+UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH = 0, 1, 2
 FLAG_EXTERNAL_POOLS = 1
 
 
@@ -346,6 +366,8 @@ class Backend:
         self._sig("get_memory_mb", C.c_int, [C.c_void_p, C.POINTER(_f)])
         self._sig("sizeof", _u32, [_u32])
         self._sig("last_error", C.c_char_p, [C.c_void_p])
+        self._sig("confidence_blur", C.c_int, [C.POINTER(ConfidenceBlurDesc), C.c_void_p])
+        self._sig("backend_unpack", C.c_int, [C.POINTER(UnpackDesc), C.c_void_p])
 
     def _sig(self, name, res, args):
         f = getattr(self.lib, self.prefix + name)
@@ -359,7 +381,8 @@ class Backend:
         raise AttributeError(name)
 
     def check_abi(self):
-        want = [CommonSettings, ReblurSettings, RelaxSettings, SigmaSettings, ReferenceSettings, CreateDesc, PlaneInfo, DispatchInfo]
+        want = [CommonSettings, ReblurSettings, RelaxSettings, SigmaSettings, ReferenceSettings, CreateDesc, PlaneInfo, DispatchInfo,
+                ConfidenceBlurDesc, UnpackDesc]
         for i, cls in enumerate(want):
             got = self.sizeof(i)
             if got != C.sizeof(cls):

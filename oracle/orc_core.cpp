@@ -478,6 +478,8 @@ NRDHIP_API uint32_t orc_sizeof(uint32_t which) {
         case 5: return sizeof(nrdhip_create_desc);
         case 6: return sizeof(nrdhip_plane_info);
         case 7: return sizeof(nrdhip_dispatch_info);
+        case 8: return sizeof(nrdhip_confidence_blur_desc);
+        case 9: return sizeof(nrdhip_unpack_desc);
     }
     return 0;
 }
