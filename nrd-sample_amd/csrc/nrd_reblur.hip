@@ -94,6 +94,123 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
 }
 
 // =====================================================================================================================
+// K1 PrepareInputs - recorded only when the inputs are checkerboarded or hit distances must be reconstructed (the sample's
+// default operating mode, Source/NRDSample.cpp:267, :545-548). Writes dense RGBA16F copies of the noisy inputs for the PrePass:
+//  * checkerboard resolve: half-width inputs hold pixel (x, y) at texel (x >> 1, y) on the squares of
+//    Sequence::CheckerBoard(pixelPos, frameIndex) that carry the signal (Shaders/TraceOpaque.cs.hlsl:482-508); a pixel of the
+//    other colour takes the depth-weighted mean of its left / right neighbours;
+//  * hit distance reconstruction (AREA_3X3 / AREA_5X5): a texel without hit distance (w == 0) takes the bilateral mean of the
+//    valid hit distances around it.
+// An optional mode, written for clarity rather than peak rate (branchy 3x3 / 5x5 loop on the pixels that need it only).
+// =====================================================================================================================
+NRD_DEV bool has_data(int phase, int x, int gy, uint32_t frameIndex) { return phase == 2 || ((((uint32_t)x ^ (uint32_t)gy) ^ frameIndex) & 1u) == (uint32_t)phase; }
+
+template <bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    const FrameConsts& c = p.c;
+    int x, y, tx, ty;
+    if (!my_pixel(c, x, y, tx, ty))
+        return;
+    const bool occ = p.occlusion != 0, checker = p.checker != 0, sh1 = p.sh != 0 && checker;
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    const int gy0 = y + c.yOff;
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        const PlaneRef& in = isSpec ? p.rawSpec : p.rawDiff;
+        const PlaneRef& in1 = isSpec ? p.rawSpec1 : p.rawDiff1;
+        const PlaneRef& out = isSpec ? p.inSpec : p.inDiff;
+        const PlaneRef& out1 = isSpec ? p.inSpec1 : p.inDiff1;
+        if (g.sky) {
+            st<uint2>(out, x, y, 8, uint2{0u, 0u});
+            if (sh1)
+                st<uint2>(out1, x, y, 8, uint2{0u, 0u});
+            continue;
+        }
+        const int phase = isSpec ? p.phaseSpec : p.phaseDiff;
+        f4 v = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+        if (has_data(phase, x, gy0, c.frameIndex)) {
+            int sx = checker ? x >> 1 : x;
+            v = load_signal(p, in, sx, y, 8, 0, occ);
+            if (sh1)
+                v1 = unpack_h4(ld<uint2>(in1, sx, y, 8));
+        } else { // checkerboard resolve from the left / right neighbours (they carry this signal)
+            float invDz = 1.0f / (0.03f * fmax2(absf(g.z), 1e-6f));
+            float wn[2];
+            bool ok[2];
+            f4 vn[2], v1n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                int px = x + (n ? 1 : -1);
+                ok[n] = px >= 0 && px < c.W;
+                int cpx = imin(imax(px, 0), c.W - 1);
+                Guide gn = decode_guide(ld<uint4>(p.guide, cpx, y, 16), c.denoisingRange);
+                vn[n] = load_signal(p, in, cpx >> 1, y, 8, 0, occ);
+                if (sh1)
+                    v1n[n] = unpack_h4(ld<uint2>(in1, cpx >> 1, y, 8));
+                ok[n] = ok[n] && !gn.sky;
+                float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
+                wn[n] = ok[n] ? w : 0.0f;
+            }
+            if (!(wn[0] + wn[1] > 0.0f)) { // depth edge on both sides: plain mean of whatever exists
+                wn[0] = ok[0] ? 1.0f : 0.0f;
+                wn[1] = ok[1] ? 1.0f : 0.0f;
+            }
+            float wsum = wn[0] + wn[1];
+            f4 acc = wn[0] > 0.0f ? mul4(vn[0], wn[0]) : f4{0, 0, 0, 0};
+            acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
+            f4 acc1 = wn[0] > 0.0f ? mul4(v1n[0], wn[0]) : f4{0, 0, 0, 0};
+            acc1 = wn[1] > 0.0f ? fma4(v1n[1], wn[1], acc1) : acc1;
+            float inv = 1.0f / wsum;
+            v = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
+            v1 = wsum > 0.0f ? mul4(acc1, inv) : f4{0, 0, 0, 0};
+        }
+        if (p.reconRadius > 0 && v.w == 0.0f) { // no hit distance: reconstruct it from the neighbourhood
+            PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
+            float rough = isSpec ? g.roughness : 1.0f;
+            uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
+            float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
+            float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+            float normalW2 = normalW * normalW;
+            float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+            float roughB = -rough * roughA;
+            float sum = 0.0f, wsum = 0.0f;
+            for (int j = -p.reconRadius; j <= p.reconRadius; j++)
+                for (int i = -p.reconRadius; i <= p.reconRadius; i++) {
+                    if (i == 0 && j == 0)
+                        continue;
+                    int px = x + i, py = y + j, gy = py + c.yOff;
+                    if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                        continue;
+                    if (!has_data(phase, px, gy, c.frameIndex))
+                        continue;
+                    Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
+                    if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                        continue;
+                    float h = load_signal(p, in, checker ? px >> 1 : px, py, 8, 0, occ).w;
+                    if (!(h > 0.0f))
+                        continue;
+                    float w = geo_weight(pg, (float)px, (float)gy, gs.z);
+                    w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                    if (isSpec)
+                        w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                    sum = fma_(h, w, sum);
+                    wsum += w;
+                }
+            if (wsum > 0.0f)
+                v.w = sum * (1.0f / wsum);
+        }
+        if (occ)
+            v = {v.w, 0.0f, 0.0f, v.w};
+        st<uint2>(out, x, y, 8, pack_h4(v));
+        if (sh1)
+            st<uint2>(out1, x, y, 8, pack_h4(v1));
+    }
+}
+
+// =====================================================================================================================
 // Spatial filter: PrePass (VARIANT 0), Blur (1), PostBlur (2)
 // =====================================================================================================================
 // MODE: 0 = REBLUR radiance, 1 = RELAX radiance, 2 = OCCLUSION (hit distance only), 3 = REBLUR SH, 4 = RELAX SH (compile-time so
@@ -1199,9 +1316,11 @@ void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }
 
+void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_prepare_inputs, ); }
+
 void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
     // PrePass decodes the denoiser's input convention (MODE 0..4); Blur / PostBlur only differ by the SH texel
-    int mode = p.sh ? (p.relax ? 4 : 3) : (p.relax ? 1 : (p.occlusion ? 2 : 0));
+    int mode = p.sh ? (p.relax ? 4 : 3) : (p.relax ? 1 : ((p.occlusion && !p.prepared) ? 2 : 0)); // PrepareInputs already expanded occlusion inputs to {h, 0, 0, h}
     if (variant == 0) {
         switch (mode) {
         case 0: NRD_LAUNCH3(k_spatial, 0, 0, ); break;

@@ -145,7 +145,7 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
 // ---- pool descriptions (indices must match the enums used by the builders below) ----------------------------------
 namespace rb { // REBLUR
 enum Perm { GUIDE_A, GUIDE_B, DATA1_A, DATA1_B, HIST, FAST_A, FAST_B, STAB_A, STAB_B };
-enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK, AT_A, AT_B }; // AT_*: RELAX only
+enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK, PREP_D, PREP_S, PREP_D1, PREP_S1, AT_A, AT_B }; // PREP_*: PrepareInputs outputs; AT_*: RELAX only
 } // namespace rb
 namespace sg { // SIGMA
 enum Perm { GUIDE_A, GUIDE_B, HIST_A, HIST_B };
@@ -173,6 +173,12 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"REBLUR::Data1_Tmp", F::R16_UINT, 2, 1});
         trans.push_back({"REBLUR::Data2", F::R32_UINT, 4, 1});
         trans.push_back({"REBLUR::SpecHitDistForTracking", F::R16_SFLOAT, 2, 1});
+        // PrepareInputs outputs (checkerboard resolve / hit distance reconstruction): dense RGBA16F copies of the noisy
+        // inputs; the SH1 copies are only full-size in SH mode
+        trans.push_back({"REBLUR::Prepared_Diff", F::RGBA16_SFLOAT, 8, 1});
+        trans.push_back({"REBLUR::Prepared_Spec", F::RGBA16_SFLOAT, 8, 1});
+        trans.push_back({"REBLUR::Prepared_DiffSh1", F::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
+        trans.push_back({"REBLUR::Prepared_SpecSh1", F::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
     } else if (d.kind == Kind::RELAX) { // same slot order as REBLUR for the shared front half; moments live in the STAB slots
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
@@ -192,6 +198,12 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"RELAX::HistoryLength_Tmp", F::R16_UINT, 2, 1});
         trans.push_back({"RELAX::Data2", F::R32_UINT, 4, 1});
         trans.push_back({"RELAX::SpecHitDistForTracking", F::R16_SFLOAT, 2, 1});
+        // PrepareInputs outputs (checkerboard resolve / hit distance reconstruction): dense RGBA16F copies of the noisy
+        // inputs; the SH1 copies are only full-size in SH mode
+        trans.push_back({"RELAX::Prepared_Diff", F::RGBA16_SFLOAT, 8, 1});
+        trans.push_back({"RELAX::Prepared_Spec", F::RGBA16_SFLOAT, 8, 1});
+        trans.push_back({"RELAX::Prepared_DiffSh1", F::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
+        trans.push_back({"RELAX::Prepared_SpecSh1", F::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
         trans.push_back({"RELAX::Atrous_A", fmtRad, bRad, 1});
         trans.push_back({"RELAX::Atrous_B", fmtRad, bRad, 1});
     } else if (d.kind == Kind::SIGMA) {
@@ -336,6 +348,55 @@ nrd::ResourceType out_slot(const DenoiserState& d, bool spec) {
         return spec ? RT::OUT_SPEC_SH0 : RT::OUT_DIFF_SH0;
     return d.occlusion ? (spec ? RT::OUT_SPEC_HITDIST : RT::OUT_DIFF_HITDIST) : (spec ? RT::OUT_SPEC_RADIANCE_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
 }
+// PrepareInputs (nrd_reblur.hip k_prepare_inputs) is recorded when the inputs are checkerboarded or hit distances must be
+// reconstructed (Source/NRDSample.cpp:545-548: the sample's default RESOLUTION_HALF tracing sets CheckerboardMode::WHITE)
+struct PrepareMode {
+    bool any, checker;
+    int phase[2]; // per signal (0 diffuse, 1 specular): Sequence::CheckerBoard value carrying it, 2 = every pixel
+    int radius;
+};
+PrepareMode prepare_mode(const nrd::ReblurSettings& s) {
+    PrepareMode m;
+    m.checker = s.checkerboardMode != nrd::CheckerboardMode::OFF;
+    bool white = s.checkerboardMode == nrd::CheckerboardMode::WHITE;
+    m.phase[0] = !m.checker ? 2 : (white ? 1 : 0);
+    m.phase[1] = !m.checker ? 2 : (white ? 0 : 1);
+    m.radius = s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::OFF ? 0 : (s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::AREA_3X3 ? 1 : 2);
+    m.any = m.checker || m.radius > 0;
+    return m;
+}
+// the planes the PrePass gathers its signals from: the input slots, or the PrepareInputs copies
+void push_prepass_inputs(const DenoiserState& d, const PrepareMode& pm, uint32_t tb, std::vector<uint32_t>& list) {
+    using RT = nrd::ResourceType;
+    for (int spec = 0; spec < 2; spec++) {
+        if (spec ? !d.hasSpec : !d.hasDiff)
+            continue;
+        list.push_back(pm.any ? enc_trans(tb + rb::PREP_D + spec) : enc_slot(in_slot(d, spec != 0)));
+        if (d.sh)
+            list.push_back(pm.checker ? enc_trans(tb + rb::PREP_D1 + spec) : enc_slot(spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1));
+    }
+}
+// the PrepareInputs dispatch itself (shared by REBLUR and RELAX)
+void push_prepare_dispatch(DenoiserState& d, const PrepareMode& pm, const ReblurParams& p, const char* name, uint32_t guide, uint32_t tb) {
+    using RT = nrd::ResourceType;
+    float n = (float)d.nsig;
+    float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
+    Dispatch x{name, "nrd_reblur_prepare_inputs", (uint16_t)pm.radius, 16.0f + n * (inB + 8.0f) + ((d.sh && pm.checker) ? n * (4.0f + 8.0f) : 0.0f), {}, {}, nullptr};
+    x.read = {guide};
+    for (int spec = 0; spec < 2; spec++) {
+        if (spec ? !d.hasSpec : !d.hasDiff)
+            continue;
+        x.read.push_back(enc_slot(in_slot(d, spec != 0)));
+        x.written.push_back(enc_trans(tb + rb::PREP_D + spec));
+        if (d.sh && pm.checker) {
+            x.read.push_back(enc_slot(spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1));
+            x.written.push_back(enc_trans(tb + rb::PREP_D1 + spec));
+        }
+    }
+    x.launch = [p](hipStream_t st) { launch_reblur_prepare_inputs(p, st); };
+    d.dispatches.push_back(x);
+}
+
 // appends the signal slots (SH0 [+ SH1]) of the active signals to a dispatch's read / written list
 void push_signal_slots(const DenoiserState& d, std::vector<uint32_t>& list, bool outputs) {
     using RT = nrd::ResourceType;
@@ -400,6 +461,25 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.inSpec = SP(in_slot(d, true));
     p.inDiff1 = SP(RT::IN_DIFF_SH1);
     p.inSpec1 = SP(RT::IN_SPEC_SH1);
+    // PrepareInputs reads the slots ("raw") and hands dense copies to the PrePass
+    PrepareMode pm = prepare_mode(s);
+    p.rawDiff = p.inDiff;
+    p.rawSpec = p.inSpec;
+    p.rawDiff1 = p.inDiff1;
+    p.rawSpec1 = p.inSpec1;
+    p.prepared = pm.any ? 1 : 0;
+    p.checker = pm.checker ? 1 : 0;
+    p.phaseDiff = pm.phase[0];
+    p.phaseSpec = pm.phase[1];
+    p.reconRadius = pm.radius;
+    if (pm.any) {
+        p.inDiff = TP(rb::PREP_D);
+        p.inSpec = TP(rb::PREP_S);
+        if (pm.checker) {
+            p.inDiff1 = TP(rb::PREP_D1);
+            p.inSpec1 = TP(rb::PREP_S1);
+        }
+    }
     p.outDiff1 = SP(RT::OUT_DIFF_SH1);
     p.outSpec1 = SP(RT::OUT_SPEC_SH1);
     p.sh = d.sh ? 1 : 0;
@@ -451,10 +531,13 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
         d.dispatches.push_back(x);
     }
+    const PrepareMode pm = prepare_mode(s);
+    if (pm.any)
+        push_prepare_dispatch(d, pm, p, "REBLUR::PrepareInputs", P(rb::GUIDE_A + cur), tb);
     {
         Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * nr + 8 * nr + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
-        push_signal_slots(d, x.read, false);
+        push_prepass_inputs(d, pm, tb, x.read);
         x.written = {T(rb::TMP1), T(rb::HITTRACK)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);
@@ -517,6 +600,8 @@ nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
     s.fastHistoryClampingSigmaScale = r.fastHistoryClampingSigmaScale;
     s.minMaterialForDiffuse = r.minMaterialForDiffuse;
     s.minMaterialForSpecular = r.minMaterialForSpecular;
+    s.checkerboardMode = r.checkerboardMode;
+    s.hitDistanceReconstructionMode = r.hitDistanceReconstructionMode;
     return s;
 }
 
@@ -544,10 +629,13 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
         d.dispatches.push_back(x);
     }
+    const PrepareMode pm = prepare_mode(s);
+    if (pm.any)
+        push_prepare_dispatch(d, pm, p, "RELAX::PrepareInputs", P(rb::GUIDE_A + cur), tb);
     {
         Dispatch x{"RELAX::PrePass", "nrd_reblur_prepass", (uint16_t)p.reachPre, GB + 8 * nr + 8 * nr + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
-        push_signal_slots(d, x.read, false);
+        push_prepass_inputs(d, pm, tb, x.read);
         x.written = {T(rb::TMP1), T(rb::HITTRACK)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);

@@ -128,6 +128,32 @@ class Harness:
         return self.fetch(p["buf"])
 
 
+CHECKERBOARD_KEYS = ("diff", "spec", "diff_sh1", "spec_sh1", "diff_hitdist", "spec_hitdist")
+
+
+def to_checkerboard(frame, frame_index, white=True):
+    """Dense synthetic frame -> the half-width checkerboarded inputs the sample produces in RESOLUTION_HALF tracing
+    (Shaders/TraceOpaque.cs.hlsl:482-508): pixel (x, y) lands at texel (x >> 1, y); with CheckerboardMode::WHITE the diffuse
+    signal is kept on the squares where Sequence::CheckerBoard(pixelPos, frameIndex) = ((x ^ y) ^ frameIndex) & 1 is 1, the
+    specular signal on the 0 squares (BLACK swaps them). Works on numpy arrays and torch tensors."""
+    out = dict(frame)
+    for key in CHECKERBOARD_KEYS:
+        if key not in frame:
+            continue
+        a = frame[key]
+        h, w = a.shape[0], a.shape[1]
+        spec = key.startswith("spec")
+        phase = (1 if white else 0) ^ (1 if spec else 0)
+        half = a[:, 0::2].clone() if hasattr(a, "clone") else a[:, 0::2].copy()  # (w + 1) // 2 texels per row
+        for y in range(2):  # row parity decides which pixel of the pair (2k, 2k+1) carries the signal
+            # pixel x carries it iff ((x ^ y) ^ frame) & 1 == phase  ->  x parity = phase ^ y ^ frame
+            xpar = (phase ^ y ^ frame_index) & 1
+            src = a[y::2, xpar::2]
+            half[y::2, : src.shape[1]] = src
+        out[key] = half
+    return out
+
+
 def pingpong(n, f):
     """camera path position of step f: 0,1,..,n-1,n-2,..,1,0,1,.. (motion vectors stay consistent in both directions)"""
     if n == 1:

@@ -19,7 +19,7 @@ namespace {
 
 // pool plane indices relative to permBase / transBase
 enum Perm { P_GUIDE_A, P_GUIDE_B, P_DATA1_A, P_DATA1_B, P_HIST, P_FAST_A, P_FAST_B, P_STAB_A, P_STAB_B, P_NUM };
-enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_NUM };
+enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_PREP_D, T_PREP_S, T_PREP_D1, T_PREP_S1, T_NUM };
 
 const float MAX_ACCUM = 63.0f;
 const float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
@@ -152,6 +152,138 @@ static inline float geo_weight(const PixelGeo& p, float px, float gy, float zs) 
 // --------------------------------------------------------------------------------------------------
 enum Variant { PRE = 0, BLUR = 1, POST = 2 };
 
+// --------------------------------------------------------------------------------------------------
+// K1 PrepareInputs - recorded only when checkerboardMode != OFF or hitDistanceReconstructionMode != OFF (the sample's default
+// operating mode: tracingMode RESOLUTION_HALF -> CheckerboardMode::WHITE, Source/NRDSample.cpp:267, :545-548, :565-568).
+// Produces dense, full-resolution RGBA16F copies of the noisy inputs for the PrePass:
+//  * checkerboard resolve: the half-width inputs hold pixel (x, y) at texel (x >> 1, y) on the squares of
+//    Sequence::CheckerBoard(pixelPos, frameIndex) that carry the signal (WHITE: diffuse on 1, specular on 0;
+//    Shaders/TraceOpaque.cs.hlsl:482-508); a pixel of the other colour takes the depth-weighted mean of its left / right
+//    neighbours;
+//  * hit distance reconstruction (AREA_3X3 / AREA_5X5): a texel without hit distance (w == 0) takes the bilateral mean
+//    (plane distance x normal [x roughness]) of the valid hit distances around it.
+// --------------------------------------------------------------------------------------------------
+struct PrepareMode {
+    bool any, checker;
+    int phase[2]; // per signal (0 diffuse, 1 specular): checkerboard value carrying it, 2 = every pixel
+    int radius;   // hit distance reconstruction radius, 0 = off
+};
+static inline PrepareMode prepare_mode(const nrd::ReblurSettings& s) {
+    PrepareMode m;
+    m.checker = s.checkerboardMode != nrd::CheckerboardMode::OFF;
+    bool white = s.checkerboardMode == nrd::CheckerboardMode::WHITE;
+    m.phase[0] = !m.checker ? 2 : (white ? 1 : 0);
+    m.phase[1] = !m.checker ? 2 : (white ? 0 : 1);
+    m.radius = s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::OFF ? 0 : (s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::AREA_3X3 ? 1 : 2);
+    m.any = m.checker || m.radius > 0;
+    return m;
+}
+static inline bool has_data(int phase, int x, int gy, uint32_t frameIndex) { return phase == 2 || ((((uint32_t)x ^ (uint32_t)gy) ^ frameIndex) & 1u) == (uint32_t)phase; }
+
+void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const nrd::ReblurSettings& s = d.reblur;
+    const PrepareMode m = prepare_mode(s);
+    const Plane& G = k.guide();
+    const bool sh1 = d.sh && m.checker;
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            const int gy0 = y + c.yOff;
+            for (int sig = 0; sig < d.nsig; sig++) {
+                const bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+                const int si = isSpec ? 1 : 0;
+                const Plane& in = k.slot(in_slot(d, isSpec));
+                const Plane& out = k.trans(T_PREP_D + si);
+                const Plane* in1 = sh1 ? &k.slot(in1_slot(isSpec)) : nullptr;
+                const Plane* out1 = sh1 ? &k.trans(T_PREP_D1 + si) : nullptr;
+                if (g.sky) {
+                    st_h4(out, x, y, {0, 0, 0, 0});
+                    if (sh1)
+                        st_h4(*out1, x, y, {0, 0, 0, 0});
+                    continue;
+                }
+                const int phase = m.phase[si];
+                f4 v = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+                if (has_data(phase, x, gy0, c.frameIndex)) {
+                    int sx = m.checker ? x >> 1 : x;
+                    v = load_signal(in, sx, y, 0, d.occlusion);
+                    if (sh1)
+                        v1 = ld_h4(*in1, sx, y, 0);
+                } else { // checkerboard resolve from the left / right neighbours (they carry this signal)
+                    float invDz = 1.0f / (0.03f * fmax2(absf(g.z), 1e-6f));
+                    float wn[2];
+                    bool ok[2];
+                    f4 vn[2], v1n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                    for (int n = 0; n < 2; n++) {
+                        int px = x + (n ? 1 : -1);
+                        ok[n] = px >= 0 && px < c.W;
+                        int cpx = px < 0 ? 0 : (px >= c.W ? c.W - 1 : px);
+                        Guide gn = load_guide(G, cpx, y, c.denoisingRange);
+                        vn[n] = load_signal(in, cpx >> 1, y, 0, d.occlusion);
+                        if (sh1)
+                            v1n[n] = ld_h4(*in1, cpx >> 1, y, 0);
+                        ok[n] = ok[n] && !gn.sky;
+                        float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
+                        wn[n] = ok[n] ? w : 0.0f;
+                    }
+                    if (!(wn[0] + wn[1] > 0.0f)) { // depth edge on both sides: plain mean of whatever exists
+                        wn[0] = ok[0] ? 1.0f : 0.0f;
+                        wn[1] = ok[1] ? 1.0f : 0.0f;
+                    }
+                    float wsum = wn[0] + wn[1];
+                    f4 acc = wn[0] > 0.0f ? mul4(vn[0], wn[0]) : f4{0, 0, 0, 0};
+                    acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
+                    f4 acc1 = wn[0] > 0.0f ? mul4(v1n[0], wn[0]) : f4{0, 0, 0, 0};
+                    acc1 = wn[1] > 0.0f ? fma4(v1n[1], wn[1], acc1) : acc1;
+                    float inv = 1.0f / wsum;
+                    v = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
+                    v1 = wsum > 0.0f ? mul4(acc1, inv) : f4{0, 0, 0, 0};
+                }
+                if (m.radius > 0 && v.w == 0.0f) { // no hit distance: reconstruct it from the neighbourhood
+                    PixelGeo pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
+                    float rough = isSpec ? g.roughness : 1.0f;
+                    uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
+                    float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
+                    float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                    float normalW2 = normalW * normalW;
+                    float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                    float roughB = -rough * roughA;
+                    float sum = 0.0f, wsum = 0.0f;
+                    for (int j = -m.radius; j <= m.radius; j++)
+                        for (int i = -m.radius; i <= m.radius; i++) {
+                            if (i == 0 && j == 0)
+                                continue;
+                            int px = x + i, py = y + j, gy = py + c.yOff;
+                            if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                                continue;
+                            if (!has_data(phase, px, gy, c.frameIndex))
+                                continue;
+                            Guide gs = load_guide(G, px, py, c.denoisingRange);
+                            if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                                continue;
+                            float h = load_signal(in, m.checker ? px >> 1 : px, py, 0, d.occlusion).w;
+                            if (!(h > 0.0f))
+                                continue;
+                            float w = geo_weight(pg, (float)px, (float)gy, gs.z);
+                            w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                            if (isSpec)
+                                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                            sum = fma_(h, w, sum);
+                            wsum += w;
+                        }
+                    if (wsum > 0.0f)
+                        v.w = sum * (1.0f / wsum);
+                }
+                if (d.occlusion)
+                    v = {v.w, 0.0f, 0.0f, v.w};
+                st_h4(out, x, y, v);
+                if (sh1)
+                    st_h4(*out1, x, y, v1);
+            }
+        }
+}
+
 struct SpatialIO {
     const Plane* in[2]; // per signal slot
     int inOff[2];       // byte offset of the signal inside the texel
@@ -176,7 +308,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const Plane& HT = k.trans(T_HITTRACK);
     const float* hp = &s.hitDistanceParameters.A;
     const bool relaxIn = k.d.kind == Kind::RELAX && variant == PRE; // RELAX inputs: linear RGB + world-space hit distance
-    const bool occIn = k.d.occlusion && variant == PRE;
+    const bool occIn = k.d.occlusion && variant == PRE && !prepare_mode(s).any; // PrepareInputs already expanded them to {h, 0, 0, h}
     const bool sh = k.d.sh;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
@@ -1068,6 +1200,12 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
     trans.push_back({"REBLUR::Data1_Tmp", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     trans.push_back({"REBLUR::Data2", (uint32_t)nrd::Format::R32_UINT, 4, 1});
     trans.push_back({"REBLUR::SpecHitDistForTracking", (uint32_t)nrd::Format::R16_SFLOAT, 2, 1});
+    // PrepareInputs outputs (checkerboard resolve / hit distance reconstruction): dense RGBA16F copies of the noisy inputs;
+    // the SH1 copies are only full-size in SH mode
+    trans.push_back({"REBLUR::Prepared_Diff", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, 1});
+    trans.push_back({"REBLUR::Prepared_Spec", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, 1});
+    trans.push_back({"REBLUR::Prepared_DiffSh1", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
+    trans.push_back({"REBLUR::Prepared_SpecSh1", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
 }
 
 void reblur_build(Instance& I, DenoiserState& d) {
@@ -1094,6 +1232,28 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
+    const PrepareMode pm = prepare_mode(s);
+    if (pm.any) {
+        Pass p;
+        p.name = "REBLUR::PrepareInputs";
+        p.kernel = "nrd_reblur_prepare_inputs";
+        p.haloRows = (uint16_t)pm.radius;
+        float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
+        p.bytesPerPixel = GB + n * (inB + 8.0f) + ((d.sh && pm.checker) ? n * (4.0f + 8.0f) : 0.0f);
+        p.read = {P(P_GUIDE_A + cur)};
+        for (int si = 0; si < 2; si++) {
+            if (!(si ? d.hasSpec : d.hasDiff))
+                continue;
+            p.read.push_back(enc_slot(in_slot(d, si != 0)));
+            p.written.push_back(T(T_PREP_D + si));
+            if (d.sh && pm.checker) {
+                p.read.push_back(enc_slot(in1_slot(si != 0)));
+                p.written.push_back(T(T_PREP_D1 + si));
+            }
+        }
+        p.run = prepare_inputs;
+        d.passes.push_back(p);
+    }
     {
         Pass p;
         p.name = "REBLUR::PrePass";
@@ -1101,15 +1261,12 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.haloRows = (uint16_t)rr.pre;
         p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
-        if (d.hasDiff) {
-            p.read.push_back(enc_slot(in_slot(d, false)));
+        for (int si = 0; si < 2; si++) {
+            if (!(si ? d.hasSpec : d.hasDiff))
+                continue;
+            p.read.push_back(pm.any ? T(T_PREP_D + si) : enc_slot(in_slot(d, si != 0)));
             if (d.sh)
-                p.read.push_back(enc_slot(in1_slot(false)));
-        }
-        if (d.hasSpec) {
-            p.read.push_back(enc_slot(in_slot(d, true)));
-            if (d.sh)
-                p.read.push_back(enc_slot(in1_slot(true)));
+                p.read.push_back(pm.checker ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
         }
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
@@ -1120,8 +1277,9 @@ void reblur_build(Instance& I, DenoiserState& d) {
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                io.in[sig] = &k.slot(in_slot(d, isSpec));
-                io.in1[sig] = d.sh ? &k.slot(in1_slot(isSpec)) : nullptr;
+                PrepareMode pm = prepare_mode(d.reblur);
+                io.in[sig] = pm.any ? &k.trans(T_PREP_D + (isSpec ? 1 : 0)) : &k.slot(in_slot(d, isSpec));
+                io.in1[sig] = d.sh ? (pm.checker ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
                 io.outOff[sig] = sig * sb;
@@ -1244,6 +1402,8 @@ static nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
     s.fastHistoryClampingSigmaScale = r.fastHistoryClampingSigmaScale;
     s.minMaterialForDiffuse = r.minMaterialForDiffuse;
     s.minMaterialForSpecular = r.minMaterialForSpecular;
+    s.checkerboardMode = r.checkerboardMode;
+    s.hitDistanceReconstructionMode = r.hitDistanceReconstructionMode;
     return s;
 }
 
@@ -1266,6 +1426,12 @@ void relax_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<
     trans.push_back({"RELAX::HistoryLength_Tmp", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     trans.push_back({"RELAX::Data2", (uint32_t)nrd::Format::R32_UINT, 4, 1});
     trans.push_back({"RELAX::SpecHitDistForTracking", (uint32_t)nrd::Format::R16_SFLOAT, 2, 1});
+    // PrepareInputs outputs (checkerboard resolve / hit distance reconstruction): dense RGBA16F copies of the noisy inputs;
+    // the SH1 copies are only full-size in SH mode
+    trans.push_back({"RELAX::Prepared_Diff", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, 1});
+    trans.push_back({"RELAX::Prepared_Spec", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, 1});
+    trans.push_back({"RELAX::Prepared_DiffSh1", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
+    trans.push_back({"RELAX::Prepared_SpecSh1", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
     trans.push_back({"RELAX::Atrous_A", fmtRad, bRad, 1});
     trans.push_back({"RELAX::Atrous_B", fmtRad, bRad, 1});
 }
@@ -1296,6 +1462,28 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
+    const PrepareMode pm = prepare_mode(s);
+    if (pm.any) {
+        Pass p;
+        p.name = "RELAX::PrepareInputs";
+        p.kernel = "nrd_reblur_prepare_inputs";
+        p.haloRows = (uint16_t)pm.radius;
+        float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
+        p.bytesPerPixel = GB + n * (inB + 8.0f) + ((d.sh && pm.checker) ? n * (4.0f + 8.0f) : 0.0f);
+        p.read = {P(P_GUIDE_A + cur)};
+        for (int si = 0; si < 2; si++) {
+            if (!(si ? d.hasSpec : d.hasDiff))
+                continue;
+            p.read.push_back(enc_slot(in_slot(d, si != 0)));
+            p.written.push_back(T(T_PREP_D + si));
+            if (d.sh && pm.checker) {
+                p.read.push_back(enc_slot(in1_slot(si != 0)));
+                p.written.push_back(T(T_PREP_D1 + si));
+            }
+        }
+        p.run = prepare_inputs;
+        d.passes.push_back(p);
+    }
     {
         Pass p;
         p.name = "RELAX::PrePass";
@@ -1303,15 +1491,12 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.haloRows = (uint16_t)rr.pre;
         p.bytesPerPixel = GB + 8 * nr + 8 * nr + sp;
         p.read = {P(P_GUIDE_A + cur)};
-        if (d.hasDiff) {
-            p.read.push_back(enc_slot(in_slot(d, false)));
+        for (int si = 0; si < 2; si++) {
+            if (!(si ? d.hasSpec : d.hasDiff))
+                continue;
+            p.read.push_back(pm.any ? T(T_PREP_D + si) : enc_slot(in_slot(d, si != 0)));
             if (d.sh)
-                p.read.push_back(enc_slot(in1_slot(false)));
-        }
-        if (d.hasSpec) {
-            p.read.push_back(enc_slot(in_slot(d, true)));
-            if (d.sh)
-                p.read.push_back(enc_slot(in1_slot(true)));
+                p.read.push_back(pm.checker ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
         }
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
@@ -1322,8 +1507,9 @@ void relax_build(Instance& I, DenoiserState& d) {
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                io.in[sig] = &k.slot(in_slot(d, isSpec));
-                io.in1[sig] = d.sh ? &k.slot(in1_slot(isSpec)) : nullptr;
+                PrepareMode pm = prepare_mode(d.reblur);
+                io.in[sig] = pm.any ? &k.trans(T_PREP_D + (isSpec ? 1 : 0)) : &k.slot(in_slot(d, isSpec));
+                io.in1[sig] = d.sh ? (pm.checker ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
                 io.outOff[sig] = sig * sb;
