@@ -22,11 +22,11 @@ namespace nrd {
 struct Instance; // opaque (== nrdhip_instance)
 
 inline const LibraryDesc* GetLibraryDesc() {
-    // every enumerator except REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION (creation returns Result::UNSUPPORTED for it)
+    // every enumerator of nrd::Denoiser (Source/NRDSample.cpp:49-51, :871-921)
     static const Denoiser supported[] = {Denoiser::REBLUR_DIFFUSE, Denoiser::REBLUR_DIFFUSE_OCCLUSION, Denoiser::REBLUR_DIFFUSE_SH,
                                          Denoiser::REBLUR_SPECULAR, Denoiser::REBLUR_SPECULAR_OCCLUSION, Denoiser::REBLUR_SPECULAR_SH,
                                          Denoiser::REBLUR_DIFFUSE_SPECULAR, Denoiser::REBLUR_DIFFUSE_SPECULAR_OCCLUSION, Denoiser::REBLUR_DIFFUSE_SPECULAR_SH,
-                                         Denoiser::RELAX_DIFFUSE, Denoiser::RELAX_DIFFUSE_SH, Denoiser::RELAX_SPECULAR, Denoiser::RELAX_SPECULAR_SH,
+                                         Denoiser::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION, Denoiser::RELAX_DIFFUSE, Denoiser::RELAX_DIFFUSE_SH, Denoiser::RELAX_SPECULAR, Denoiser::RELAX_SPECULAR_SH,
                                          Denoiser::RELAX_DIFFUSE_SPECULAR, Denoiser::RELAX_DIFFUSE_SPECULAR_SH,
                                          Denoiser::SIGMA_SHADOW, Denoiser::SIGMA_SHADOW_TRANSLUCENCY, Denoiser::REFERENCE};
     static LibraryDesc desc = {};

@@ -40,6 +40,11 @@ NRD_DEV f4 load_signal(const ReblurParams& p, const PlaneRef& P, int x, int y, i
     float h = p.ioF16 ? h2f(raw) : (float)raw * (1.0f / 65535.0f);
     return {h, 0.0f, 0.0f, h};
 }
+// DIRECTIONAL_OCCLUSION split-screen passthrough: the noisy {direction * h, h} texel rebuilt from its prepared SH0 / SH1 halves
+NRD_DEV f4 dir_pass(const ReblurParams& p, int x, int y) {
+    f4 a = unpack_h4(ld<uint2>(p.inDiff, x, y, 8)), b = unpack_h4(ld<uint2>(p.inDiff1, x, y, 8));
+    return {b.x, b.y, b.z, a.x};
+}
 NRD_DEV void store_signal(const ReblurParams& p, const PlaneRef& P, int x, int y, f4 v) {
     if (!p.occlusion) {
         st<uint2>(P, x, y, 8, pack_h4(v));
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
     int x, y, tx, ty;
     if (!my_pixel(c, x, y, tx, ty))
         return;
-    const bool occ = p.occlusion != 0, checker = p.checker != 0, sh1 = p.sh != 0 && checker;
+    const bool occ = p.occlusion != 0, checker = p.checker != 0, sh1 = p.prepSh1 != 0, dirOcc = p.dirOcc != 0;
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     const int gy0 = y + c.yOff;
 #pragma unroll
@@ -130,12 +135,21 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             continue;
         }
         const int phase = isSpec ? p.phaseSpec : p.phaseDiff;
+        // one input position -> (SH0-like signal, SH1 texel)
+        auto load_pair = [&](int sx, int sy, f4& a, f4& b) {
+            if (dirOcc) { // {direction * h, h}
+                f4 t = unpack_h4(ld<uint2>(in, sx, sy, 8));
+                a = {t.w, 0.0f, 0.0f, t.w};
+                b = {t.x, t.y, t.z, 0.0f};
+            } else {
+                a = load_signal(p, in, sx, sy, 8, 0, occ);
+                b = sh1 ? unpack_h4(ld<uint2>(in1, sx, sy, 8)) : f4{0, 0, 0, 0};
+            }
+        };
         f4 v = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
         if (has_data(phase, x, gy0, c.frameIndex)) {
             int sx = checker ? x >> 1 : x;
-            v = load_signal(p, in, sx, y, 8, 0, occ);
-            if (sh1)
-                v1 = unpack_h4(ld<uint2>(in1, sx, y, 8));
+            load_pair(sx, y, v, v1);
         } else { // checkerboard resolve from the left / right neighbours (they carry this signal)
             float invDz = 1.0f / (0.03f * fmax2(absf(g.z), 1e-6f));
             float wn[2];
@@ -147,9 +161,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                 ok[n] = px >= 0 && px < c.W;
                 int cpx = imin(imax(px, 0), c.W - 1);
                 Guide gn = decode_guide(ld<uint4>(p.guide, cpx, y, 16), c.denoisingRange);
-                vn[n] = load_signal(p, in, cpx >> 1, y, 8, 0, occ);
-                if (sh1)
-                    v1n[n] = unpack_h4(ld<uint2>(in1, cpx >> 1, y, 8));
+                load_pair(cpx >> 1, y, vn[n], v1n[n]);
                 ok[n] = ok[n] && !gn.sky;
                 float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
                 wn[n] = ok[n] ? w : 0.0f;
@@ -189,7 +201,9 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                     Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
                     if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                         continue;
-                    float h = load_signal(p, in, checker ? px >> 1 : px, py, 8, 0, occ).w;
+                    f4 hv, hv1;
+                    load_pair(checker ? px >> 1 : px, py, hv, hv1);
+                    float h = hv.w;
                     if (!(h > 0.0f))
                         continue;
                     float w = geo_weight(pg, (float)px, (float)gy, gs.z);
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             if (wsum > 0.0f)
                 v.w = sum * (1.0f / wsum);
         }
-        if (occ)
+        if (occ || dirOcc)
             v = {v.w, 0.0f, 0.0f, v.w};
         st<uint2>(out, x, y, 8, pack_h4(v));
         if (sh1)
@@ -1043,8 +1057,12 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
             const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-            store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : f4{0, 0, 0, 0});
-            if (SH)
+            // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
+            if (SH && p.dirOcc) // single {SH1.xyz, SH0.x} texel out
+                st<uint2>(o, x, y, 8, split ? pack_h4(dir_pass(p, x, y)) : uint2{0u, 0u});
+            else
+                store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : f4{0, 0, 0, 0});
+            if (SH && !p.dirOcc)
                 st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
             st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
@@ -1100,7 +1118,12 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         st<uint16_t>(p.stab, x, y, LBPT, f2h(Yout), sig * 2);
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-        store_signal(p, op, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0) : o);
+        if (SH && p.dirOcc) {
+            f4 c1 = unpack_h4(ctex[sig * SW + S1]);
+            st<uint2>(op, x, y, 8, split ? pack_h4(dir_pass(p, x, y)) : pack_h4({c1.x * scale, c1.y * scale, c1.z * scale, Yout}));
+            continue;
+        }
+        store_signal(p, op, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : o);
         if (SH) {
             f4 c1 = unpack_h4(ctex[sig * SW + S1]);
             f4 o1 = {c1.x * scale, c1.y * scale, c1.z * scale, c1.w};

@@ -75,6 +75,7 @@ struct DenoiserState {
     nrd::Denoiser denoiser = nrd::Denoiser::MAX_NUM;
     Kind kind = Kind::REFERENCE;
     bool hasDiff = false, hasSpec = false, translucency = false, occlusion = false, sh = false;
+    bool dirOcc = false; // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: one {direction * h, h} texel in / out, filtered as SH0 = {h,0,0,h} + SH1
     int nsig = 0;
     uint32_t permBase = 0, permEnd = 0, transBase = 0;
     uint32_t frameCounter = 0, framesSinceReset = 0;
@@ -124,6 +125,7 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.occlusion = true; break;
         case D::REBLUR_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasSpec = d.occlusion = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.occlusion = true; break;
+        case D::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.sh = d.dirOcc = true; break;
         case D::REBLUR_DIFFUSE_SH: d.kind = Kind::REBLUR; d.hasDiff = d.sh = true; break;
         case D::REBLUR_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasSpec = d.sh = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.sh = true; break;
@@ -338,12 +340,16 @@ void build_reference(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c)
 
 nrd::ResourceType in_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
+    if (d.dirOcc)
+        return RT::IN_DIFF_DIRECTION_HITDIST;
     if (d.sh)
         return spec ? RT::IN_SPEC_SH0 : RT::IN_DIFF_SH0;
     return d.occlusion ? (spec ? RT::IN_SPEC_HITDIST : RT::IN_DIFF_HITDIST) : (spec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
 }
 nrd::ResourceType out_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
+    if (d.dirOcc)
+        return RT::OUT_DIFF_DIRECTION_HITDIST;
     if (d.sh)
         return spec ? RT::OUT_SPEC_SH0 : RT::OUT_DIFF_SH0;
     return d.occlusion ? (spec ? RT::OUT_SPEC_HITDIST : RT::OUT_DIFF_HITDIST) : (spec ? RT::OUT_SPEC_RADIANCE_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
@@ -354,15 +360,18 @@ struct PrepareMode {
     bool any, checker;
     int phase[2]; // per signal (0 diffuse, 1 specular): Sequence::CheckerBoard value carrying it, 2 = every pixel
     int radius;
+    bool sh1; // the SH1 texels are (re)written too: checkerboarded SH inputs, or DIRECTIONAL_OCCLUSION (its single
+              // {direction * h, h} input texel is always split into SH0 = {h,0,0,h} and SH1 = {direction * h, 0} there)
 };
-PrepareMode prepare_mode(const nrd::ReblurSettings& s) {
+PrepareMode prepare_mode(const DenoiserState& d, const nrd::ReblurSettings& s) {
     PrepareMode m;
     m.checker = s.checkerboardMode != nrd::CheckerboardMode::OFF;
     bool white = s.checkerboardMode == nrd::CheckerboardMode::WHITE;
     m.phase[0] = !m.checker ? 2 : (white ? 1 : 0);
     m.phase[1] = !m.checker ? 2 : (white ? 0 : 1);
     m.radius = s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::OFF ? 0 : (s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::AREA_3X3 ? 1 : 2);
-    m.any = m.checker || m.radius > 0;
+    m.any = m.checker || m.radius > 0 || d.dirOcc;
+    m.sh1 = d.sh && (m.checker || d.dirOcc);
     return m;
 }
 // the planes the PrePass gathers its signals from: the input slots, or the PrepareInputs copies
@@ -373,7 +382,7 @@ void push_prepass_inputs(const DenoiserState& d, const PrepareMode& pm, uint32_t
             continue;
         list.push_back(pm.any ? enc_trans(tb + rb::PREP_D + spec) : enc_slot(in_slot(d, spec != 0)));
         if (d.sh)
-            list.push_back(pm.checker ? enc_trans(tb + rb::PREP_D1 + spec) : enc_slot(spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1));
+            list.push_back(pm.sh1 ? enc_trans(tb + rb::PREP_D1 + spec) : enc_slot(spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1));
     }
 }
 // the PrepareInputs dispatch itself (shared by REBLUR and RELAX)
@@ -381,15 +390,16 @@ void push_prepare_dispatch(DenoiserState& d, const PrepareMode& pm, const Reblur
     using RT = nrd::ResourceType;
     float n = (float)d.nsig;
     float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
-    Dispatch x{name, "nrd_reblur_prepare_inputs", (uint16_t)pm.radius, 16.0f + n * (inB + 8.0f) + ((d.sh && pm.checker) ? n * (4.0f + 8.0f) : 0.0f), {}, {}, nullptr};
+    Dispatch x{name, "nrd_reblur_prepare_inputs", (uint16_t)pm.radius, 16.0f + n * (inB + 8.0f) + (pm.sh1 ? n * ((d.dirOcc ? 0.0f : 4.0f) + 8.0f) : 0.0f), {}, {}, nullptr};
     x.read = {guide};
     for (int spec = 0; spec < 2; spec++) {
         if (spec ? !d.hasSpec : !d.hasDiff)
             continue;
         x.read.push_back(enc_slot(in_slot(d, spec != 0)));
         x.written.push_back(enc_trans(tb + rb::PREP_D + spec));
-        if (d.sh && pm.checker) {
-            x.read.push_back(enc_slot(spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1));
+        if (pm.sh1) {
+            if (!d.dirOcc)
+                x.read.push_back(enc_slot(spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1));
             x.written.push_back(enc_trans(tb + rb::PREP_D1 + spec));
         }
     }
@@ -404,7 +414,7 @@ void push_signal_slots(const DenoiserState& d, std::vector<uint32_t>& list, bool
         if (spec ? !d.hasSpec : !d.hasDiff)
             continue;
         list.push_back(enc_slot(outputs ? out_slot(d, spec != 0) : in_slot(d, spec != 0)));
-        if (d.sh)
+        if (d.sh && !d.dirOcc)
             list.push_back(enc_slot(outputs ? (spec ? RT::OUT_SPEC_SH1 : RT::OUT_DIFF_SH1) : (spec ? RT::IN_SPEC_SH1 : RT::IN_DIFF_SH1)));
     }
 }
@@ -462,7 +472,7 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.inDiff1 = SP(RT::IN_DIFF_SH1);
     p.inSpec1 = SP(RT::IN_SPEC_SH1);
     // PrepareInputs reads the slots ("raw") and hands dense copies to the PrePass
-    PrepareMode pm = prepare_mode(s);
+    PrepareMode pm = prepare_mode(d, s);
     p.rawDiff = p.inDiff;
     p.rawSpec = p.inSpec;
     p.rawDiff1 = p.inDiff1;
@@ -472,10 +482,12 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.phaseDiff = pm.phase[0];
     p.phaseSpec = pm.phase[1];
     p.reconRadius = pm.radius;
+    p.prepSh1 = pm.sh1 ? 1 : 0;
+    p.dirOcc = d.dirOcc ? 1 : 0;
     if (pm.any) {
         p.inDiff = TP(rb::PREP_D);
         p.inSpec = TP(rb::PREP_S);
-        if (pm.checker) {
+        if (pm.sh1) {
             p.inDiff1 = TP(rb::PREP_D1);
             p.inSpec1 = TP(rb::PREP_S1);
         }
@@ -531,7 +543,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
         d.dispatches.push_back(x);
     }
-    const PrepareMode pm = prepare_mode(s);
+    const PrepareMode pm = prepare_mode(d, s);
     if (pm.any)
         push_prepare_dispatch(d, pm, p, "REBLUR::PrepareInputs", P(rb::GUIDE_A + cur), tb);
     {
@@ -629,7 +641,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
         d.dispatches.push_back(x);
     }
-    const PrepareMode pm = prepare_mode(s);
+    const PrepareMode pm = prepare_mode(d, s);
     if (pm.any)
         push_prepare_dispatch(d, pm, p, "RELAX::PrepareInputs", P(rb::GUIDE_A + cur), tb);
     {

@@ -27,6 +27,7 @@ INPUT_SLOTS = {
     RT.IN_DIFF_SH1: ("diff_sh1", F.RGBA16_SFLOAT),
     RT.IN_SPEC_SH0: ("spec", F.RGBA16_SFLOAT),
     RT.IN_SPEC_SH1: ("spec_sh1", F.RGBA16_SFLOAT),
+    RT.IN_DIFF_DIRECTION_HITDIST: ("diff_dirocc", F.RGBA16_SFLOAT),  # DIRECTIONAL_OCCLUSION (Source/NRDSample.cpp:488-491)
 }
 OUTPUT_SLOTS = {
     RT.OUT_DIFF_RADIANCE_HITDIST: ("out_diff", F.RGBA16_SFLOAT, 8),
@@ -39,6 +40,7 @@ OUTPUT_SLOTS = {
     RT.OUT_DIFF_SH1: ("out_diff_sh1", F.RGBA16_SFLOAT, 8),
     RT.OUT_SPEC_SH0: ("out_spec", F.RGBA16_SFLOAT, 8),
     RT.OUT_SPEC_SH1: ("out_spec_sh1", F.RGBA16_SFLOAT, 8),
+    RT.OUT_DIFF_DIRECTION_HITDIST: ("out_diff_dirocc", F.RGBA16_SFLOAT, 8),
 }
 
 
@@ -128,7 +130,7 @@ class Harness:
         return self.fetch(p["buf"])
 
 
-CHECKERBOARD_KEYS = ("diff", "spec", "diff_sh1", "spec_sh1", "diff_hitdist", "spec_hitdist")
+CHECKERBOARD_KEYS = ("diff", "spec", "diff_sh1", "spec_sh1", "diff_hitdist", "spec_hitdist", "diff_dirocc")
 
 
 def to_checkerboard(frame, frame_index, white=True):

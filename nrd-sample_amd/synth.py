@@ -299,6 +299,14 @@ class Scene:
             return torch.where(hit[..., None], v, torch.zeros_like(v)).to(torch.float16)
         out["diff_sh1"] = sh1(n, diff)
         out["spec_sh1"] = sh1(refl, spec)
+        if not self.relax:
+            # DIRECTIONAL_OCCLUSION (REBLUR_FrontEnd_PackDirectionalOcclusion, Shaders/TraceOpaque.cs.hlsl:753-754):
+            # one RGBA16F texel {ray direction * normHitDist, normHitDist}; the noisy direction scatters around the normal
+            jit = torch.stack([nd, 1.0 - nd, nd * 0.5], -1) - 0.5  # deterministic per-pixel perturbation from the noisy hit distance
+            dirn = n + 0.35 * jit
+            dirn = dirn / torch.sqrt((dirn * dirn).sum(-1, keepdim=True))
+            do4 = torch.cat([dirn * nd[..., None], nd[..., None]], -1)
+            out["diff_dirocc"] = torch.where(hit[..., None], do4, torch.zeros_like(do4)).to(torch.float16)
         if not self.relax:  # OCCLUSION variants take the normalised hit distance alone, R16_UNORM
             for key, src in (("diff_hitdist", d4), ("spec_hitdist", s4)):
                 q = torch.floor(torch.clamp(src[..., 3], 0, 1) * 65535 + 0.5).to(torch.int32)  # 0..65535 (sky = 0)

@@ -156,6 +156,7 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::REBLUR_DIFFUSE_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.occlusion = true; break;
         case D::REBLUR_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasSpec = d.occlusion = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.occlusion = true; break;
+        case D::REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: d.kind = Kind::REBLUR; d.hasDiff = d.sh = d.dirOcc = true; break;
         case D::REBLUR_DIFFUSE_SH: d.kind = Kind::REBLUR; d.hasDiff = d.sh = true; break;
         case D::REBLUR_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasSpec = d.sh = true; break;
         case D::REBLUR_DIFFUSE_SPECULAR_SH: d.kind = Kind::REBLUR; d.hasDiff = d.hasSpec = d.sh = true; break;
@@ -168,7 +169,7 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
         case D::SIGMA_SHADOW: d.kind = Kind::SIGMA; break;
         case D::SIGMA_SHADOW_TRANSLUCENCY: d.kind = Kind::SIGMA; d.translucency = true; break;
         case D::REFERENCE: d.kind = Kind::REFERENCE; break;
-        default: return false; // OCCLUSION / SH / DIRECTIONAL_OCCLUSION variants: not in this round
+        default: return false;
     }
     d.nsig = (d.hasDiff ? 1 : 0) + (d.hasSpec ? 1 : 0);
     return true;

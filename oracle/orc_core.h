@@ -175,6 +175,7 @@ struct DenoiserState {
     nrd::Denoiser denoiser = nrd::Denoiser::MAX_NUM;
     Kind kind = Kind::REFERENCE;
     bool hasDiff = false, hasSpec = false, sh = false, occlusion = false, translucency = false;
+    bool dirOcc = false; // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: one {direction * h, h} texel in / out, filtered as SH0 = {h,0,0,h} + SH1 = direction * h
     int nsig = 0;
     uint32_t permBase = 0, transBase = 0; // first plane index in the instance pools
     uint32_t frameCounter = 0;            // denoise calls so far (ping-pong selector)

@@ -49,8 +49,15 @@ static inline void store_signal(const Plane& P, int x, int y, f4 v, bool occlusi
     else
         st_u16(P, x, y, (uint16_t)floorf(fma_(sat(v.x), 65535.0f, 0.5f)));
 }
+// DIRECTIONAL_OCCLUSION split-screen passthrough: the noisy {direction * h, h} texel rebuilt from its prepared SH0 / SH1 halves
+static inline f4 dir_pass(const Plane& sh0, const Plane& sh1, int x, int y) {
+    f4 a = ld_h4(sh0, x, y), b = ld_h4(sh1, x, y);
+    return {b.x, b.y, b.z, a.x};
+}
 static inline nrd::ResourceType in_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
+    if (d.dirOcc)
+        return RT::IN_DIFF_DIRECTION_HITDIST;
     if (d.sh)
         return spec ? RT::IN_SPEC_SH0 : RT::IN_DIFF_SH0;
     return d.occlusion ? (spec ? RT::IN_SPEC_HITDIST : RT::IN_DIFF_HITDIST) : (spec ? RT::IN_SPEC_RADIANCE_HITDIST : RT::IN_DIFF_RADIANCE_HITDIST);
@@ -59,6 +66,8 @@ static inline nrd::ResourceType in1_slot(bool spec) { return spec ? nrd::Resourc
 static inline nrd::ResourceType out1_slot(bool spec) { return spec ? nrd::ResourceType::OUT_SPEC_SH1 : nrd::ResourceType::OUT_DIFF_SH1; }
 static inline nrd::ResourceType out_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
+    if (d.dirOcc)
+        return RT::OUT_DIFF_DIRECTION_HITDIST;
     if (d.sh)
         return spec ? RT::OUT_SPEC_SH0 : RT::OUT_DIFF_SH0;
     return d.occlusion ? (spec ? RT::OUT_SPEC_HITDIST : RT::OUT_DIFF_HITDIST) : (spec ? RT::OUT_SPEC_RADIANCE_HITDIST : RT::OUT_DIFF_RADIANCE_HITDIST);
@@ -167,15 +176,19 @@ struct PrepareMode {
     bool any, checker;
     int phase[2]; // per signal (0 diffuse, 1 specular): checkerboard value carrying it, 2 = every pixel
     int radius;   // hit distance reconstruction radius, 0 = off
+    bool sh1;     // the SH1 texels are (re)written too: checkerboarded SH inputs, or DIRECTIONAL_OCCLUSION (its single
+                  // {direction * h, h} input texel is always split into SH0 = {h,0,0,h} and SH1 = {direction * h, 0} here)
 };
-static inline PrepareMode prepare_mode(const nrd::ReblurSettings& s) {
+static inline PrepareMode prepare_mode(const DenoiserState& d) {
+    const nrd::ReblurSettings& s = d.reblur;
     PrepareMode m;
     m.checker = s.checkerboardMode != nrd::CheckerboardMode::OFF;
     bool white = s.checkerboardMode == nrd::CheckerboardMode::WHITE;
     m.phase[0] = !m.checker ? 2 : (white ? 1 : 0);
     m.phase[1] = !m.checker ? 2 : (white ? 0 : 1);
     m.radius = s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::OFF ? 0 : (s.hitDistanceReconstructionMode == nrd::HitDistanceReconstructionMode::AREA_3X3 ? 1 : 2);
-    m.any = m.checker || m.radius > 0;
+    m.any = m.checker || m.radius > 0 || d.dirOcc;
+    m.sh1 = d.sh && (m.checker || d.dirOcc);
     return m;
 }
 static inline bool has_data(int phase, int x, int gy, uint32_t frameIndex) { return phase == 2 || ((((uint32_t)x ^ (uint32_t)gy) ^ frameIndex) & 1u) == (uint32_t)phase; }
@@ -183,9 +196,9 @@ static inline bool has_data(int phase, int x, int gy, uint32_t frameIndex) { ret
 void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
     const nrd::ReblurSettings& s = d.reblur;
-    const PrepareMode m = prepare_mode(s);
+    const PrepareMode m = prepare_mode(d);
     const Plane& G = k.guide();
-    const bool sh1 = d.sh && m.checker;
+    const bool sh1 = m.sh1;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
@@ -195,7 +208,18 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                 const int si = isSpec ? 1 : 0;
                 const Plane& in = k.slot(in_slot(d, isSpec));
                 const Plane& out = k.trans(T_PREP_D + si);
-                const Plane* in1 = sh1 ? &k.slot(in1_slot(isSpec)) : nullptr;
+                const Plane* in1 = (sh1 && !d.dirOcc) ? &k.slot(in1_slot(isSpec)) : nullptr;
+                // one input position -> (SH0-like signal, SH1 texel)
+                auto load_pair = [&](int sx, int sy, f4& a, f4& b) {
+                    if (d.dirOcc) { // {direction * h, h}
+                        f4 t = ld_h4(in, sx, sy, 0);
+                        a = {t.w, 0.0f, 0.0f, t.w};
+                        b = {t.x, t.y, t.z, 0.0f};
+                    } else {
+                        a = load_signal(in, sx, sy, 0, d.occlusion);
+                        b = sh1 ? ld_h4(*in1, sx, sy, 0) : f4{0, 0, 0, 0};
+                    }
+                };
                 const Plane* out1 = sh1 ? &k.trans(T_PREP_D1 + si) : nullptr;
                 if (g.sky) {
                     st_h4(out, x, y, {0, 0, 0, 0});
@@ -207,9 +231,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                 f4 v = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
                 if (has_data(phase, x, gy0, c.frameIndex)) {
                     int sx = m.checker ? x >> 1 : x;
-                    v = load_signal(in, sx, y, 0, d.occlusion);
-                    if (sh1)
-                        v1 = ld_h4(*in1, sx, y, 0);
+                    load_pair(sx, y, v, v1);
                 } else { // checkerboard resolve from the left / right neighbours (they carry this signal)
                     float invDz = 1.0f / (0.03f * fmax2(absf(g.z), 1e-6f));
                     float wn[2];
@@ -220,9 +242,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                         ok[n] = px >= 0 && px < c.W;
                         int cpx = px < 0 ? 0 : (px >= c.W ? c.W - 1 : px);
                         Guide gn = load_guide(G, cpx, y, c.denoisingRange);
-                        vn[n] = load_signal(in, cpx >> 1, y, 0, d.occlusion);
-                        if (sh1)
-                            v1n[n] = ld_h4(*in1, cpx >> 1, y, 0);
+                        load_pair(cpx >> 1, y, vn[n], v1n[n]);
                         ok[n] = ok[n] && !gn.sky;
                         float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
                         wn[n] = ok[n] ? w : 0.0f;
@@ -262,7 +282,9 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                             Guide gs = load_guide(G, px, py, c.denoisingRange);
                             if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                                 continue;
-                            float h = load_signal(in, m.checker ? px >> 1 : px, py, 0, d.occlusion).w;
+                            f4 hv, hv1;
+                            load_pair(m.checker ? px >> 1 : px, py, hv, hv1);
+                            float h = hv.w;
                             if (!(h > 0.0f))
                                 continue;
                             float w = geo_weight(pg, (float)px, (float)gy, gs.z);
@@ -275,7 +297,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                     if (wsum > 0.0f)
                         v.w = sum * (1.0f / wsum);
                 }
-                if (d.occlusion)
+                if (d.occlusion || d.dirOcc)
                     v = {v.w, 0.0f, 0.0f, v.w};
                 st_h4(out, x, y, v);
                 if (sh1)
@@ -308,7 +330,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const Plane& HT = k.trans(T_HITTRACK);
     const float* hp = &s.hitDistanceParameters.A;
     const bool relaxIn = k.d.kind == Kind::RELAX && variant == PRE; // RELAX inputs: linear RGB + world-space hit distance
-    const bool occIn = k.d.occlusion && variant == PRE && !prepare_mode(s).any; // PrepareInputs already expanded them to {h, 0, 0, h}
+    const bool occIn = k.d.occlusion && variant == PRE && !prepare_mode(k.d).any; // PrepareInputs already expanded them to {h, 0, 0, h}
     const bool sh = k.d.sh;
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
@@ -904,20 +926,24 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
     const Plane& D2 = k.trans(T_DATA2);
     const Plane& HT = k.trans(T_HITTRACK);
     const Plane* outP[2] = {nullptr, nullptr};
+    // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
+    const PrepareMode pm = prepare_mode(d);
+    const bool occIn = d.occlusion && !pm.any;
     const Plane* inP[2] = {nullptr, nullptr};
     const Plane* out1P[2] = {nullptr, nullptr};
     const Plane* in1P[2] = {nullptr, nullptr};
     if (d.hasDiff) {
         outP[k.sigDiff()] = &k.slot(out_slot(d, false));
-        inP[k.sigDiff()] = &k.slot(in_slot(d, false));
+        inP[k.sigDiff()] = pm.any ? &k.trans(T_PREP_D) : &k.slot(in_slot(d, false));
         out1P[k.sigDiff()] = &k.slot(out1_slot(false));
-        in1P[k.sigDiff()] = &k.slot(in1_slot(false));
+        in1P[k.sigDiff()] = pm.sh1 ? &k.trans(T_PREP_D1) : &k.slot(in1_slot(false));
     }
+    const bool dirOcc = d.dirOcc; // single {SH1.xyz, SH0.x} texel out, raw texel copy left of the split screen
     if (d.hasSpec) {
         outP[k.sigSpec()] = &k.slot(out_slot(d, true));
-        inP[k.sigSpec()] = &k.slot(in_slot(d, true));
+        inP[k.sigSpec()] = pm.any ? &k.trans(T_PREP_S) : &k.slot(in_slot(d, true));
         out1P[k.sigSpec()] = &k.slot(out1_slot(true));
-        in1P[k.sigSpec()] = &k.slot(in1_slot(true));
+        in1P[k.sigSpec()] = pm.sh1 ? &k.trans(T_PREP_S1) : &k.slot(in1_slot(true));
     }
     bool historyOk = d.historyValid && !c.reset;
     float maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
@@ -929,8 +955,11 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
-                    store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, d.occlusion) : f4{0, 0, 0, 0}, d.occlusion);
-                    if (d.sh)
+                    if (dirOcc)
+                        st_h4(*outP[sig], x, y, split ? dir_pass(*inP[sig], *in1P[sig], x, y) : f4{0, 0, 0, 0});
+                    else
+                        store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, occIn) : f4{0, 0, 0, 0}, d.occlusion);
+                    if (d.sh && !dirOcc)
                         st_h4(*out1P[sig], x, y, split ? ld_h4(*in1P[sig], x, y) : f4{0, 0, 0, 0});
                     st_h(STABC, x, y, 0.0f, sig * 2);
                 }
@@ -1018,7 +1047,12 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 float scale = (Yout + 1e-6f) / (Y + 1e-6f);
                 f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
                 st_h(STABC, x, y, Yout, sig * 2);
-                store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, d.occlusion) : o, d.occlusion);
+                if (dirOcc) {
+                    f4 c1 = ld_h4(HIST, x, y, sig * sb + 8);
+                    st_h4(*outP[sig], x, y, split ? dir_pass(*inP[sig], *in1P[sig], x, y) : f4{c1.x * scale, c1.y * scale, c1.z * scale, Yout});
+                    continue;
+                }
+                store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, occIn) : o, d.occlusion);
                 if (d.sh) {
                     f4 c1 = ld_h4(HIST, x, y, sig * sb + 8);
                     st_h4(*out1P[sig], x, y, split ? ld_h4(*in1P[sig], x, y) : f4{c1.x * scale, c1.y * scale, c1.z * scale, c1.w});
@@ -1050,20 +1084,21 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
     const Plane& IN = it == 0 ? HIST : k.trans(T_AT_A + ((it - 1) & 1));
     const Plane& OUTP = k.trans(T_AT_A + (it & 1));
     const Plane* outSlot[2] = {nullptr, nullptr};
+    const PrepareMode pmA = prepare_mode(d); // split screen shows the noisy input (its dense copy when PrepareInputs ran)
     const Plane* inSlot[2] = {nullptr, nullptr};
     const Plane* out1Slot[2] = {nullptr, nullptr};
     const Plane* in1Slot[2] = {nullptr, nullptr};
     if (d.hasDiff) {
         outSlot[k.sigDiff()] = &k.slot(out_slot(d, false));
-        inSlot[k.sigDiff()] = &k.slot(in_slot(d, false));
+        inSlot[k.sigDiff()] = pmA.any ? &k.trans(T_PREP_D) : &k.slot(in_slot(d, false));
         out1Slot[k.sigDiff()] = &k.slot(out1_slot(false));
-        in1Slot[k.sigDiff()] = &k.slot(in1_slot(false));
+        in1Slot[k.sigDiff()] = pmA.sh1 ? &k.trans(T_PREP_D1) : &k.slot(in1_slot(false));
     }
     if (d.hasSpec) {
         outSlot[k.sigSpec()] = &k.slot(out_slot(d, true));
-        inSlot[k.sigSpec()] = &k.slot(in_slot(d, true));
+        inSlot[k.sigSpec()] = pmA.any ? &k.trans(T_PREP_S) : &k.slot(in_slot(d, true));
         out1Slot[k.sigSpec()] = &k.slot(out1_slot(true));
-        in1Slot[k.sigSpec()] = &k.slot(in1_slot(true));
+        in1Slot[k.sigSpec()] = pmA.sh1 ? &k.trans(T_PREP_S1) : &k.slot(in1_slot(true));
     }
     const int stride = 1 << it;
     const float depthSens = fmax2(s.depthThreshold, 0.001f) * 4.0f;
@@ -1232,22 +1267,23 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
-    const PrepareMode pm = prepare_mode(s);
+    const PrepareMode pm = prepare_mode(d);
     if (pm.any) {
         Pass p;
         p.name = "REBLUR::PrepareInputs";
         p.kernel = "nrd_reblur_prepare_inputs";
         p.haloRows = (uint16_t)pm.radius;
         float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
-        p.bytesPerPixel = GB + n * (inB + 8.0f) + ((d.sh && pm.checker) ? n * (4.0f + 8.0f) : 0.0f);
+        p.bytesPerPixel = GB + n * (inB + 8.0f) + (pm.sh1 ? n * ((d.dirOcc ? 0.0f : 4.0f) + 8.0f) : 0.0f);
         p.read = {P(P_GUIDE_A + cur)};
         for (int si = 0; si < 2; si++) {
             if (!(si ? d.hasSpec : d.hasDiff))
                 continue;
             p.read.push_back(enc_slot(in_slot(d, si != 0)));
             p.written.push_back(T(T_PREP_D + si));
-            if (d.sh && pm.checker) {
-                p.read.push_back(enc_slot(in1_slot(si != 0)));
+            if (pm.sh1) {
+                if (!d.dirOcc)
+                    p.read.push_back(enc_slot(in1_slot(si != 0)));
                 p.written.push_back(T(T_PREP_D1 + si));
             }
         }
@@ -1266,7 +1302,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
                 continue;
             p.read.push_back(pm.any ? T(T_PREP_D + si) : enc_slot(in_slot(d, si != 0)));
             if (d.sh)
-                p.read.push_back(pm.checker ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
+                p.read.push_back(pm.sh1 ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
         }
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
@@ -1277,9 +1313,9 @@ void reblur_build(Instance& I, DenoiserState& d) {
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                PrepareMode pm = prepare_mode(d.reblur);
+                PrepareMode pm = prepare_mode(d);
                 io.in[sig] = pm.any ? &k.trans(T_PREP_D + (isSpec ? 1 : 0)) : &k.slot(in_slot(d, isSpec));
-                io.in1[sig] = d.sh ? (pm.checker ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
+                io.in1[sig] = d.sh ? (pm.sh1 ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
                 io.outOff[sig] = sig * sb;
@@ -1366,10 +1402,10 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.written = {P(P_STAB_A + cur)};
         if (d.hasDiff) {
             p.written.push_back(enc_slot(out_slot(d, false)));
-            if (d.sh)
+            if (d.sh && !d.dirOcc)
                 p.written.push_back(enc_slot(out1_slot(false)));
             p.read.push_back(enc_slot(in_slot(d, false)));
-            if (d.sh)
+            if (d.sh && !d.dirOcc)
                 p.read.push_back(enc_slot(in1_slot(false)));
         }
         if (d.hasSpec) {
@@ -1462,22 +1498,23 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
-    const PrepareMode pm = prepare_mode(s);
+    const PrepareMode pm = prepare_mode(d);
     if (pm.any) {
         Pass p;
         p.name = "RELAX::PrepareInputs";
         p.kernel = "nrd_reblur_prepare_inputs";
         p.haloRows = (uint16_t)pm.radius;
         float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
-        p.bytesPerPixel = GB + n * (inB + 8.0f) + ((d.sh && pm.checker) ? n * (4.0f + 8.0f) : 0.0f);
+        p.bytesPerPixel = GB + n * (inB + 8.0f) + (pm.sh1 ? n * ((d.dirOcc ? 0.0f : 4.0f) + 8.0f) : 0.0f);
         p.read = {P(P_GUIDE_A + cur)};
         for (int si = 0; si < 2; si++) {
             if (!(si ? d.hasSpec : d.hasDiff))
                 continue;
             p.read.push_back(enc_slot(in_slot(d, si != 0)));
             p.written.push_back(T(T_PREP_D + si));
-            if (d.sh && pm.checker) {
-                p.read.push_back(enc_slot(in1_slot(si != 0)));
+            if (pm.sh1) {
+                if (!d.dirOcc)
+                    p.read.push_back(enc_slot(in1_slot(si != 0)));
                 p.written.push_back(T(T_PREP_D1 + si));
             }
         }
@@ -1496,7 +1533,7 @@ void relax_build(Instance& I, DenoiserState& d) {
                 continue;
             p.read.push_back(pm.any ? T(T_PREP_D + si) : enc_slot(in_slot(d, si != 0)));
             if (d.sh)
-                p.read.push_back(pm.checker ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
+                p.read.push_back(pm.sh1 ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
         }
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
@@ -1507,9 +1544,9 @@ void relax_build(Instance& I, DenoiserState& d) {
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
                 bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                PrepareMode pm = prepare_mode(d.reblur);
+                PrepareMode pm = prepare_mode(d);
                 io.in[sig] = pm.any ? &k.trans(T_PREP_D + (isSpec ? 1 : 0)) : &k.slot(in_slot(d, isSpec));
-                io.in1[sig] = d.sh ? (pm.checker ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
+                io.in1[sig] = d.sh ? (pm.sh1 ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
                 io.inOff[sig] = 0;
                 io.out[sig] = &k.trans(T_TMP1);
                 io.outOff[sig] = sig * sb;

@@ -47,8 +47,8 @@ def test_error_convention(request, api, which):
     b = request.getfixturevalue(which)
     nrd = api.Integration(b)
     D = api.Denoiser
-    # unsupported denoiser and duplicate identifiers are reported, not raised (sample: "!= SUCCESS -> return false")
-    assert nrd.recreate([(0, D.REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION)], 64, 64) == api.Result.UNSUPPORTED
+    # unknown denoiser and duplicate identifiers are reported, not raised (sample: "!= SUCCESS -> return false")
+    assert nrd.recreate([(0, 200)], 64, 64) == api.Result.UNSUPPORTED  # not an nrd::Denoiser enumerator
     assert nrd.recreate([(7, D.REFERENCE), (7, D.SIGMA_SHADOW)], 64, 64) == api.Result.NON_UNIQUE_IDENTIFIER
     assert nrd.recreate([(int(D.REFERENCE), D.REFERENCE)], 64, 64) == api.Result.SUCCESS
     # Denoise before SetCommonSettings / with unknown identifier / with unbound slots fails with INVALID_ARGUMENT

@@ -10,7 +10,8 @@ import util
 @pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"], ["REBLUR_DIFFUSE"],
                                   ["REBLUR_SPECULAR", "SIGMA_SHADOW"], ["RELAX_DIFFUSE_SPECULAR"], ["RELAX_DIFFUSE"], ["RELAX_SPECULAR"],
                                   ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], ["REBLUR_DIFFUSE_OCCLUSION"], ["REBLUR_SPECULAR_OCCLUSION"],
-                                  ["REBLUR_DIFFUSE_SPECULAR_SH"], ["REBLUR_SPECULAR_SH"], ["RELAX_DIFFUSE_SPECULAR_SH"], ["RELAX_DIFFUSE_SH"]])
+                                  ["REBLUR_DIFFUSE_SPECULAR_SH"], ["REBLUR_SPECULAR_SH"], ["RELAX_DIFFUSE_SPECULAR_SH"], ["RELAX_DIFFUSE_SH"],
+                                  ["REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION"]])
 def test_emulated_kernels_bit_exact(pkg, api, oracle, emulated, dens):
     w, h = 72, 40  # not a multiple of 16: exercises partial tiles
     scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")

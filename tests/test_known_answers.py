@@ -355,3 +355,32 @@ def test_sh_fixed_point_and_linearity(request, pkg, api, backend, den):
     else:  # RELAX outputs linear RGB in SH0 while SH1 stays in its own space: just require a denoised, finite SH1
         sh1 = hz.output("out_diff_sh1").astype(np.float32)
         assert np.isfinite(sh1).all() and sh1[8:-8, 8:-8, 0].std() < 0.5 * fr["diff_sh1"].astype(np.float32)[8:-8, 8:-8, 0].std()
+
+
+def test_directional_occlusion_fixed_point_and_layout(pkg, api, oracle):
+    """REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION (Source/NRDSample.cpp:488-491): one {direction * h, h} texel in and out. A constant
+    texel on a static flat plane is a fixed point of the whole pipeline; the split screen returns the noisy texel."""
+    D = api.Denoiser
+    w, h = 48, 32
+    dens = [D.REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION]
+    hz = pkg.harness.Harness(oracle, dens, w, h)
+    names = None
+    texel = np.array([0.1, -0.2, 0.3, 0.5], np.float16)
+    for f in range(4):
+        fr = util.flat_frame(pkg, w, h)
+        fr["diff_dirocc"] = np.broadcast_to(texel, (h, w, 4)).copy()
+        cs = util.static_common(api, w, h, frame_index=f, reset=(f == 0))
+        hz.frame(cs, hz.upload(fr), {dens[0]: api.ReblurSettings()})
+        assert util.max_ulp_f16(hz.output("out_diff_dirocc"), fr["diff_dirocc"]) <= 2, f
+        names = [x["name"] for x in hz.nrd.dispatches([int(dens[0])])]
+    assert names[:3] == ["REBLUR::ClassifyTiles", "REBLUR::PrepareInputs", "REBLUR::PrePass"]  # the split into SH0 / SH1 halves
+    # split screen: left half shows the (noisy) input texel
+    rng = np.random.default_rng(0)
+    fr = util.flat_frame(pkg, w, h)
+    fr["diff_dirocc"] = (np.broadcast_to(texel, (h, w, 4)) * (1 + 0.3 * rng.standard_normal((h, w, 1)))).astype(np.float16)
+    cs = util.static_common(api, w, h, frame_index=4)
+    cs.splitScreen = 0.5
+    hz.frame(cs, hz.upload(fr), {dens[0]: api.ReblurSettings()})
+    out = hz.output("out_diff_dirocc")
+    assert np.array_equal(out[:, : w // 2].view(np.uint16), fr["diff_dirocc"][:, : w // 2].view(np.uint16))
+    assert not np.array_equal(out[:, w // 2:].view(np.uint16), fr["diff_dirocc"][:, w // 2:].view(np.uint16))

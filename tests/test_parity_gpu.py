@@ -22,6 +22,7 @@ VARIANTS = [
     ["REBLUR_DIFFUSE_SH", "REBLUR_SPECULAR_SH"],
     ["RELAX_DIFFUSE_SPECULAR_SH"],
     ["RELAX_DIFFUSE_SH", "RELAX_SPECULAR_SH"],
+    ["REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION"],
 ]
 
 

@@ -13,7 +13,7 @@ def hooks(pkg, api, checker, holes, seed=3):
 
     def hook(f, fr):
         if holes:
-            for key in ("diff", "spec"):
+            for key in ("diff", "spec", "diff_dirocc"):
                 if key in fr:
                     a = np.array(fr[key])
                     m = rng.random(a.shape[:2]) < 0.4
@@ -106,7 +106,7 @@ def test_hit_distance_reconstruction_fills_holes(pkg, api, oracle):
 @pytest.mark.parametrize("dens,checker,recon", [
     (["REBLUR_DIFFUSE_SPECULAR"], "WHITE", "AREA_5X5"), (["REBLUR_DIFFUSE"], "BLACK", None), (["REBLUR_SPECULAR"], None, "AREA_3X3"),
     (["RELAX_DIFFUSE_SPECULAR_SH"], "WHITE", "AREA_3X3"), (["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], "WHITE", "AREA_3X3"),
-    (["REBLUR_DIFFUSE_SPECULAR_SH"], "BLACK", None)])
+    (["REBLUR_DIFFUSE_SPECULAR_SH"], "BLACK", None), (["REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION"], "WHITE", "AREA_3X3")])
 def test_prepare_inputs_emulated_bit_exact(pkg, api, oracle, emulated, dens, checker, recon):
     w, h = 56, 40
     scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")

@@ -58,7 +58,7 @@ def run_frames(api, harness_mod, backend, scene, denoisers, nframes, settings=No
 def compare_all(ha, hb, exact=True, ulp=1):
     """compare outputs and every pool plane of two harnesses; returns list of (name, detail) mismatches"""
     bad = []
-    for key in ("out_diff", "out_spec", "out_diff_sh1", "out_spec_sh1"):
+    for key in ("out_diff", "out_spec", "out_diff_sh1", "out_spec_sh1", "out_diff_dirocc"):
         a, b = ha.fetch(ha.outputs[key]), hb.fetch(hb.outputs[key])
         if exact:
             if not np.array_equal(a, b):
