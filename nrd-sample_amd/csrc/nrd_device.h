@@ -78,11 +78,6 @@ NRD_DEV f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 NRD_DEV f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 NRD_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 NRD_DEV f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-NRD_DEV f3 normalize3(f3 a) {
-    float l2 = dot3(a, a);
-    float inv = 1.0f / __builtin_sqrtf(fmax2(l2, 1e-30f));
-    return mul3(a, inv);
-}
 NRD_DEV f3 rot3(const float* m, f3 v) {
     return {fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[5], v.z, fma_(m[4], v.y, m[3] * v.x)), fma_(m[8], v.z, fma_(m[7], v.y, m[6] * v.x))};
 }
@@ -92,6 +87,37 @@ NRD_DEV f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b
 
 NRD_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 NRD_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ---- software reciprocal / reciprocal square root (numerics contract) ---------------------------------------------
+// IEEE a / b and sqrt() expand to ~10 instructions around a quarter-rate v_rcp_f32 / v_sqrt_f32 on gfx950 (~13 issue slots); the
+// per-pixel set-up of every pass is full of them. These are plain fma sequences (7 and 12 full-rate instructions) the CPU
+// oracle repeats bit for bit: magic-constant seed + 3 Newton steps. rcp_ is correctly rounded for > 99.99 % of inputs
+// (max 0.5 ulp), rsqrt_ is good to 1.3e-7 relative. Domain: positive, normal, finite x (the call sites guarantee it).
+NRD_DEV float rcp_(float x) {
+    float r = u2f(0x7EF311C7u - f2u(x));
+    r = fma_(r, fma_(-x, r, 1.0f), r);
+    r = fma_(r, fma_(-x, r, 1.0f), r);
+    r = fma_(r, fma_(-x, r, 1.0f), r);
+    return r;
+}
+NRD_DEV float rcps_(float x) { // any sign
+    float r = rcp_(x < 0.0f ? -x : x);
+    return x < 0.0f ? -r : r;
+}
+NRD_DEV float rsqrt_(float x) {
+    float h = 0.5f * x;
+    float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
+    r = r * fma_(-(h * r), r, 1.5f);
+    r = r * fma_(-(h * r), r, 1.5f);
+    r = r * fma_(-(h * r), r, 1.5f);
+    return r;
+}
+NRD_DEV float sqrt_(float x) { return x * rsqrt_(x); } // sqrt_(0) = 0
+NRD_DEV f3 normalize3(f3 a) {
+    float l2 = dot3(a, a);
+    float inv = rsqrt_(fmax2(l2, 1e-30f));
+    return mul3(a, inv);
+}
 
 // ---- fp16 (hardware RNE converts, denormals on) ------------------------------------------------------------------
 #define NRD_FP16_MAX 65504.0f
@@ -152,7 +178,7 @@ NRD_DEV float pow01(float x, float y) {
 
 NRD_DEV float atan_pos(float x) {
     bool inv = x > 1.0f;
-    float t = inv ? 1.0f / x : x;
+    float t = inv ? rcp_(x) : x;
     float s = t * t;
     float p = 0.0208351f;
     p = fma_(p, s, -0.0851330f);
@@ -223,7 +249,7 @@ NRD_DEV f4 rgb_to_ycocg4(f4 v) {
 
 NRD_DEV float spec_magic_curve(float roughness) {
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
-    return f * __builtin_sqrtf(sat(roughness));
+    return f * sqrt_(sat(roughness));
 }
 
 NRD_DEV float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
@@ -239,7 +265,7 @@ NRD_DEV float spec_lobe_half_angle(float roughness) {
 
 NRD_DEV float spec_dominant_factor(float roughness) {
     float s = sat(1.0f - roughness);
-    return s * (__builtin_sqrtf(s) + roughness);
+    return s * (sqrt_(s) + roughness);
 }
 
 NRD_HD uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
@@ -252,7 +278,7 @@ NRD_HD uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
 
 NRD_DEV void basis3(f3 n, f3& t, f3& b) {
     float sz = n.z >= 0.0f ? 1.0f : -1.0f;
-    float a = -1.0f / (sz + n.z);
+    float a = -rcps_(sz + n.z);
     float bb = n.x * n.y * a;
     t = {1.0f + sz * n.x * n.x * a, sz * bb, -sz * n.x};
     b = {bb, sz + n.y * n.y * a, -n.y};
@@ -264,7 +290,7 @@ NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
     float cw = pj[4] * X.z;
     if (!(cw > 1e-6f))
         return false;
-    float inv = 1.0f / cw;
+    float inv = rcp_(cw);
     u = 0.5f + 0.5f * ((pj[0] * X.x + pj[2] * X.z) * inv);
     v = 0.5f - 0.5f * ((pj[1] * X.y + pj[3] * X.z) * inv);
     return true;
@@ -284,7 +310,7 @@ NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, 
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
     p.frustumSize = c.minRectDimMulUnproject * p.absZ;
-    float geoA = 1.0f / (planeDistSensitivity * p.frustumSize);
+    float geoA = rcp_(planeDistSensitivity * p.frustumSize);
     p.gax = p.Nv.x * c.pv[2] * geoA;
     p.gay = p.Nv.y * c.pv[3] * geoA;
     p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;

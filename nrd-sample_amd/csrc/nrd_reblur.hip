@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             int sx = checker ? x >> 1 : x;
             load_pair(sx, y, v, v1);
         } else { // checkerboard resolve from the left / right neighbours (they carry this signal)
-            float invDz = 1.0f / (0.03f * fmax2(absf(g.z), 1e-6f));
+            float invDz = rcp_(0.03f * fmax2(absf(g.z), 1e-6f));
             float wn[2];
             bool ok[2];
             f4 vn[2], v1n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
             f4 acc1 = wn[0] > 0.0f ? mul4(v1n[0], wn[0]) : f4{0, 0, 0, 0};
             acc1 = wn[1] > 0.0f ? fma4(v1n[1], wn[1], acc1) : acc1;
-            float inv = 1.0f / wsum;
+            float inv = rcp_(wsum);
             v = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
             v1 = wsum > 0.0f ? mul4(acc1, inv) : f4{0, 0, 0, 0};
         }
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             float rough = isSpec ? g.roughness : 1.0f;
             uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
             float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
-            float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+            float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
             float normalW2 = normalW * normalW;
-            float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+            float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             float roughB = -rough * roughA;
             float sum = 0.0f, wsum = 0.0f;
             for (int j = -p.reconRadius; j <= p.reconRadius; j++)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                     wsum += w;
                 }
             if (wsum > 0.0f)
-                v.w = sum * (1.0f / wsum);
+                v.w = sum * (rcp_(wsum));
         }
         if (occ || dirOcc)
             v = {v.w, 0.0f, 0.0f, v.w};
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
     f3 V = mul3(normalize3(pg.Xv), -1.0f);
     // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane)
-    float inv = 1.0f / (c.pj[4] * g.z);
+    float inv = rcps_(c.pj[4] * g.z);
     float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
     float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
     float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
@@ -297,9 +297,9 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
         f4 sum1 = SH ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
         float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
         float hitDist = center.w * hitNorm;
-        float hitDistFactor = sat(hitDist / pg.frustumSize);
+        float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
         float A = isSpec ? specA : diffA;
-        float nonLin = VARIANT == 0 ? 1.0f : 1.0f / (1.0f + A);
+        float nonLin = VARIANT == 0 ? 1.0f : rcp_(1.0f + A);
         float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
         float radius;
         if (VARIANT == 0) {
@@ -336,12 +336,12 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
             float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
             float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
-            float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+            float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
             float normalW2 = normalW * normalW;
-            float hitScale = relaxIn ? 1.0f / fmax2(center.w, 1e-3f) : 1.0f; // RELAX hit distances are world units: compare relatively
-            float hitA = hitScale / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
+            float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
+            float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
             float hitB = -center.w * hitA;
-            float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+            float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             float roughB = -rough * roughA;
             const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
 #pragma unroll
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                 minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
             }
         }
-        float invw = 1.0f / wsum;
+        float invw = rcp_(wsum);
         st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, invw)), sig * sb);
         if (SH)
             st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum1, invw)), sig * sb + 8);
@@ -442,106 +442,6 @@ struct Footprint {
     uint32_t bits;
 };
 
-NRD_DEV Footprint footprint(const ReblurParams& p, float pu, float pv, f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
-    const FrameConsts& c = p.c;
-    Footprint f;
-    float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
-    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-    float fx = px - fx0, fy = py - fy0;
-    bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
-    f.ix = sane ? (int)fx0 : -4;
-    f.iy = sane ? (int)fy0 : -4;
-    float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
-    f.wsum = 0.0f;
-    f.bits = 0;
-    float planeRef = dot3(NvPrev, XvPrev);
-    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
-    float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
-    // the four guide texels are fetched unconditionally at clamped addresses (one round trip), then validated
-    uint4 graw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tx = f.ix + (i & 1), ty = f.iy + (i >> 1) - c.yOff;
-        tx = tx < 0 ? 0 : (tx >= c.Wprev ? c.Wprev - 1 : tx);
-        ty = ty < 0 ? 0 : (ty >= c.resH ? c.resH - 1 : ty);
-        graw[i] = ld<uint4>(p.guidePrev, tx, ty, 16);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
-        bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
-        if (ok) {
-            Guide gp = decode_guide(graw[i], c.denoisingRange);
-            float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
-            ok = !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
-        }
-        f.w[i] = ok ? bw[i] : 0.0f;
-        f.wsum += f.w[i];
-        f.bits |= ok ? (1u << i) : 0u;
-    }
-    return f;
-}
-
-// footprint fetches: the four texels are loaded unconditionally at clamped addresses (independent loads, one round trip);
-// only taps with a non-zero weight are accumulated, so rejected texels never reach the result
-NRD_DEV void tap_xy(const FrameConsts& c, const Footprint& f, int i, int& tx, int& ty) {
-    tx = f.ix + (i & 1);
-    ty = f.iy + (i >> 1) - c.yOff;
-    tx = tx < 0 ? 0 : (tx >= c.Wprev ? c.Wprev - 1 : tx);
-    ty = ty < 0 ? 0 : (ty >= c.resH ? c.resH - 1 : ty);
-}
-NRD_DEV f4 fetch4(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
-    uint2 raw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tx, ty;
-        tap_xy(c, f, i, tx, ty);
-        raw[i] = ld<uint2>(P, tx, ty, bpt, off);
-    }
-    f4 s = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (f.w[i] > 0.0f)
-            s = fma4(unpack_h4(raw[i]), f.w[i], s);
-    return mul4(s, 1.0f / f.wsum);
-}
-NRD_DEV float fetch1(const FrameConsts& c, const PlaneRef& P, int bpt, int off, const Footprint& f) {
-    uint16_t raw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tx, ty;
-        tap_xy(c, f, i, tx, ty);
-        raw[i] = ld<uint16_t>(P, tx, ty, bpt, off);
-    }
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (f.w[i] > 0.0f)
-            s = fma_(h2f(raw[i]), f.w[i], s);
-    return s * (1.0f / f.wsum);
-}
-NRD_DEV void fetchA(const FrameConsts& c, const PlaneRef& P, const Footprint& f, float& dA, float& sA) {
-    uint16_t raw[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int tx, ty;
-        tap_xy(c, f, i, tx, ty);
-        raw[i] = ld<uint16_t>(P, tx, ty, 2);
-    }
-    dA = sA = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (f.w[i] > 0.0f) {
-            float a, b;
-            unpack_data1(raw[i], a, b);
-            dA = fma_(a, f.w[i], dA);
-            sA = fma_(b, f.w[i], sA);
-        }
-    float inv = 1.0f / f.wsum;
-    dA *= inv;
-    sA *= inv;
-}
-
 NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
     f3 toCam = normalize3(r.Xw);
     float f = spec_dominant_factor(roughness);
@@ -568,9 +468,9 @@ NRD_DEV float sample_confidence(const PlaneRef& P, float u, float v) {
 
 NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
     float acos01sq = sat(1.0f - NoV * 0.99999f);
-    float a = __builtin_sqrtf(acos01sq);
+    float a = sqrt_(acos01sq);
     float b = fma_(roughness, roughness, 1.1f);
-    float parallaxSensitivity = (b + a) / (b - a);
+    float parallaxSensitivity = (b + a) * rcp_(b - a);
     float powerScale = fma_(parallaxSensitivity * parallaxPx, 2.0f, 1.0f);
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
     f *= pow01(roughness, 0.5f * powerScale);
@@ -623,7 +523,7 @@ NRD_DEV void load_foot(const ReblurParams& p, const FootPos& fp, FootRaw<RBPT, L
         r.m[i] = RELAX ? load_luma(p.stabPrev, tx, ty, LBPT) : 0u;
     }
 }
-// validation of the four texels (same tests, same order as footprint())
+// validation of the four texels of a footprint
 NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const uint4 (&graw)[4], f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
     Footprint f;
     f.ix = fp.ix;
@@ -648,7 +548,7 @@ NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const ui
     }
     return f;
 }
-// weighted texel blends of an already fetched footprint (identical arithmetic to fetch4 / fetch1 / fetchA)
+// weighted texel blends of an already fetched footprint
 template <int WORDS>
 NRD_DEV f4 blend4(const Footprint& f, const uint2 (&t)[4][WORDS], int word) {
     f4 s = {0, 0, 0, 0};
@@ -658,7 +558,7 @@ NRD_DEV f4 blend4(const Footprint& f, const uint2 (&t)[4][WORDS], int word) {
         bool on = f.w[i] > 0.0f;
         s = {on ? acc.x : s.x, on ? acc.y : s.y, on ? acc.z : s.z, on ? acc.w : s.w};
     }
-    return mul4(s, 1.0f / f.wsum);
+    return mul4(s, rcp_(f.wsum));
 }
 NRD_DEV float blend1(const Footprint& f, const uint32_t (&r)[4], int half) {
     float s = 0.0f;
@@ -667,7 +567,7 @@ NRD_DEV float blend1(const Footprint& f, const uint32_t (&r)[4], int half) {
         float acc = fma_(h2f((uint16_t)(r[i] >> (16 * half))), f.w[i], s);
         s = f.w[i] > 0.0f ? acc : s;
     }
-    return s * (1.0f / f.wsum);
+    return s * (rcp_(f.wsum));
 }
 NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, float& sA) {
     dA = sA = 0.0f;
@@ -679,7 +579,7 @@ NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, flo
         dA = on ? fma_(a, f.w[i], dA) : dA;
         sA = on ? fma_(b, f.w[i], sA) : sA;
     }
-    float inv = 1.0f / f.wsum;
+    float inv = rcp_(f.wsum);
     dA *= inv;
     sA *= inv;
 }
@@ -757,8 +657,8 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         f4 in = unpack_h4(ctex[0]);
         float A = prevDiffA;
         A *= confD;
-        A *= lerpf(quality, 1.0f, 1.0f / (1.0f + A));
-        float nonLin = 1.0f / (1.0f + A);
+        A *= lerpf(quality, 1.0f, rcp_(1.0f + A));
+        float nonLin = rcp_(1.0f + A);
         f4 hist = smbOk ? blend4(smb, sraw.t, 0) : in;
         float fastHist = smbOk ? blend1(smb, sraw.f, 0) : in.x;
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), 0);
@@ -767,7 +667,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
             f4 hist1 = smbOk ? blend4(smb, sraw.t, S1) : in1;
             st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist1, in1, nonLin)), 8);
         }
-        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastA)))), 0);
+        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastA)))), 0);
         if (RELAX) { // second luma moment history (lives in the stabilized-luma slots)
             float m2 = in.x * in.x;
             float m2prev = smbOk ? blend1(smb, sraw.m, 0) : m2;
@@ -784,7 +684,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         float pu, pv, parallax = 0.0f;
         if (project(c.pj, XparV, pu, pv)) {
             float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
-            parallax = __builtin_sqrtf(fma_(dx, dx, dy * dy));
+            parallax = sqrt_(fma_(dx, dx, dy * dy));
         }
         float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
         Footprint vmb = foot_weights(c, vpos, vraw.g, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
@@ -793,7 +693,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         // roughness of the virtual footprint: guide texel bytes 10..11 = upper half of .z
         uint32_t rr[4] = {vraw.g[0].z, vraw.g[1].z, vraw.g[2].z, vraw.g[3].z};
         float prevRough = blend1(vmb, rr, 1);
-        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction));
+        float roughA = rcp_(lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction)));
         float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
         float amount = vmbOk ? spec_dominant_factor(g.roughness) * vmb.wsum * rconf : 0.0f;
         float dA, sA;
@@ -808,12 +708,12 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         float A = lerpf(Asmb, Avmb, amount);
         A *= confS;
         float q = lerpf(quality, 1.0f, amount);
-        A *= lerpf(q, 1.0f, 1.0f / (1.0f + A));
+        A *= lerpf(q, 1.0f, rcp_(1.0f + A));
         if (p.responsiveRoughnessThreshold > 0.0f) {
             float t = smoothstep01(g.roughness / p.responsiveRoughnessThreshold);
             A = fmin2(A, lerpf(p.responsiveMinAccum, p.maxASpec, t));
         }
-        float nonLin = 1.0f / (1.0f + A);
+        float nonLin = rcp_(1.0f + A);
         f4 hist = lerp4(smbHist, vmbHist, amount);
         float fastHist = lerpf(smbFast, vmbFast, amount);
         st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
@@ -823,7 +723,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
             f4 vmb1 = vmbOk ? blend4(vmb, vraw.t, sw + S1) : in1;
             st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin)), so + 8);
         }
-        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, p.maxFastASpec)))), lo);
+        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastASpec)))), lo);
         if (RELAX) {
             float m2 = in.x * in.x;
             float m2smb = smbOk ? blend1(smb, sraw.m, SIG_SPEC) : m2;
@@ -925,10 +825,10 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                     pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
                     geoReady = true;
                 }
-                float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, 1.0f / (1.0f + Acur));
-                float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, rcp_(1.0f + Acur));
+                float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                 float normalW2 = normalW * normalW;
-                float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+                float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
                 float roughB = -rough * roughA;
                 f4 sum = mul4(val, 1.0f + Acur);
                 f4 sum1 = mul4(val1, 1.0f + Acur);
@@ -943,7 +843,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                         Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
                         if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                             continue;
-                        float w = 1.0f / (1.0f + (float)(i * i + j * j));
+                        float w = rcp_(1.0f + (float)(i * i + j * j));
                         w *= geo_weight(pg, (float)px, (float)gy, gs.z);
                         w *= normal_weight(dot3(g.n, gs.n), normalW2);
                         if (isSpec)
@@ -956,25 +856,25 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                             sum1 = fma4(unpack_h4(ld<uint2>(p.tmp2, px, py, RBPT, sig * sb + 8)), w, sum1);
                         wsum += w;
                     }
-                val = mul4(sum, 1.0f / wsum);
-                val1 = mul4(sum1, 1.0f / wsum);
+                val = mul4(sum, rcp_(wsum));
+                val1 = mul4(sum1, rcp_(wsum));
             }
         }
         if (p.clampEnabled) {
             float fc = h2f(ld<uint16_t>(p.fast, x, y, LBPT, sig * 2));
             float m1, m2;
             moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, m1, m2);
-            float sigma = __builtin_sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fastHistoryClampingSigmaScale;
+            float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fastHistoryClampingSigmaScale;
             float Y = val.x;
             float Yc = clampf(Y, m1 - sigma, m1 + sigma);
-            float scale = (Yc + 1e-6f) / (Y + 1e-6f);
+            float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
             val.x = Yc;
             val.y *= scale;
             val.z *= scale;
             val1.x *= scale;
             val1.y *= scale;
             val1.z *= scale;
-            float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
+            float f = sat(absf(Yc - Y) * rcp_(fmax2(fmax2(Y, Yc), 1e-6f)));
             outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? p.maxFastASpec : p.maxFastA), f);
         }
         st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * sb);
@@ -1008,7 +908,7 @@ NRD_DEV bool blend_stab(const FootPos& fp, const uint32_t (&raw)[4], int half, u
         sum = on ? acc : sum;
         wsum = on ? wsum + bw[i] : wsum;
     }
-    out = sum * (1.0f / wsum);
+    out = sum * (rcp_(wsum));
     return fp.sane && wsum > 0.0f;
 }
 
@@ -1096,7 +996,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         f4 cur = unpack_h4(ctex[sig * SW]);
         float m1, m2;
         moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, m1, m2);
-        float sigma = __builtin_sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f));
+        float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f));
         float smbY, vmbY = 0.0f;
         bool smbOk = blend_stab(spos, sraw, sig, data2 & 15u, smbY) && historyOk;
         bool vmbOk = false;
@@ -1107,13 +1007,13 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         float Acur = A[isSpec ? 1 : 0];
         float Y = cur.x;
         float band = sigma * p.antilagSigmaScale;
-        float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) / (fmax2(Yhist, m1) + 1e-6f);
-        float antilag = 1.0f / fma_(dlt * p.antilagSensitivity, Acur, 1.0f);
+        float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) * rcps_(fmax2(Yhist, m1) + 1e-6f);
+        float antilag = rcps_(fma_(dlt * p.antilagSensitivity, Acur, 1.0f));
         float Yclamped = clampf(Yhist, m1 - band, m1 + band);
         float stabFrames = have ? fmin2(Acur, p.maxStab) * antilag : 0.0f;
-        float wHist = stabFrames / (1.0f + stabFrames);
+        float wHist = stabFrames * rcp_(1.0f + stabFrames);
         float Yout = lerpf(Y, Yclamped, wHist);
-        float scale = (Yout + 1e-6f) / (Y + 1e-6f);
+        float scale = (Yout + 1e-6f) * rcps_(Y + 1e-6f);
         f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
         st<uint16_t>(p.stab, x, y, LBPT, f2h(Yout), sig * 2);
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
@@ -1215,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                         sy2 = fma_(Y, Y, sy2);
                         n += 1.0f;
                     }
-                float inv = 1.0f / n;
+                float inv = rcp_(n);
                 float my = sy * inv;
                 var = fmax2(var, fmax2(fma_(-my, my, sy2 * inv), 0.0f));
             }
@@ -1223,13 +1123,13 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 var = fma_(var, p.specularVarianceBoost, var);
         } else
             var = c0[sig].w;
-        float sigma = __builtin_sqrtf(var);
-        invL[sig] = 0.3333f / fma_(p.phi[si], sigma, 1e-4f);
+        float sigma = sqrt_(var);
+        invL[sig] = 0.3333f * rcp_(fma_(p.phi[si], sigma, 1e-4f));
         float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
-        float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+        float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
         normalW2[sig] = normalW * normalW;
         if (isSpec) {
-            roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction));
+            roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             roughB = -rough * roughA;
         }
         sum[sig] = {c0[sig].x, c0[sig].y, c0[sig].z};
@@ -1287,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-        float inv = 1.0f / wsum[sig];
+        float inv = rcp_(wsum[sig]);
         f3 o = mul3(sum[sig], inv);
         float ov = sumVar[sig] * inv * inv;
         if (last) {

@@ -95,7 +95,7 @@ static inline bool project(const float* pj, f3 X, float& u, float& v) {
     float cw = pj[4] * X.z;
     if (!(cw > 1e-6f))
         return false;
-    float inv = 1.0f / cw;
+    float inv = rcp_(cw);
     u = 0.5f + 0.5f * ((pj[0] * X.x + pj[2] * X.z) * inv);
     v = 0.5f - 0.5f * ((pj[1] * X.y + pj[3] * X.z) * inv);
     return true;

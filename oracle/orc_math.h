@@ -36,6 +36,32 @@ static inline float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
 static inline float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
 // fused multiply-add: ONE rounding (hardware FMA on both sides: x86 -mfma / v_fma_f32); everything else stays unfused
 static inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ---- software reciprocal / reciprocal square root (numerics contract) ---------------------------------------------
+// The kernels avoid IEEE divide / sqrt in the per-pixel set-up (quarter-rate v_rcp_f32 / v_sqrt_f32 + fix-up code on gfx950);
+// these plain fma sequences are the frozen definition both sides execute bit for bit: magic-constant seed + 3 Newton steps.
+// rcp_ is correctly rounded for > 99.99 % of inputs (max 0.5 ulp), rsqrt_ is good to 1.3e-7 relative.
+// Domain: positive, normal, finite x (the call sites guarantee it).
+static inline float rcp_(float x) {
+    float r = u2f(0x7EF311C7u - f2u(x));
+    r = fma_(r, fma_(-x, r, 1.0f), r);
+    r = fma_(r, fma_(-x, r, 1.0f), r);
+    r = fma_(r, fma_(-x, r, 1.0f), r);
+    return r;
+}
+static inline float rcps_(float x) { // any sign
+    float r = rcp_(x < 0.0f ? -x : x);
+    return x < 0.0f ? -r : r;
+}
+static inline float rsqrt_(float x) {
+    float h = 0.5f * x;
+    float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
+    r = r * fma_(-(h * r), r, 1.5f);
+    r = r * fma_(-(h * r), r, 1.5f);
+    r = r * fma_(-(h * r), r, 1.5f);
+    return r;
+}
+static inline float sqrt_(float x) { return x * rsqrt_(x); } // sqrt_(0) = 0
 static inline float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 static inline float smoothstep01(float x) { x = sat(x); return x * x * (3.0f - 2.0f * x); }
 static inline float absf(float x) { return x < 0.0f ? -x : x; }
@@ -47,7 +73,7 @@ static inline float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x 
 static inline f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 static inline f3 normalize3(f3 a) {
     float l2 = dot3(a, a);
-    float inv = 1.0f / sqrtf(fmax2(l2, 1e-30f));
+    float inv = rsqrt_(fmax2(l2, 1e-30f));
     return mul3(a, inv);
 }
 // 3x3 matrix (row-major m[r*3+c]) times vector
@@ -164,7 +190,7 @@ static inline float pow01(float x, float y) {
 // atan(x), x >= 0 (Abramowitz-Stegun 4.4.49 on [0,1], reflected above 1)
 static inline float atan_pos(float x) {
     bool inv = x > 1.0f;
-    float t = inv ? 1.0f / x : x;
+    float t = inv ? rcp_(x) : x;
     float s = t * t;
     float p = 0.0208351f;
     p = fma_(p, s, -0.0851330f);
@@ -253,7 +279,7 @@ static inline f3 ycocg_to_linear(f3 c) {
 // (1 - 2^(-200 r^2)) * sqrt(r)   [Shaders/Shared.hlsli:305-311]
 static inline float spec_magic_curve(float roughness) {
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
-    return f * sqrtf(sat(roughness));
+    return f * sqrt_(sat(roughness));
 }
 
 // REBLUR hit distance normalisation: (A + |z| B) * lerp(1, C, 2^(D r^2))
@@ -272,7 +298,7 @@ static inline float spec_lobe_half_angle(float roughness) {
 // Frostbite-style dominant direction factor
 static inline float spec_dominant_factor(float roughness) {
     float s = sat(1.0f - roughness);
-    return s * (sqrtf(s) + roughness);
+    return s * (sqrt_(s) + roughness);
 }
 
 // integer hash -> rotation table index
@@ -287,7 +313,7 @@ static inline uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t 
 // tangent basis of a unit vector (branchless Frisvad/Duff form)
 static inline void basis3(f3 n, f3& t, f3& b) {
     float sz = n.z >= 0.0f ? 1.0f : -1.0f;
-    float a = -1.0f / (sz + n.z);
+    float a = -rcps_(sz + n.z);
     float bb = n.x * n.y * a;
     t = {1.0f + sz * n.x * n.x * a, sz * bb, -sz * n.x};
     b = {bb, sz + n.y * n.y * a, -n.y};

@@ -144,7 +144,7 @@ static inline PixelGeo pixel_geo(const Consts& c, const Guide& g, int x, int gy,
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
     p.frustumSize = c.minRectDimMulUnproject * p.absZ;
-    float geoA = 1.0f / (planeDistSensitivity * p.frustumSize);
+    float geoA = rcp_(planeDistSensitivity * p.frustumSize);
     p.gax = p.Nv.x * c.pv[2] * geoA;
     p.gay = p.Nv.y * c.pv[3] * geoA;
     p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
@@ -233,7 +233,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                     int sx = m.checker ? x >> 1 : x;
                     load_pair(sx, y, v, v1);
                 } else { // checkerboard resolve from the left / right neighbours (they carry this signal)
-                    float invDz = 1.0f / (0.03f * fmax2(absf(g.z), 1e-6f));
+                    float invDz = rcp_(0.03f * fmax2(absf(g.z), 1e-6f));
                     float wn[2];
                     bool ok[2];
                     f4 vn[2], v1n[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -256,7 +256,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                     acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
                     f4 acc1 = wn[0] > 0.0f ? mul4(v1n[0], wn[0]) : f4{0, 0, 0, 0};
                     acc1 = wn[1] > 0.0f ? fma4(v1n[1], wn[1], acc1) : acc1;
-                    float inv = 1.0f / wsum;
+                    float inv = rcp_(wsum);
                     v = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
                     v1 = wsum > 0.0f ? mul4(acc1, inv) : f4{0, 0, 0, 0};
                 }
@@ -265,9 +265,9 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                     float rough = isSpec ? g.roughness : 1.0f;
                     uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
                     float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
-                    float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                    float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                     float normalW2 = normalW * normalW;
-                    float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                    float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
                     float sum = 0.0f, wsum = 0.0f;
                     for (int j = -m.radius; j <= m.radius; j++)
@@ -295,7 +295,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                             wsum += w;
                         }
                     if (wsum > 0.0f)
-                        v.w = sum * (1.0f / wsum);
+                        v.w = sum * (rcp_(wsum));
                 }
                 if (d.occlusion || d.dirOcc)
                     v = {v.w, 0.0f, 0.0f, v.w};
@@ -349,7 +349,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
             PixelGeo pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
             f3 V = mul3(normalize3(pg.Xv), -1.0f);
             // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane)
-            float inv = 1.0f / (c.pj[4] * g.z);
+            float inv = rcps_(c.pj[4] * g.z);
             float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
             float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
             float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
@@ -372,9 +372,9 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
                 float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
                 float hitDist = center.w * hitNorm;
-                float hitDistFactor = sat(hitDist / pg.frustumSize);
+                float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
                 float A = isSpec ? specA : diffA;
-                float nonLin = variant == PRE ? 1.0f : 1.0f / (1.0f + A);
+                float nonLin = variant == PRE ? 1.0f : rcp_(1.0f + A);
                 float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
                 float radius;
                 if (variant == PRE) {
@@ -413,12 +413,12 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
                     float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
                     float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
-                    float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                    float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                     float normalW2 = normalW * normalW;
-                    float hitScale = relaxIn ? 1.0f / fmax2(center.w, 1e-3f) : 1.0f; // RELAX hit distances are world units: compare relatively
-                    float hitA = hitScale / lerpf(1e-6f, 1.0f, fmin2(nonLin, smc));
+                    float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
+                    float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
                     float hitB = -center.w * hitA;
-                    float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                    float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
                     for (int t = 0; t < 8; t++) {
                         float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
@@ -453,7 +453,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                             minHit = fmin2(minHit, sv.w * hitNorm);
                     }
                 }
-                float invw = 1.0f / wsum;
+                float invw = rcp_(wsum);
                 st_h4(*io.out[sig], x, y, mul4(sum, invw), io.outOff[sig]);
                 if (sh)
                     st_h4(*io.out[sig], x, y, mul4(sum1, invw), io.outOff[sig] + 8);
@@ -547,14 +547,14 @@ static inline f4 fetch4(const Ctx& k, const Plane& P, int off, const Footprint& 
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
             s = fma4(ld_h4(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off), f.w[i], s);
-    return mul4(s, 1.0f / f.wsum);
+    return mul4(s, rcp_(f.wsum));
 }
 static inline float fetch1(const Ctx& k, const Plane& P, int off, const Footprint& f) {
     float s = 0.0f;
     for (int i = 0; i < 4; i++)
         if (f.w[i] > 0.0f)
             s = fma_(ld_h(P, f.ix + (i & 1), f.iy + (i >> 1) - k.c.yOff, off), f.w[i], s);
-    return s * (1.0f / f.wsum);
+    return s * (rcp_(f.wsum));
 }
 static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, float& dA, float& sA) {
     dA = sA = 0.0f;
@@ -565,7 +565,7 @@ static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, floa
             dA = fma_(a, f.w[i], dA);
             sA = fma_(b, f.w[i], sA);
         }
-    float inv = 1.0f / f.wsum;
+    float inv = rcp_(f.wsum);
     dA *= inv;
     sA *= inv;
 }
@@ -602,9 +602,9 @@ static inline float sample_confidence(const Plane& P, float u, float v) {
 // surface-motion specular accumulation limit under parallax
 static inline float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
     float acos01sq = sat(1.0f - NoV * 0.99999f);
-    float a = sqrtf(acos01sq);
+    float a = sqrt_(acos01sq);
     float b = fma_(roughness, roughness, 1.1f);
-    float parallaxSensitivity = (b + a) / (b - a);
+    float parallaxSensitivity = (b + a) * rcp_(b - a);
     float powerScale = fma_(parallaxSensitivity * parallaxPx, 2.0f, 1.0f);
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
     f *= pow01(roughness, 0.5f * powerScale);
@@ -685,8 +685,8 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 float A = prevDiffA;
                 if (c.confAvail)
                     A *= sample_confidence(confD, u, v);
-                A *= lerpf(quality, 1.0f, 1.0f / (1.0f + A));
-                float nonLin = 1.0f / (1.0f + A);
+                A *= lerpf(quality, 1.0f, rcp_(1.0f + A));
+                float nonLin = rcp_(1.0f + A);
                 f4 hist = smbOk ? fetch4(k, HIST, sig * sb, smb) : in;
                 float fastHist = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
                 st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * sb);
@@ -695,7 +695,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                     f4 hist1 = smbOk ? fetch4(k, HIST, sig * sb + 8, smb) : in1;
                     st_h4(OUT, x, y, lerp4(hist1, in1, nonLin), sig * sb + 8);
                 }
-                st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastA))), sig * 2);
+                st_h(FASTC, x, y, lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, maxFastA))), sig * 2);
                 if (relax) {
                     float m2 = in.x * in.x;
                     float m2prev = smbOk ? fetch1(k, MOMP, sig * 2, smb) : m2;
@@ -713,7 +713,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 float pu, pv, parallax = 0.0f;
                 if (project(c.pj, XparV, pu, pv)) {
                     float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
-                    parallax = sqrtf(fma_(dx, dx, dy * dy));
+                    parallax = sqrt_(fma_(dx, dx, dy * dy));
                 }
                 float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
                 // virtual motion
@@ -732,8 +732,8 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                         for (int i = 0; i < 4; i++)
                             if (vmb.w[i] > 0.0f)
                                 prevRough = fma_(guide_roughness(k.guidePrev(), vmb.ix + (i & 1), vmb.iy + (i >> 1) - c.yOff), vmb.w[i], prevRough);
-                        prevRough *= 1.0f / vmb.wsum;
-                        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(g.roughness * s.roughnessFraction));
+                        prevRough *= rcp_(vmb.wsum);
+                        float roughA = rcp_(lerpf(0.01f, 1.0f, sat(g.roughness * s.roughnessFraction)));
                         float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
                         amount = spec_dominant_factor(g.roughness) * vmb.wsum * rconf;
                         float dA, sA;
@@ -751,13 +751,13 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 if (c.confAvail)
                     A *= sample_confidence(confS, u, v);
                 float q = lerpf(quality, 1.0f, amount);
-                A *= lerpf(q, 1.0f, 1.0f / (1.0f + A));
+                A *= lerpf(q, 1.0f, rcp_(1.0f + A));
                 // responsive accumulation for very smooth surfaces
                 if (s.responsiveAccumulationSettings.roughnessThreshold > 0.0f) {
                     float t = smoothstep01(g.roughness / s.responsiveAccumulationSettings.roughnessThreshold);
                     A = fmin2(A, lerpf((float)s.responsiveAccumulationSettings.minAccumulatedFrameNum, maxAs, t));
                 }
-                float nonLin = 1.0f / (1.0f + A);
+                float nonLin = rcp_(1.0f + A);
                 f4 hist = lerp4(smbHist, vmbHist, amount);
                 float fastHist = lerpf(smbFast, vmbFast, amount);
                 st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * sb);
@@ -767,7 +767,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                     f4 vmb1 = vmb.wsum > 0.0f ? fetch4(k, HIST, sig * sb + 8, vmb) : in1;
                     st_h4(OUT, x, y, lerp4(lerp4(smb1, vmb1, amount), in1, nonLin), sig * sb + 8);
                 }
-                st_h(FASTC, x, y, lerpf(fastHist, in.x, 1.0f / (1.0f + fmin2(A, maxFastAs))), sig * 2);
+                st_h(FASTC, x, y, lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, maxFastAs))), sig * 2);
                 if (relax) {
                     float m2 = in.x * in.x;
                     float m2smb = smbOk ? fetch1(k, MOMP, sig * 2, smb) : m2;
@@ -835,10 +835,10 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                             pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
                             geoReady = true;
                         }
-                        float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, 1.0f / (1.0f + Acur));
-                        float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                        float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, rcp_(1.0f + Acur));
+                        float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                         float normalW2 = normalW * normalW;
-                        float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                        float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                         float roughB = -rough * roughA;
                         f4 sum = mul4(val, 1.0f + Acur);
                         f4 sum1 = mul4(val1, 1.0f + Acur);
@@ -853,7 +853,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                 Guide gs = load_guide(G, px, py, c.denoisingRange);
                                 if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                                     continue;
-                                float w = 1.0f / (1.0f + (float)(i * i + j * j));
+                                float w = rcp_(1.0f + (float)(i * i + j * j));
                                 w *= geo_weight(pg, (float)px, (float)gy, gs.z);
                                 w *= normal_weight(dot3(g.n, gs.n), normalW2);
                                 if (isSpec)
@@ -866,8 +866,8 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                     sum1 = fma4(ld_h4(IN, px, py, sig * sb + 8), w, sum1);
                                 wsum += w;
                             }
-                        val = mul4(sum, 1.0f / wsum);
-                        val1 = mul4(sum1, 1.0f / wsum);
+                        val = mul4(sum, rcp_(wsum));
+                        val1 = mul4(sum1, rcp_(wsum));
                     }
                 }
                 // ---- fast history clamping (5x5 moments of the fast luma history)
@@ -888,17 +888,17 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                         }
                     m1 *= 1.0f / 25.0f;
                     m2 *= 1.0f / 25.0f;
-                    float sigma = sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f)) * s.fastHistoryClampingSigmaScale;
+                    float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * s.fastHistoryClampingSigmaScale;
                     float Y = val.x;
                     float Yc = clampf(Y, m1 - sigma, m1 + sigma);
-                    float scale = (Yc + 1e-6f) / (Y + 1e-6f);
+                    float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
                     val.x = Yc;
                     val.y *= scale;
                     val.z *= scale;
                     val1.x *= scale;
                     val1.y *= scale;
                     val1.z *= scale;
-                    float f = sat(absf(Yc - Y) / fmax2(fmax2(Y, Yc), 1e-6f));
+                    float f = sat(absf(Yc - Y) * rcp_(fmax2(fmax2(Y, Yc), 1e-6f)));
                     outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? maxFastAs : maxFastAd), f);
                 }
                 st_h4(OUT, x, y, val, sig * sb);
@@ -989,7 +989,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     }
                 m1 *= 1.0f / 25.0f;
                 m2 *= 1.0f / 25.0f;
-                float sigma = sqrtf(fmax2(fma_(-m1, m1, m2), 0.0f));
+                float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f));
                 // stabilized luma history: surface motion footprint (validity bits from TA), virtual motion for specular
                 auto fetchStab = [&](float pu, float pv, uint32_t bits, float& out) -> bool {
                     float px = fma_(pu, (float)c.Wprev, -0.5f), py = fma_(pv, (float)c.Hprev, -0.5f);
@@ -1008,7 +1008,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                         }
                     if (!(wsum > 0.0f))
                         return false;
-                    out = sum * (1.0f / wsum);
+                    out = sum * (rcp_(wsum));
                     return true;
                 };
                 float Yhist = cur.x;
@@ -1038,13 +1038,13 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 float Acur = A[isSpec ? 1 : 0];
                 float Y = cur.x;
                 float band = sigma * s.antilagSettings.luminanceSigmaScale;
-                float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) / (fmax2(Yhist, m1) + 1e-6f);
-                float antilag = 1.0f / fma_(dlt * s.antilagSettings.luminanceSensitivity, Acur, 1.0f);
+                float dlt = fmax2(absf(Yhist - m1) - band, 0.0f) * rcps_(fmax2(Yhist, m1) + 1e-6f);
+                float antilag = rcps_(fma_(dlt * s.antilagSettings.luminanceSensitivity, Acur, 1.0f));
                 float Yclamped = clampf(Yhist, m1 - band, m1 + band);
                 float stabFrames = have ? fmin2(Acur, maxStab) * antilag : 0.0f;
-                float wHist = stabFrames / (1.0f + stabFrames);
+                float wHist = stabFrames * rcp_(1.0f + stabFrames);
                 float Yout = lerpf(Y, Yclamped, wHist);
-                float scale = (Yout + 1e-6f) / (Y + 1e-6f);
+                float scale = (Yout + 1e-6f) * rcps_(Y + 1e-6f);
                 f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
                 st_h(STABC, x, y, Yout, sig * 2);
                 if (dirOcc) {
@@ -1151,7 +1151,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                                 sy2 = fma_(Y, Y, sy2);
                                 n += 1.0f;
                             }
-                        float inv = 1.0f / n;
+                        float inv = rcp_(n);
                         float my = sy * inv;
                         var = fmax2(var, fmax2(fma_(-my, my, sy2 * inv), 0.0f));
                     }
@@ -1159,14 +1159,14 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         var = fma_(var, s.specularVarianceBoost, var);
                 } else
                     var = c0.w;
-                float sigma = sqrtf(var);
+                float sigma = sqrt_(var);
                 float phi = isSpec ? s.specularPhiLuminance : s.diffusePhiLuminance;
                 float minLw = isSpec ? s.specularMinLuminanceWeight : s.diffuseMinLuminanceWeight;
-                float invL = 0.3333f / fma_(phi, sigma, 1e-4f);
+                float invL = 0.3333f * rcp_(fma_(phi, sigma, 1e-4f));
                 float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
-                float normalW = 1.0f / fmax2(angle, NORMAL_ANGLE_MIN);
+                float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                 float normalW2 = normalW * normalW;
-                float roughA = 1.0f / lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction));
+                float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                 float roughB = -rough * roughA;
                 f3 sum = {c0.x, c0.y, c0.z};
                 float sumVar = var, wsum = 1.0f;
@@ -1196,7 +1196,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         sumVar = fma_(vs, w * w, sumVar);
                         wsum += w;
                     }
-                float inv = 1.0f / wsum;
+                float inv = rcp_(wsum);
                 f3 o = mul3(sum, inv);
                 float ov = sumVar * inv * inv;
                 if (last) {
