@@ -15,6 +15,12 @@ namespace nrdhip {
 
 namespace {
 
+// taps gathered per memory round trip in the spatial passes (8 = all taps of a signal; 4 halves the registers held by loads
+// in flight and buys one more wave per SIMD)
+#ifndef NRD_TAP_BATCH
+#define NRD_TAP_BATCH 8
+#endif
+
 constexpr float MAX_ACCUM = 63.0f;
 constexpr float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
 constexpr float POST_BLUR_RADIUS_SCALE = 2.0f;
@@ -44,6 +50,18 @@ NRD_DEV f4 load_signal(const ReblurParams& p, const PlaneRef& P, int x, int y, i
 NRD_DEV f4 dir_pass(const ReblurParams& p, int x, int y) {
     f4 a = unpack_h4(ld<uint2>(p.inDiff, x, y, 8)), b = unpack_h4(ld<uint2>(p.inDiff1, x, y, 8));
     return {b.x, b.y, b.z, a.x};
+}
+// the same in two steps (gather now, decode later)
+NRD_DEV uint2 load_signal_raw(const PlaneRef& P, int x, int y, int bpt, int off, bool occlusion) {
+    if (!occlusion)
+        return ld<uint2>(P, x, y, bpt, off);
+    return uint2{(uint32_t)ld<uint16_t>(P, x, y, 2), 0u};
+}
+NRD_DEV f4 decode_signal(const ReblurParams& p, uint2 raw, bool occlusion) {
+    if (!occlusion)
+        return unpack_h4(raw);
+    float h = p.ioF16 ? h2f((uint16_t)raw.x) : (float)raw.x * (1.0f / 65535.0f);
+    return {h, 0.0f, 0.0f, h};
 }
 NRD_DEV void store_signal(const ReblurParams& p, const PlaneRef& P, int x, int y, f4 v) {
     if (!p.occlusion) {
@@ -344,48 +362,62 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             float roughB = -rough * roughA;
             const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
+            // Phase 1: positions + ALL gathers of this signal's 8 taps (clamped, always valid addresses), nothing consumed yet.
+            // The tap window [lo, hi] folds the frame bounds, the rows this instance holds and the hard reach of the pass into
+            // one range test per axis. Phase 2 validates and accumulates: a rejected tap is SELECTED out (sums untouched),
+            // exactly like an early "continue". The scheduling barrier keeps the compiler from serialising load -> use pairs
+            // when registers get tight (one memory round trip per signal instead of eight).
+            float fpx[NRD_TAP_BATCH], fpy[NRD_TAP_BATCH];
+            bool inWin[NRD_TAP_BATCH];
+            uint4 graw[NRD_TAP_BATCH];
+            uint2 sraw[NRD_TAP_BATCH], sraw1[NRD_TAP_BATCH];
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                float ox, oy;
-                if (PER_PIXEL) {
-                    ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
-                    oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
-                } else {
-                    ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
-                    oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
+            for (int t0 = 0; t0 < 8; t0 += NRD_TAP_BATCH) {
+#pragma unroll
+                for (int k = 0; k < NRD_TAP_BATCH; k++) {
+                    const int t = t0 + k;
+                    float ox, oy;
+                    if (PER_PIXEL) {
+                        ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+                        oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                    } else {
+                        ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
+                        oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
+                    }
+                    fpx[k] = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
+                    fpy[k] = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
+                    int ipx = (int)__builtin_amdgcn_fmed3f(fpx[k], loXf, hiXf), ipy = (int)__builtin_amdgcn_fmed3f(fpy[k], loYf, hiYf);
+                    inWin[k] = ((uint32_t)(ipx - loX) <= spanX) & ((uint32_t)(ipy - loY) <= spanY);
+                    int px = imin(imax(ipx, loX), hiX), cpy = imin(imax(ipy, loY), hiY) - c.yOff;
+                    graw[k] = ld<uint4>(p.guide, px, cpy, 16);
+                    sraw[k] = load_signal_raw(srcP, px, cpy, srcBpt, srcOff, occIn);
+                    sraw1[k] = SH ? ld<uint2>(src1P, px, cpy, srcBpt, src1Off) : uint2{0u, 0u};
                 }
-                float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
-                float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
-                // Latency: both gathers of the tap are issued UNCONDITIONALLY at a clamped (always valid) address and only
-                // then is the tap validated - one memory round trip per tap instead of three dependent ones. A rejected tap
-                // contributes nothing, exactly like an early "continue". The tap window [lo, hi] folds the frame bounds, the
-                // rows this instance holds and the hard reach of the pass into one range test per axis.
-                int ipx = (int)__builtin_amdgcn_fmed3f(fpx, loXf, hiXf), ipy = (int)__builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
-                bool valid = ((uint32_t)(ipx - loX) <= spanX) & ((uint32_t)(ipy - loY) <= spanY);
-                int px = imin(imax(ipx, loX), hiX), cpy = imin(imax(ipy, loY), hiY) - c.yOff;
-                uint4 graw = ld<uint4>(p.guide, px, cpy, 16);
-                f4 sv = load_signal(p, srcP, px, cpy, srcBpt, srcOff, occIn);
-                f4 sv1 = SH ? unpack_h4(ld<uint2>(src1P, px, cpy, srcBpt, src1Off)) : f4{0, 0, 0, 0};
-                Guide gs = decode_guide(graw, c.denoisingRange);
-                // branch-free from here: a rejected tap is SELECTED out (sums untouched), which is exactly what skipping it
-                // would do, but keeps the unrolled taps in one basic block so their gathers overlap
-                valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
-                float w = g_poisson8[t][2];
-                w *= geo_weight(pg, fpx, fpy, gs.z);
-                w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                if (isSpec)
-                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                if (relaxIn)
-                    sv = rgb_to_ycocg4(sv);
-                w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
-                f4 acc = fma4(sv, w, sum);
-                sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
-                if (SH) {
-                    f4 acc1 = fma4(sv1, w, sum1);
-                    sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NRD_TAP_BATCH; k++) {
+                    const int t = t0 + k;
+                    Guide gs = decode_guide(graw[k], c.denoisingRange);
+                    f4 sv = decode_signal(p, sraw[k], occIn);
+                    bool valid = inWin[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
+                    float w = g_poisson8[t][2];
+                    w *= geo_weight(pg, fpx[k], fpy[k], gs.z);
+                    w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                    if (isSpec)
+                        w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                    if (relaxIn)
+                        sv = rgb_to_ycocg4(sv);
+                    w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
+                    f4 acc = fma4(sv, w, sum);
+                    sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
+                    if (SH) {
+                        f4 acc1 = fma4(unpack_h4(sraw1[k]), w, sum1);
+                        sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                    }
+                    wsum = valid ? wsum + w : wsum;
+                    minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
                 }
-                wsum = valid ? wsum + w : wsum;
-                minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         float invw = rcp_(wsum);

@@ -131,6 +131,7 @@ inline float hipemu_fmed3f(float a, float b, float c) {
     return lo > m ? lo : m;    // max(min(a, b), .)
 }
 #define __builtin_amdgcn_fmed3f hipemu_fmed3f
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 inline void __syncthreads() { hipemu::sync(); }
 inline int __syncthreads_or(int v) {
     hipemu::sync();
