@@ -25,6 +25,8 @@ struct ReblurParams {
     float tapsPre[8][2], tapsPost[8][2]; // Poisson disk rotated for this frame (PrePass / PostBlur rotate per frame)
     uint32_t minMatDiff, minMatSpec;
     int clampEnabled;
+    int antiFirefly;    // HistoryFix: clamp the luma to the centre-less 5x5 moments of the incoming signal
+    float fireflyScale; //   sigma scale of that clamp (ReblurSettings::fireflySuppressorMinRelativeScale)
     int hasDiff, hasSpec;
     // resource slots
     PlaneRef inZ, inNR, inMV, inDiff, inSpec, confD, confS, outDiff, outSpec;

@@ -798,13 +798,14 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     constexpr int RBPT = sb * NSIG;
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
-    __shared__ float tile[NSIG][400];
+    __shared__ float tile[NSIG][400];    // fast luma history
+    __shared__ float tileCur[NSIG][400]; // incoming luma (anti-firefly only)
     const FrameConsts& c = p.c;
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
-    if (p.clampEnabled) {
-        // 20x20 fast-luma tiles of all signals in one sweep (depth + one luma texel per position, clamped unconditional loads)
+    if (p.clampEnabled || p.antiFirefly) {
+        // 20x20 luma tiles of all signals in one sweep (depth + one luma texel per position, clamped unconditional loads)
         int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
         for (int i = tid; i < 400; i += 256) {
             int lx = i % 20, ly = i / 20;
@@ -817,6 +818,11 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
 #pragma unroll
             for (int sig = 0; sig < NSIG; sig++)
                 tile[sig][i] = ok ? h2f((uint16_t)(l >> (16 * sig))) : u2f(0x7fc00000u);
+            if (p.antiFirefly) {
+#pragma unroll
+                for (int sig = 0; sig < NSIG; sig++)
+                    tileCur[sig][i] = ok ? h2f(ld<uint16_t>(p.tmp2, cx, cy, RBPT, sig * sb)) : u2f(0x7fc00000u);
+            }
         }
         __syncthreads();
     }
@@ -908,6 +914,33 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             val1.z *= scale;
             float f = sat(absf(Yc - Y) * rcp_(fmax2(fmax2(Y, Yc), 1e-6f)));
             outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? p.maxFastASpec : p.maxFastA), f);
+        }
+        if (p.antiFirefly) { // luma clamped to the centre-less 5x5 moments of the incoming signal
+            float cc = tileCur[sig][((int)threadIdx.y + 2) * 20 + (int)threadIdx.x + 2];
+            float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    if (i == 2 && j == 2)
+                        continue;
+                    float f = tileCur[sig][((int)threadIdx.y + j) * 20 + (int)threadIdx.x + i];
+                    f = f != f ? cc : f;
+                    m1 += f;
+                    m2 = fma_(f, f, m2);
+                }
+            m1 *= 1.0f / 24.0f;
+            m2 *= 1.0f / 24.0f;
+            float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fireflyScale;
+            float Y = val.x;
+            float Yc = clampf(Y, m1 - sigma, m1 + sigma);
+            float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
+            val.x = Yc;
+            val.y *= scale;
+            val.z *= scale;
+            val1.x *= scale;
+            val1.y *= scale;
+            val1.z *= scale;
         }
         st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * sb);
         if (SH)

@@ -462,6 +462,8 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.minMatDiff = s.minMaterialForDiffuse;
     p.minMatSpec = s.minMaterialForSpecular;
     p.clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum ? 1 : 0;
+    p.antiFirefly = s.enableAntiFirefly ? 1 : 0;
+    p.fireflyScale = s.fireflySuppressorMinRelativeScale;
     p.hasDiff = d.hasDiff;
     p.hasSpec = d.hasSpec;
     p.inZ = SP(RT::IN_VIEWZ);
@@ -614,6 +616,7 @@ nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
     s.minMaterialForSpecular = r.minMaterialForSpecular;
     s.checkerboardMode = r.checkerboardMode;
     s.hitDistanceReconstructionMode = r.hitDistanceReconstructionMode;
+    s.enableAntiFirefly = r.enableAntiFirefly;
     return s;
 }
 

@@ -901,6 +901,38 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     float f = sat(absf(Yc - Y) * rcp_(fmax2(fmax2(Y, Yc), 1e-6f)));
                     outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? maxFastAs : maxFastAd), f);
                 }
+                // ---- anti-firefly (enableAntiFirefly, sample UI Source/NRDSample.cpp:1515-1582): luma clamped to the moments of the
+                // 5x5 neighbourhood of the incoming signal WITHOUT its centre, chroma (and SH1) re-scaled with it
+                if (s.enableAntiFirefly) {
+                    float cc = ld_h(IN, x, y, sig * sb);
+                    float m1 = 0.0f, m2 = 0.0f;
+                    for (int j = -2; j <= 2; j++)
+                        for (int i = -2; i <= 2; i++) {
+                            if (i == 0 && j == 0)
+                                continue;
+                            int px = x + i, py = y + j, gy = py + c.yOff;
+                            float f = cc;
+                            if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
+                                float zt = ld_f32(G, px, py, 0);
+                                if (absf(zt) <= c.denoisingRange)
+                                    f = ld_h(IN, px, py, sig * sb);
+                            }
+                            m1 += f;
+                            m2 = fma_(f, f, m2);
+                        }
+                    m1 *= 1.0f / 24.0f;
+                    m2 *= 1.0f / 24.0f;
+                    float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * s.fireflySuppressorMinRelativeScale;
+                    float Y = val.x;
+                    float Yc = clampf(Y, m1 - sigma, m1 + sigma);
+                    float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
+                    val.x = Yc;
+                    val.y *= scale;
+                    val.z *= scale;
+                    val1.x *= scale;
+                    val1.y *= scale;
+                    val1.z *= scale;
+                }
                 st_h4(OUT, x, y, val, sig * sb);
                 if (d.sh)
                     st_h4(OUT, x, y, val1, sig * sb + 8);
@@ -1440,6 +1472,7 @@ static nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
     s.minMaterialForSpecular = r.minMaterialForSpecular;
     s.checkerboardMode = r.checkerboardMode;
     s.hitDistanceReconstructionMode = r.hitDistanceReconstructionMode;
+    s.enableAntiFirefly = r.enableAntiFirefly;
     return s;
 }
 

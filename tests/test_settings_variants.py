@@ -1,0 +1,87 @@
+"""Settings the sample's UI can flip (Source/NRDSample.cpp:1515-1663) beyond the defaults: anti-firefly, dynamic resolution
+(rectSize < resourceSize changing between frames, :3847-3854), history-confidence inputs - known answers on the oracle, bit-exact
+emulated kernels on CPU, bit-exact HIP on the GPU."""
+import numpy as np
+import pytest
+
+import util
+
+
+def test_anti_firefly_suppresses_outlier(pkg, api, oracle):
+    D = api.Denoiser
+    w, h = 48, 32
+    for den, mk in ((D.REBLUR_DIFFUSE, api.ReblurSettings), (D.RELAX_DIFFUSE, api.RelaxSettings)):
+        res = {}
+        for on in (False, True):
+            hz = pkg.harness.Harness(oracle, [den], w, h)
+            st = {den: mk(enableAntiFirefly=on, diffusePrepassBlurRadius=0.0)}
+            fr = util.flat_frame(pkg, w, h)
+            if den == D.RELAX_DIFFUSE:
+                fr["diff"][..., :3] = np.float16(0.5)
+            fr["diff"][16, 24, 0] = 60.0  # one firefly (luma channel of REBLUR's YCoCg / red of RELAX's RGB)
+            hz.frame(util.static_common(api, w, h, reset=True), hz.upload(fr), st)
+            res[on] = hz.output("out_diff")[12:21, 20:29, 0].astype(np.float32).max()
+        base = 0.5 if den == D.RELAX_DIFFUSE else float(util.flat_frame(pkg, w, h)["diff"][0, 0, 0])
+        assert abs(res[True] - base) < 0.5 * abs(res[False] - base), (den, res)  # the firefly's footprint is at least halved
+
+
+def run_pair(pkg, api, a, b, dens, frames, st, common_hook=None, frame_hook=None):
+    w, h = 60, 44
+    scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].name.startswith("RELAX") else "REBLUR")
+    ha = util.run_frames(api, pkg.harness, a, scene, dens, frames, settings=st(scene), common_hook=common_hook, frame_hook=frame_hook)
+    hb = util.run_frames(api, pkg.harness, b, scene, dens, frames, settings=st(scene), common_hook=common_hook, frame_hook=frame_hook)
+    return util.compare_all(ha, hb, exact=True)
+
+
+def drs_hook(f, cs):
+    """dynamic resolution: the rect shrinks and grows inside a fixed resource (Source/NRDSample.cpp:3847-3854)"""
+    sizes = [(60, 44), (48, 36), (54, 40), (60, 44)]
+    w, h = sizes[f % 4]
+    pw, ph = sizes[(f - 1) % 4] if f > 0 else (w, h)
+    cs.rectSize[0], cs.rectSize[1] = w, h
+    cs.rectSizePrev[0], cs.rectSizePrev[1] = pw, ph
+    cs.motionVectorScale[0], cs.motionVectorScale[1] = 1.0 / w, 1.0 / h
+
+
+def conf_hook(f, cs):
+    cs.isHistoryConfidenceAvailable = True
+
+
+def conf_frames(f, fr):
+    c = np.array(fr["confidence"], copy=True)
+    c[..., 0] = np.float16(0.25) + np.float16(0.5) * (np.arange(c.shape[1], dtype=np.float32) / c.shape[1]).astype(np.float16)[None, :]
+    fr["confidence"] = c
+
+
+CASES = [
+    ("antifirefly_reblur", ["REBLUR_DIFFUSE_SPECULAR"], dict(enableAntiFirefly=True), None, None),
+    ("antifirefly_relax_sh", ["RELAX_DIFFUSE_SPECULAR_SH"], dict(enableAntiFirefly=True), None, None),
+    ("drs_reblur_sigma", ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY"], {}, drs_hook, None),
+    ("drs_relax", ["RELAX_DIFFUSE_SPECULAR"], {}, drs_hook, None),
+    ("confidence_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, conf_hook, conf_frames),
+    ("confidence_relax", ["RELAX_DIFFUSE_SPECULAR"], {}, conf_hook, conf_frames),
+]
+
+
+def settings_factory(api, dens, kw):
+    def make(scene):
+        st = util.default_settings(api, scene, dens, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+        for d in dens:
+            if d.name.startswith("REBLUR") or d.name.startswith("RELAX"):
+                for k, v in kw.items():
+                    setattr(st[d], k, v)
+        return st
+    return make
+
+
+@pytest.mark.parametrize("name,dens,kw,chook,fhook", CASES, ids=[c[0] for c in CASES])
+def test_variants_emulated_bit_exact(pkg, api, oracle, emulated, name, dens, kw, chook, fhook):
+    dd = [api.Denoiser[x] for x in dens]
+    assert run_pair(pkg, api, oracle, emulated, dd, 3, settings_factory(api, dd, kw), chook, fhook) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dens,kw,chook,fhook", CASES, ids=[c[0] for c in CASES])
+def test_variants_hip_bit_exact(pkg, api, oracle, hip, name, dens, kw, chook, fhook):
+    dd = [api.Denoiser[x] for x in dens]
+    assert run_pair(pkg, api, oracle, hip, dd, 4, settings_factory(api, dd, kw), chook, fhook) == []
