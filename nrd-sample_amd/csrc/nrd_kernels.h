@@ -31,6 +31,7 @@ struct ReblurParams {
     // resource slots
     PlaneRef inZ, inNR, inMV, inDiff, inSpec, confD, confS, outDiff, outSpec;
     PlaneRef inDiff1, inSpec1, outDiff1, outSpec1; // SH mode: IN/OUT_*_SH1
+    PlaneRef outValidation;                        // OUT_VALIDATION (RGBA8), only with CommonSettings::enableValidation
     // PrepareInputs (checkerboard resolve / hit distance reconstruction): reads the raw slots, writes the planes the PrePass
     // then sees as inDiff / inSpec (/ inDiff1 / inSpec1)
     PlaneRef rawDiff, rawSpec, rawDiff1, rawSpec1;
@@ -73,6 +74,7 @@ void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s);
 
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s);
 void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s);
+void launch_reblur_validation(const ReblurParams& p, hipStream_t s);
 void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); // 0 PrePass, 1 Blur, 2 PostBlur
 void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s);
 void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s);

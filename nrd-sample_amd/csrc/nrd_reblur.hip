@@ -1098,6 +1098,29 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
 }
 
 // =====================================================================================================================
+// Validation overlay (CommonSettings::enableValidation, OUT_VALIDATION bound at Source/NRDSample.cpp:452, RGBA8): per pixel
+// {diffuse accumulated frames / 63, specular accumulated frames / 63, |viewZ| / denoisingRange, virtual-motion amount}; 0 on sky
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_validation(const ReblurParams p) {
+    const FrameConsts& c = p.c;
+    int x, y, tx, ty;
+    if (!my_pixel(c, x, y, tx, ty))
+        return;
+    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    uint32_t packed = 0;
+    if (!g.sky) {
+        float dA, sA;
+        unpack_data1(ld<uint16_t>(p.data1, x, y, 2), dA, sA);
+        uint32_t r = (uint32_t)__builtin_floorf(fma_(sat(dA * (1.0f / 63.0f)), 255.0f, 0.5f));
+        uint32_t gg = (uint32_t)__builtin_floorf(fma_(sat(sA * (1.0f / 63.0f)), 255.0f, 0.5f));
+        uint32_t b = (uint32_t)__builtin_floorf(fma_(sat(absf(g.z) * rcp_(c.denoisingRange)), 255.0f, 0.5f));
+        uint32_t a = (ld<uint32_t>(p.data2, x, y, 4) >> 8) & 255u;
+        packed = r | (gg << 8) | (b << 16) | (a << 24);
+    }
+    st<uint32_t>(p.outValidation, x, y, 4, packed);
+}
+
+// =====================================================================================================================
 // RELAX A-trous iteration: variance-guided 3x3 at stride 2^it (Source/NRDSample.cpp:1642-1657 feeds the settings; outputs are
 // decoded by RELAX_BackEnd_UnpackRadiance, Shaders/Composition.cs.hlsl:160-161). All lanes use the same tap offsets, so the
 // gathers of a 16x4-pixel wave are 16x4-texel groups: fully coalesced at every stride; neighbouring tiles share taps in L2.
@@ -1305,6 +1328,7 @@ void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
 }
 
 void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_prepare_inputs, ); }
+void launch_reblur_validation(const ReblurParams& p, hipStream_t s) { hipLaunchKernelGGL(k_validation, grid_for(p.c), dim3(16, 16, 1), 0, s, p); }
 
 void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
     // PrePass decodes the denoiser's input convention (MODE 0..4); Blur / PostBlur only differ by the SH texel

@@ -407,6 +407,17 @@ void push_prepare_dispatch(DenoiserState& d, const PrepareMode& pm, const Reblur
     d.dispatches.push_back(x);
 }
 
+// validation overlay dispatch (REBLUR and RELAX), recorded only when asked for and OUT_VALIDATION is bound
+void push_validation_dispatch(nrdhip_instance& I, DenoiserState& d, const ReblurParams& p, const char* name, uint32_t guide, uint32_t data1, uint32_t data2) {
+    if (!I.common.enableValidation || !I.slots[(size_t)nrd::ResourceType::OUT_VALIDATION].p)
+        return;
+    Dispatch x{name, "nrd_reblur_validation", 0, 16.0f + 2.0f + 4.0f + 4.0f, {}, {}, nullptr};
+    x.read = {guide, data1, data2};
+    x.written = {enc_slot(nrd::ResourceType::OUT_VALIDATION)};
+    x.launch = [p](hipStream_t st) { launch_reblur_validation(p, st); };
+    d.dispatches.push_back(x);
+}
+
 // appends the signal slots (SH0 [+ SH1]) of the active signals to a dispatch's read / written list
 void push_signal_slots(const DenoiserState& d, std::vector<uint32_t>& list, bool outputs) {
     using RT = nrd::ResourceType;
@@ -471,6 +482,7 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.inMV = SP(RT::IN_MV);
     p.inDiff = SP(in_slot(d, false));
     p.inSpec = SP(in_slot(d, true));
+    p.outValidation = SP(RT::OUT_VALIDATION);
     p.inDiff1 = SP(RT::IN_DIFF_SH1);
     p.inSpec1 = SP(RT::IN_SPEC_SH1);
     // PrepareInputs reads the slots ("raw") and hands dense copies to the PrePass
@@ -597,6 +609,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_stabilization(p, st); };
         d.dispatches.push_back(x);
     }
+    push_validation_dispatch(I, d, p, "REBLUR::Validation", P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::DATA2));
 }
 
 nrd::ReblurSettings relax_as_reblur(const nrd::RelaxSettings& r) {
@@ -729,6 +742,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [ap](hipStream_t st) { launch_relax_atrous(ap, st); };
         d.dispatches.push_back(x);
     }
+    push_validation_dispatch(I, d, p, "RELAX::Validation", P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::DATA2));
 }
 
 void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {

@@ -1248,6 +1248,46 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
 
 } // namespace
 
+// --------------------------------------------------------------------------------------------------
+// Validation overlay (CommonSettings::enableValidation, OUT_VALIDATION bound at Source/NRDSample.cpp:452, RGBA8): per pixel
+// {diffuse accumulated frames / 63, specular accumulated frames / 63, |viewZ| / denoisingRange, virtual-motion amount}; 0 on sky
+// --------------------------------------------------------------------------------------------------
+void validation(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+    Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+    const Plane& G = k.guide();
+    const Plane& D1 = k.perm(P_DATA1_A + k.cur);
+    const Plane& D2 = k.trans(T_DATA2);
+    const Plane& OUT = k.slot(nrd::ResourceType::OUT_VALIDATION);
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < c.W; x++) {
+            Guide g = load_guide(G, x, y, c.denoisingRange);
+            uint32_t packed = 0;
+            if (!g.sky) {
+                float dA, sA;
+                unpack_data1(ld_u16(D1, x, y), dA, sA);
+                uint32_t r = (uint32_t)floorf(fma_(sat(dA * (1.0f / 63.0f)), 255.0f, 0.5f));
+                uint32_t gg = (uint32_t)floorf(fma_(sat(sA * (1.0f / 63.0f)), 255.0f, 0.5f));
+                uint32_t b = (uint32_t)floorf(fma_(sat(absf(g.z) * rcp_(c.denoisingRange)), 255.0f, 0.5f));
+                uint32_t a = (ld_u32(D2, x, y) >> 8) & 255u;
+                packed = r | (gg << 8) | (b << 16) | (a << 24);
+            }
+            st_u32(OUT, x, y, packed);
+        }
+}
+static void push_validation_pass(Instance& I, DenoiserState& d, const char* name, uint32_t guide, uint32_t data1, uint32_t data2) {
+    if (!I.common.enableValidation || !I.slots[(size_t)nrd::ResourceType::OUT_VALIDATION].p)
+        return;
+    Pass p;
+    p.name = name;
+    p.kernel = "nrd_reblur_validation";
+    p.haloRows = 0;
+    p.bytesPerPixel = 16.0f + 2.0f + 4.0f + 4.0f;
+    p.read = {guide, data1, data2};
+    p.written = {enc_slot(nrd::ResourceType::OUT_VALIDATION)};
+    p.run = validation;
+    d.passes.push_back(p);
+}
+
 void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
     uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
     uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
@@ -1276,7 +1316,6 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
 }
 
 void reblur_build(Instance& I, DenoiserState& d) {
-    (void)I;
     using RT = nrd::ResourceType;
     int cur = (int)(d.frameCounter & 1);
     uint32_t pb = d.permBase, tb = d.transBase;
@@ -1451,6 +1490,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.run = temporal_stabilization;
         d.passes.push_back(p);
     }
+    push_validation_pass(I, d, "REBLUR::Validation", P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2));
 }
 
 
@@ -1506,7 +1546,6 @@ void relax_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<
 }
 
 void relax_build(Instance& I, DenoiserState& d) {
-    (void)I;
     using RT = nrd::ResourceType;
     d.reblur = relax_as_reblur(d.relax); // the shared passes read their parameters from here
     int cur = (int)(d.frameCounter & 1);
@@ -1650,6 +1689,7 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.run = [it, last](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { atrous(I, d, c, y0, y1, it, last); };
         d.passes.push_back(p);
     }
+    push_validation_pass(I, d, "RELAX::Validation", P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2));
 }
 
 } // namespace orc

@@ -60,6 +60,7 @@ CASES = [
     ("drs_relax", ["RELAX_DIFFUSE_SPECULAR"], {}, drs_hook, None),
     ("confidence_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, conf_hook, conf_frames),
     ("confidence_relax", ["RELAX_DIFFUSE_SPECULAR"], {}, conf_hook, conf_frames),
+    ("validation_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: setattr(cs, "enableValidation", True), None),
 ]
 
 
@@ -85,3 +86,29 @@ def test_variants_emulated_bit_exact(pkg, api, oracle, emulated, name, dens, kw,
 def test_variants_hip_bit_exact(pkg, api, oracle, hip, name, dens, kw, chook, fhook):
     dd = [api.Denoiser[x] for x in dens]
     assert run_pair(pkg, api, oracle, hip, dd, 4, settings_factory(api, dd, kw), chook, fhook) == []
+
+
+def validation_hook(f, cs):
+    cs.enableValidation = True
+
+
+def test_validation_overlay(pkg, api, oracle, emulated):
+    """CommonSettings::enableValidation (Source/NRDSample.cpp:3867) adds a Validation dispatch writing OUT_VALIDATION (:452)"""
+    D = api.Denoiser
+    for dens in ([D.REBLUR_DIFFUSE_SPECULAR], [D.RELAX_DIFFUSE_SPECULAR]):
+        w, h = 60, 44
+        scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].name.startswith("RELAX") else "REBLUR")
+        st = util.default_settings(api, scene, dens, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+        outs = []
+        for b in (oracle, emulated):
+            hz = util.run_frames(api, pkg.harness, b, scene, dens, 4, settings=st, common_hook=validation_hook)
+            names = [x["name"] for x in hz.nrd.dispatches([int(dens[0])])]
+            assert names[-1].endswith("::Validation")
+            outs.append(hz.fetch(hz.outputs["out_validation"]).reshape(h, w, 4).copy())
+        assert np.array_equal(outs[0], outs[1])
+        v = outs[0]
+        sky = scene.frame(3)["viewz"] > 1e4
+        assert np.all(v[sky] == 0) and v[~sky][:, 0].max() >= int(3 / 63 * 255)  # accumulated frames show up, sky stays black
+        # off by default: no such dispatch
+        hz = util.run_frames(api, pkg.harness, oracle, scene, dens, 1, settings=st)
+        assert not any(x["name"].endswith("Validation") for x in hz.nrd.dispatches([int(dens[0])]))

@@ -74,6 +74,9 @@ def compare_all(ha, hb, exact=True, ulp=1):
     a, b = ha.fetch(ha.outputs["out_shadow"]).astype(np.int32), hb.fetch(hb.outputs["out_shadow"]).astype(np.int32)
     if (exact and not np.array_equal(a, b)) or np.abs(a - b).max() > 1:
         bad.append(("out_shadow", int(np.abs(a - b).max())))
+    a, b = ha.fetch(ha.outputs["out_validation"]), hb.fetch(hb.outputs["out_validation"])
+    if not np.array_equal(a, b):
+        bad.append(("out_validation", int((a != b).sum())))
     if exact:
         for pool in (0, 1):
             for pa, pb in zip(ha.nrd.pools[pool], hb.nrd.pools[pool]):
