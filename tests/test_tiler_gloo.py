@@ -21,11 +21,30 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,frame_h", [(2, 224), (3, 336)])
-def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h):
+def apply_mode(api, reblur_settings, mode):
+    """"cb": the sample's default operating point - checkerboarded inputs + hit distance reconstruction - plus anti-firefly"""
+    if mode == "cb":
+        reblur_settings.checkerboardMode = int(api.CheckerboardMode.WHITE)
+        reblur_settings.hitDistanceReconstructionMode = int(api.HitDistanceReconstructionMode.AREA_5X5)
+        reblur_settings.enableAntiFirefly = True
+
+
+def mode_frame_hook(pkg, mode, f, fr):
+    if mode != "cb":
+        return
+    rng = np.random.default_rng(100 + f)
+    for key in ("diff", "spec"):
+        a = np.array(fr[key])
+        a[rng.random(a.shape[:2]) < 0.4, 3] = 0
+        fr[key] = a
+    fr.update(pkg.harness.to_checkerboard(fr, f, white=True))
+
+
+@pytest.mark.parametrize("world,frame_h,mode", [(2, 224, "default"), (3, 336, "default"), (2, 224, "cb")])
+def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mode):
     w, nframes, halo = 96, 3, 80
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo)]
+           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo), mode]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -35,8 +54,9 @@ def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h):
     scene = pkg.synth.Scene(w, frame_h, dolly=0.03)
     st = {D.REBLUR_DIFFUSE_SPECULAR: api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1),
           D.SIGMA_SHADOW_TRANSLUCENCY: api.SigmaSettings(lightDirection=list(scene.sun))}
+    apply_mode(api, st[D.REBLUR_DIFFUSE_SPECULAR], mode)
     keep = []
-    hz = util.run_frames(api, pkg.harness, oracle, scene, dens, nframes, settings=st, keep=keep)
+    hz = util.run_frames(api, pkg.harness, oracle, scene, dens, nframes, settings=st, keep=keep, frame_hook=lambda f, fr: mode_frame_hook(pkg, mode, f, fr))
     parts = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
     for f in range(nframes):
         for key in ("out_diff", "out_spec", "out_shadow"):

@@ -13,6 +13,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 def main():
     outdir, w, frame_h, nframes, halo = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    mode = sys.argv[6] if len(sys.argv) > 6 else "default"
     pkg = graft.load_package()
     api = pkg.api
     from nrd_sample_amd import tiler
@@ -27,9 +28,13 @@ def main():
     scene = pkg.synth.Scene(w, frame_h, dolly=0.03)  # every rank renders the same global frame and keeps its window
     st = {D.REBLUR_DIFFUSE_SPECULAR: api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1),
           D.SIGMA_SHADOW_TRANSLUCENCY: api.SigmaSettings(lightDirection=list(scene.sun))}
+    sys.path.insert(0, HERE)
+    import test_tiler_gloo as tt
+    tt.apply_mode(api, st[D.REBLUR_DIFFUSE_SPECULAR], mode)
     blob = {}
     for f in range(nframes):
         fr = scene.frame(f)
+        tt.mode_frame_hook(pkg, mode, f, fr)
         local = {k: band.local_rows(v) for k, v in fr.items() if k in ("viewz", "mv", "normal_roughness", "diff", "spec", "penumbra", "translucency")}
         local["confidence"] = fr["confidence"]
         # poison the halo rows of the inputs: the tiler must refresh them from the neighbours
