@@ -212,6 +212,21 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
+    // tile check (block-uniform): no penumbra in this tile or its 8 neighbours (SmoothTiles) -> every texel of the 5x5 windows
+    // is an unfiltered lit / umbra value: nothing to stabilize, the history simply follows the signal - a streaming copy
+    if (!(ld<uint16_t>(p.tilesSmooth, tx, ty, 2) & 1u)) {
+        int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+        if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+            return;
+        float u = ((float)x + 0.5f) * c.invW;
+        bool split = u < c.splitScreen;
+        float z = ld<float>(p.guide, x, y, 16, 0);
+        bool sky = !(absf(z) <= c.denoisingRange);
+        uint32_t packed = sky ? 0u : encode_shadow(unpack_h4(ld<uint2>(p.shadow2, x, y, 8)));
+        st<uint32_t>(p.hist, x, y, 4, packed);
+        store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : packed);
+        return;
+    }
     int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
     for (int i = tid; i < 400; i += 256) {
         int lx = i % 20, ly = i / 20;

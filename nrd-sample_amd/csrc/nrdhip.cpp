@@ -810,7 +810,7 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"SIGMA::TemporalStabilization", "nrd_sigma_temporal_stabilization", 2, GB + GB + 8 + 8 + 4 + 4 + 4, {}, {}, nullptr};
-        x.read = {P(sg::GUIDE_A + cur), P(sg::GUIDE_A + (cur ^ 1)), P(sg::HIST_A + (cur ^ 1)), T(sg::SHADOW2), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
+        x.read = {P(sg::GUIDE_A + cur), P(sg::GUIDE_A + (cur ^ 1)), P(sg::HIST_A + (cur ^ 1)), T(sg::SHADOW2), T(sg::TILES_SMOOTH), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             x.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
         x.written = {P(sg::HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};

@@ -222,6 +222,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
     const Plane& HP = k.perm(P_HIST_A + (k.cur ^ 1));
     const Plane& HC = k.perm(P_HIST_A + k.cur);
     const Plane& SH = k.trans(T_SHADOW2);
+    const Plane& ST = k.trans(T_TILES_SMOOTH);
     const Plane& MV = k.slot(nrd::ResourceType::IN_MV);
     const Plane& OUT = k.slot(nrd::ResourceType::OUT_SHADOW_TRANSLUCENCY);
     const Plane& inPen = k.slot(nrd::ResourceType::IN_PENUMBRA);
@@ -245,6 +246,14 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 continue;
             }
             f4 cur = ld_h4(SH, x, y);
+            // tile check: no penumbra in this tile or its 8 neighbours (SmoothTiles) -> every texel of the 5x5 window is an
+            // unfiltered lit / umbra value: nothing to stabilize, the history simply follows the signal
+            if (!(ld_u16(ST, x / 16, y / 16) & 1u)) {
+                uint32_t packed = encode_shadow(cur);
+                st_u32(HC, x, y, packed);
+                store_out(x, y, split ? encode_shadow(input_visibility(k, x, y, ld_h(inPen, x, y))) : packed);
+                continue;
+            }
             // 5x5 moments per channel
             float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
             for (int j = -2; j <= 2; j++)
@@ -409,7 +418,7 @@ void sigma_build(Instance&, DenoiserState& d) {
         p.kernel = "nrd_sigma_temporal_stabilization";
         p.haloRows = 2;
         p.bytesPerPixel = GB + GB + 8 + 8 + 4 + 4 + 4;
-        p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), P(P_HIST_A + (cur ^ 1)), T(T_SHADOW2), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
+        p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), P(P_HIST_A + (cur ^ 1)), T(T_SHADOW2), T(T_TILES_SMOOTH), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             p.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
         p.written = {P(P_HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};
