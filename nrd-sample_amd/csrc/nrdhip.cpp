@@ -257,23 +257,28 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     c.invWprev = 1.0f / (float)c.Wprev;
     c.invHprev = 1.0f / (float)c.Hprev;
 
-    auto projection = [](const float* M, float* pj, float* fr) {
+    // cameraJitter (pixels, Source/NRDSample.cpp:3843-3846): the G-buffer of pixel (x, y) was rendered through uv + jitter / rect
+    // (Shaders/Composition.cs.hlsl:77 "pixelUv + gJitter") while the matrices are un-jittered - fold the constant uv offset into
+    // the projection's x/y shear terms so that reconstruct / project / the tap Jacobian all see the jittered pixel grid
+    auto projection = [](const float* M, float* pj, float* fr, const float* jitter, float invW, float invH) {
         float s = M[11];
         if (s == 0.0f || M[0] == 0.0f || M[5] == 0.0f)
             return false; // orthographic / degenerate: unsupported
         s = s > 0.0f ? 1.0f : -1.0f;
+        float m8 = M[8] - 2.0f * s * jitter[0] * invW, m9 = M[9] + 2.0f * s * jitter[1] * invH;
         pj[0] = M[0];
         pj[1] = M[5];
-        pj[2] = M[8];
-        pj[3] = M[9];
+        pj[2] = m8;
+        pj[3] = m9;
         pj[4] = s;
         fr[2] = 2.0f * s / M[0];
-        fr[0] = (-s - M[8]) / M[0];
+        fr[0] = (-s - m8) / M[0];
         fr[3] = -2.0f * s / M[5];
-        fr[1] = (s - M[9]) / M[5];
+        fr[1] = (s - m9) / M[5];
         return true;
     };
-    if (!projection(cs.viewToClipMatrix, c.pj, c.fr) || !projection(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev)) {
+    if (!projection(cs.viewToClipMatrix, c.pj, c.fr, cs.cameraJitter, c.invW, c.invH) ||
+        !projection(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev, cs.cameraJitterPrev, c.invWprev, c.invHprev)) {
         err = "only perspective projections are supported";
         return false;
     }

@@ -52,12 +52,16 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
     c.invWprev = 1.0f / (float)c.Wprev;
     c.invHprev = 1.0f / (float)c.Hprev;
 
-    auto proj = [&](const float* M, float* pj, float* fr) -> bool {
+    // cameraJitter (pixels, Source/NRDSample.cpp:3843-3846): the G-buffer of pixel (x, y) was rendered through uv + jitter / rect
+    // (Shaders/Composition.cs.hlsl:77 "pixelUv + gJitter") while the matrices are un-jittered - fold the constant uv offset into
+    // the projection's x/y shear terms so that reconstruct / project / the tap Jacobian all see the jittered pixel grid
+    auto proj = [&](const float* M, float* pj, float* fr, const float* jitter, float invW, float invH) -> bool {
         float s = M[11];
         if (s == 0.0f)
             return false; // orthographic projection: unsupported
         s = s > 0.0f ? 1.0f : -1.0f;
-        float m0 = M[0], m5 = M[5], m8 = M[8], m9 = M[9];
+        float m0 = M[0], m5 = M[5];
+        float m8 = M[8] - 2.0f * s * jitter[0] * invW, m9 = M[9] + 2.0f * s * jitter[1] * invH;
         if (m0 == 0.0f || m5 == 0.0f)
             return false;
         pj[0] = m0;
@@ -71,7 +75,7 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
         fr[1] = (s - m9) / m5;
         return true;
     };
-    if (!proj(cs.viewToClipMatrix, c.pj, c.fr) || !proj(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev)) {
+    if (!proj(cs.viewToClipMatrix, c.pj, c.fr, cs.cameraJitter, c.invW, c.invH) || !proj(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev, cs.cameraJitterPrev, c.invWprev, c.invHprev)) {
         err = "only perspective projections are supported";
         return false;
     }
