@@ -174,6 +174,23 @@ typedef struct nrdhip_unpack_desc {
 } nrdhip_unpack_desc;
 NRDHIP_API int nrdhip_backend_unpack(const nrdhip_unpack_desc* desc, void* hip_stream);
 
+/* Temporal anti-aliasing = Shaders/Taa.cs.hlsl:11-159 (one 16x16-group dispatch over the rect): 20x20 LDS tiles of the tonemapped
+ * colour and of the motion vectors, 3x3 / 5x5 Gaussian moments, closest-depth motion vector, bicubic (5-tap "no corners")
+ * history fetch, AABB clip + CIELAB-distance driven mix rate. */
+typedef struct nrdhip_taa_desc {
+    const void* mv; uint32_t mv_pitch;             /* gIn_Mv RGBA16F: xy = motion in pixels, w = viewZ * FP16_VIEWZ_SCALE * (+-1), < 0 asks for 5x5 */
+    const void* composed; uint32_t composed_pitch; /* gIn_Composed RGBA16F (rgb) */
+    const void* history; uint32_t history_pitch;   /* gIn_History RGBA16F {rgb, mix rate} = last frame's result */
+    void* result; uint32_t result_pitch;           /* gOut_Result RGBA16F {rgb, mix rate} */
+    uint16_t rect_width, rect_height;              /* gRectSize */
+    uint16_t rect_width_prev, rect_height_prev;    /* gRectSizePrev */
+    uint16_t render_width, render_height;          /* 1 / gInvRenderSize: size of the history texture (Source/NRDSample.cpp:3721) */
+    uint32_t tonemap;                              /* ApplyTonemap active (NRD_MODE < OCCLUSION and gOnScreen <= SHOW_DENOISED_SPECULAR, Shared.hlsli:337-347) */
+    float hdr_scale;                               /* gHdrScale (:3743) */
+    float taa;                                     /* gTAA: lower bound of the mix rate (:3742) */
+} nrdhip_taa_desc;
+NRDHIP_API int nrdhip_taa(const nrdhip_taa_desc* desc, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

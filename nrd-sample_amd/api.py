@@ -330,6 +330,14 @@ class UnpackDesc(C.Structure):
                 ("view_to_world", _f * 9), ("camera_frustum", _f * 4), ("inv_rect_size", _f * 2)]
 
 
+class TaaDesc(C.Structure):
+    """nrdhip_taa_desc (Shaders/Taa.cs.hlsl)"""
+    _fields_ = [("mv", C.c_void_p), ("mv_pitch", _u32), ("composed", C.c_void_p), ("composed_pitch", _u32),
+                ("history", C.c_void_p), ("history_pitch", _u32), ("result", C.c_void_p), ("result_pitch", _u32),
+                ("rect_width", _u16), ("rect_height", _u16), ("rect_width_prev", _u16), ("rect_height_prev", _u16),
+                ("render_width", _u16), ("render_height", _u16), ("tonemap", _u32), ("hdr_scale", _f), ("taa", _f)]
+
+
 UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH = 0, 1, 2
 FLAG_EXTERNAL_POOLS = 1
 
@@ -368,6 +376,7 @@ class Backend:
         self._sig("last_error", C.c_char_p, [C.c_void_p])
         self._sig("confidence_blur", C.c_int, [C.POINTER(ConfidenceBlurDesc), C.c_void_p])
         self._sig("backend_unpack", C.c_int, [C.POINTER(UnpackDesc), C.c_void_p])
+        self._sig("taa", C.c_int, [C.POINTER(TaaDesc), C.c_void_p])
 
     def _sig(self, name, res, args):
         f = getattr(self.lib, self.prefix + name)
@@ -382,7 +391,7 @@ class Backend:
 
     def check_abi(self):
         want = [CommonSettings, ReblurSettings, RelaxSettings, SigmaSettings, ReferenceSettings, CreateDesc, PlaneInfo, DispatchInfo,
-                ConfidenceBlurDesc, UnpackDesc]
+                ConfidenceBlurDesc, UnpackDesc, TaaDesc]
         for i, cls in enumerate(want):
             got = self.sizeof(i)
             if got != C.sizeof(cls):

@@ -189,6 +189,174 @@ __global__ __launch_bounds__(256) void k_backend_unpack(const UnpackParams p) {
     }
 }
 
+// =====================================================================================================================
+// TAA (Shaders/Taa.cs.hlsl:11-159). Helpers outside that file: ApplyTonemap and BicubicFilterNoCorners are in-tree
+// (Shaders/Shared.hlsli:337-387); Color::ClampAabb, Color::RgbToXyz, Math::PositiveRcp are MathLib [RECOLLECTION].
+// =====================================================================================================================
+struct TaaParams {
+    PlaneRef mv, composed, history, result;
+    int W, H, RW, RH, tonemap;
+    float Wp, Hp, invW, invH, invRW, invRH, hdrScale, taa;
+};
+
+NRD_DEV float positive_rcp(float x) { return rcp_(fmax2(x, 1e-15f)); }
+NRD_DEV float pow_pos(float x, float y) { return x > 0.0f ? exp2_poly(y * log2_poly(x)) : 0.0f; }
+NRD_DEV f3 taa_tonemap(const TaaParams& p, f3 c) { // ApplyTonemap (Shared.hlsli:337-347)
+    if (!p.tonemap)
+        return c;
+    return {p.hdrScale * hdr_to_linear_uncharted(c.x), p.hdrScale * hdr_to_linear_uncharted(c.y), p.hdrScale * hdr_to_linear_uncharted(c.z)};
+}
+// SampleLevel( gLinearClamp, uv, 0 ) of an RGBA16F texture
+NRD_DEV f4 sample_linear_clamp(const PlaneRef& P, float u, float v, int w, int h) {
+    float x = fma_(u, (float)w, -0.5f), y = fma_(v, (float)h, -0.5f);
+    float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    float fx = x - x0, fy = y - y0;
+    x0 = clampf(x0, -1.0f, (float)w);
+    y0 = clampf(y0, -1.0f, (float)h);
+    int ix0 = imin(imax((int)x0, 0), w - 1), ix1 = imin(imax((int)x0 + 1, 0), w - 1);
+    int iy0 = imin(imax((int)y0, 0), h - 1), iy1 = imin(imax((int)y0 + 1, 0), h - 1);
+    f4 a = unpack_h4(ld<uint2>(P, ix0, iy0, 8)), b = unpack_h4(ld<uint2>(P, ix1, iy0, 8));
+    f4 c = unpack_h4(ld<uint2>(P, ix0, iy1, 8)), d = unpack_h4(ld<uint2>(P, ix1, iy1, 8));
+    return lerp4(lerp4(a, b, fx), lerp4(c, d, fx), fy);
+}
+// BicubicFilterNoCorners (Shared.hlsli:349-387)
+NRD_DEV f4 bicubic_no_corners(const TaaParams& p, float sx, float sy) {
+    const float sh = 0.66f; // TAA_HISTORY_SHARPNESS (Shared.hlsli:148)
+    float cx = __builtin_floorf(sx - 0.5f) + 0.5f, cy = __builtin_floorf(sy - 0.5f) + 0.5f;
+    float f[2] = {sat(sx - cx), sat(sy - cy)};
+    float w0[2], w3[2], wl2[2], tc2[2];
+    const float c[2] = {cx, cy}, inv[2] = {p.invRW, p.invRH};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        float f1 = f[k], f2 = f1 * f1, f3v = f1 * f2;
+        w0[k] = -sh * f3v + 2.0f * sh * f2 - sh * f1;
+        float w1 = (2.0f - sh) * f3v - (3.0f - sh) * f2 + 1.0f;
+        float w2 = -(2.0f - sh) * f3v + (3.0f - 2.0f * sh) * f2 + sh * f1;
+        w3[k] = sh * f3v - sh * f2;
+        wl2[k] = w1 + w2;
+        tc2[k] = inv[k] * (c[k] + w2 * positive_rcp(wl2[k]));
+    }
+    float tc0x = p.invRW * (cx - 1.0f), tc0y = p.invRH * (cy - 1.0f), tc3x = p.invRW * (cx + 2.0f), tc3y = p.invRH * (cy + 2.0f);
+    float w = wl2[0] * w0[1];
+    f4 color = mul4(sample_linear_clamp(p.history, tc2[0], tc0y, p.RW, p.RH), w);
+    float sum = w;
+    w = w0[0] * wl2[1];
+    color = fma4(sample_linear_clamp(p.history, tc0x, tc2[1], p.RW, p.RH), w, color);
+    sum += w;
+    w = wl2[0] * wl2[1];
+    color = fma4(sample_linear_clamp(p.history, tc2[0], tc2[1], p.RW, p.RH), w, color);
+    sum += w;
+    w = w3[0] * wl2[1];
+    color = fma4(sample_linear_clamp(p.history, tc3x, tc2[1], p.RW, p.RH), w, color);
+    sum += w;
+    w = wl2[0] * w3[1];
+    color = fma4(sample_linear_clamp(p.history, tc2[0], tc3y, p.RW, p.RH), w, color);
+    sum += w;
+    return mul4(color, positive_rcp(sum));
+}
+NRD_DEV f3 rgb_to_xyz(f3 c) { // Color::RgbToXyz (sRGB primaries, D65, Y in 0..100)
+    return {100.0f * fma_(0.1804808f, c.z, fma_(0.3575843f, c.y, 0.4123908f * c.x)), 100.0f * fma_(0.0721923f, c.z, fma_(0.7151687f, c.y, 0.2126390f * c.x)),
+            100.0f * fma_(0.9505322f, c.z, fma_(0.1191948f, c.y, 0.0193308f * c.x))};
+}
+NRD_DEV f3 xyz_to_lab(f3 x) { // Taa.cs.hlsl:43-54
+    x = {x.x * (1.0f / 95.0489f), x.y * (1.0f / 100.0f), x.z * (1.0f / 108.8840f)};
+    float yIn = x.y;
+    float fx = x.x > 0.008856f ? pow_pos(x.x, 0.333333f) : fma_(7.787f, x.x, 16.0f / 116.0f);
+    float fy = x.y > 0.008856f ? pow_pos(x.y, 0.333333f) : fma_(7.787f, x.y, 16.0f / 116.0f);
+    float fz = x.z > 0.008856f ? pow_pos(x.z, 0.333333f) : fma_(7.787f, x.z, 16.0f / 116.0f);
+    // NOTE: as in the shader, "l" is computed from the ALREADY transformed y
+    (void)yIn;
+    float l = fy > 0.008856f ? fma_(116.0f, pow_pos(fy, 0.333333f), -16.0f) : 903.3f * fy;
+    return {l, 500.0f * (fx - fy), 200.0f * (fy - fz)};
+}
+NRD_DEV f3 clamp_aabb(f3 center, f3 ext, f3 prev) { // Color::ClampAabb: clip towards the box centre
+    f3 d = sub3(prev, center);
+    f3 dn = {absf(d.x * positive_rcp(ext.x)), absf(d.y * positive_rcp(ext.y)), absf(d.z * positive_rcp(ext.z))};
+    float maxd = fmax2(dn.x, fmax2(dn.y, dn.z));
+    float r = positive_rcp(maxd);
+    f3 t = {fma_(d.x, r, center.x), fma_(d.y, r, center.y), fma_(d.z, r, center.z)};
+    return maxd > 1.0f ? t : prev;
+}
+
+__global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
+    __shared__ float sColor[3][400];
+    __shared__ float sMv[3][400];
+    const int tidx = (int)threadIdx.x, tidy = (int)threadIdx.y;
+    const int x = (int)blockIdx.x * 16 + tidx, y = (int)blockIdx.y * 16 + tidy;
+    {   // PRELOAD_INTO_SMEM (:17-28, :33-39)
+        int bx = (int)blockIdx.x * 16 - 2, by = (int)blockIdx.y * 16 - 2;
+        for (int i = tidy * 16 + tidx; i < 400; i += 256) {
+            int gx = imin(imax(bx + i % 20, 0), p.W - 1), gy = imin(imax(by + i / 20, 0), p.H - 1);
+            f4 c = unpack_h4(ld<uint2>(p.composed, gx, gy, 8));
+            f3 t = taa_tonemap(p, {c.x, c.y, c.z});
+            f4 m = unpack_h4(ld<uint2>(p.mv, gx, gy, 8));
+            sColor[0][i] = t.x;
+            sColor[1][i] = t.y;
+            sColor[2][i] = t.z;
+            sMv[0][i] = m.x;
+            sMv[1][i] = m.y;
+            sMv[2][i] = m.w; // dZ is not needed
+        }
+    }
+    __syncthreads();
+    float u = ((float)x + 0.5f) * p.invW, v = ((float)y + 0.5f) * p.invH;
+    if (u > 1.0f || v > 1.0f)
+        return;
+    float sum = 0.0f;
+    f3 m1 = {0, 0, 0}, m2 = {0, 0, 0}, input = {0, 0, 0};
+    const int ci = (tidy + 2) * 20 + tidx + 2;
+    float centerZ = sMv[2][ci];
+    float minViewZ = absf(centerZ);
+    int offx = 2, offy = 2;
+    const bool want5x5 = centerZ < 0.0f;
+#pragma unroll
+    for (int dy = 0; dy <= 4; dy++)
+#pragma unroll
+        for (int dx = 0; dx <= 4; dx++) {
+            const bool border = dx == 0 || dx == 4 || dy == 0 || dy == 4;
+            if (border && !want5x5)
+                continue;
+            int si = (tidy + dy) * 20 + tidx + dx;
+            f3 c = {sColor[0][si], sColor[1][si], sColor[2][si]};
+            float viewZ = absf(sMv[2][si]);
+            if (dx == 2 && dy == 2)
+                input = c;
+            else if (viewZ < minViewZ) {
+                minViewZ = viewZ;
+                offx = dx;
+                offy = dy;
+            }
+            // r2 = LengthSquared( offset / BORDER - 1.0 ) with the INTEGER division of the shader (:103): -1,-1,0,0,1 per axis
+            const int qx = dx / 2 - 1, qy = dy / 2 - 1;
+            const int r2 = qx * qx + qy * qy;
+            const float w = r2 == 0 ? 1.0f : (r2 == 1 ? 0.36787944f : 0.13533528f); // exp( -r2 )
+            m1 = {fma_(c.x, w, m1.x), fma_(c.y, w, m1.y), fma_(c.z, w, m1.z)};
+            m2 = {fma_(c.x * c.x, w, m2.x), fma_(c.y * c.y, w, m2.y), fma_(c.z * c.z, w, m2.z)};
+            sum += w;
+        }
+    float rs = rcp_(sum);
+    m1 = mul3(m1, rs);
+    m2 = mul3(m2, rs);
+    f3 sigma = {sqrt_(absf(m2.x - m1.x * m1.x)) * 2.0f, sqrt_(absf(m2.y - m1.y * m1.y)) * 2.0f, sqrt_(absf(m2.z - m1.z * m1.z)) * 2.0f}; // TAA_SIGMA_SCALE
+    // previous pixel position (:118-119): motion of the closest-depth neighbour
+    const int mi = (tidy + offy) * 20 + tidx + offx;
+    float pu = fma_(sMv[0][mi], p.invW, u), pv = fma_(sMv[1][mi], p.invH, v);
+    f4 history = bicubic_no_corners(p, sat(pu) * p.Wp, sat(pv) * p.Hp);
+    f3 hist = {fmax2(history.x, 0.0f), fmax2(history.y, 0.0f), fmax2(history.z, 0.0f)};
+    float mixRate = sat(history.w);
+    mixRate = mixRate * rcp_(1.0f + mixRate);
+    bool inScreen = sat(pu) == pu && sat(pv) == pv;
+    mixRate = inScreen ? mixRate : 1.0f;
+    f3 clamped = clamp_aabb(m1, sigma, hist);
+    f3 a = xyz_to_lab(rgb_to_xyz(clamped)), b = xyz_to_lab(rgb_to_xyz(hist));
+    f3 dl = sub3(a, b);
+    float diff = sqrt_(dot3(dl, dl)) * (1.0f / (2.3f * 3.0f)); // JND = 2.3
+    mixRate = sat(mixRate + diff);
+    float t = fmax2(mixRate, p.taa);
+    f3 r = {lerpf(clamped.x, input.x, t), lerpf(clamped.y, input.y, t), lerpf(clamped.z, input.z, t)};
+    st<uint2>(p.result, x, y, 8, pack_h4({r.x, r.y, r.z, mixRate}));
+}
+
 PlaneRef plane(const void* p, uint32_t pitch, uint16_t w, uint16_t h) { return PlaneRef{(uint8_t*)p, pitch, w, h}; }
 
 } // namespace
@@ -258,6 +426,34 @@ NRDHIP_API int nrdhip_backend_unpack(const nrdhip_unpack_desc* d, void* hip_stre
     p.invH = d->inv_rect_size[1];
     dim3 grid((unsigned)((d->width + 63) / 64), (unsigned)((d->height + 3) / 4), 1);
     hipLaunchKernelGGL(k_backend_unpack, grid, dim3(64, 4, 1), 0, (hipStream_t)hip_stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+NRDHIP_API int nrdhip_taa(const nrdhip_taa_desc* d, void* hip_stream) {
+    using namespace nrdhip;
+    if (!d || !d->mv || !d->composed || !d->history || !d->result || !d->rect_width || !d->rect_height || !d->render_width || !d->render_height ||
+        d->rect_width > d->render_width || d->rect_height > d->render_height)
+        return 2;
+    TaaParams p = {};
+    p.mv = plane(d->mv, d->mv_pitch, d->rect_width, d->rect_height);
+    p.composed = plane(d->composed, d->composed_pitch, d->rect_width, d->rect_height);
+    p.history = plane(d->history, d->history_pitch, d->render_width, d->render_height);
+    p.result = plane(d->result, d->result_pitch, d->rect_width, d->rect_height);
+    p.W = d->rect_width;
+    p.H = d->rect_height;
+    p.RW = d->render_width;
+    p.RH = d->render_height;
+    p.Wp = (float)(d->rect_width_prev ? d->rect_width_prev : d->rect_width);
+    p.Hp = (float)(d->rect_height_prev ? d->rect_height_prev : d->rect_height);
+    p.invW = 1.0f / (float)p.W;
+    p.invH = 1.0f / (float)p.H;
+    p.invRW = 1.0f / (float)p.RW;
+    p.invRH = 1.0f / (float)p.RH;
+    p.tonemap = d->tonemap ? 1 : 0;
+    p.hdrScale = d->hdr_scale;
+    p.taa = d->taa;
+    dim3 grid((unsigned)((d->rect_width + 15) / 16), (unsigned)((d->rect_height + 15) / 16), 1);
+    hipLaunchKernelGGL(k_taa, grid, dim3(16, 16, 1), 0, (hipStream_t)hip_stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 }

@@ -75,6 +75,23 @@ def backend_unpack(backend, width, height, mode=api.UNPACK_NORMAL, relax=False, 
         raise api.NrdError("backend_unpack", int(r))
 
 
+def taa(backend, mv, composed, history, result, rect_width, rect_height, render_width=None, render_height=None, rect_width_prev=0,
+        rect_height_prev=0, tonemap=True, hdr_scale=1.0, taa_min_mix=0.1):
+    """Shaders/Taa.cs.hlsl: one dispatch; `history` is last frame's `result` (ping-pong by the caller, Source/NRDSample.cpp TAA pass)"""
+    d = api.TaaDesc()
+    d.mv, d.mv_pitch = _pp(mv)
+    d.composed, d.composed_pitch = _pp(composed)
+    d.history, d.history_pitch = _pp(history)
+    d.result, d.result_pitch = _pp(result)
+    d.rect_width, d.rect_height = rect_width, rect_height
+    d.rect_width_prev, d.rect_height_prev = rect_width_prev, rect_height_prev
+    d.render_width, d.render_height = render_width or rect_width, render_height or rect_height
+    d.tonemap, d.hdr_scale, d.taa = 1 if tonemap else 0, float(hdr_scale), float(taa_min_mix)
+    r = backend.taa(C.byref(d), _stream(backend))
+    if r != 0:
+        raise api.NrdError("taa", int(r))
+
+
 def synth_gradient(width, height, seed=0, sky_fraction=0.05):
     """Synthetic Gradient_Ping plane [H, W, 4] float16: {gradient, octahedral view normal xy, viewZ * 0.125}
     (layout of Shaders/SharcUpdate.cs.hlsl:249) - a slanted floor, a far wall and some sky texels."""

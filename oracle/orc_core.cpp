@@ -485,6 +485,7 @@ NRDHIP_API uint32_t orc_sizeof(uint32_t which) {
         case 7: return sizeof(nrdhip_dispatch_info);
         case 8: return sizeof(nrdhip_confidence_blur_desc);
         case 9: return sizeof(nrdhip_unpack_desc);
+        case 10: return sizeof(nrdhip_taa_desc);
     }
     return 0;
 }

@@ -114,9 +114,176 @@ inline void store4(void* base, uint32_t pitch, int x, int y, float a, float b, f
     o->v[3] = to_h(d);
 }
 
+// ---- TAA (Shaders/Taa.cs.hlsl:11-159; ApplyTonemap / BicubicFilterNoCorners: Shaders/Shared.hlsli:337-387; Color::ClampAabb,
+// Color::RgbToXyz, Math::PositiveRcp: MathLib [RECOLLECTION]) ----------------------------------------------------------------
+struct Taa {
+    const nrdhip_taa_desc& d;
+    int W, H, RW, RH;
+    float Wp, Hp, invW, invH, invRW, invRH;
+};
+inline float positive_rcp(float x) { return rcp_(fmax2(x, 1e-15f)); }
+inline float pow_pos(float x, float y) { return x > 0.0f ? exp2_poly(y * log2_poly(x)) : 0.0f; }
+inline f4 ld4(const void* base, uint32_t pitch, int x, int y) {
+    const H4* t = texel(base, pitch, x, y);
+    return {f16_to_f32(t->v[0]), f16_to_f32(t->v[1]), f16_to_f32(t->v[2]), f16_to_f32(t->v[3])};
+}
+inline f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+inline f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
+inline f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
+inline f3 taa_tonemap(const Taa& k, f3 c) {
+    if (!k.d.tonemap)
+        return c;
+    float s = k.d.hdr_scale;
+    return {s * hdr_to_linear_uncharted(c.x), s * hdr_to_linear_uncharted(c.y), s * hdr_to_linear_uncharted(c.z)};
+}
+inline f4 sample_linear_clamp(const Taa& k, float u, float v) {
+    const int w = k.RW, h = k.RH;
+    float x = fma_(u, (float)w, -0.5f), y = fma_(v, (float)h, -0.5f);
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    x0 = clampf(x0, -1.0f, (float)w);
+    y0 = clampf(y0, -1.0f, (float)h);
+    auto cl = [](int a, int n) { return a < 0 ? 0 : (a > n - 1 ? n - 1 : a); };
+    int ix0 = cl((int)x0, w), ix1 = cl((int)x0 + 1, w), iy0 = cl((int)y0, h), iy1 = cl((int)y0 + 1, h);
+    f4 a = ld4(k.d.history, k.d.history_pitch, ix0, iy0), b = ld4(k.d.history, k.d.history_pitch, ix1, iy0);
+    f4 c = ld4(k.d.history, k.d.history_pitch, ix0, iy1), e = ld4(k.d.history, k.d.history_pitch, ix1, iy1);
+    return lerp4(lerp4(a, b, fx), lerp4(c, e, fx), fy);
+}
+f4 bicubic_no_corners(const Taa& k, float sx, float sy) {
+    const float sh = 0.66f; // TAA_HISTORY_SHARPNESS
+    float cx = floorf(sx - 0.5f) + 0.5f, cy = floorf(sy - 0.5f) + 0.5f;
+    float f[2] = {sat(sx - cx), sat(sy - cy)};
+    float w0[2], w3[2], wl2[2], tc2[2];
+    const float c[2] = {cx, cy}, inv[2] = {k.invRW, k.invRH};
+    for (int i = 0; i < 2; i++) {
+        float f1 = f[i], f2 = f1 * f1, f3v = f1 * f2;
+        w0[i] = -sh * f3v + 2.0f * sh * f2 - sh * f1;
+        float w1 = (2.0f - sh) * f3v - (3.0f - sh) * f2 + 1.0f;
+        float w2 = -(2.0f - sh) * f3v + (3.0f - 2.0f * sh) * f2 + sh * f1;
+        w3[i] = sh * f3v - sh * f2;
+        wl2[i] = w1 + w2;
+        tc2[i] = inv[i] * (c[i] + w2 * positive_rcp(wl2[i]));
+    }
+    float tc0x = k.invRW * (cx - 1.0f), tc0y = k.invRH * (cy - 1.0f), tc3x = k.invRW * (cx + 2.0f), tc3y = k.invRH * (cy + 2.0f);
+    float w = wl2[0] * w0[1];
+    f4 color = mul4(sample_linear_clamp(k, tc2[0], tc0y), w);
+    float sum = w;
+    w = w0[0] * wl2[1];
+    color = fma4(sample_linear_clamp(k, tc0x, tc2[1]), w, color);
+    sum += w;
+    w = wl2[0] * wl2[1];
+    color = fma4(sample_linear_clamp(k, tc2[0], tc2[1]), w, color);
+    sum += w;
+    w = w3[0] * wl2[1];
+    color = fma4(sample_linear_clamp(k, tc3x, tc2[1]), w, color);
+    sum += w;
+    w = wl2[0] * w3[1];
+    color = fma4(sample_linear_clamp(k, tc2[0], tc3y), w, color);
+    sum += w;
+    return mul4(color, positive_rcp(sum));
+}
+inline f3 rgb_to_xyz(f3 c) {
+    return {100.0f * fma_(0.1804808f, c.z, fma_(0.3575843f, c.y, 0.4123908f * c.x)), 100.0f * fma_(0.0721923f, c.z, fma_(0.7151687f, c.y, 0.2126390f * c.x)),
+            100.0f * fma_(0.9505322f, c.z, fma_(0.1191948f, c.y, 0.0193308f * c.x))};
+}
+inline f3 xyz_to_lab(f3 x) { // Taa.cs.hlsl:43-54 ("l" is computed from the already transformed y, as in the shader)
+    x = {x.x * (1.0f / 95.0489f), x.y * (1.0f / 100.0f), x.z * (1.0f / 108.8840f)};
+    float fx = x.x > 0.008856f ? pow_pos(x.x, 0.333333f) : fma_(7.787f, x.x, 16.0f / 116.0f);
+    float fy = x.y > 0.008856f ? pow_pos(x.y, 0.333333f) : fma_(7.787f, x.y, 16.0f / 116.0f);
+    float fz = x.z > 0.008856f ? pow_pos(x.z, 0.333333f) : fma_(7.787f, x.z, 16.0f / 116.0f);
+    float l = fy > 0.008856f ? fma_(116.0f, pow_pos(fy, 0.333333f), -16.0f) : 903.3f * fy;
+    return {l, 500.0f * (fx - fy), 200.0f * (fy - fz)};
+}
+inline f3 clamp_aabb(f3 center, f3 ext, f3 prev) {
+    f3 d = sub3(prev, center);
+    f3 dn = {absf(d.x * positive_rcp(ext.x)), absf(d.y * positive_rcp(ext.y)), absf(d.z * positive_rcp(ext.z))};
+    float maxd = fmax2(dn.x, fmax2(dn.y, dn.z));
+    float r = positive_rcp(maxd);
+    f3 t = {fma_(d.x, r, center.x), fma_(d.y, r, center.y), fma_(d.z, r, center.z)};
+    return maxd > 1.0f ? t : prev;
+}
+
 } // namespace
 
 extern "C" {
+
+__attribute__((visibility("default"))) int orc_taa(const nrdhip_taa_desc* dp, void* /*stream*/) {
+    if (!dp || !dp->mv || !dp->composed || !dp->history || !dp->result || !dp->rect_width || !dp->rect_height || !dp->render_width || !dp->render_height ||
+        dp->rect_width > dp->render_width || dp->rect_height > dp->render_height)
+        return 2;
+    const nrdhip_taa_desc& d = *dp;
+    Taa k{d, d.rect_width, d.rect_height, d.render_width, d.render_height, 0, 0, 0, 0, 0, 0};
+    k.Wp = (float)(d.rect_width_prev ? d.rect_width_prev : d.rect_width);
+    k.Hp = (float)(d.rect_height_prev ? d.rect_height_prev : d.rect_height);
+    k.invW = 1.0f / (float)k.W;
+    k.invH = 1.0f / (float)k.H;
+    k.invRW = 1.0f / (float)k.RW;
+    k.invRH = 1.0f / (float)k.RH;
+    auto cl = [](int a, int n) { return a < 0 ? 0 : (a > n - 1 ? n - 1 : a); };
+    for (int y = 0; y < k.H; y++)
+        for (int x = 0; x < k.W; x++) {
+            float u = ((float)x + 0.5f) * k.invW, v = ((float)y + 0.5f) * k.invH;
+            if (u > 1.0f || v > 1.0f)
+                continue;
+            // the 20x20 shared-memory tile of the shader, read straight from the (clamped) planes
+            auto color_at = [&](int px, int py) {
+                f4 c = ld4(d.composed, d.composed_pitch, cl(px, k.W), cl(py, k.H));
+                return taa_tonemap(k, {c.x, c.y, c.z});
+            };
+            auto mv_at = [&](int px, int py) {
+                f4 m = ld4(d.mv, d.mv_pitch, cl(px, k.W), cl(py, k.H));
+                return f3{m.x, m.y, m.w};
+            };
+            float sum = 0.0f;
+            f3 m1 = {0, 0, 0}, m2 = {0, 0, 0}, input = {0, 0, 0};
+            float centerZ = mv_at(x, y).z;
+            float minViewZ = absf(centerZ);
+            int offx = 2, offy = 2;
+            const bool want5x5 = centerZ < 0.0f;
+            for (int dy = 0; dy <= 4; dy++)
+                for (int dx = 0; dx <= 4; dx++) {
+                    const bool border = dx == 0 || dx == 4 || dy == 0 || dy == 4;
+                    if (border && !want5x5)
+                        continue;
+                    f3 c = color_at(x + dx - 2, y + dy - 2);
+                    float viewZ = absf(mv_at(x + dx - 2, y + dy - 2).z);
+                    if (dx == 2 && dy == 2)
+                        input = c;
+                    else if (viewZ < minViewZ) {
+                        minViewZ = viewZ;
+                        offx = dx;
+                        offy = dy;
+                    }
+                    const int qx = dx / 2 - 1, qy = dy / 2 - 1; // integer division of the shader (:103)
+                    const int r2 = qx * qx + qy * qy;
+                    const float w = r2 == 0 ? 1.0f : (r2 == 1 ? 0.36787944f : 0.13533528f);
+                    m1 = {fma_(c.x, w, m1.x), fma_(c.y, w, m1.y), fma_(c.z, w, m1.z)};
+                    m2 = {fma_(c.x * c.x, w, m2.x), fma_(c.y * c.y, w, m2.y), fma_(c.z * c.z, w, m2.z)};
+                    sum += w;
+                }
+            float rs = rcp_(sum);
+            m1 = mul3(m1, rs);
+            m2 = mul3(m2, rs);
+            f3 sigma = {sqrt_(absf(m2.x - m1.x * m1.x)) * 2.0f, sqrt_(absf(m2.y - m1.y * m1.y)) * 2.0f, sqrt_(absf(m2.z - m1.z * m1.z)) * 2.0f};
+            f3 mvn = mv_at(x + offx - 2, y + offy - 2);
+            float pu = fma_(mvn.x, k.invW, u), pv = fma_(mvn.y, k.invH, v);
+            f4 history = bicubic_no_corners(k, sat(pu) * k.Wp, sat(pv) * k.Hp);
+            f3 hist = {fmax2(history.x, 0.0f), fmax2(history.y, 0.0f), fmax2(history.z, 0.0f)};
+            float mixRate = sat(history.w);
+            mixRate = mixRate * rcp_(1.0f + mixRate);
+            bool inScreen = sat(pu) == pu && sat(pv) == pv;
+            mixRate = inScreen ? mixRate : 1.0f;
+            f3 clamped = clamp_aabb(m1, sigma, hist);
+            f3 a = xyz_to_lab(rgb_to_xyz(clamped)), b = xyz_to_lab(rgb_to_xyz(hist));
+            f3 dl = sub3(a, b);
+            float diff = sqrt_(dot3(dl, dl)) * (1.0f / (2.3f * 3.0f));
+            mixRate = sat(mixRate + diff);
+            float t = fmax2(mixRate, d.taa);
+            store4(d.result, d.result_pitch, x, y, lerpf(clamped.x, input.x, t), lerpf(clamped.y, input.y, t), lerpf(clamped.z, input.z, t), mixRate);
+        }
+    return 0;
+}
+
 
 __attribute__((visibility("default"))) int orc_confidence_blur(const nrdhip_confidence_blur_desc* d, void* /*stream*/) {
     if (!d || !d->ping || !d->pong || !d->width || !d->height || d->pitch_bytes < (uint32_t)d->width * 8u || d->first_pass + d->passes_num > 5u)

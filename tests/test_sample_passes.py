@@ -193,3 +193,77 @@ def test_unpack_hip_bit_exact(pkg, api, oracle, hip, mode, relax, resolve):
     b = run_unpack(sp, api, hip, d, mode, relax, resolve, to_dev=lambda t: torch.from_numpy(t).to("cuda:0"))
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TAA (Shaders/Taa.cs.hlsl)
+def make_taa_inputs(w, h, seed, motion=(0.0, 0.0)):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([0.5 + 0.4 * np.sin(x * 0.21), 0.5 + 0.4 * np.cos(y * 0.17), 0.3 + 0.2 * np.sin((x + y) * 0.11)], -1)
+    comp = np.concatenate([img * (1 + 0.1 * rng.standard_normal((h, w, 1))), np.ones((h, w, 1))], -1).astype(np.float16)
+    mv = np.zeros((h, w, 4), np.float16)
+    mv[..., 0], mv[..., 1] = motion
+    z = np.where(x < w / 2, 4.0, 9.0) * 0.125
+    mv[..., 3] = z * np.where((y > h * 0.7), -1.0, 1.0)  # negative w: thin / noisy geometry asks for the 5x5 window
+    hist = np.concatenate([img, np.full((h, w, 1), 0.3)], -1).astype(np.float16)
+    return mv, comp, hist
+
+
+def run_taa(sp, backend, mv, comp, hist, to_dev=None, **kw):
+    h, w = mv.shape[:2]
+    b = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], -1).copy()
+    dev = (lambda a: a) if to_dev is None else to_dev
+    out = dev(np.zeros((h, w * 8), np.uint8))
+    sp.taa(backend, dev(b(mv)), dev(b(comp)), dev(b(hist)), out, w, h, render_width=hist.shape[1], render_height=hist.shape[0], **kw)
+    out = out.cpu().numpy() if hasattr(out, "cpu") else out
+    return out.view(np.float16).reshape(h, w, 4)
+
+
+def test_taa_known_answers(pkg, oracle):
+    sp = load_sp(pkg)
+    w, h = 64, 40
+    # a constant image with a constant history is a fixed point (tonemap off): result = image, mix rate decays as m / (1 + m)
+    mv, comp, hist = make_taa_inputs(w, h, 0)
+    comp[..., :3] = np.float16(0.4)
+    hist[..., :3] = np.float16(0.4)
+    hist[..., 3] = np.float16(0.5)
+    out = run_taa(sp, oracle, mv, comp, hist, tonemap=False, taa_min_mix=0.05).astype(np.float32)
+    assert np.allclose(out[..., :3], 0.4, atol=1e-3)
+    assert np.allclose(out[..., 3], 0.5 / 1.5, atol=2e-3)
+    # motion pointing outside the screen: no history -> the (tonemapped) input passes through with mix rate 1
+    mv2, comp2, hist2 = make_taa_inputs(w, h, 1, motion=(-3.0 * w, 0.0))
+    out = run_taa(sp, oracle, mv2, comp2, hist2, tonemap=False).astype(np.float32)
+    assert np.allclose(out[..., :3], comp2[..., :3].astype(np.float32), atol=2e-3) and np.all(out[..., 3] == 1.0)
+    # a history far outside the neighbourhood colour box is clipped back to it and mostly rejected
+    mv3, comp3, hist3 = make_taa_inputs(w, h, 2)
+    hist3[..., :3] = np.float16(5.0)
+    out = run_taa(sp, oracle, mv3, comp3, hist3, tonemap=False).astype(np.float32)
+    assert out[..., :3].max() < 1.5 and out[..., 3].mean() > 0.9
+    # integer-pixel motion fetches the history exactly one pixel to the side (bicubic weights collapse at f = 0)
+    mv4, comp4, hist4 = make_taa_inputs(w, h, 3, motion=(1.0, 0.0))
+    comp4[..., :3] = hist4[..., :3]
+    shifted = np.roll(hist4, -1, axis=1)
+    out = run_taa(sp, oracle, mv4, comp4, hist4, tonemap=False, taa_min_mix=0.0).astype(np.float32)
+    ref0 = run_taa(sp, oracle, np.zeros_like(mv4) + mv4 * np.array([0, 0, 0, 1], np.float16), comp4, shifted, tonemap=False, taa_min_mix=0.0).astype(np.float32)
+    assert np.allclose(out[:, 2:-3], ref0[:, 2:-3], atol=2e-3)
+
+
+@pytest.mark.parametrize("tonemap,motion", [(True, (0.4, -0.7)), (False, (2.5, 1.25))])
+def test_taa_emulated_bit_exact(pkg, oracle, emulated, tonemap, motion):
+    sp = load_sp(pkg)
+    mv, comp, hist = make_taa_inputs(70, 37, 5, motion=motion)
+    a = run_taa(sp, oracle, mv, comp, hist, tonemap=tonemap, hdr_scale=1.25)
+    b = run_taa(sp, emulated, mv, comp, hist, tonemap=tonemap, hdr_scale=1.25)
+    assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tonemap,motion", [(True, (0.4, -0.7)), (False, (2.5, 1.25))])
+def test_taa_hip_bit_exact(pkg, oracle, hip, tonemap, motion):
+    import torch
+    sp = load_sp(pkg)
+    mv, comp, hist = make_taa_inputs(500, 281, 6, motion=motion)
+    a = run_taa(sp, oracle, mv, comp, hist, tonemap=tonemap, hdr_scale=1.25)
+    b = run_taa(sp, hip, mv, comp, hist, to_dev=lambda t: torch.from_numpy(t).to("cuda:0"), tonemap=tonemap, hdr_scale=1.25)
+    assert np.array_equal(a.view(np.uint16), b.view(np.uint16))
