@@ -25,6 +25,19 @@ for f in glob.glob(os.path.join(root, "gpurun_out", "prof_" + tag, "**", "*kerne
             if "nrdhip::" in r["Name"]:
                 o.write('"%s",%s,%s,%.0f,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
 
+# steady-state view from the per-dispatch trace: mean over the LAST `steps` launches of each kernel (the timed region of the
+# bench; rocprofv3's own --stats average above also spans the warm-up launches, where histories are short and the passes slower)
+for f in glob.glob(os.path.join(root, "gpurun_out", "prof_" + tag, "**", "*kernel_trace.csv"), recursive=True):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "nrdhip::" in r["Kernel_Name"]:
+            per[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(out, "%s_kernel_steady_%s.csv" % (tag, wl)), "w") as o:
+        o.write("kernel,launches_total,timed_launches,avg_ns_timed_region,avg_ns_all\n")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1][-steps:])):
+            t = v[-steps:]
+            o.write('"%s",%d,%d,%.0f,%.0f\n' % (k, len(v), len(t), sum(t) / len(t), sum(v) / len(v)))
+
 # PMC passes: per kernel, per counter: mean over launches
 acc = defaultdict(lambda: defaultdict(list))
 for d in glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_*" % tag)):
