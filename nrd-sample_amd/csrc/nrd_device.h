@@ -18,6 +18,9 @@
 
 #define NRD_DEV static __device__ __forceinline__
 #define NRD_HD static __host__ __device__ __forceinline__
+#ifndef NRD_WAVES_PER_EU // occupancy target of a kernel (the host emulation of the tests defines it away)
+#define NRD_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 
 namespace nrdhip {
 

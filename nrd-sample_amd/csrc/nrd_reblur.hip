@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
 // MODE: 0 = REBLUR radiance, 1 = RELAX radiance, 2 = OCCLUSION (hit distance only), 3 = REBLUR SH, 4 = RELAX SH (compile-time so
 // the unrolled tap loop stays one basic block)
 template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
-__global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
+// 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
+// carry 16 more registers of tap data and stay at 3
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spatial(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr bool SH = MODE == 3 || MODE == 4;
     constexpr int sb = SH ? 16 : 8;   // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
             // one range test per axis. Phase 2 validates and accumulates: a rejected tap is SELECTED out (sums untouched),
             // exactly like an early "continue". The scheduling barrier keeps the compiler from serialising load -> use pairs
             // when registers get tight (one memory round trip per signal instead of eight).
-            float fpx[NRD_TAP_BATCH], fpy[NRD_TAP_BATCH];
+            float gaT[NRD_TAP_BATCH]; // plane-equation term of geo_weight at the tap position
             bool inWin[NRD_TAP_BATCH];
             uint4 graw[NRD_TAP_BATCH];
             uint2 sraw[NRD_TAP_BATCH], sraw1[NRD_TAP_BATCH];
@@ -384,9 +386,10 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                         ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
                         oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
                     }
-                    fpx[k] = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
-                    fpy[k] = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
-                    int ipx = (int)__builtin_amdgcn_fmed3f(fpx[k], loXf, hiXf), ipy = (int)__builtin_amdgcn_fmed3f(fpy[k], loYf, hiYf);
+                    float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
+                    float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
+                    gaT[k] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
+                    int ipx = (int)__builtin_amdgcn_fmed3f(fpx, loXf, hiXf), ipy = (int)__builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
                     inWin[k] = ((uint32_t)(ipx - loX) <= spanX) & ((uint32_t)(ipy - loY) <= spanY);
                     int px = imin(imax(ipx, loX), hiX), cpy = imin(imax(ipy, loY), hiY) - c.yOff;
                     graw[k] = ld<uint4>(p.guide, px, cpy, 16);
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void k_spatial(const ReblurParams p) {
                     f4 sv = decode_signal(p, sraw[k], occIn);
                     bool valid = inWin[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
                     float w = g_poisson8[t][2];
-                    w *= geo_weight(pg, fpx[k], fpy[k], gs.z);
+                    w *= smoothstep01(1.0f - absf(fma_(gs.z, gaT[k], pg.geoB))); // == geo_weight(pg, fpx, fpy, gs.z)
                     w *= normal_weight(dot3(g.n, gs.n), normalW2);
                     if (isSpec)
                         w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));

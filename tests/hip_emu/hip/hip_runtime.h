@@ -22,6 +22,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define NRD_WAVES_PER_EU(n)
 #define __shared__ static
 
 struct dim3 {
