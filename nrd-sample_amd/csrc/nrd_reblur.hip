@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
     // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per pixel for Blur (decorrelation)
     constexpr bool PER_PIXEL = VARIANT == 1;
-    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x : 0u, PER_PIXEL ? (uint32_t)gy0 : 0u, c.frameIndex, (uint32_t)VARIANT + 1u);
+    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x >> 1 : 0u, PER_PIXEL ? (uint32_t)gy0 >> 1 : 0u, c.frameIndex, (uint32_t)VARIANT + 1u); // one rotation per 2x2 quad
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)
