@@ -34,6 +34,7 @@ WORKLOADS = {
     "relax_ds_4k": (3840, 2160, ["RELAX_DIFFUSE_SPECULAR"]),
     "relax_ds_sh_4k": (3840, 2160, ["RELAX_DIFFUSE_SPECULAR_SH"]),  # BASELINE.json configs[3]
     "reblur_ds_sh_4k": (3840, 2160, ["REBLUR_DIFFUSE_SPECULAR_SH"]),
+    "reblur_ds_8k": (7680, 4320, ["REBLUR_DIFFUSE_SPECULAR"]),  # BASELINE.json configs[4] on ONE GPU (the 8-GPU run row-tiles 4K bands)
 }
 
 
