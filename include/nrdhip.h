@@ -105,6 +105,15 @@ NRDHIP_API int nrdhip_dispatch_info_get(nrdhip_instance* inst, const uint32_t* i
 NRDHIP_API int nrdhip_denoise_range(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, uint32_t first,
                                     uint32_t count, void* hip_stream);
 
+/* One dispatch restricted to LOCAL rows [row_first, row_first + row_count) of the rows this instance owns (clipped to them;
+ * multiples of 16 keep whole tiles together). A row-tiling host launches the boundary strips of a pass first, starts the halo
+ * exchange of those rows, and computes the interior while the exchange is in flight. `part`: bit 0 = first part of
+ * this dispatch this frame (performs the CLEAR_AND_RESTART clear when due), bit 1 = last part (advances the frame state when the
+ * dispatch is the denoiser's last). nrdhip_denoise_range(.., index, 1, ..) == nrdhip_denoise_rows(.., index, 0, all rows, 3, ..). */
+enum { NRDHIP_PART_FIRST = 1u, NRDHIP_PART_LAST = 2u };
+NRDHIP_API int nrdhip_denoise_rows(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, uint32_t index,
+                                   uint32_t row_first, uint32_t row_count, uint32_t part, void* hip_stream);
+
 /* nrd::GetInstanceDesc pools (permanent = 0, transient = 1): description and (external pools) binding */
 NRDHIP_API int nrdhip_pool_size(nrdhip_instance* inst, uint32_t pool, uint32_t* count);
 NRDHIP_API int nrdhip_pool_info(nrdhip_instance* inst, uint32_t pool, uint32_t index, nrdhip_plane_info* out);

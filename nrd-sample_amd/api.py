@@ -368,6 +368,7 @@ class Backend:
         self._sig("dispatch_count", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.POINTER(_u32)])
         self._sig("dispatch_info_get", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, _u32, C.POINTER(DispatchInfo)])
         self._sig("denoise_range", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, _u32, _u32, C.c_void_p])
+        self._sig("denoise_rows", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, _u32, _u32, _u32, _u32, C.c_void_p])
         self._sig("pool_size", C.c_int, [C.c_void_p, _u32, C.POINTER(_u32)])
         self._sig("pool_info", C.c_int, [C.c_void_p, _u32, _u32, C.POINTER(PlaneInfo)])
         self._sig("bind_pool", C.c_int, [C.c_void_p, _u32, _u32, C.c_void_p, _u32])
@@ -522,6 +523,14 @@ class Integration:
     def denoise_range(self, identifiers, first, count):
         ids, n = self._ids(identifiers)
         self._check(self.backend.denoise_range(self.handle, ids, n, first, count, self._stream()), "Denoise(range)")
+
+    PART_FIRST, PART_LAST = 1, 2
+
+    def denoise_rows(self, identifiers, index, row_first, row_count, part=3):
+        """one dispatch restricted to local rows [row_first, row_first + row_count) (nrdhip_denoise_rows): row-tiling hosts
+        launch boundary strips first so that their halo exchange overlaps the interior"""
+        ids, n = self._ids(identifiers)
+        self._check(self.backend.denoise_rows(self.handle, ids, n, index, row_first, row_count, part, self._stream()), "Denoise(rows)")
 
     def memory_usage_mb(self):
         out = (_f * 3)()

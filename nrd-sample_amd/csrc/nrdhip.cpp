@@ -1049,7 +1049,40 @@ NRDHIP_API int nrdhip_dispatch_info_get(nrdhip_instance* inst, const uint32_t* i
     return 0;
 }
 
+static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, uint32_t part, void* stream);
+
 NRDHIP_API int nrdhip_denoise_range(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, void* stream) {
+    return denoise_parts(inst, ids, n, first, count, NRDHIP_PART_FIRST | NRDHIP_PART_LAST, stream);
+}
+
+NRDHIP_API int nrdhip_denoise_rows(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t index, uint32_t row_first, uint32_t row_count,
+                                   uint32_t part, void* stream) {
+    if (!inst)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    nrdhip_instance& I = *inst;
+    // clip the requested window to the rows this instance owns, run the dispatch on it, restore
+    const int own0 = I.ownY0, ownN = I.ownRows;
+    int lo = std::max((int)row_first, own0), hi = (int)(row_first + row_count);
+    if (ownN)
+        hi = std::min(hi, own0 + ownN);
+    hi = std::min(hi, (int)I.resH);
+    int r = 0;
+    if (hi > lo) {
+        I.ownY0 = lo;
+        I.ownRows = hi - lo;
+        r = denoise_parts(inst, ids, n, index, 1, part, stream);
+        I.ownY0 = own0;
+        I.ownRows = ownN;
+    } else if (part & NRDHIP_PART_LAST) { // nothing to compute, but the frame state must still advance
+        I.ownY0 = own0;
+        I.ownRows = ownN;
+        r = denoise_parts(inst, ids, n, index, 1, (part & ~NRDHIP_PART_FIRST) | 4u, stream);
+    }
+    return r;
+}
+
+// part: NRDHIP_PART_FIRST / NRDHIP_PART_LAST, bit 2 = bookkeeping only (no launch)
+static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, uint32_t part, void* stream) {
     if (!inst)
         return (int)nrd::Result::INVALID_ARGUMENT;
     nrdhip_instance& I = *inst;
@@ -1079,11 +1112,12 @@ NRDHIP_API int nrdhip_denoise_range(nrdhip_instance* inst, const uint32_t* ids, 
                     I.error = std::string("resource slot not bound for pass ") + x.name;
                     return (int)nrd::Result::INVALID_ARGUMENT;
                 }
-        if (fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
+        if ((part & NRDHIP_PART_FIRST) && fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
             for (uint32_t k = d.permBase; k < d.permEnd; k++)
                 (void)hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);
-        x.launch(st);
-        if (fl[i].index + 1 == d.dispatches.size()) {
+        if (!(part & 4u))
+            x.launch(st);
+        if ((part & NRDHIP_PART_LAST) && fl[i].index + 1 == d.dispatches.size()) {
             d.framesSinceReset = (reset || !d.historyValid) ? 1 : d.framesSinceReset + 1;
             d.frameCounter++;
             d.historyValid = true;

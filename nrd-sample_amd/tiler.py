@@ -58,6 +58,7 @@ class Tiler:
     def __init__(self, band, dist, group=None):
         self.band, self.dist, self.group = band, dist, group
         self.bytes_exchanged = 0
+        self.split_dispatches = 0  # dispatches run as boundary strips + interior with the exchange in flight
         self._plan_cache = {}
 
     def _as_tensor(self, buf):
@@ -72,8 +73,10 @@ class Tiler:
         return self.band.nrd.pools[pool][index]
 
     def _plan(self, ids, dispatches):
-        """for every dispatch: the pool planes whose halo rows must be refreshed before a later reader runs"""
-        key = tuple((d["name"], tuple(d["written"])) for d in dispatches)
+        """for every dispatch: [(plane code, rows)] - the pool planes it writes whose boundary rows a neighbour will read, and
+        how many rows: the largest halo of the dispatches that read the plane before it is written again; permanent planes
+        that survive the frame get the full halo (next frame's reprojection reads them at motion-displaced rows)"""
+        key = tuple((d["name"], tuple(d["written"]), tuple(d["read"]), d["halo_rows"]) for d in dispatches)
         if key in self._plan_cache:
             return self._plan_cache[key]
         plan = []
@@ -82,22 +85,28 @@ class Tiler:
             for code in d["written"]:
                 if (code >> 16) > 1:
                     continue  # output slots are final
-                permanent = (code >> 16) == 0
-                later_stencil = any(code in r["read"] and r["halo_rows"] > 0 for r in dispatches[i + 1:])
-                if permanent or later_stencil:
-                    todo.append(code)
+                rows, rewritten = 0, False
+                for r in dispatches[i + 1:]:
+                    if code in r["read"]:
+                        rows = max(rows, r["halo_rows"])
+                    if code in r["written"]:
+                        rewritten = True
+                        break
+                if (code >> 16) == 0 and not rewritten:
+                    rows = self.band.halo
+                if rows > 0:
+                    todo.append((code, min(rows, self.band.halo)))
             plan.append(todo)
         self._plan_cache[key] = plan
         return plan
 
-    def exchange(self, bufs_rows):
-        """bufs_rows: list of (2-D byte tensor [local rows, pitch], rows-per-texel-row divisor). Exchanges the owned boundary
-        rows with rank-1 / rank+1 into their halos."""
+    def _ops(self, bufs_rows):
+        """send / recv descriptors for [(2-D byte tensor [local rows, pitch], rows-per-texel-row divisor, rows)]"""
         dist, b = self.dist, self.band
-        L, halo = b.layout, b.halo
-        ops, keep = [], []
-        for t, div in bufs_rows:
-            hrows = max(halo // div, 1)
+        L = b.layout
+        ops = []
+        for t, div, rows in bufs_rows:
+            hrows = max((rows + div - 1) // div, 1)
             first, n = L["own_first"] // div, max(L["own_rows"] // div, 1)
             total = t.shape[0]
             if b.rank > 0:  # upper neighbour: send my first owned rows, receive into my top halo
@@ -114,13 +123,23 @@ class Tiler:
                 ops.append((dist.isend, send, b.rank + 1))
                 if recv.shape[0] > 0:
                     ops.append((dist.irecv, recv, b.rank + 1))
+        return ops
+
+    def exchange_start(self, bufs_rows):
+        """enqueue the exchange (RCCL: on the communicator's stream, ordered after the work already on the current stream);
+        returns the handles to wait on"""
+        ops = self._ops(bufs_rows)
         if not ops:
-            return
-        p2p = [dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops]
+            return []
+        dist = self.dist
         for fn, ten, _ in ops:
             if fn is dist.isend:
                 self.bytes_exchanged += ten.numel() * ten.element_size()
-        for w in dist.batch_isend_irecv(p2p):
+        return dist.batch_isend_irecv([dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops])
+
+    def exchange(self, bufs_rows):
+        """blocking exchange of the full halo of [(tensor, divisor)] planes (external inputs)"""
+        for w in self.exchange_start([(t, div, self.band.halo) for t, div in bufs_rows]):
             w.wait()
 
     def exchange_inputs(self, planes):
@@ -132,21 +151,49 @@ class Tiler:
             items.append((self._as_tensor(planes[key]), 1))
         self.exchange(items)
 
+    def items_of(self, todo):
+        local_h = self.band.layout["local_h"]
+        items = []
+        for code, rows in todo:
+            p = self._plane_of(code)
+            div = max(int(round(local_h / p["height"])), 1)
+            items.append((self._as_tensor(p["buf"]), div, rows))
+        return items
+
+    def run_dispatch(self, ids, i, todo):
+        """one dispatch + the halo exchange of what it wrote. When the band is tall enough the rows a neighbour needs are
+        computed FIRST (boundary strips), their exchange is started, and the interior is computed while the rows travel -
+        the copies overlap the compute instead of serialising with it (nrdhip_denoise_rows)."""
+        nrd, L, b = self.band.nrd, self.band.layout, self.band
+        own0, own_n = L["own_first"], L["own_rows"]
+        strip = (max([r for _, r in todo] + [0]) + 15) // 16 * 16
+        up, down = b.rank > 0, b.rank < b.world - 1
+        if not todo or not (up or down) or own_n < 4 * strip or own0 % 16:
+            nrd.denoise_range(ids, i, 1)
+            for w in self.exchange_start(self.items_of(todo)):
+                w.wait()
+            return
+        self.split_dispatches += 1
+        lo = own0 + (strip if up else 0)
+        hi = own0 + own_n - (strip if down else 0)
+        first = True
+        if up:
+            nrd.denoise_rows(ids, i, own0, strip, part=1)
+            first = False
+        if down:
+            nrd.denoise_rows(ids, i, hi, own0 + own_n - hi, part=1 if first else 0)
+        works = self.exchange_start(self.items_of(todo))
+        nrd.denoise_rows(ids, i, lo, hi - lo, part=2)
+        for w in works:
+            w.wait()
+
     def denoise(self, identifiers):
         ids = [int(i) for i in identifiers]
         nrd = self.band.nrd
         dispatches = nrd.dispatches(ids)
         plan = self._plan(ids, dispatches)
-        local_h = self.band.layout["local_h"]
         for i, todo in enumerate(plan):
-            nrd.denoise_range(ids, i, 1)
-            items = []
-            for code in todo:
-                p = self._plane_of(code)
-                div = max(int(round(local_h / p["height"])), 1)
-                items.append((self._as_tensor(p["buf"]), div))
-            if items:
-                self.exchange(items)
+            self.run_dispatch(ids, i, todo)
 
 
 class TiledRunner:
@@ -201,23 +248,20 @@ class TiledRunner:
         if not self.events_on:
             self.tiler.denoise(self.ids)
             return
-        # timed variant: same stepping, HIP events around each kernel (exchange excluded from the per-kernel time)
+        # timed variant: same stepping, HIP events around each dispatch (its strips + interior; the wait for the rows in
+        # flight falls between the events of consecutive dispatches)
         ids = self.ids
         dispatches = band.nrd.dispatches(ids)
         if self.names is None:
             self.names = [(x["name"], x["bytes_per_pixel"]) for x in dispatches]
         plan = self.tiler._plan(ids, dispatches)
-        local_h = band.layout["local_h"]
         evs = []
         for i, todo in enumerate(plan):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            band.nrd.denoise_range(ids, i, 1)
+            self.tiler.run_dispatch(ids, i, todo)
             b.record()
             evs.append((a, b))
-            items = [(self.tiler._as_tensor(self.tiler._plane_of(c)["buf"]), max(int(round(local_h / self.tiler._plane_of(c)["height"])), 1)) for c in todo]
-            if items:
-                self.tiler.exchange(items)
         self.events.append(evs)
 
     def pass_times_ms(self):

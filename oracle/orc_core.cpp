@@ -397,7 +397,36 @@ NRDHIP_API int orc_dispatch_info_get(nrdhip_instance* inst, const uint32_t* ids,
     return 0;
 }
 
+static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, uint32_t part);
+
 NRDHIP_API int orc_denoise_range(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, void*) {
+    return denoise_parts(inst, ids, n, first, count, NRDHIP_PART_FIRST | NRDHIP_PART_LAST);
+}
+
+// mirror of nrdhip_denoise_rows (include/nrdhip.h): one pass restricted to a window of the owned local rows
+NRDHIP_API int orc_denoise_rows(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t index, uint32_t row_first, uint32_t row_count,
+                                uint32_t part, void*) {
+    if (!inst)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    Instance& I = inst->I;
+    const int own0 = I.ownY0, ownN = I.ownRows;
+    int lo = std::max((int)row_first, own0), hi = (int)(row_first + row_count);
+    if (ownN)
+        hi = std::min(hi, own0 + ownN);
+    hi = std::min(hi, (int)I.resH);
+    int r = 0;
+    if (hi > lo) {
+        I.ownY0 = lo;
+        I.ownRows = hi - lo;
+        r = denoise_parts(inst, ids, n, index, 1, part);
+        I.ownY0 = own0;
+        I.ownRows = ownN;
+    } else if (part & NRDHIP_PART_LAST)
+        r = denoise_parts(inst, ids, n, index, 1, (part & ~NRDHIP_PART_FIRST) | 4u);
+    return r;
+}
+
+static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t first, uint32_t count, uint32_t part) {
     if (!inst || !inst->I.commonSet)
         return (int)nrd::Result::INVALID_ARGUMENT;
     Instance& I = inst->I;
@@ -433,7 +462,7 @@ NRDHIP_API int orc_denoise_range(nrdhip_instance* inst, const uint32_t* ids, uin
                 I.error = std::string("output slot not bound for pass ") + p.name;
                 return (int)nrd::Result::INVALID_ARGUMENT;
             }
-        if (fl[i].passIndex == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART) {
+        if ((part & NRDHIP_PART_FIRST) && fl[i].passIndex == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART) {
             // clear this denoiser's permanent planes (history content is discarded)
             uint32_t end = (uint32_t)I.perm.size();
             for (auto& o : I.denoisers)
@@ -443,8 +472,9 @@ NRDHIP_API int orc_denoise_range(nrdhip_instance* inst, const uint32_t* ids, uin
                 for (int y = 0; y < I.perm[k].h; y++)
                     std::memset(I.perm[k].p + (size_t)y * I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt);
         }
-        run_pass(I, d, c, p);
-        if (fl[i].passIndex + 1 == d.passes.size()) { // frame of this denoiser complete
+        if (!(part & 4u))
+            run_pass(I, d, c, p);
+        if ((part & NRDHIP_PART_LAST) && fl[i].passIndex + 1 == d.passes.size()) { // frame of this denoiser complete
             d.framesSinceReset = (c.reset || !d.historyValid) ? 1 : d.framesSinceReset + 1;
             d.frameCounter++;
             d.historyValid = true;

@@ -40,7 +40,8 @@ def mode_frame_hook(pkg, mode, f, fr):
     fr.update(pkg.harness.to_checkerboard(fr, f, white=True))
 
 
-@pytest.mark.parametrize("world,frame_h,mode", [(2, 224, "default"), (3, 336, "default"), (2, 224, "cb")])
+@pytest.mark.parametrize("world,frame_h,mode", [(2, 224, "default"), (3, 336, "default"), (2, 224, "cb"),
+                                                 (2, 640, "default"), (3, 1008, "cb")])  # tall bands: boundary strips first, exchange overlapped
 def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mode):
     w, nframes, halo = 96, 3, 80
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -65,4 +66,8 @@ def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mo
     hist = np.concatenate([p["history"] for p in parts], 0)
     assert np.array_equal(hist, hz.pool("REBLUR::History"))
     assert sum(int(p["bytes"][0]) for p in parts) > 0
+    if frame_h // world >= 320:  # tall bands take the overlapped path: boundary strips, exchange in flight, interior
+        assert all(int(p["split"][0]) > 0 for p in parts)
+    else:
+        assert all(int(p["split"][0]) == 0 for p in parts)
     assert [int(p["own0"][0]) for p in parts] == sorted(int(p["own0"][0]) for p in parts)

@@ -60,6 +60,7 @@ def main():
     blob["history"] = band.own_rows(band.pool("REBLUR::History")).copy()
     blob["own0"] = np.array([band.layout["own0"], band.layout["own1"]])
     blob["bytes"] = np.array([t.bytes_exchanged])
+    blob["split"] = np.array([t.split_dispatches])
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **blob)
     dist.barrier()
     dist.destroy_process_group()
