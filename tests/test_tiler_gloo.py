@@ -67,7 +67,5 @@ def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mo
     assert np.array_equal(hist, hz.pool("REBLUR::History"))
     assert sum(int(p["bytes"][0]) for p in parts) > 0
     if frame_h // world >= 320:  # tall bands take the overlapped path: boundary strips, exchange in flight, interior
-        assert all(int(p["split"][0]) > 0 for p in parts)
-    else:
-        assert all(int(p["split"][0]) == 0 for p in parts)
+        assert all(int(p["split"][0]) >= 3 * 7 for p in parts)  # every REBLUR dispatch of every frame at least
     assert [int(p["own0"][0]) for p in parts] == sorted(int(p["own0"][0]) for p in parts)
