@@ -43,9 +43,21 @@ def mode_frame_hook(pkg, mode, f, fr):
 @pytest.mark.parametrize("world,frame_h,mode", [(2, 224, "default"), (3, 336, "default"), (2, 224, "cb"),
                                                  (2, 640, "default"), (3, 1008, "cb")])  # tall bands: boundary strips first, exchange overlapped
 def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mode):
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, "oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,frame_h,mode", [(2, 640, "default"), (2, 704, "cb")])
+def test_row_tiling_hip_bit_identical(tmp_path, pkg, api, oracle, hip, world, frame_h, mode):
+    """the real kernels, two ranks sharing the one GPU of the box (gloo moves the rows): exercises nrdhip_denoise_rows, the strip /
+    interior split and the stream ordering of the overlapped exchange; the result must equal the single-instance oracle run"""
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, "hip")
+
+
+def run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, backend):
     w, nframes, halo = 96, 3, 80
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo), mode]
+           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo), mode, backend]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
