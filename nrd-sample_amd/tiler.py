@@ -135,6 +135,11 @@ class Tiler:
         for fn, ten, _ in ops:
             if fn is dist.isend:
                 self.bytes_exchanged += ten.numel() * ten.element_size()
+        if ops[0][1].is_cuda and dist.get_backend(self.group) != "nccl":
+            # only RCCL orders itself after the work already enqueued on the current stream; any other backend (gloo in the
+            # tests) must see finished rows
+            import torch
+            torch.cuda.current_stream().synchronize()
         return dist.batch_isend_irecv([dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops])
 
     def exchange(self, bufs_rows):
