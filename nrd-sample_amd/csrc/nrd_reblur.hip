@@ -1230,29 +1230,40 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     // rows / columns a tap may land on: inside the frame and inside the rows this instance holds
     const int loY = imax(0, -c.yOff), hiY = imin(c.resH, c.H - c.yOff) - 1;
     const bool roughStop = p.roughnessEdgeStopping != 0;
+    // the 8 taps in row-major order; gathered in batches (all loads of a batch in flight, then a scheduling barrier, then the
+    // arithmetic - one memory round trip per batch instead of one per tap)
+    constexpr int TI[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, TJ[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    constexpr int AB = SH ? 4 : 8; // 32-byte SH texels: half batches keep the kernel within its registers
 #pragma unroll
-    for (int j = -1; j <= 1; j++)
+    for (int t0 = 0; t0 < 8; t0 += AB) {
+        uint4 graw[AB];
+        uint2 stex[AB][RBPT / 8];
+        uint16_t mraw[AB][NSIG];
+        bool inside[AB];
 #pragma unroll
-        for (int i = -1; i <= 1; i++) {
-            if (i == 0 && j == 0)
-                continue;
-            int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
-            bool inside = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+        for (int k = 0; k < AB; k++) {
+            const int i = TI[t0 + k], j = TJ[t0 + k];
+            int px = x + i * stride, py = y + j * stride;
+            inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
             int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
-            uint4 graw = ld<uint4>(p.guide, cpx, cpy, 16); // all loads of the tap issued before it is validated
-            uint2 stex[RBPT / 8];
-            load_texel<RBPT>(p.in, cpx, cpy, stex);
-            uint16_t mraw[NSIG];
+            graw[k] = ld<uint4>(p.guide, cpx, cpy, 16);
+            load_texel<RBPT>(p.in, cpx, cpy, stex[k]);
 #pragma unroll
             for (int sig = 0; sig < NSIG; sig++)
-                mraw[sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
-            Guide gs = decode_guide(graw, c.denoisingRange);
+                mraw[k][sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < AB; k++) {
+            const int i = TI[t0 + k], j = TJ[t0 + k];
+            int px = x + i * stride, gy = y + j * stride + c.yOff;
+            Guide gs = decode_guide(graw[k], c.denoisingRange);
             float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
             float nDot = dot3(g.n, gs.n);
 #pragma unroll
             for (int sig = 0; sig < NSIG; sig++) {
                 const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-                bool valid = inside && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
+                bool valid = inside[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
                 float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
                 w *= geoW;
                 w *= normal_weight(nDot, normalW2[sig]);
@@ -1260,21 +1271,23 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                     float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                     w *= roughStop ? rw : 1.0f;
                 }
-                f4 sv = unpack_h4(stex[sig * SW]);
+                f4 sv = unpack_h4(stex[k][sig * SW]);
                 float vs = sv.w;
                 if (FIRST)
-                    vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[sig])), 0.0f);
+                    vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[k][sig])), 0.0f);
                 w *= fmax2(exp_weight(absf(sv.x - c0[sig].x) * invL[sig]), minLw[sig]);
                 sum[sig] = {valid ? fma_(sv.x, w, sum[sig].x) : sum[sig].x, valid ? fma_(sv.y, w, sum[sig].y) : sum[sig].y,
                             valid ? fma_(sv.z, w, sum[sig].z) : sum[sig].z};
                 if (SH) {
-                    f4 acc1 = fma4(unpack_h4(stex[sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
+                    f4 acc1 = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
                     sum1[sig] = {valid ? acc1.x : sum1[sig].x, valid ? acc1.y : sum1[sig].y, valid ? acc1.z : sum1[sig].z, valid ? acc1.w : sum1[sig].w};
                 }
                 sumVar[sig] = valid ? fma_(vs, w * w, sumVar[sig]) : sumVar[sig];
                 wsum[sig] = valid ? wsum[sig] + w : wsum[sig];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
