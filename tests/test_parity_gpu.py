@@ -115,3 +115,67 @@ def test_4k_properties(pkg, api, hip):
     assert np.isfinite(y_out).all()
     assert abs(y_out[64:-64, 64:-64].mean() / y_in[64:-64, 64:-64].mean() - 1) < 0.02
     assert y_out[64:-64, 64:-64].std() < 0.25 * y_in[64:-64, 64:-64].std()
+
+
+def test_4k_relax_sh_properties(pkg, api, hip):
+    """BASELINE config 4 size: RELAX_DIFFUSE_SPECULAR_SH at 3840x2160 - linear-RGB fixed point, SH1 rides along, determinism."""
+    import torch
+
+    w, h = 3840, 2160
+    D = api.Denoiser
+    d = D.RELAX_DIFFUSE_SPECULAR_SH
+    st = {d: api.RelaxSettings()}
+    fr = util.flat_frame(pkg, w, h)
+    for key, rgb in (("diff", (0.6, 0.5, 0.4)), ("spec", (0.3, 0.4, 0.5))):
+        fr[key][..., :3] = np.asarray(rgb, np.float16)  # RELAX takes linear RGB + world-space hit distance
+        fr[key][..., 3] = np.float16(2.0)
+        fr[key + "_sh1"] = np.broadcast_to(np.array([0.1, -0.2, 0.3, 0.0], np.float16), (h, w, 4)).copy()
+    outs = []
+    for rep in range(2):
+        hz = pkg.harness.Harness(hip, [d], w, h)
+        planes = hz.upload(fr)
+        for f in range(3):
+            hz.frame(util.static_common(api, w, h, f, reset=(f == 0)), planes, st)
+        torch.cuda.synchronize()
+        outs.append({k: hz.fetch(hz.outputs[k]).copy() for k in ("out_diff", "out_spec", "out_diff_sh1", "out_spec_sh1")})
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    o = outs[0]["out_diff"].view(np.float16).reshape(h, w, 4)
+    assert util.max_ulp_f16(o[..., :3], fr["diff"][..., :3]) <= 2
+    o1 = outs[0]["out_spec_sh1"].view(np.float16).reshape(h, w, 4)
+    assert util.max_ulp_f16(o1[..., :3], fr["spec_sh1"][..., :3]) <= 2
+
+
+def test_4k_row_window_dispatch_is_identical(pkg, api, hip):
+    """nrdhip_denoise_rows (boundary strips first, then the interior - what the row tiler does to overlap its halo exchange):
+    three row windows per dispatch must give exactly the frame a whole-frame dispatch gives, at the headline size."""
+    import torch
+
+    w, h = 3840, 2160
+    D = api.Denoiser
+    dens = [D.REBLUR_DIFFUSE_SPECULAR]
+    scene = pkg.synth.Scene(w, h, dolly=0.01, device="cuda:0")
+    st = util.default_settings(api, scene, dens, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    frames = [scene.frame(f) for f in range(3)]
+    res = []
+    for split in (False, True):
+        hz = pkg.harness.Harness(hip, dens, w, h)
+        ids = [int(dens[0])]
+        for f in range(3):
+            cs = scene.common_settings(api, frames[f], f, reset=(f == 0))
+            hz.nrd.new_frame()
+            hz.nrd.set_common_settings(cs)
+            hz.bind(hz.upload(frames[f]))
+            hz.nrd.set_denoiser_settings(ids[0], st[dens[0]])
+            n = len(hz.nrd.dispatches(ids))
+            for i in range(n):
+                if not split:
+                    hz.nrd.denoise_range(ids, i, 1)
+                else:
+                    hz.nrd.denoise_rows(ids, i, 0, 80, part=1)
+                    hz.nrd.denoise_rows(ids, i, h - 80, 80, part=0)
+                    hz.nrd.denoise_rows(ids, i, 80, h - 160, part=2)
+        torch.cuda.synchronize()
+        res.append((hz.fetch(hz.outputs["out_diff"]).copy(), hz.fetch(hz.outputs["out_spec"]).copy(), hz.pool("REBLUR::History").copy()))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
