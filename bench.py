@@ -110,11 +110,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the denoiser passes are HIP kernels, there is no CPU fallback")
+    # one rank per GPU over RCCL. NRD_BENCH_DRYRUN_BACKEND=gloo is a plumbing check only (ranks share the GPUs that exist,
+    # rows travel through the host): it exercises the N > 1 code path on a 1-GPU box, its numbers mean nothing.
+    backend = os.environ.get("NRD_BENCH_DRYRUN_BACKEND", "nccl")
+    local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     w, band_h, den_names = WORKLOADS[args.workload]
     dens = [api.Denoiser[n] for n in den_names]
