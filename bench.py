@@ -55,9 +55,9 @@ def cpu_baseline(pkg, denoiser_names, settings_of, device):
     """Oracle (scalar C++ port of the same passes, oracle/) on a bounded sample of the same workload: 1920x1080, 2 warm-up +
     3 timed frames, row-striped over the host's hardware threads. Frames are rendered on the GPU and copied to the host."""
     api, synth, harness = pkg.api, pkg.synth, pkg.harness
-    if not os.path.exists(pkg.ORACLE_LIB):
+    if not os.path.exists(graft.ORACLE_LIB):
         return None
-    orc = pkg.oracle_backend()
+    orc = graft.oracle_backend()  # the only use of oracle/ outside tests/ and smoke(): the reported CPU baseline
     w, h, frames, warm = 1920, 1080, 3, 2
     cores = min(os.cpu_count() or 1, h // 8)
     scene = synth.Scene(w, h, dolly=0.004, device=device, denoiser="RELAX" if denoiser_names[0].startswith("RELAX") else "REBLUR")

@@ -15,7 +15,6 @@ from . import api, harness, synth  # noqa: F401
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HIP_LIB = os.path.join(PKG_DIR, "csrc", "libnrdhip.so")
-ORACLE_LIB = os.path.join(REPO_DIR, "oracle", "_build", "liboracle.so")
 
 
 def hip_backend(device="cuda:0"):
@@ -32,12 +31,5 @@ def hip_backend(device="cuda:0"):
 def hip_library_symbols():
     """Load libnrdhip.so without touching a device (CPU-side ABI checks)."""
     b = api.Backend(HIP_LIB, "nrdhip_", "cuda:0")
-    b.check_abi()
-    return b
-
-
-def oracle_backend():
-    """TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline): the CPU oracle behind the same entry points."""
-    b = api.Backend(ORACLE_LIB, "orc_", "cpu")
     b.check_abi()
     return b

@@ -27,9 +27,9 @@ def api(pkg):
 @pytest.fixture(scope="session")
 def oracle(pkg):
     """CPU oracle backend (test infrastructure)."""
-    if not os.path.exists(pkg.ORACLE_LIB):
+    if not os.path.exists(graft.ORACLE_LIB):
         graft.build_oracle()
-    return pkg.oracle_backend()
+    return graft.oracle_backend()
 
 
 @pytest.fixture(scope="session")

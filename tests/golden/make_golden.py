@@ -42,7 +42,7 @@ def main():
     pkg = graft.load_package()
     graft.build_oracle()
     api, synth, harness = pkg.api, pkg.synth, pkg.harness
-    orc = pkg.oracle_backend()
+    orc = graft.oracle_backend()
     scene = synth.Scene(W, H, dolly=0.03)
     frames = [scene.frame(f) for f in range(FRAMES)]
     out_dir = os.path.dirname(os.path.abspath(__file__))
