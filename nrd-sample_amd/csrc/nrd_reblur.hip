@@ -297,8 +297,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     // tap window (global pixel coordinates): within `reach` of the centre, inside the frame and inside the held rows
     const int loX = imax(x - reach, 0), hiX = imin(x + reach, c.W - 1);
     const int loY = imax(gy0 - reach, imax(c.yOff, 0)), hiY = imin(gy0 + reach, imin(c.yOff + c.resH, c.H) - 1);
-    const uint32_t spanX = (uint32_t)(hiX - loX), spanY = (uint32_t)(hiY - loY);
-    const float loXf = (float)(loX - 1), hiXf = (float)(hiX + 1), loYf = (float)(loY - 1), hiYf = (float)(hiY + 1);
+    const float loXf = (float)loX, hiXf = (float)hiX, loYf = (float)loY, hiYf = (float)hiY; // floored tap positions are compared / clamped as floats
 
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
@@ -389,9 +388,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
                     float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
                     gaT[k] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
-                    int ipx = (int)__builtin_amdgcn_fmed3f(fpx, loXf, hiXf), ipy = (int)__builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
-                    inWin[k] = ((uint32_t)(ipx - loX) <= spanX) & ((uint32_t)(ipy - loY) <= spanY);
-                    int px = imin(imax(ipx, loX), hiX), cpy = imin(imax(ipy, loY), hiY) - c.yOff;
+                    inWin[k] = (fpx >= loXf) & (fpx <= hiXf) & (fpy >= loYf) & (fpy <= hiYf); // NaN positions fail every test
+                    int px = (int)__builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cpy = (int)__builtin_amdgcn_fmed3f(fpy, loYf, hiYf) - c.yOff;
                     graw[k] = ld<uint4>(p.guide, px, cpy, 16);
                     sraw[k] = load_signal_raw(srcP, px, cpy, srcBpt, srcOff, occIn);
                     sraw1[k] = SH ? ld<uint2>(src1P, px, cpy, srcBpt, src1Off) : uint2{0u, 0u};
