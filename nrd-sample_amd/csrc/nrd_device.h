@@ -70,7 +70,7 @@ NRD_DEV float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); 
 NRD_DEV float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 NRD_DEV float smoothstep01(float x) {
     x = sat(x);
-    return x * x * (3.0f - 2.0f * x);
+    return x * x * fma_(x, -2.0f, 3.0f); // == 3 - 2x rounded once: 2x is exact, so this is bit-identical to "3.0f - 2.0f * x"
 }
 NRD_DEV float absf(float x) { return x < 0.0f ? -x : x; }
 NRD_DEV int imin(int a, int b) { return a < b ? a : b; }
@@ -199,6 +199,9 @@ NRD_DEV float exp_weight(float ax) {
 }
 // normal weight on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; w2 = 1 / angleMax^2
 NRD_DEV float normal_weight(float cosa, float w2) { return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), w2, 1.0f)); }
+// same value with the factor -2 folded into the per-pixel constant (m2w2 = -2 * w2): scaling by 2 is exact, so
+// fma(-2 t, w2, 1) and fma(t, -2 w2, 1) round the same exact product - one multiply less per tap
+NRD_DEV float normal_weight_m2(float cosa, float m2w2) { return smoothstep01(fma_(sat(1.0f - cosa), m2w2, 1.0f)); }
 
 // ---- input decode (once per pixel, in the ClassifyTiles passes) ---------------------------------------------------
 NRD_DEV f3 oct_decode(float px, float py) {

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
             float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
             float normalW2 = normalW * normalW;
+            const float m2w2 = -2.0f * normalW2;
             float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
             float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
             float hitB = -center.w * hitA;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     bool valid = inWin[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
                     float w = g_poisson8[t][2];
                     w *= smoothstep01(1.0f - absf(fma_(gs.z, gaT[k], pg.geoB))); // == geo_weight(pg, fpx, fpy, gs.z)
-                    w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                    w *= normal_weight_m2(dot3(g.n, gs.n), m2w2);
                     if (isSpec)
                         w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                     if (relaxIn)
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         invL[sig] = 0.3333f * rcp_(fma_(p.phi[si], sigma, 1e-4f));
         float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
-        normalW2[sig] = normalW * normalW;
+        normalW2[sig] = -2.0f * (normalW * normalW); // holds -2 w^2 (normal_weight_m2)
         if (isSpec) {
             roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             roughB = -rough * roughA;
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 bool valid = inside[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
                 float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
                 w *= geoW;
-                w *= normal_weight(nDot, normalW2[sig]);
+                w *= normal_weight_m2(nDot, normalW2[sig]);
                 if (isSpec) {
                     float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                     w *= roughStop ? rw : 1.0f;
