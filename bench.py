@@ -174,7 +174,7 @@ def main():
         out = {
             "metric": "Mpixels/s full %s diff+spec pipeline" % den_names[0].split("_")[0], "value": round(value, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp16 planes)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s, %dx%d%s, steady state (accumulation saturated)" % (
                 args.workload, "+".join(den_names), w, frame_h, "" if world == 1 else " row-tiled %d x %d rows, RCCL halo exchange" % (world, band_h)),
                 "unique_input_frames": args.unique_frames, "algorithmic_bytes_per_pixel": round(sum_bpp, 2)},
