@@ -1378,8 +1378,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
-    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    (void)sb;
+            const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+            (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
@@ -1427,8 +1427,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.written = {T(T_TMP2)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
-    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    (void)sb;
+            const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+            (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).blur;
             for (int sig = 0; sig < d.nsig; sig++) {
@@ -1450,8 +1450,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.written = {P(P_HIST)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
-    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    (void)sb;
+            const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+            (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).post;
             for (int sig = 0; sig < d.nsig; sig++) {
@@ -1610,8 +1610,8 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.written = {T(T_TMP1), T(T_HITTRACK)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
-    const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-    (void)sb;
+            const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+            (void)sb;
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).pre;
             for (int sig = 0; sig < d.nsig; sig++) {
