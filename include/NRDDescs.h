@@ -174,6 +174,24 @@ struct ResourceDesc {
     bool isWritten;       // storage (true) or read-only (false) binding
 };
 
+// Formats this backend accepts per resource slot (the sample's texture formats, Source/NRDSample.cpp:2934-2990); a slot bound
+// with anything else makes Denoise fail with INVALID_ARGUMENT instead of silently misreading memory
+inline bool IsFormatAllowed(ResourceType type, Format format) {
+    switch (type) {
+        case ResourceType::IN_NORMAL_ROUGHNESS: return format == Format::R10_G10_B10_A2_UNORM;
+        case ResourceType::IN_VIEWZ: return format == Format::R32_SFLOAT;
+        case ResourceType::IN_DIFF_HITDIST:
+        case ResourceType::IN_SPEC_HITDIST:
+        case ResourceType::OUT_DIFF_HITDIST:
+        case ResourceType::OUT_SPEC_HITDIST: return format == Format::R16_UNORM || format == Format::R16_SFLOAT;
+        case ResourceType::IN_PENUMBRA: return format == Format::R16_SFLOAT;
+        case ResourceType::IN_TRANSLUCENCY:
+        case ResourceType::OUT_VALIDATION: return format == Format::RGBA8_UNORM;
+        case ResourceType::OUT_SHADOW_TRANSLUCENCY: return format == Format::RGBA8_UNORM || format == Format::R8_UNORM;
+        default: return format == Format::RGBA16_SFLOAT; // motion vectors, radiance / SH / direction planes, confidence, REFERENCE signal
+    }
+}
+
 // One recorded kernel launch ("dispatch" in the reference's vocabulary)
 struct DispatchDesc {
     const char* name;

@@ -1111,6 +1111,9 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                         continue;
                     I.error = std::string("resource slot not bound for pass ") + x.name;
                     return (int)nrd::Result::INVALID_ARGUMENT;
+                } else if ((s >> 16) == 2 && I.slots[s & 0xffff].p && !nrd::IsFormatAllowed((nrd::ResourceType)(s & 0xffff), (nrd::Format)I.slots[s & 0xffff].fmt)) {
+                    I.error = std::string("resource slot bound with an unsupported format for pass ") + x.name;
+                    return (int)nrd::Result::INVALID_ARGUMENT;
                 }
         if ((part & NRDHIP_PART_FIRST) && fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
             for (uint32_t k = d.permBase; k < d.permEnd; k++)

@@ -457,6 +457,12 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                 I.error = std::string("resource slot not bound for pass ") + p.name;
                 return (int)nrd::Result::INVALID_ARGUMENT;
             }
+        for (const auto* lst : {&p.read, &p.written})
+            for (uint32_t s : *lst)
+                if ((s >> 16) == 2 && I.slots[s & 0xffff].p && !nrd::IsFormatAllowed((nrd::ResourceType)(s & 0xffff), (nrd::Format)I.slots[s & 0xffff].fmt)) {
+                    I.error = std::string("resource slot bound with an unsupported format for pass ") + p.name;
+                    return (int)nrd::Result::INVALID_ARGUMENT;
+                }
         for (uint32_t s : p.written)
             if ((s >> 16) == 2 && !I.slots[s & 0xffff].p) {
                 I.error = std::string("output slot not bound for pass ") + p.name;

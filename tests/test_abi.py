@@ -69,6 +69,14 @@ def test_error_convention(request, api, which):
         nrd.denoise([int(D.REFERENCE)])  # IN_SIGNAL / OUT_SIGNAL not bound
     with pytest.raises(api.NrdError):
         nrd.set_denoiser_settings(int(D.REFERENCE), api.SigmaSettings())  # wrong settings struct for the denoiser
+    # a slot bound with a format the backend does not read is refused, not misread
+    import numpy as np
+    sig = np.zeros((64, 64 * 8), np.uint8)
+    nrd.set_resource(api.ResourceType.IN_SIGNAL, sig, api.Format.RGBA16_SFLOAT, width=64, height=64)
+    nrd.set_resource(api.ResourceType.OUT_SIGNAL, sig, api.Format.RGBA32_SFLOAT, width=32, height=64)
+    with pytest.raises(api.NrdError) as e:
+        nrd.denoise([int(D.REFERENCE)])
+    assert e.value.code == api.Result.INVALID_ARGUMENT and "format" in str(e.value)
     mem = nrd.memory_usage_mb()
     assert abs(mem["persistent"] - 64 * 64 * 16 / 1048576.0) < 1e-6
     nrd.destroy()
