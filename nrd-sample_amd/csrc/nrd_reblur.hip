@@ -774,18 +774,31 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
 // =====================================================================================================================
 // 5x5 luma tile in LDS: 20x20 floats, NaN marks "sky / outside" (the consumer substitutes its own centre value)
 // =====================================================================================================================
-NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, float& m1, float& m2) {
+// `holes` is block-uniform: false when every texel of the staged 20x20 tile is valid (the common case), and the per-tap NaN test
+// of the substitution is dropped - the sums are the same either way
+NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, bool holes, float& m1, float& m2) {
     m1 = 0.0f;
     m2 = 0.0f;
+    if (holes) {
 #pragma unroll
-    for (int j = 0; j < 5; j++)
+        for (int j = 0; j < 5; j++)
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            float f = tile[(ly + j) * 20 + lx + i];
-            f = f != f ? centre : f;
-            m1 += f;
-            m2 = fma_(f, f, m2);
-        }
+            for (int i = 0; i < 5; i++) {
+                float f = tile[(ly + j) * 20 + lx + i];
+                f = f != f ? centre : f;
+                m1 += f;
+                m2 = fma_(f, f, m2);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                float f = tile[(ly + j) * 20 + lx + i];
+                m1 += f;
+                m2 = fma_(f, f, m2);
+            }
+    }
     m1 *= 1.0f / 25.0f;
     m2 *= 1.0f / 25.0f;
 }
@@ -806,9 +819,11 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
+    bool holes = false; // some texel of the staged tiles is sky / outside (block-uniform)
     if (p.clampEnabled || p.antiFirefly) {
         // 20x20 luma tiles of all signals in one sweep (depth + one luma texel per position, clamped unconditional loads)
         int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+        int bad = 0;
         for (int i = tid; i < 400; i += 256) {
             int lx = i % 20, ly = i / 20;
             int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
@@ -817,6 +832,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             float zt = ld<float>(p.guide, cx, cy, 16, 0);
             uint32_t l = load_luma(p.fast, cx, cy, LBPT);
             bool ok = inside && absf(zt) <= c.denoisingRange;
+            bad |= ok ? 0 : 1;
 #pragma unroll
             for (int sig = 0; sig < NSIG; sig++)
                 tile[sig][i] = ok ? h2f((uint16_t)(l >> (16 * sig))) : u2f(0x7fc00000u);
@@ -826,7 +842,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                     tileCur[sig][i] = ok ? h2f(ld<uint16_t>(p.tmp2, cx, cy, RBPT, sig * sb)) : u2f(0x7fc00000u);
             }
         }
-        __syncthreads();
+        holes = __syncthreads_or(bad) != 0;
     }
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
@@ -903,7 +919,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         if (p.clampEnabled) {
             float fc = h2f(ld<uint16_t>(p.fast, x, y, LBPT, sig * 2));
             float m1, m2;
-            moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, m1, m2);
+            moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, holes, m1, m2);
             float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fastHistoryClampingSigmaScale;
             float Y = val.x;
             float Yc = clampf(Y, m1 - sigma, m1 + sigma);
@@ -994,6 +1010,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         return;
     // 20x20 luma tiles of all signals in one sweep: guide depth + whole radiance texel per position, fetched unconditionally
     // at clamped coordinates (NaN marks "sky / outside")
+    int bad = 0;
     {
         int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
         for (int i = tid; i < 400; i += 256) {
@@ -1005,12 +1022,13 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             uint2 t[RBPT / 8];
             load_texel<RBPT>(p.hist, cx, cy, t);
             bool ok = inside && absf(zt) <= c.denoisingRange;
+            bad |= ok ? 0 : 1;
 #pragma unroll
             for (int sig = 0; sig < NSIG; sig++)
                 tile[sig][i] = ok ? h2f((uint16_t)t[sig * SW].x) : u2f(0x7fc00000u);
         }
     }
-    __syncthreads();
+    const bool holes = __syncthreads_or(bad) != 0; // some texel of the staged tiles is sky / outside (block-uniform)
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
         return;
@@ -1062,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         f4 cur = unpack_h4(ctex[sig * SW]);
         float m1, m2;
-        moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, m1, m2);
+        moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, holes, m1, m2);
         float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f));
         float smbY, vmbY = 0.0f;
         bool smbOk = blend_stab(spos, sraw, sig, data2 & 15u, smbY) && historyOk;
