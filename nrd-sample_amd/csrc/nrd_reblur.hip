@@ -1148,25 +1148,62 @@ __global__ __launch_bounds__(256) void k_validation(const ReblurParams p) {
 // FIRST: iteration 0 (variance from the luminance moments, 3x3 spatial estimate for short histories). The 3x3 taps of the
 // signals share their positions, so the tap loop is the OUTER loop: one guide gather + decode + plane/normal terms per tap
 // serve both signals (each signal still sees exactly the operation sequence of the oracle).
-template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool FIRST>
+// LS > 0 (strides 1, 2, 4 = iterations 0..2): the workgroup's (16 + 2 LS)^2 window of guide + radiance (+ moment) texels is staged
+// in LDS once - every texel is read by up to 9 pixels - and the taps become LDS reads at compile-time offsets: no per-tap
+// address arithmetic, no bounds tests (a texel outside the frame / the held rows is staged with viewZ = NaN, i.e. as sky).
+// LS = 0 (strides >= 8, window too large for LDS at a useful occupancy): coalesced global gathers, batched.
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool FIRST, int LS>
 __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
     constexpr int SW = sb / 8; // uint2 words per signal
+    constexpr int TW = RBPT / 8; // uint2 words per radiance texel
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
+    constexpr int T = 16 + 2 * LS; // staged window edge
+    __shared__ uint4 sG[LS ? T * T : 1];
+    __shared__ uint2 sT[LS ? T * T * TW : 1];
+    __shared__ uint32_t sM[(LS && FIRST) ? T * T : 1];
     const FrameConsts& c = p.c;
+    // rows / columns a tap may land on: inside the frame and inside the rows this instance holds
+    const int loY = imax(0, -c.yOff), hiY = imin(c.resH, c.H - c.yOff) - 1;
     int x, y, tx, ty;
-    if (!my_pixel(c, x, y, tx, ty))
+    if (LS) {
+        if (!xcd_tile(c, tx, ty))
+            return;
+        const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+        for (int i = tid; i < T * T; i += 256) {
+            int lx = i % T, ly = i / T;
+            int px = tx * 16 + lx - LS, py = ty * 16 + ly - LS;
+            bool inside = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+            int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
+            uint4 gq = ld<uint4>(p.guide, cpx, cpy, 16);
+            gq.x = inside ? gq.x : 0x7fc00000u;
+            sG[i] = gq;
+            uint2 t[TW];
+            load_texel<RBPT>(p.in, cpx, cpy, t);
+#pragma unroll
+            for (int w = 0; w < TW; w++)
+                sT[i * TW + w] = t[w];
+            if (FIRST)
+                sM[i] = load_luma(p.mom, cpx, cpy, LBPT);
+        }
+        __syncthreads();
+        x = tx * 16 + (int)threadIdx.x;
+        y = ty * 16 + (int)threadIdx.y;
+        if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+            return;
+    } else if (!my_pixel(c, x, y, tx, ty))
         return;
+    const int ci = ((int)threadIdx.y + LS) * T + (int)threadIdx.x + LS; // this pixel in the staged window
     const int it = p.it;
     const bool last = p.last != 0;
-    const int stride = 1 << it;
+    const int stride = LS ? LS : 1 << it;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW;
     bool split = last && u < c.splitScreen;
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(LS ? sG[ci] : ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
@@ -1190,7 +1227,12 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     if (FIRST)
         unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
     uint2 ctex[RBPT / 8];
-    load_texel<RBPT>(p.in, x, y, ctex);
+    if (LS) {
+#pragma unroll
+        for (int w = 0; w < TW; w++)
+            ctex[w] = sT[ci * TW + w];
+    } else
+        load_texel<RBPT>(p.in, x, y, ctex);
     f4 c0[NSIG], sum1[NSIG];
     f3 sum[NSIG];
     float sumVar[NSIG], wsum[NSIG], invL[NSIG], normalW2[NSIG], minLw[NSIG];
@@ -1207,18 +1249,26 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         sum1[sig] = SH ? unpack_h4(ctex[sig * SW + (SH ? 1 : 0)]) : f4{0, 0, 0, 0};
         float var;
         if (FIRST) {
-            float m2 = h2f(ld<uint16_t>(p.mom, x, y, LBPT, sig * 2));
+            float m2 = h2f(LS ? (uint16_t)(sM[ci] >> (16 * sig)) : ld<uint16_t>(p.mom, x, y, LBPT, sig * 2));
             var = fmax2(fma_(-c0[sig].x, c0[sig].x, m2), 0.0f);
             if (A[si] < p.histThreshold) { // short history: 3x3 spatial estimate
                 float sy = 0.0f, sy2 = 0.0f, n = 0.0f;
                 for (int j = -1; j <= 1; j++)
                     for (int i = -1; i <= 1; i++) {
-                        int px = x + i, py = y + j, gy = py + c.yOff;
-                        if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
-                            continue;
-                        if (!(absf(ld<float>(p.guide, px, py, 16, 0)) <= c.denoisingRange))
-                            continue;
-                        float Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb));
+                        float Y;
+                        if (LS) { // iteration 0 filters the history itself: the staged window holds these texels
+                            int q = ci + j * T + i;
+                            if (!(absf(u2f(sG[q].x)) <= c.denoisingRange))
+                                continue;
+                            Y = h2f((uint16_t)sT[q * TW + sig * SW].x);
+                        } else {
+                            int px = x + i, py = y + j, gy = py + c.yOff;
+                            if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
+                                continue;
+                            if (!(absf(ld<float>(p.guide, px, py, 16, 0)) <= c.denoisingRange))
+                                continue;
+                            Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb));
+                        }
                         sy += Y;
                         sy2 = fma_(Y, Y, sy2);
                         n += 1.0f;
@@ -1244,8 +1294,6 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         sumVar[sig] = var;
         wsum[sig] = 1.0f;
     }
-    // rows / columns a tap may land on: inside the frame and inside the rows this instance holds
-    const int loY = imax(0, -c.yOff), hiY = imin(c.resH, c.H - c.yOff) - 1;
     const bool roughStop = p.roughnessEdgeStopping != 0;
     // the 8 taps in row-major order; gathered in batches (all loads of a batch in flight, then a scheduling barrier, then the
     // arithmetic - one memory round trip per batch instead of one per tap)
@@ -1260,6 +1308,18 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
 #pragma unroll
         for (int k = 0; k < AB; k++) {
             const int i = TI[t0 + k], j = TJ[t0 + k];
+            if (LS) {
+                const int q = ci + (j * T + i) * LS;
+                inside[k] = true; // outside texels were staged as sky
+                graw[k] = sG[q];
+#pragma unroll
+                for (int w = 0; w < TW; w++)
+                    stex[k][w] = sT[q * TW + w];
+#pragma unroll
+                for (int sig = 0; sig < NSIG; sig++)
+                    mraw[k][sig] = FIRST ? (uint16_t)(sM[q] >> (16 * sig)) : (uint16_t)0;
+                continue;
+            }
             int px = x + i * stride, py = y + j * stride;
             inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
             int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
@@ -1413,17 +1473,21 @@ void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s) 
         NRD_LAUNCH4(k_temporal_stabilization, false);
 }
 void launch_relax_atrous(const AtrousParams& p, hipStream_t s) {
-    bool first = p.it == 0;
+    // iteration -> (FIRST, LDS stride): 0 -> stride 1 with the moment plane, 1 -> 2, 2 -> 4, later ones gather from global memory
     if (p.sh) {
-        if (first)
-            NRD_LAUNCH4(k_relax_atrous, true, true);
-        else
-            NRD_LAUNCH4(k_relax_atrous, true, false);
+        switch (p.it) {
+        case 0: NRD_LAUNCH4(k_relax_atrous, true, true, 1); break;
+        case 1: NRD_LAUNCH4(k_relax_atrous, true, false, 2); break;
+        case 2: NRD_LAUNCH4(k_relax_atrous, true, false, 4); break;
+        default: NRD_LAUNCH4(k_relax_atrous, true, false, 0); break;
+        }
     } else {
-        if (first)
-            NRD_LAUNCH4(k_relax_atrous, false, true);
-        else
-            NRD_LAUNCH4(k_relax_atrous, false, false);
+        switch (p.it) {
+        case 0: NRD_LAUNCH4(k_relax_atrous, false, true, 1); break;
+        case 1: NRD_LAUNCH4(k_relax_atrous, false, false, 2); break;
+        case 2: NRD_LAUNCH4(k_relax_atrous, false, false, 4); break;
+        default: NRD_LAUNCH4(k_relax_atrous, false, false, 0); break;
+        }
     }
 }
 
