@@ -582,25 +582,22 @@ NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const ui
     }
     return f;
 }
-// weighted texel blends of an already fetched footprint
+// weighted texel blends of an already fetched footprint. A rejected texel has weight exactly 0 and every history plane holds
+// finite values (clamped fp16 stores, zeros on sky / never-written texels), so accumulating it unconditionally adds +-0 to a sum
+// that is never -0: bit-identical to skipping it (what the oracle does), without a select per component
 template <int WORDS>
 NRD_DEV f4 blend4(const Footprint& f, const uint2 (&t)[4][WORDS], int word) {
     f4 s = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        f4 acc = fma4(unpack_h4(t[i][word]), f.w[i], s);
-        bool on = f.w[i] > 0.0f;
-        s = {on ? acc.x : s.x, on ? acc.y : s.y, on ? acc.z : s.z, on ? acc.w : s.w};
-    }
+    for (int i = 0; i < 4; i++)
+        s = fma4(unpack_h4(t[i][word]), f.w[i], s);
     return mul4(s, rcp_(f.wsum));
 }
 NRD_DEV float blend1(const Footprint& f, const uint32_t (&r)[4], int half) {
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float acc = fma_(h2f((uint16_t)(r[i] >> (16 * half))), f.w[i], s);
-        s = f.w[i] > 0.0f ? acc : s;
-    }
+    for (int i = 0; i < 4; i++)
+        s = fma_(h2f((uint16_t)(r[i] >> (16 * half))), f.w[i], s);
     return s * (rcp_(f.wsum));
 }
 NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, float& sA) {
@@ -609,9 +606,8 @@ NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, flo
     for (int i = 0; i < 4; i++) {
         float a, b;
         unpack_data1(raw[i], a, b);
-        bool on = f.w[i] > 0.0f;
-        dA = on ? fma_(a, f.w[i], dA) : dA;
-        sA = on ? fma_(b, f.w[i], sA) : sA;
+        dA = fma_(a, f.w[i], dA);
+        sA = fma_(b, f.w[i], sA);
     }
     float inv = rcp_(f.wsum);
     dA *= inv;
