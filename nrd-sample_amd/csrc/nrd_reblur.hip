@@ -410,14 +410,25 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     if (relaxIn)
                         sv = rgb_to_ycocg4(sv);
                     w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
-                    f4 acc = fma4(sv, w, sum);
-                    sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
-                    if (SH) {
-                        f4 acc1 = fma4(unpack_h4(sraw1[k]), w, sum1);
-                        sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                    if (VARIANT == 0) {
+                        // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): a rejected tap is
+                        // selected out component by component
+                        f4 acc = fma4(sv, w, sum);
+                        sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
+                        if (SH) {
+                            f4 acc1 = fma4(unpack_h4(sraw1[k]), w, sum1);
+                            sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
+                        }
+                        wsum = valid ? wsum + w : wsum;
+                        minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
+                    } else {
+                        // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0 - one select
+                        w = valid ? w : 0.0f;
+                        sum = fma4(sv, w, sum);
+                        if (SH)
+                            sum1 = fma4(unpack_h4(sraw1[k]), w, sum1);
+                        wsum += w;
                     }
-                    wsum = valid ? wsum + w : wsum;
-                    minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1349,14 +1360,14 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 if (FIRST)
                     vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[k][sig])), 0.0f);
                 w *= fmax2(exp_weight(absf(sv.x - c0[sig].x) * invL[sig]), minLw[sig]);
-                sum[sig] = {valid ? fma_(sv.x, w, sum[sig].x) : sum[sig].x, valid ? fma_(sv.y, w, sum[sig].y) : sum[sig].y,
-                            valid ? fma_(sv.z, w, sum[sig].z) : sum[sig].z};
-                if (SH) {
-                    f4 acc1 = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
-                    sum1[sig] = {valid ? acc1.x : sum1[sig].x, valid ? acc1.y : sum1[sig].y, valid ? acc1.z : sum1[sig].z, valid ? acc1.w : sum1[sig].w};
-                }
-                sumVar[sig] = valid ? fma_(vs, w * w, sumVar[sig]) : sumVar[sig];
-                wsum[sig] = valid ? wsum[sig] + w : wsum[sig];
+                // a rejected tap enters with weight 0 (its texel is a finite value of an internal plane, fetched at the clamped
+                // position): one select on the weight instead of one per accumulated component
+                w = valid ? w : 0.0f;
+                sum[sig] = {fma_(sv.x, w, sum[sig].x), fma_(sv.y, w, sum[sig].y), fma_(sv.z, w, sum[sig].z)};
+                if (SH)
+                    sum1[sig] = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
+                sumVar[sig] = fma_(vs, w * w, sumVar[sig]);
+                wsum[sig] += w;
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -425,26 +425,32 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
                         float fpx = floorf(fma_(ox, jtx, fma_(oy, jbx, (float)x + 0.5f)));
                         float fpy = floorf(fma_(ox, jty, fma_(oy, jby, (float)gy0 + 0.5f)));
-                        if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
+                        // tap window: inside the frame, inside the held rows, within the hard reach of the pass
+                        const int loX = std::max(x - io.reach, 0), hiX = std::min(x + io.reach, c.W - 1);
+                        const int loY = std::max(gy0 - io.reach, std::max(c.yOff, 0)), hiY = std::min(gy0 + io.reach, std::min(c.yOff + c.resH, c.H) - 1);
+                        bool valid = fpx >= (float)loX && fpx <= (float)hiX && fpy >= (float)loY && fpy <= (float)hiY;
+                        // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): rejected taps are skipped.
+                        // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0, its texel
+                        // fetched at the position clamped into the window - no per-component select in the kernels.
+                        if (variant == PRE && !valid)
                             continue;
-                        int px = (int)fpx, gy = (int)fpy, py = gy - c.yOff;
-                        int ddx = px - x, ddy = gy - gy0;
-                        if (ddx > io.reach || -ddx > io.reach || ddy > io.reach || -ddy > io.reach)
-                            continue;
-                        if (py < 0 || py >= c.resH)
-                            continue;
+                        int px = (int)clampf(fpx, (float)loX, (float)hiX), py = (int)clampf(fpy, (float)loY, (float)hiY) - c.yOff;
                         Guide gs = load_guide(G, px, py, c.denoisingRange);
-                        if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
+                        valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
+                        if (variant == PRE && !valid)
                             continue;
-                        float w = g_poisson8[t][2];
-                        w *= geo_weight(pg, fpx, fpy, gs.z);
-                        w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                        if (isSpec)
-                            w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         f4 sv = load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
                         if (relaxIn)
                             sv = rgb_to_ycocg4(sv);
-                        w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
+                        float w = 0.0f;
+                        if (valid) {
+                            w = g_poisson8[t][2];
+                            w *= geo_weight(pg, fpx, fpy, gs.z);
+                            w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                            if (isSpec)
+                                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                            w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
+                        }
                         sum = fma4(sv, w, sum);
                         if (sh)
                             sum1 = fma4(load_sh1(io, sig, px, py, variant == PRE), w, sum1);
@@ -1206,25 +1212,30 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                     for (int i = -1; i <= 1; i++) {
                         if (i == 0 && j == 0)
                             continue;
+                        // a rejected tap (outside the frame / the held rows, sky, other material) enters with weight 0: its texel
+                        // is fetched at the clamped position (always a finite value of an internal plane)
                         int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
-                        if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
-                            continue;
-                        Guide gs = load_guide(G, px, py, c.denoisingRange);
-                        if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
-                            continue;
-                        float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
-                        w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                        w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                        if (isSpec && s.enableRoughnessEdgeStopping)
-                            w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                        f4 sv = ld_h4(IN, px, py, sig * sb);
+                        bool valid = !(px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH);
+                        const int loY = std::max(0, -c.yOff), hiY = std::min(c.resH, c.H - c.yOff) - 1;
+                        int cpx = std::min(std::max(px, 0), c.W - 1), cpy = std::min(std::max(py, loY), hiY);
+                        Guide gs = load_guide(G, cpx, cpy, c.denoisingRange);
+                        valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
+                        f4 sv = ld_h4(IN, cpx, cpy, sig * sb);
                         float vs = sv.w;
                         if (it == 0)
-                            vs = fmax2(fma_(-sv.x, sv.x, ld_h(MOM, px, py, sig * 2)), 0.0f);
-                        w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), minLw);
+                            vs = fmax2(fma_(-sv.x, sv.x, ld_h(MOM, cpx, cpy, sig * 2)), 0.0f);
+                        float w = 0.0f;
+                        if (valid) {
+                            w = (i == 0 || j == 0) ? 0.5f : 0.25f;
+                            w *= geo_weight(pg, (float)px, (float)gy, gs.z);
+                            w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                            if (isSpec && s.enableRoughnessEdgeStopping)
+                                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                            w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), minLw);
+                        }
                         sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
                         if (d.sh)
-                            sum1 = fma4(ld_h4(IN, px, py, sig * sb + 8), w, sum1);
+                            sum1 = fma4(ld_h4(IN, cpx, cpy, sig * sb + 8), w, sum1);
                         sumVar = fma_(vs, w * w, sumVar);
                         wsum += w;
                     }
