@@ -384,3 +384,33 @@ def test_directional_occlusion_fixed_point_and_layout(pkg, api, oracle):
     out = hz.output("out_diff_dirocc")
     assert np.array_equal(out[:, : w // 2].view(np.uint16), fr["diff_dirocc"][:, : w // 2].view(np.uint16))
     assert not np.array_equal(out[:, w // 2:].view(np.uint16), fr["diff_dirocc"][:, w // 2:].view(np.uint16))
+
+
+def test_baseline_config1_reference_256(pkg, api, oracle, emulated):
+    """BASELINE.json configs[0] as SURVEY.md 8d states it: REFERENCE, 256x256, analytic gradient x (1 + 0.5 U(-1, 1)), 64 frames,
+    maxAccumulatedFrameNum 1024, CLEAR_AND_RESTART at frame 32 - on the CPU oracle and on the emulated kernels (no GPU)."""
+    D = api.Denoiser
+    w = h = 256
+    x = (np.arange(w) + 0.5) / w
+    y = ((np.arange(h) + 0.5) / h)[:, None]
+    clean = np.stack([np.broadcast_to(x, (h, w)), np.broadcast_to(y, (h, w)), np.full((h, w), 0.5), np.ones((h, w))], -1)
+    st = {D.REFERENCE: api.ReferenceSettings(maxAccumulatedFrameNum=1024)}
+    outs = {}
+    for name, b in (("oracle", oracle), ("emulated", emulated)):
+        hz = pkg.harness.Harness(b, [D.REFERENCE], w, h)
+        rng = np.random.default_rng(0x9E3779B9 & 0xFFFF)
+        errs = []
+        for f in range(64):
+            noisy = clean.copy()
+            noisy[..., :3] *= 1.0 + 0.5 * rng.uniform(-1, 1, (h, w, 1))
+            planes = hz.upload({"signal": noisy.astype(np.float16)})
+            cs = util.static_common(api, w, h, f, reset=(f == 0 or f == 32))
+            hz.frame(cs, planes, st)
+            out = hz.fetch(planes["signal"]).view(np.float16).reshape(h, w, 4).astype(np.float64)
+            errs.append(((out[..., :3] - clean[..., :3]) ** 2).mean())
+            if f == 32:  # restart: the output is the (fp16) input of this frame
+                assert np.array_equal(out.astype(np.float16), noisy.astype(np.float16))
+        outs[name] = (errs, out)
+        # running mean: error variance ~ 1 / (frames since restart)
+        assert errs[31] < errs[0] / 20 and errs[63] < errs[32] / 20 and errs[33] > 5 * errs[31]
+    assert np.array_equal(outs["oracle"][1], outs["emulated"][1])
