@@ -179,3 +179,22 @@ def test_4k_row_window_dispatch_is_identical(pkg, api, hip):
         res.append((hz.fetch(hz.outputs["out_diff"]).copy(), hz.fetch(hz.outputs["out_spec"]).copy(), hz.pool("REBLUR::History").copy()))
     for a, b in zip(*res):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("den", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
+def test_4k_against_oracle(pkg, api, oracle, hip, den):
+    """the headline configuration (and BASELINE config 4) at FULL size, 3 frames of the moving-camera scene: every output and every
+    pool plane of the HIP path equals the CPU oracle bit for bit (the oracle needs ~1 s per 4K frame on the box's host cores)"""
+    w, h = 3840, 2160
+    scene = pkg.synth.Scene(w, h, dolly=0.01, denoiser="RELAX" if den.startswith("RELAX") else "REBLUR")
+    dd = [api.Denoiser[den]]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    ho = pkg.harness.Harness(oracle, dd, w, h)
+    oracle.lib.orc_set_threads(ho.nrd.handle, 128)
+    hg = pkg.harness.Harness(hip, dd, w, h)
+    for f in range(3):
+        fr = scene.frame(f)
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        ho.frame(cs, ho.upload(fr), st)
+        hg.frame(cs, hg.upload(fr), st)
+    assert util.compare_all(ho, hg, exact=True) == []
