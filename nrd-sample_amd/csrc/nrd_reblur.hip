@@ -7,16 +7,16 @@
 // pixel so a bilateral tap costs ONE 16-byte gather and four converts for all guides; diffuse+specular radiance interleaved
 // in one 16-byte texel; accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles, assigned to XCDs
 // in contiguous runs (nrd_device.h xcd_tile) so stencil / gather overlap between neighbouring tiles is served by one XCD's
-// L2. These are gather / stencil filters (measured VALU-bound, profiles/): no MFMA. 5x5 moment stencils stage their tile
-// (+2 halo) in LDS.
+// L2. These are gather / stencil filters (VALU-issue / gather-latency bound, profiles/): no MFMA. 5x5 moment stencils and the
+// first RELAX A-trous iterations stage their tile (+ halo) in LDS.
 #include "nrd_kernels.h"
 
 namespace nrdhip {
 
 namespace {
 
-// taps gathered per memory round trip in the spatial passes (8 = all taps of a signal; 4 halves the registers held by loads
-// in flight and buys one more wave per SIMD)
+// taps gathered per memory round trip in the spatial passes (8 = all taps of a signal; 4 or 2 were measured slower: more round
+// trips and no extra wave)
 #ifndef NRD_TAP_BATCH
 #define NRD_TAP_BATCH 8
 #endif
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
     float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
     // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
-    // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per pixel for Blur (decorrelation)
+    // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
     constexpr bool PER_PIXEL = VARIANT == 1;
     uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x >> 1 : 0u, PER_PIXEL ? (uint32_t)gy0 >> 1 : 0u, c.frameIndex, (uint32_t)VARIANT + 1u); // one rotation per 2x2 quad
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];

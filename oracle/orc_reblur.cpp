@@ -354,7 +354,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
             float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
             float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
             float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
-            // Poisson rotation: per frame for PrePass / PostBlur (neighbouring pixels then gather neighbouring texels), per pixel for Blur
+            // Poisson rotation: per frame for PrePass / PostBlur (neighbouring pixels then gather neighbouring texels), per 2x2 quad for Blur
             bool perPixel = variant == BLUR;
             uint32_t h = hash_px(perPixel ? (uint32_t)x >> 1 : 0u, perPixel ? (uint32_t)gy0 >> 1 : 0u, c.frameIndex, (uint32_t)variant + 1u); // one rotation per 2x2 quad
             float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
