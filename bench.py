@@ -276,6 +276,8 @@ PASS_KERNEL = {
     "REBLUR::ClassifyTiles": "k_classify_tiles", "REBLUR::PrePass": "k_spatial<0", "REBLUR::Blur": "k_spatial<1",
     "REBLUR::PostBlur": "k_spatial<2", "REBLUR::TemporalAccumulation": "k_temporal_accumulation",
     "REBLUR::HistoryFix": "k_history_fix", "REBLUR::TemporalStabilization": "k_temporal_stabilization",
+    "RELAX::ClassifyTiles": "k_classify_tiles", "RELAX::PrePass": "k_spatial<0", "RELAX::TemporalAccumulation": "k_temporal_accumulation",
+    "RELAX::HistoryFix": "k_history_fix",
 }
 
 
