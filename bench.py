@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
+    ap.add_argument("--checkerboard", action="store_true",
+                    help="the sample's default operating point (tracingMode RESOLUTION_HALF): half-width checkerboarded inputs, "
+                         "CheckerboardMode::WHITE -> the PrepareInputs pass runs (single-GPU runner)")
+    ap.add_argument("--atrous", type=int, default=0, help="RELAX: atrousIterationNum override (2..8; BASELINE config 4 also asks for an 8-iteration stress run)")
     return ap.parse_args()
 
 
@@ -80,6 +84,9 @@ def cpu_baseline(pkg, denoiser_names, settings_of, device):
             "sample": "%dx%d, %d frames after %d warm-up, same pipeline (%s), oracle/ row-striped over %d threads" % (w, h, frames, warm, "+".join(denoiser_names), cores)}
 
 
+OPTIONS = {"checkerboard": False, "atrous": 0}
+
+
 def settings_of(api, scene, dens):
     s = {}
     for d in dens:
@@ -93,6 +100,10 @@ def settings_of(api, scene, dens):
             s[d] = api.SigmaSettings(lightDirection=list(scene.sun))
         else:
             s[d] = api.ReferenceSettings()
+        if OPTIONS["checkerboard"] and (d.name.startswith("REBLUR") or d.name.startswith("RELAX")):
+            s[d].checkerboardMode = int(api.CheckerboardMode.WHITE)
+        if OPTIONS["atrous"] and d.name.startswith("RELAX"):
+            s[d].atrousIterationNum = OPTIONS["atrous"]
     return s
 
 
@@ -120,6 +131,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    OPTIONS["checkerboard"], OPTIONS["atrous"] = args.checkerboard, args.atrous
+    if args.checkerboard and (world > 1 or args.force_tiled):
+        raise SystemExit("--checkerboard is wired into the single-GPU runner only")
     w, band_h, den_names = WORKLOADS[args.workload]
     dens = [api.Denoiser[n] for n in den_names]
     hip = pkg.hip_backend(dev)
@@ -219,7 +233,11 @@ class SingleRunner:
             bwd = scene.frame(i, prev_index=min(i + 1, unique - 1))
             planes = hz.upload(fwd)
             mv_b = hz.upload({"mv": bwd["mv"]})["mv"]
-            self.frames.append(dict(planes=planes, mv_f=planes["mv"], mv_b=mv_b, fwd=fwd, bwd=bwd))
+            rec = dict(planes=planes, mv_f=planes["mv"], mv_b=mv_b, fwd=fwd, bwd=bwd)
+            if OPTIONS["checkerboard"]:  # the squares carrying a signal alternate with the parity of frameIndex
+                from nrd_sample_amd.harness import to_checkerboard
+                rec["cb"] = [hz.upload(to_checkerboard(fwd, par, white=True)) for par in (0, 1)]
+            self.frames.append(rec)
         torch.cuda.synchronize()
         self.events_on = False
         self.events = []
@@ -236,7 +254,7 @@ class SingleRunner:
         prev = pingpong(self.unique, f - 1) if f > 0 else min(1, self.unique - 1)
         fr = self.frames[cur]
         backward = prev > cur
-        planes = dict(fr["planes"])
+        planes = dict(fr["cb"][f & 1] if "cb" in fr else fr["planes"])
         planes["mv"] = fr["mv_b"] if backward else fr["mv_f"]
         cs = self.scene.common_settings(api, fr["bwd"] if backward else fr["fwd"], f, reset=reset)
         hz.nrd.new_frame()
