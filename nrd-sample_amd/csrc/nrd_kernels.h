@@ -21,6 +21,9 @@ struct ReblurParams {
     int sh;                       // 1: SH variants - every signal carries a second texel (SH1) filtered with the weights of SH0
     int relax;                    // 1: RELAX front half (linear RGB + world-space hitT inputs, luma-moment history, HistoryFix writes History)
     int historyFixFrameNum, historyFixStride;
+    // RELAX only (nrd::RelaxSettings / RelaxAntilagSettings, Source/NRDSample.cpp:1600-1606, :1626)
+    float hfNormalPower;                           // HistoryFix normal weight = pow(N.Ns, historyFixEdgeStoppingNormalPower)
+    float alAccel, alSpatial, alTemporal, alReset; // antilag: acceleration / spatial + temporal sigma scales / reset amount
     int reachPre, reachBlur, reachPost; // hard per-pass bound (pixels) on tap distance = halo rows of the pass
     float tapsPre[8][2], tapsPost[8][2]; // Poisson disk rotated for this frame (PrePass / PostBlur rotate per frame)
     uint32_t minMatDiff, minMatSpec;
@@ -50,8 +53,9 @@ struct AtrousParams {
     float lobeAngleFraction, roughnessFraction;
     uint32_t minMatDiff, minMatSpec;
     int roughnessEdgeStopping;
+    float lumRelax, normRelax, roughRelax; // {luminance, normal, roughness}EdgeStoppingRelaxation, saturated
     int it, last, hasDiff, hasSpec, sh;
-    PlaneRef guide, data1, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec, inDiff1, inSpec1, outDiff1, outSpec1;
+    PlaneRef guide, data1, data2, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec, inDiff1, inSpec1, outDiff1, outSpec1;
 };
 
 struct SigmaParams {

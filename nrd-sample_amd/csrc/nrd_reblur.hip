@@ -772,7 +772,8 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
             st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)), lo);
         }
         outSpecA = A;
-        data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8);
+        // bits 16..23: reprojection confidence of the specular history (RELAX A-trous edge-stopping relaxation)
+        data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8) | (RELAX ? (uint32_t)__builtin_floorf(fma_(sat(q), 255.0f, 0.5f)) << 16 : 0u);
     }
     st<uint16_t>(p.data1Tmp, x, y, 2, pack_data1(outDiffA, outSpecA));
     st<uint32_t>(p.data2, x, y, 4, data2);
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                             continue;
                         float w = rcp_(1.0f + (float)(i * i + j * j));
                         w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                        w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                        w *= p.relax ? pow01(dot3(g.n, gs.n), p.hfNormalPower) : normal_weight(dot3(g.n, gs.n), normalW2);
                         if (isSpec)
                             w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         float tA[2];
@@ -938,7 +939,16 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             val1.y *= scale;
             val1.z *= scale;
             float f = sat(absf(Yc - Y) * rcp_(fmax2(fmax2(Y, Yc), 1e-6f)));
+            if (p.relax)
+                f *= p.alAccel;
             outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? p.maxFastASpec : p.maxFastA), f);
+            if (p.relax) { // antilag: histories far from the fast 5x5 mean (in spatial + temporal sigmas) are reset
+                float sigS = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f));
+                float sigT = sqrt_(fmax2(fma_(-Y, Y, h2f(ld<uint16_t>(p.stab, x, y, LBPT, sig * 2))), 0.0f));
+                float thr = fma_(p.alSpatial, sigS, p.alTemporal * sigT);
+                float over = sat(fma_(absf(Y - m1), rcp_(fmax2(thr, 1e-6f)), -1.0f));
+                outA[ai] *= fma_(-p.alReset, over, 1.0f);
+            }
         }
         if (p.antiFirefly) { // luma clamped to the centre-less 5x5 moments of the incoming signal
             float cc = tileCur[sig][((int)threadIdx.y + 2) * 20 + (int)threadIdx.x + 2];
@@ -1244,7 +1254,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     f3 sum[NSIG];
     float sumVar[NSIG], wsum[NSIG], invL[NSIG], normalW2[NSIG], minLw[NSIG];
     uint32_t minMat[NSIG];
-    float roughA = 0.0f, roughB = 0.0f;
+    float roughA = 0.0f, roughB = 0.0f, roughRelax = 1.0f;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
@@ -1292,6 +1302,12 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         invL[sig] = 0.3333f * rcp_(fma_(p.phi[si], sigma, 1e-4f));
         float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+        if (LS && isSpec) { // fine iterations: relax the edge stopping where the specular history was reprojected with low confidence
+            float conf = (float)((ld<uint32_t>(p.data2, x, y, 4) >> 16) & 255u) * (1.0f / 255.0f);
+            invL[sig] *= lerpf(1.0f, conf, p.lumRelax);
+            normalW *= lerpf(1.0f, conf, p.normRelax);
+            roughRelax = lerpf(1.0f, conf, p.roughRelax);
+        }
         normalW2[sig] = -2.0f * (normalW * normalW); // holds -2 w^2 (normal_weight_m2)
         if (isSpec) {
             roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
@@ -1353,6 +1369,8 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                 w *= normal_weight_m2(nDot, normalW2[sig]);
                 if (isSpec) {
                     float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                    if (LS)
+                        rw = lerpf(1.0f, rw, roughRelax);
                     w *= roughStop ? rw : 1.0f;
                 }
                 f4 sv = unpack_h4(stex[k][sig * SW]);

@@ -651,6 +651,12 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.relax = 1;
     p.maxASpec = (float)std::min<uint32_t>(r.specularMaxAccumulatedFrameNum, 63);
     p.maxFastASpec = (float)std::min<uint32_t>(r.specularMaxFastAccumulatedFrameNum, 63);
+    auto sat01 = [](float v) { return std::min(std::max(v, 0.0f), 1.0f); };
+    p.hfNormalPower = r.historyFixEdgeStoppingNormalPower;
+    p.alAccel = sat01(r.antilagSettings.accelerationAmount);
+    p.alSpatial = r.antilagSettings.spatialSigmaScale;
+    p.alTemporal = r.antilagSettings.temporalSigmaScale;
+    p.alReset = sat01(r.antilagSettings.resetAmount);
     float n = (float)d.nsig;
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     float sp = d.hasSpec ? 2.0f : 0.0f;
@@ -684,8 +690,8 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"RELAX::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
-                   GB + 2 + 8 * nr + 2 * n + 8 * nr + 2, {}, {}, nullptr};
-        x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
+                   GB + 2 + 8 * nr + 2 * n + 2 * n + 8 * nr + 2, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur), P(rb::STAB_A + cur)}; // moments: antilag
         x.written = {P(rb::HIST), P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
         d.dispatches.push_back(x);
@@ -705,6 +711,10 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     a.minMatDiff = r.minMaterialForDiffuse;
     a.minMatSpec = r.minMaterialForSpecular;
     a.roughnessEdgeStopping = r.enableRoughnessEdgeStopping ? 1 : 0;
+    a.lumRelax = sat01(r.luminanceEdgeStoppingRelaxation);
+    a.normRelax = sat01(r.normalEdgeStoppingRelaxation);
+    a.roughRelax = sat01(r.roughnessEdgeStoppingRelaxation);
+    a.data2 = p.data2;
     a.hasDiff = d.hasDiff;
     a.hasSpec = d.hasSpec;
     a.sh = d.sh ? 1 : 0;
@@ -729,8 +739,10 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         a.out = I.trans[tb + rb::AT_A + (it & 1)].ref();
         static const char* atrousNames[8] = {"RELAX::Atrous0", "RELAX::Atrous1", "RELAX::Atrous2", "RELAX::Atrous3", "RELAX::Atrous4", "RELAX::Atrous5", "RELAX::Atrous6", "RELAX::Atrous7"};
         Dispatch x{atrousNames[it], "nrd_relax_atrous", (uint16_t)(1 << it),
-                   GB + (it == 0 ? 2 + 8 * nr + 2 * n : 8 * nr) + (last ? 8 * nr : 0.0f) + 8 * nr, {}, {}, nullptr};
+                   GB + (it == 0 ? 2 + 8 * nr + 2 * n : 8 * nr) + (last ? 8 * nr : 0.0f) + 8 * nr + ((it <= 2 && d.hasSpec) ? 4.0f : 0.0f), {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
+        if (it <= 2 && d.hasSpec) // edge-stopping relaxation reads the reprojection confidence
+            x.read.push_back(T(rb::DATA2));
         if (it == 0) {
             x.read.push_back(P(rb::DATA1_A + cur));
             x.read.push_back(P(rb::HIST));

@@ -781,7 +781,8 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                     st_h(MOMC, x, y, lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin), sig * 2);
                 }
                 outSpecA = A;
-                data2 |= (vmb.bits << 4) | ((uint32_t)floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8);
+                // bits 16..23: reprojection confidence of the specular history (read by the RELAX A-trous edge-stopping relaxation)
+                data2 |= (vmb.bits << 4) | ((uint32_t)floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8) | (relax ? (uint32_t)floorf(fma_(sat(q), 255.0f, 0.5f)) << 16 : 0u);
             }
             st_u16(D1T, x, y, pack_data1(outDiffA, outSpecA));
             st_u32(D2, x, y, data2);
@@ -803,6 +804,8 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
     const Plane& FAST = k.perm(P_FAST_A + k.cur);
     const Plane& D1T = k.trans(T_DATA1);
     const Plane& D1C = k.perm(P_DATA1_A + k.cur);
+    const Plane& MOM = k.perm(P_STAB_A + k.cur); // RELAX: accumulated second luma moment (antilag)
+    const nrd::RelaxAntilagSettings& al = d.relax.antilagSettings;
     float maxFastAd = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
     float maxFastAs = relax ? (float)std::min<uint32_t>(d.relax.specularMaxFastAccumulatedFrameNum, 63) : maxFastAd;
     bool clampEnabled = s.maxFastAccumulatedFrameNum < s.maxAccumulatedFrameNum;
@@ -861,7 +864,8 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                     continue;
                                 float w = rcp_(1.0f + (float)(i * i + j * j));
                                 w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                                w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                                // RELAX: pow(N.Ns, historyFixEdgeStoppingNormalPower) (sample UI Source/NRDSample.cpp:1626) instead of the lobe weight
+                                w *= relax ? pow01(dot3(g.n, gs.n), d.relax.historyFixEdgeStoppingNormalPower) : normal_weight(dot3(g.n, gs.n), normalW2);
                                 if (isSpec)
                                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 float tA[2];
@@ -905,7 +909,19 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     val1.y *= scale;
                     val1.z *= scale;
                     float f = sat(absf(Yc - Y) * rcp_(fmax2(fmax2(Y, Yc), 1e-6f)));
+                    // RELAX antilag (RelaxAntilagSettings, sample UI Source/NRDSample.cpp:1600-1606): a clamped pixel accelerates its
+                    // history by accelerationAmount; a history further from the fast 5x5 mean than spatialSigmaScale x spatial sigma +
+                    // temporalSigmaScale x temporal sigma is reset by up to resetAmount (ramp over one more threshold)
+                    if (relax)
+                        f *= sat(al.accelerationAmount);
                     outA[ai] = lerpf(Acur, fmin2(Acur, isSpec ? maxFastAs : maxFastAd), f);
+                    if (relax) {
+                        float sigS = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f));
+                        float sigT = sqrt_(fmax2(fma_(-Y, Y, ld_h(MOM, x, y, sig * 2)), 0.0f));
+                        float thr = fma_(al.spatialSigmaScale, sigS, al.temporalSigmaScale * sigT);
+                        float over = sat(fma_(absf(Y - m1), rcp_(fmax2(thr, 1e-6f)), -1.0f));
+                        outA[ai] *= fma_(-sat(al.resetAmount), over, 1.0f);
+                    }
                 }
                 // ---- anti-firefly (enableAntiFirefly, sample UI Source/NRDSample.cpp:1515-1582): luma clamped to the moments of the
                 // 5x5 neighbourhood of the incoming signal WITHOUT its centre, chroma (and SH1) re-scaled with it
@@ -1139,6 +1155,8 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
         in1Slot[k.sigSpec()] = pmA.sh1 ? &k.trans(T_PREP_S1) : &k.slot(in1_slot(true));
     }
     const int stride = 1 << it;
+    const Plane& D2 = k.trans(T_DATA2);
+    const bool relaxEdges = stride <= 4; // edge-stopping relaxation acts on the fine iterations only
     const float depthSens = fmax2(s.depthThreshold, 0.001f) * 4.0f;
     const float histThreshold = (float)s.spatialVarianceEstimationHistoryThreshold;
     for (int y = y0; y < y1; y++)
@@ -1203,6 +1221,15 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 float invL = 0.3333f * rcp_(fma_(phi, sigma, 1e-4f));
                 float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
                 float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                // {luminance, normal, roughness}EdgeStoppingRelaxation (sample UI Source/NRDSample.cpp:1650): where the specular history
+                // was reprojected with low confidence (DATA2 bits 16..23) the three edge-stopping terms are relaxed toward "accept"
+                float roughRelax = 1.0f;
+                if (isSpec && relaxEdges) {
+                    float conf = (float)((ld_u32(D2, x, y) >> 16) & 255u) * (1.0f / 255.0f);
+                    invL *= lerpf(1.0f, conf, sat(s.luminanceEdgeStoppingRelaxation));
+                    normalW *= lerpf(1.0f, conf, sat(s.normalEdgeStoppingRelaxation));
+                    roughRelax = lerpf(1.0f, conf, sat(s.roughnessEdgeStoppingRelaxation));
+                }
                 float normalW2 = normalW * normalW;
                 float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                 float roughB = -rough * roughA;
@@ -1229,8 +1256,10 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                             w = (i == 0 || j == 0) ? 0.5f : 0.25f;
                             w *= geo_weight(pg, (float)px, (float)gy, gs.z);
                             w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                            if (isSpec && s.enableRoughnessEdgeStopping)
-                                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                            if (isSpec && s.enableRoughnessEdgeStopping) {
+                                float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                                w *= relaxEdges ? lerpf(1.0f, rw, roughRelax) : rw;
+                            }
                             w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), minLw);
                         }
                         sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
@@ -1655,8 +1684,8 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.name = "RELAX::HistoryFix";
         p.kernel = "nrd_reblur_history_fix";
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
-        p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + 8 * nr + 2;
-        p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
+        p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + 2 * n + 8 * nr + 2;
+        p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur), P(P_STAB_A + cur)};
         p.written = {P(P_HIST), P(P_DATA1_A + cur)};
         p.run = history_fix;
         d.passes.push_back(p);
@@ -1669,8 +1698,11 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.name = atrousNames[it];
         p.kernel = "nrd_relax_atrous";
         p.haloRows = (uint16_t)(1 << it);
-        p.bytesPerPixel = GB + (it == 0 ? 2 + 8 * nr + 2 * n : 8 * nr) + (last ? 8 * nr : 0.0f) + 8 * nr;
+        const bool relaxEdges = it <= 2 && d.hasSpec; // reads the reprojection confidence (DATA2)
+        p.bytesPerPixel = GB + (it == 0 ? 2 + 8 * nr + 2 * n : 8 * nr) + (last ? 8 * nr : 0.0f) + 8 * nr + (relaxEdges ? 4.0f : 0.0f);
         p.read = {P(P_GUIDE_A + cur)};
+        if (relaxEdges)
+            p.read.push_back(T(T_DATA2));
         if (it == 0) {
             p.read.push_back(P(P_DATA1_A + cur));
             p.read.push_back(P(P_HIST));

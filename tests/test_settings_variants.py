@@ -62,6 +62,13 @@ CASES = [
     ("confidence_relax", ["RELAX_DIFFUSE_SPECULAR"], {}, conf_hook, conf_frames),
     ("validation_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: setattr(cs, "enableValidation", True), None),
     ("jitter_reblur_sigma", ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW"], {}, lambda f, cs: jitter_hook(f, cs), None),
+    # RELAX tuning fields of the sample's UI (Source/NRDSample.cpp:1600-1606 antilag, :1626 history-fix normal power, :1650 relaxation)
+    ("relax_tuning", ["RELAX_DIFFUSE_SPECULAR"], {"luminanceEdgeStoppingRelaxation": 1.0, "normalEdgeStoppingRelaxation": 0.8,
+                                                  "roughnessEdgeStoppingRelaxation": 0.4, "historyFixEdgeStoppingNormalPower": 3.0,
+                                                  "antilagSettings.accelerationAmount": 0.8, "antilagSettings.spatialSigmaScale": 0.5,
+                                                  "antilagSettings.temporalSigmaScale": 0.1, "antilagSettings.resetAmount": 1.0}, None, None),
+    ("relax_tuning_sh", ["RELAX_SPECULAR_SH"], {"luminanceEdgeStoppingRelaxation": 0.0, "normalEdgeStoppingRelaxation": 1.0,
+                                                "antilagSettings.resetAmount": 0.0, "antilagSettings.accelerationAmount": 0.0}, None, None),
 ]
 
 
@@ -78,7 +85,12 @@ def settings_factory(api, dens, kw):
         for d in dens:
             if d.name.startswith("REBLUR") or d.name.startswith("RELAX"):
                 for k, v in kw.items():
-                    setattr(st[d], k, v)
+                    obj = st[d]
+                    *path, leaf = k.split(".")
+                    for part in path:
+                        obj = getattr(obj, part)
+                    assert hasattr(obj, leaf), k
+                    setattr(obj, leaf, v)
         return st
     return make
 
@@ -143,3 +155,44 @@ def test_camera_jitter_is_a_pure_pixel_grid_shift(pkg, api, oracle):
     cs.cameraJitter[0], cs.cameraJitterPrev[0] = 0.5, -0.5
     hz.frame(cs, hz.upload(fr), {dens[0]: api.ReblurSettings()})
     assert util.max_ulp_f16(hz.output("out_diff"), fr["diff"]) <= 1
+
+
+RELAX_FIELDS = [
+    {"luminanceEdgeStoppingRelaxation": 0.0}, {"normalEdgeStoppingRelaxation": 1.0}, {"roughnessEdgeStoppingRelaxation": 0.0},
+    {"historyFixEdgeStoppingNormalPower": 1.0}, {"antilagSettings.accelerationAmount": 1.0},
+    {"antilagSettings.resetAmount": 1.0, "antilagSettings.spatialSigmaScale": 0.25, "antilagSettings.temporalSigmaScale": 0.0},
+]
+
+
+@pytest.mark.parametrize("kw", RELAX_FIELDS, ids=[next(iter(k)).split(".")[-1] for k in RELAX_FIELDS])
+def test_relax_tuning_fields_are_honoured(pkg, api, oracle, kw):
+    """every RELAX tuning field the sample's UI exposes changes the result under camera motion (none is silently ignored)"""
+    den = api.Denoiser.RELAX_DIFFUSE_SPECULAR
+    w, h = 60, 44
+    scene = pkg.synth.Scene(w, h, dolly=0.06, denoiser="RELAX")
+    fast = {"diffuseMaxFastAccumulatedFrameNum": 1, "specularMaxFastAccumulatedFrameNum": 1}  # the clamp acts from frame 2 on
+    base = util.run_frames(api, pkg.harness, oracle, scene, [den], 4, settings=settings_factory(api, [den], fast)(scene))
+    var = util.run_frames(api, pkg.harness, oracle, scene, [den], 4, settings=settings_factory(api, [den], {**fast, **kw})(scene))
+    diffs = util.compare_all(base, var, exact=True)
+    assert diffs != [], kw
+
+
+def test_relax_antilag_reset_speeds_up_a_lighting_change(pkg, api, oracle):
+    """RelaxAntilagSettings: after an abrupt brightness change a full reset (resetAmount 1, tight sigma scales) follows the new
+    signal faster than antilag off (resetAmount 0, accelerationAmount 0)"""
+    den = api.Denoiser.RELAX_DIFFUSE
+    w, h = 48, 32
+    out = {}
+    for name, al in (("off", dict(resetAmount=0.0, accelerationAmount=0.0)),
+                     ("on", dict(resetAmount=1.0, accelerationAmount=1.0, spatialSigmaScale=0.5, temporalSigmaScale=0.0))):
+        hz = pkg.harness.Harness(oracle, [den], w, h)
+        st = api.RelaxSettings(diffusePrepassBlurRadius=0.0, diffuseMaxAccumulatedFrameNum=30, diffuseMaxFastAccumulatedFrameNum=2)
+        for k, v in al.items():
+            setattr(st.antilagSettings, k, v)
+        for f in range(12):
+            fr = util.flat_frame(pkg, w, h)
+            fr["diff"][..., :3] = np.float16(0.2 if f < 10 else 1.0)
+            hz.frame(util.static_common(api, w, h, reset=(f == 0)), hz.upload(fr), {den: st})
+        out[name] = float(hz.output("out_diff")[8:24, 8:40, 0].astype(np.float32).mean())
+    assert out["on"] > out["off"] + 0.05, out
+    assert out["on"] <= 1.0 + 1e-3
