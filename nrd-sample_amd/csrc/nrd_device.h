@@ -22,7 +22,26 @@
 #define NRD_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
 
+// Projection flavour of a translation unit: the kernels are compiled twice from the same sources - perspective (default) and
+// orthographic (nrd_reblur_ortho.hip / nrd_sigma_ortho.hip define NRD_ORTHO 1; the sample's "Ortho" camera, Source/NRDSample.cpp:1214,
+// :1971). The flavour is a compile-time constant so that the perspective kernels carry no select for it; the host picks the launch
+// namespace from FrameConsts::ortho.
+#ifndef NRD_ORTHO
+#define NRD_ORTHO 0
+#endif
+#if NRD_ORTHO
+#define NRD_PROJ_NS ortho
+#define NRD_KERNELS_BEGIN namespace ortho { namespace {
+#define NRD_KERNELS_END } }
+#else
+#define NRD_PROJ_NS persp
+#define NRD_KERNELS_BEGIN namespace {
+#define NRD_KERNELS_END }
+#endif
+
 namespace nrdhip {
+
+constexpr bool ORTHO = NRD_ORTHO != 0;
 
 // ---- per-frame constants, identical layout on host and device -----------------------------------------------
 struct FrameConsts {
@@ -43,6 +62,7 @@ struct FrameConsts {
     float viewZScale;
     uint32_t frameIndex;
     int mvWorld, confAvail, historyOk;
+    int ortho; // orthographic projection: view position of pixel (px, gy) = (pv0 + pv2 px, pv1 + pv3 gy, z); pj = {m0, m5, m12, m13, 1}
     int tilesX, tilesY; // tile grid covering the owned rows: tile row 0 starts at local row tileY0 * 16
     int tileY0;
     float rot[64][2];
@@ -290,9 +310,22 @@ NRD_DEV void basis3(f3 n, f3& t, f3& b) {
     b = {bb, sz + n.y * n.y * a, -n.y};
 }
 
-NRD_DEV f3 reconstruct(const float* fr, float u, float v, float z) { return {z * (u * fr[2] + fr[0]), z * (v * fr[3] + fr[1]), z}; }
-NRD_DEV f3 reconstruct_px(const float* pv, float px, float gy, float z) { return {z * fma_(pv[2], px, pv[0]), z * fma_(pv[3], gy, pv[1]), z}; }
+// perspective: the view-space xy of a pixel scale with z; orthographic: they do not
+NRD_DEV float zpersp(float z) { return ORTHO ? 1.0f : z; }
+NRD_DEV f3 reconstruct(const float* fr, float u, float v, float z) { return {zpersp(z) * (u * fr[2] + fr[0]), zpersp(z) * (v * fr[3] + fr[1]), z}; }
+NRD_DEV f3 reconstruct_px(const float* pv, float px, float gy, float z) { return {zpersp(z) * fma_(pv[2], px, pv[0]), zpersp(z) * fma_(pv[3], gy, pv[1]), z}; }
+// unit vector from the view-space point toward the viewer
+NRD_DEV f3 to_viewer(f3 Xv) {
+    if (ORTHO)
+        return {0.0f, 0.0f, Xv.z >= 0.0f ? -1.0f : 1.0f};
+    return mul3(normalize3(Xv), -1.0f);
+}
 NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
+    if (ORTHO) {
+        u = 0.5f + 0.5f * (pj[0] * X.x + pj[2]);
+        v = 0.5f - 0.5f * (pj[1] * X.y + pj[3]);
+        return true;
+    }
     float cw = pj[4] * X.z;
     if (!(cw > 1e-6f))
         return false;
@@ -305,6 +338,7 @@ NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
 NRD_DEV bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
 
 // per-pixel geometry of the bilateral passes: plane-distance weight is |zs * (ga0 + gax px + gay gy) + geoB|
+// (orthographic: |zs * geoB + (ga0 + gax px + gay gy)| - geoB holds the z coefficient, ga0 absorbs the plane offset)
 struct PixelGeo {
     f3 Xv, Nv;
     float absZ, frustumSize;
@@ -315,17 +349,24 @@ NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, 
     p.Xv = reconstruct_px(c.pv, (float)x, (float)gy, g.z);
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
-    p.frustumSize = c.minRectDimMulUnproject * p.absZ;
+    p.frustumSize = c.minRectDimMulUnproject * zpersp(p.absZ);
     float geoA = rcp_(planeDistSensitivity * p.frustumSize);
     p.gax = p.Nv.x * c.pv[2] * geoA;
     p.gay = p.Nv.y * c.pv[3] * geoA;
-    p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
-    p.geoB = -dot3(p.Nv, p.Xv) * geoA;
+    if (ORTHO) {
+        p.ga0 = (fma_(p.Nv.x, c.pv[0], p.Nv.y * c.pv[1]) - dot3(p.Nv, p.Xv)) * geoA;
+        p.geoB = p.Nv.z * geoA;
+    } else {
+        p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
+        p.geoB = -dot3(p.Nv, p.Xv) * geoA;
+    }
     return p;
 }
+// plane-distance term of a tap from its precomputed linear part ga = ga0 + gax px + gay gy
+NRD_DEV float geo_plane(const PixelGeo& p, float ga, float zs) { return ORTHO ? fma_(zs, p.geoB, ga) : fma_(zs, ga, p.geoB); }
 NRD_DEV float geo_weight(const PixelGeo& p, float px, float gy, float zs) {
     float ga = fma_(p.gax, px, fma_(p.gay, gy, p.ga0));
-    return smoothstep01(1.0f - absf(fma_(zs, ga, p.geoB)));
+    return smoothstep01(1.0f - absf(geo_plane(p, ga, zs)));
 }
 
 // ---- plane access ------------------------------------------------------------------------------------------------

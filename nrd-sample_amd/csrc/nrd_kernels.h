@@ -73,21 +73,31 @@ struct ReferenceParams {
     PlaneRef in, out, hist;
 };
 
-// grid = XCD-swizzled 16x16 tiles over the owned rows (nrd_device.h xcd_tile)
-void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s);
-
-void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s);
-void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s);
-void launch_reblur_validation(const ReblurParams& p, hipStream_t s);
-void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); // 0 PrePass, 1 Blur, 2 PostBlur
-void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s);
-void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s);
-void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s);
-void launch_relax_atrous(const AtrousParams& p, hipStream_t s);
-
-void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s);
-void launch_sigma_smooth_tiles(const SigmaParams& p, hipStream_t s);
-void launch_sigma_blur(const SigmaParams& p, int pass, hipStream_t s);
-void launch_sigma_temporal_stabilization(const SigmaParams& p, hipStream_t s);
+// grid = XCD-swizzled 16x16 tiles over the owned rows (nrd_device.h xcd_tile). Every launcher exists per projection flavour
+// (nrd_device.h NRD_ORTHO): nrdhip::persp::launch_* (nrd_reblur.hip, nrd_sigma.hip) and nrdhip::ortho::launch_* (*_ortho.hip)
+#define NRD_LAUNCH_DECLS \
+    void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s); \
+    void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s); \
+    void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s); \
+    void launch_reblur_validation(const ReblurParams& p, hipStream_t s); \
+    void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); \
+    void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s); \
+    void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s); \
+    void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s); \
+    void launch_relax_atrous(const AtrousParams& p, hipStream_t s); \
+    void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s); \
+    void launch_sigma_smooth_tiles(const SigmaParams& p, hipStream_t s); \
+    void launch_sigma_blur(const SigmaParams& p, int pass, hipStream_t s); \
+    void launch_sigma_temporal_stabilization(const SigmaParams& p, hipStream_t s);
+// launch_reblur_spatial variant: 0 PrePass, 1 Blur, 2 PostBlur; launch_sigma_blur pass: 0 Blur, 1 PostBlur
+namespace persp {
+NRD_LAUNCH_DECLS
+}
+namespace ortho {
+NRD_LAUNCH_DECLS
+}
+#undef NRD_LAUNCH_DECLS
+// the launcher of the frame's projection flavour
+#define NRD_PICK(consts, fn) ((consts).ortho ? ::nrdhip::ortho::fn : ::nrdhip::persp::fn)
 
 } // namespace nrdhip

@@ -13,7 +13,7 @@
 
 namespace nrdhip {
 
-namespace {
+NRD_KERNELS_BEGIN
 
 // taps gathered per memory round trip in the spatial passes (8 = all taps of a signal; 4 or 2 were measured slower: more round
 // trips and no extra wave)
@@ -279,13 +279,18 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     }
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
-    f3 V = mul3(normalize3(pg.Xv), -1.0f);
-    // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane)
-    float inv = rcps_(c.pj[4] * g.z);
-    float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
-    float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
+    f3 V = to_viewer(pg.Xv);
+    // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic: no
+    // perspective divide and no z terms
+    float inv = 1.0f, kuz = 0.0f, kvz = 0.0f;
+    if (!ORTHO) {
+        inv = rcps_(c.pj[4] * g.z);
+        float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
+        float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
+        kuz = c.pj[2] - nu * c.pj[4];
+        kvz = c.pj[3] - nv * c.pj[4];
+    }
     float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
-    float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
     // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
     // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
     constexpr bool PER_PIXEL = VARIANT == 1;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
         float wsum = 1.0f;
         float minHit = hitDist;
         if (radius > 0.0f) {
-            float worldRadius = radius * c.unproject * pg.absZ;
+            float worldRadius = radius * c.unproject * zpersp(pg.absZ);
             f3 T, B;
             basis3(pg.Nv, T, B);
             if (isSpec) {
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     f4 sv = decode_signal(p, sraw[k], occIn);
                     bool valid = inWin[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
                     float w = g_poisson8[t][2];
-                    w *= smoothstep01(1.0f - absf(fma_(gs.z, gaT[k], pg.geoB))); // == geo_weight(pg, fpx, fpy, gs.z)
+                    w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[k], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
                     w *= normal_weight_m2(dot3(g.n, gs.n), m2w2);
                     if (isSpec)
                         w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
@@ -488,7 +493,7 @@ struct Footprint {
 };
 
 NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
-    f3 toCam = normalize3(r.Xw);
+    f3 toCam = ORTHO ? rot3(c.v2w, f3{0.0f, 0.0f, r.zPrev >= 0.0f ? 1.0f : -1.0f}) : normalize3(r.Xw); // direction camera -> surface
     float f = spec_dominant_factor(roughness);
     f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
     f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
@@ -578,14 +583,15 @@ NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const ui
     f.wsum = 0.0f;
     f.bits = 0;
     float planeRef = dot3(NvPrev, XvPrev);
-    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+    float g0 = ORTHO ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
     float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
         bool ok = fp.sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
         Guide gp = decode_guide(graw[i], c.denoisingRange);
-        float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+        float lin = fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+        float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin; // N . X of the previous-frame texel
         ok = ok && !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
         f.w[i] = ok ? bw[i] : 0.0f;
         f.wsum += f.w[i];
@@ -662,11 +668,11 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     float confS = (HAS_SPEC && c.confAvail) ? sample_confidence(p.confS, u, v) : 1.0f;
     f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
     f3 Nv = rot3(c.w2v, g.n);
-    f3 V = mul3(normalize3(Xv), -1.0f);
+    f3 V = to_viewer(Xv);
     float NoV = absf(dot3(Nv, V));
     Reproj r = reproject(c, Xv, u, v, mvRaw);
     f3 NvPrev = rot3(c.w2vPrev, g.n);
-    float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(r.zPrev);
+    float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * zpersp(absf(r.zPrev));
     uint32_t minMatAny = p.minMatDiff < p.minMatSpec ? p.minMatDiff : p.minMatSpec;
     const bool historyOk = c.historyOk != 0;
     // ---- both footprints: positions, then ALL their gathers, then validation
@@ -1418,7 +1424,9 @@ dim3 grid_for(const FrameConsts& c) {
     return dim3((unsigned)(chunk * 8), 1, 1);
 }
 
-} // namespace
+NRD_KERNELS_END
+
+namespace NRD_PROJ_NS {
 
 #define NRD_LAUNCH3(KERNEL, ...)                                                                                 \
     do {                                                                                                          \
@@ -1515,5 +1523,7 @@ void launch_relax_atrous(const AtrousParams& p, hipStream_t s) {
         }
     }
 }
+
+} // namespace NRD_PROJ_NS
 
 } // namespace nrdhip

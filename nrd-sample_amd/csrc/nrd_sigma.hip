@@ -10,7 +10,7 @@
 
 namespace nrdhip {
 
-namespace {
+NRD_KERNELS_BEGIN
 
 constexpr float MAX_PIXEL_RADIUS = 48.0f;
 constexpr int BLUR_REACH = 56; // (int)(48 * 1.1) + 3
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams 
                 lit = 1;
             else {
                 shadowed = 1;
-                r = fmin2(pen / (c.unproject * absf(z)), 255.0f);
+                r = fmin2(pen / (c.unproject * zpersp(absf(z))), 255.0f);
             }
         }
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
             st<uint16_t>(p.pen1, x, y, 2, f2h(lit ? 0.0f : pen));
         return;
     }
-    float pixelWorld = c.unproject * absZ;
+    float pixelWorld = c.unproject * zpersp(absZ);
     float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
     radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
     float worldRadius = radiusPx * pixelWorld;
@@ -140,20 +140,25 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
     Guide g = decode_guide(graw, c.denoisingRange);
     f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
     f3 Nv = rot3(c.w2v, g.n);
-    float frustumSize = c.minRectDimMulUnproject * absZ;
+    float frustumSize = c.minRectDimMulUnproject * zpersp(absZ);
     float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
     float gax = Nv.x * c.pv[2] * geoA, gay = Nv.y * c.pv[3] * geoA;
-    float ga0 = fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
-    float geoB = -dot3(Nv, Xv) * geoA;
+    // plane distance of a tap = |zs * (ga0 + gax px + gay gy) + geoB|; orthographic: |zs * geoB + (ga0 + gax px + gay gy)|
+    float ga0 = ORTHO ? (fma_(Nv.x, c.pv[0], Nv.y * c.pv[1]) - dot3(Nv, Xv)) * geoA : fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
+    float geoB = ORTHO ? Nv.z * geoA : -dot3(Nv, Xv) * geoA;
     f3 T, B;
     basis3(Nv, T, B);
     T = mul3(T, worldRadius);
     B = mul3(B, worldRadius);
-    float inv = 1.0f / (c.pj[4] * z);
-    float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
-    float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
+    float inv = 1.0f, kuz = 0.0f, kvz = 0.0f; // pixel-space Jacobian of the projection (orthographic: no divide, no z terms)
+    if (!ORTHO) {
+        inv = 1.0f / (c.pj[4] * z);
+        float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
+        float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
+        kuz = c.pj[2] - nu * c.pj[4];
+        kvz = c.pj[3] - nv * c.pj[4];
+    }
     float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
-    float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
     float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
     float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
     constexpr bool PER_PIXEL = PASS == 0; // Blur rotates per pixel, PostBlur per frame (coalesced gathers)
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
             if (!valid || !(absf(zs) <= c.denoisingRange))
                 continue;
             float ga = fma_(gax, fpx, fma_(gay, fpy, ga0));
-            float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(fma_(zs, ga, geoB)));
+            float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(ORTHO ? fma_(zs, geoB, ga) : fma_(zs, ga, geoB)));
             float ps = h2f(praw);
             bool lits = PASS == 0 ? ps >= NRD_FP16_MAX : !(ps > 0.0f);
             f4 sv = PASS == 0 ? input_visibility(p, px, py, ps) : unpack_h4(sraw);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
     bool have = false;
     if (c.historyOk && uvOk) {
         f3 NvPrev = rot3(c.w2vPrev, g.n);
-        float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(XvPrev.z);
+        float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * zpersp(absf(XvPrev.z));
         float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
         float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
         float fx = px - fx0, fy = py - fy0;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
             int ix = (int)fx0, iy = (int)fy0;
             float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
             float planeRef = dot3(NvPrev, XvPrev);
-            float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+            float g0 = ORTHO ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
             float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
             f4 sum = {0, 0, 0, 0};
             float wsum = 0.0f;
@@ -315,7 +320,8 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
                 Guide gp = decode_guide(ld<uint4>(p.guidePrev, ttx, tty, 16), c.denoisingRange);
                 if (gp.sky)
                     continue;
-                float plane = gp.z * fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
+                float lin = fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
+                float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin;
                 if (!(absf(plane - planeRef) <= threshold) || !(dot3(g.n, gp.n) > PREV_NORMAL_COS))
                     continue;
                 sum = fma4(decode_shadow(ld<uint32_t>(p.histPrev, ttx, tty, 4)), bw[i], sum);
@@ -367,7 +373,9 @@ dim3 grid_for(const FrameConsts& c) {
     return dim3((unsigned)(chunk * 8), 1, 1);
 }
 
-} // namespace
+NRD_KERNELS_END
+
+namespace NRD_PROJ_NS {
 
 void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_sigma_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
@@ -388,5 +396,7 @@ void launch_sigma_temporal_stabilization(const SigmaParams& p, hipStream_t s) {
 void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_reference_accumulate, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }
+
+} // namespace NRD_PROJ_NS
 
 } // namespace nrdhip

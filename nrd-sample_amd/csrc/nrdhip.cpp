@@ -20,6 +20,27 @@ using namespace nrdhip;
 
 namespace {
 
+// every kernel launcher exists per projection flavour (nrd_kernels.h): forward to the one the frame's matrices select
+#define NRD_FORWARD(fn, Params) \
+    void fn(const Params& p, hipStream_t s) { NRD_PICK(p.c, fn)(p, s); }
+#define NRD_FORWARD_I(fn, Params) \
+    void fn(const Params& p, int v, hipStream_t s) { NRD_PICK(p.c, fn)(p, v, s); }
+NRD_FORWARD(launch_reference_accumulate, ReferenceParams)
+NRD_FORWARD(launch_reblur_classify_tiles, ReblurParams)
+NRD_FORWARD(launch_reblur_prepare_inputs, ReblurParams)
+NRD_FORWARD(launch_reblur_validation, ReblurParams)
+NRD_FORWARD_I(launch_reblur_spatial, ReblurParams)
+NRD_FORWARD(launch_reblur_temporal_accumulation, ReblurParams)
+NRD_FORWARD(launch_reblur_history_fix, ReblurParams)
+NRD_FORWARD(launch_reblur_temporal_stabilization, ReblurParams)
+NRD_FORWARD(launch_relax_atrous, AtrousParams)
+NRD_FORWARD(launch_sigma_classify_tiles, SigmaParams)
+NRD_FORWARD(launch_sigma_smooth_tiles, SigmaParams)
+NRD_FORWARD_I(launch_sigma_blur, SigmaParams)
+NRD_FORWARD(launch_sigma_temporal_stabilization, SigmaParams)
+#undef NRD_FORWARD
+#undef NRD_FORWARD_I
+
 enum class Kind { REBLUR, RELAX, SIGMA, REFERENCE };
 
 struct Plane {
@@ -260,10 +281,31 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     // cameraJitter (pixels, Source/NRDSample.cpp:3843-3846): the G-buffer of pixel (x, y) was rendered through uv + jitter / rect
     // (Shaders/Composition.cs.hlsl:77 "pixelUv + gJitter") while the matrices are un-jittered - fold the constant uv offset into
     // the projection's x/y shear terms so that reconstruct / project / the tap Jacobian all see the jittered pixel grid
-    auto projection = [](const float* M, float* pj, float* fr, const float* jitter, float invW, float invH) {
+    // Orthographic matrices (the sample's "Ortho" camera, Source/NRDSample.cpp:1214, :1971: clip.w == 1) put the constant uv offset
+    // into m12 / m13 instead; the kernels of that flavour live in nrdhip::ortho (nrd_device.h NRD_ORTHO)
+    auto is_ortho = [](const float* M) { return M[11] == 0.0f && M[15] != 0.0f; };
+    c.ortho = is_ortho(cs.viewToClipMatrix) ? 1 : 0;
+    auto projection = [](const float* M, float* pj, float* fr, const float* jitter, float invW, float invH, bool ortho) {
+        if (M[0] == 0.0f || M[5] == 0.0f)
+            return false; // degenerate
+        if (ortho) {
+            float w = M[15];
+            float m0 = M[0] / w, m5 = M[5] / w;
+            float m12 = M[12] / w - 2.0f * jitter[0] * invW, m13 = M[13] / w + 2.0f * jitter[1] * invH;
+            pj[0] = m0;
+            pj[1] = m5;
+            pj[2] = m12;
+            pj[3] = m13;
+            pj[4] = 1.0f;
+            fr[2] = 2.0f / m0;
+            fr[0] = (-1.0f - m12) / m0;
+            fr[3] = -2.0f / m5;
+            fr[1] = (1.0f - m13) / m5;
+            return true;
+        }
         float s = M[11];
-        if (s == 0.0f || M[0] == 0.0f || M[5] == 0.0f)
-            return false; // orthographic / degenerate: unsupported
+        if (s == 0.0f)
+            return false;
         s = s > 0.0f ? 1.0f : -1.0f;
         float m8 = M[8] - 2.0f * s * jitter[0] * invW, m9 = M[9] + 2.0f * s * jitter[1] * invH;
         pj[0] = M[0];
@@ -277,9 +319,13 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
         fr[1] = (s - m9) / M[5];
         return true;
     };
-    if (!projection(cs.viewToClipMatrix, c.pj, c.fr, cs.cameraJitter, c.invW, c.invH) ||
-        !projection(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev, cs.cameraJitterPrev, c.invWprev, c.invHprev)) {
-        err = "only perspective projections are supported";
+    // a projection-mode switch between frames comes with an accumulation restart (Source/NRDSample.cpp:2142): the previous
+    // projection then only has to be well-formed, so the current one stands in for it
+    const bool prevSameMode = (is_ortho(cs.viewToClipMatrixPrev) ? 1 : 0) == c.ortho;
+    const float* Mprev = prevSameMode ? cs.viewToClipMatrixPrev : cs.viewToClipMatrix;
+    if (!projection(cs.viewToClipMatrix, c.pj, c.fr, cs.cameraJitter, c.invW, c.invH, c.ortho != 0) ||
+        !projection(Mprev, c.pjPrev, c.frPrev, cs.cameraJitterPrev, c.invWprev, c.invHprev, c.ortho != 0)) {
+        err = "viewToClipMatrix is neither a perspective nor an orthographic projection";
         return false;
     }
     for (int k = 0; k < 2; k++) {

@@ -72,6 +72,18 @@ def perspective(hfov_deg, aspect):
     return m
 
 
+def orthographic(half_width, aspect):
+    """Left-handed column-major orthographic projection (clip.w = 1) - the sample's "Ortho" camera (Source/NRDSample.cpp:1214, :1971)."""
+    near, far = 0.05, 1000.0
+    m = np.zeros(16, dtype=np.float32)
+    m[0] = 1.0 / half_width
+    m[5] = m[0] * aspect
+    m[10] = 1.0 / (far - near)
+    m[14] = -near / (far - near)
+    m[15] = 1.0
+    return m
+
+
 def world_to_view(pos, yaw=0.0, pitch=0.0):
     cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
     ry = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
@@ -90,8 +102,9 @@ class Scene:
     on a GPU so that large (4K/8K) frames are produced where the denoiser consumes them."""
 
     def __init__(self, width, height, seed=0x9E3779B9, hfov=90.0, dolly=0.01, denoiser="REBLUR", rough_bands=True,
-                 translucent_sphere=True, device="cpu", frame_height=None, row0=0):
+                 translucent_sphere=True, device="cpu", frame_height=None, row0=0, ortho=False):
         self.w, self.h, self.seed = width, height, seed
+        self.ortho = ortho
         self.hfov, self.dolly = hfov, dolly
         self.relax = denoiser == "RELAX"
         self.rough_bands = rough_bands
@@ -100,7 +113,7 @@ class Scene:
         # row band of a taller frame (row tiling): this scene renders rows [row0, row0 + height) of a frame_height-row image
         self.frame_h = frame_height or height
         self.row0 = row0
-        self.proj = perspective(hfov, width / self.frame_h)
+        self.proj = orthographic(4.0, width / self.frame_h) if ortho else perspective(hfov, width / self.frame_h)
         # spheres: centre, radius, roughness, materialID
         self.spheres = [((-1.6, 0.7, 4.0), 0.7, 0.05, 1), ((0.3, 1.0, 5.5), 1.0, 0.3, 0), ((2.2, 0.6, 3.5), 0.6, 0.7, 1)]
         self.wall_z = 9.0
@@ -194,11 +207,16 @@ class Scene:
         u = (torch.arange(w, dtype=torch.float64, device=dev) + 0.5) / w
         v = (torch.arange(h, dtype=torch.float64, device=dev) + self.row0 + 0.5) / self.frame_h
         vv, uu = torch.meshgrid(v, u, indexing="ij")
-        dv = torch.stack([(2 * uu - 1) / m0, (1 - 2 * vv) / m5, torch.ones_like(uu)], -1)  # view-space ray, z = 1
+        if self.ortho:  # parallel rays along the view axis, origins spread over the view plane
+            ov = torch.stack([(2 * uu - 1) / m0, (1 - 2 * vv) / m5, torch.zeros_like(uu)], -1)
+            dv = torch.stack([torch.zeros_like(uu), torch.zeros_like(uu), torch.ones_like(uu)], -1)
+        else:
+            ov = None
+            dv = torch.stack([(2 * uu - 1) / m0, (1 - 2 * vv) / m5, torch.ones_like(uu)], -1)  # view-space ray, z = 1
         dw = dv @ rot_t  # R^T applied to row vectors
         dlen = torch.sqrt((dw * dw).sum(-1, keepdim=True))
         dn = dw / dlen
-        o = pos_t.expand_as(dn)
+        o = pos_t.expand_as(dn) if ov is None else pos_t + ov @ rot_t
         t, obj = self._intersect(o, dn)
         hit = obj >= 0
         tt = torch.where(hit, t, torch.zeros_like(t))
@@ -222,8 +240,9 @@ class Scene:
         # motion: previous-frame projection of the same (static) world point
         pv_prev = (p - pos_pt) @ rot_pt.T
         zp = torch.where(hit, pv_prev[..., 2], torch.ones_like(tt))
-        up = 0.5 + 0.5 * (m0 * pv_prev[..., 0] / zp)
-        vp = 0.5 - 0.5 * (m5 * pv_prev[..., 1] / zp)
+        wp = torch.ones_like(zp) if self.ortho else zp  # clip.w
+        up = 0.5 + 0.5 * (m0 * pv_prev[..., 0] / wp)
+        vp = 0.5 - 0.5 * (m5 * pv_prev[..., 1] / wp)
         zero = torch.zeros_like(tt)
         mv = torch.stack([torch.where(hit, (up - uu) * w, zero), torch.where(hit, (vp - vv) * self.frame_h, zero),
                           torch.where(hit, zp - view_z, zero), zero], -1)

@@ -55,10 +55,32 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
     // cameraJitter (pixels, Source/NRDSample.cpp:3843-3846): the G-buffer of pixel (x, y) was rendered through uv + jitter / rect
     // (Shaders/Composition.cs.hlsl:77 "pixelUv + gJitter") while the matrices are un-jittered - fold the constant uv offset into
     // the projection's x/y shear terms so that reconstruct / project / the tap Jacobian all see the jittered pixel grid
+    auto is_ortho = [](const float* M) { return M[11] == 0.0f && M[15] != 0.0f; };
+    c.ortho = is_ortho(cs.viewToClipMatrix);
+    const float orthoFlag = c.ortho ? 1.0f : 0.0f;
     auto proj = [&](const float* M, float* pj, float* fr, const float* jitter, float invW, float invH) -> bool {
+        fr[4] = orthoFlag;
+        pj[5] = orthoFlag;
+        if (c.ortho) { // clip.w == m15: the constant uv offset of the jitter goes into m12 / m13
+            float w = M[15];
+            float m0 = M[0] / w, m5 = M[5] / w;
+            float m12 = M[12] / w - 2.0f * jitter[0] * invW, m13 = M[13] / w + 2.0f * jitter[1] * invH;
+            if (m0 == 0.0f || m5 == 0.0f)
+                return false;
+            pj[0] = m0;
+            pj[1] = m5;
+            pj[2] = m12;
+            pj[3] = m13;
+            pj[4] = 1.0f;
+            fr[2] = 2.0f / m0;
+            fr[0] = (-1.0f - m12) / m0;
+            fr[3] = -2.0f / m5;
+            fr[1] = (1.0f - m13) / m5;
+            return true;
+        }
         float s = M[11];
         if (s == 0.0f)
-            return false; // orthographic projection: unsupported
+            return false;
         s = s > 0.0f ? 1.0f : -1.0f;
         float m0 = M[0], m5 = M[5];
         float m8 = M[8] - 2.0f * s * jitter[0] * invW, m9 = M[9] + 2.0f * s * jitter[1] * invH;
@@ -75,8 +97,10 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
         fr[1] = (s - m9) / m5;
         return true;
     };
-    if (!proj(cs.viewToClipMatrix, c.pj, c.fr, cs.cameraJitter, c.invW, c.invH) || !proj(cs.viewToClipMatrixPrev, c.pjPrev, c.frPrev, cs.cameraJitterPrev, c.invWprev, c.invHprev)) {
-        err = "only perspective projections are supported";
+    // a projection-mode switch comes with an accumulation restart (Source/NRDSample.cpp:2142): the current matrix stands in for the previous one
+    const float* Mprev = is_ortho(cs.viewToClipMatrixPrev) == c.ortho ? cs.viewToClipMatrixPrev : cs.viewToClipMatrix;
+    if (!proj(cs.viewToClipMatrix, c.pj, c.fr, cs.cameraJitter, c.invW, c.invH) || !proj(Mprev, c.pjPrev, c.frPrev, cs.cameraJitterPrev, c.invWprev, c.invHprev)) {
+        err = "viewToClipMatrix is neither a perspective nor an orthographic projection";
         return false;
     }
     for (int k = 0; k < 2; k++) {
@@ -87,6 +111,7 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
         pv[3] = fr[3] * ih;
         pv[0] = fr[0] + 0.5f * pv[2];
         pv[1] = fr[1] + 0.5f * pv[3];
+        pv[4] = orthoFlag;
     }
     auto rotpos = [&](const float* M, float* R, float* pos) {
         for (int r = 0; r < 3; r++)

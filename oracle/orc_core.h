@@ -71,9 +71,12 @@ struct Consts {
     int yOff = 0;             // global row stored at local row 0 (row tiling), else 0
     int ownY0 = 0, ownY1 = 0; // local rows this instance produces [ownY0, ownY1)
     float invW = 0, invH = 0, invWprev = 0, invHprev = 0;
-    float fr[4] = {}, frPrev[4] = {}; // x0, y0, dx, dy : Xv.xy = z * (uv * d + o)
-    float pv[4] = {}, pvPrev[4] = {}; // view ray of pixel (px, gy): (pv0 + pv2 * px, pv1 + pv3 * gy, 1)
-    float pj[5] = {}, pjPrev[5] = {}; // m0, m5, m8, m9, s (clip.w = s * z)
+    // orthographic projections (the sample's "Ortho" camera, Source/NRDSample.cpp:1214, :1971): Xv.xy = uv * d + o (no z factor),
+    // pj = {m0, m5, m12, m13, 1}; the trailing element of fr / pv / pj is the flag (1 = orthographic) for the helpers below
+    float fr[5] = {}, frPrev[5] = {}; // x0, y0, dx, dy : Xv.xy = z * (uv * d + o)
+    float pv[5] = {}, pvPrev[5] = {}; // view ray of pixel (px, gy): (pv0 + pv2 * px, pv1 + pv3 * gy, 1)
+    float pj[6] = {}, pjPrev[6] = {}; // m0, m5, m8, m9, s (clip.w = s * z)
+    bool ortho = false;
     float w2v[9] = {}, w2vPrev[9] = {}, v2w[9] = {}, v2wPrev[9] = {};
     float camDelta[3] = {}; // camera position prev - current (world)
     float unproject = 0, minRectDimMulUnproject = 0;
@@ -87,11 +90,22 @@ struct Consts {
 bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err);
 
 // view position from uv and (signed) viewZ
-static inline f3 reconstruct(const float* fr, float u, float v, float z) { return {z * (u * fr[2] + fr[0]), z * (v * fr[3] + fr[1]), z}; }
+static inline f3 reconstruct(const float* fr, float u, float v, float z) {
+    float k = fr[4] != 0.0f ? 1.0f : z;
+    return {k * (u * fr[2] + fr[0]), k * (v * fr[3] + fr[1]), z};
+}
 // view position of the centre of pixel (px, gy) at (signed) viewZ
-static inline f3 reconstruct_px(const float* pv, float px, float gy, float z) { return {z * fma_(pv[2], px, pv[0]), z * fma_(pv[3], gy, pv[1]), z}; }
+static inline f3 reconstruct_px(const float* pv, float px, float gy, float z) {
+    float k = pv[4] != 0.0f ? 1.0f : z;
+    return {k * fma_(pv[2], px, pv[0]), k * fma_(pv[3], gy, pv[1]), z};
+}
 // view position -> uv; false when the point is not in front of the camera
 static inline bool project(const float* pj, f3 X, float& u, float& v) {
+    if (pj[5] != 0.0f) {
+        u = 0.5f + 0.5f * (pj[0] * X.x + pj[2]);
+        v = 0.5f - 0.5f * (pj[1] * X.y + pj[3]);
+        return true;
+    }
     float cw = pj[4] * X.z;
     if (!(cw > 1e-6f))
         return false;

@@ -136,6 +136,7 @@ struct PixelGeo {
     f3 Xv, Nv;
     float absZ, frustumSize;
     float ga0, gax, gay, geoB; // plane-distance weight: |zs * (ga0 + gax px + gay gy) + geoB|
+    bool ortho;                // orthographic: |zs * geoB + (ga0 + gax px + gay gy)| (geoB = z coefficient, ga0 absorbs the offset)
 };
 
 static inline PixelGeo pixel_geo(const Consts& c, const Guide& g, int x, int gy, float planeDistSensitivity) {
@@ -143,17 +144,29 @@ static inline PixelGeo pixel_geo(const Consts& c, const Guide& g, int x, int gy,
     p.Xv = reconstruct_px(c.pv, (float)x, (float)gy, g.z);
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
-    p.frustumSize = c.minRectDimMulUnproject * p.absZ;
+    p.ortho = c.ortho;
+    p.frustumSize = c.minRectDimMulUnproject * (c.ortho ? 1.0f : p.absZ);
     float geoA = rcp_(planeDistSensitivity * p.frustumSize);
     p.gax = p.Nv.x * c.pv[2] * geoA;
     p.gay = p.Nv.y * c.pv[3] * geoA;
-    p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
-    p.geoB = -dot3(p.Nv, p.Xv) * geoA;
+    if (c.ortho) {
+        p.ga0 = (fma_(p.Nv.x, c.pv[0], p.Nv.y * c.pv[1]) - dot3(p.Nv, p.Xv)) * geoA;
+        p.geoB = p.Nv.z * geoA;
+    } else {
+        p.ga0 = fma_(p.Nv.x, c.pv[0], fma_(p.Nv.y, c.pv[1], p.Nv.z)) * geoA;
+        p.geoB = -dot3(p.Nv, p.Xv) * geoA;
+    }
     return p;
 }
 static inline float geo_weight(const PixelGeo& p, float px, float gy, float zs) {
     float ga = fma_(p.gax, px, fma_(p.gay, gy, p.ga0));
-    return smoothstep01(1.0f - absf(fma_(zs, ga, p.geoB)));
+    return smoothstep01(1.0f - absf(p.ortho ? fma_(zs, p.geoB, ga) : fma_(zs, ga, p.geoB)));
+}
+// unit vector from the view-space point toward the viewer
+static inline f3 to_viewer(const Consts& c, f3 Xv) {
+    if (c.ortho)
+        return {0.0f, 0.0f, Xv.z >= 0.0f ? -1.0f : 1.0f};
+    return mul3(normalize3(Xv), -1.0f);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -347,13 +360,18 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
             }
             int gy0 = y + c.yOff;
             PixelGeo pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
-            f3 V = mul3(normalize3(pg.Xv), -1.0f);
-            // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane)
-            float inv = rcps_(c.pj[4] * g.z);
-            float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
-            float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
+            f3 V = to_viewer(c, pg.Xv);
+            // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic:
+            // no perspective divide and no z terms
+            float inv = 1.0f, kuz = 0.0f, kvz = 0.0f;
+            if (!c.ortho) {
+                inv = rcps_(c.pj[4] * g.z);
+                float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
+                float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
+                kuz = c.pj[2] - nu * c.pj[4];
+                kvz = c.pj[3] - nv * c.pj[4];
+            }
             float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
-            float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
             // Poisson rotation: per frame for PrePass / PostBlur (neighbouring pixels then gather neighbouring texels), per 2x2 quad for Blur
             bool perPixel = variant == BLUR;
             uint32_t h = hash_px(perPixel ? (uint32_t)x >> 1 : 0u, perPixel ? (uint32_t)gy0 >> 1 : 0u, c.frameIndex, (uint32_t)variant + 1u); // one rotation per 2x2 quad
@@ -389,7 +407,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 float wsum = 1.0f;
                 float minHit = hitDist;
                 if (radius > 0.0f) {
-                    float worldRadius = radius * c.unproject * pg.absZ;
+                    float worldRadius = radius * c.unproject * (c.ortho ? 1.0f : pg.absZ);
                     // kernel basis in view space
                     f3 T, B;
                     basis3(pg.Nv, T, B);
@@ -531,14 +549,15 @@ static inline Footprint footprint(const Ctx& k, float pu, float pv, f3 NvPrev, f
     f.wsum = 0.0f;
     f.bits = 0;
     float planeRef = dot3(NvPrev, XvPrev);
-    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+    float g0 = c.ortho ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
     float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
         bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
         if (ok) {
             Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
-            float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+            float lin = fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+            float plane = c.ortho ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin; // N . X of the previous-frame texel
             ok = !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
         }
         f.w[i] = ok ? bw[i] : 0.0f;
@@ -578,7 +597,7 @@ static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, floa
 
 // virtual-motion previous uv of the specular reflection (shared by TA and TS)
 static inline bool virtual_uv(const Consts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
-    f3 toCam = normalize3(r.Xw); // direction camera -> surface
+    f3 toCam = c.ortho ? rot3(c.v2w, f3{0.0f, 0.0f, r.zPrev >= 0.0f ? 1.0f : -1.0f}) : normalize3(r.Xw); // direction camera -> surface
     float f = spec_dominant_factor(roughness);
     f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
     f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
@@ -667,11 +686,11 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
             float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
             f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
             f3 Nv = rot3(c.w2v, g.n);
-            f3 V = mul3(normalize3(Xv), -1.0f);
+            f3 V = to_viewer(c, Xv);
             float NoV = absf(dot3(Nv, V));
             Reproj r = reproject(c, Xv, u, v, ld_h4(MV, x, y));
             f3 NvPrev = rot3(c.w2vPrev, g.n);
-            float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(r.zPrev);
+            float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * (c.ortho ? 1.0f : absf(r.zPrev));
             uint32_t minMatAny = std::min<uint32_t>(s.minMaterialForDiffuse, s.minMaterialForSpecular);
             Footprint smb = footprint(k, r.su, r.sv, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
             bool smbOk = historyOk && smb.wsum > 0.0f;

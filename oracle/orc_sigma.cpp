@@ -88,7 +88,7 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
                         flags |= 2u;
                     else {
                         flags |= 1u;
-                        maxR = fmax2(maxR, fmin2(pen / (c.unproject * absf(z)), 255.0f));
+                        maxR = fmax2(maxR, fmin2(pen / (c.unproject * (c.ortho ? 1.0f : absf(z))), 255.0f));
                     }
                 }
             uint32_t r = (uint32_t)floorf(maxR + 0.999f);
@@ -149,7 +149,7 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
                     st_h(outPen, x, y, lit ? 0.0f : pen);
                 continue;
             }
-            float pixelWorld = c.unproject * absZ;
+            float pixelWorld = c.unproject * (c.ortho ? 1.0f : absZ);
             float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
             radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
             float worldRadius = radiusPx * pixelWorld;
@@ -157,20 +157,25 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
             Guide g = load_guide(G, x, y, c.denoisingRange);
             f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
             f3 Nv = rot3(c.w2v, g.n);
-            float frustumSize = c.minRectDimMulUnproject * absZ;
+            float frustumSize = c.minRectDimMulUnproject * (c.ortho ? 1.0f : absZ);
             float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
             float gax = Nv.x * c.pv[2] * geoA, gay = Nv.y * c.pv[3] * geoA;
-            float ga0 = fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
-            float geoB = -dot3(Nv, Xv) * geoA;
+            // plane distance of a tap = |zs * (ga0 + gax px + gay gy) + geoB|; orthographic: |zs * geoB + (ga0 + gax px + gay gy)|
+            float ga0 = c.ortho ? (fma_(Nv.x, c.pv[0], Nv.y * c.pv[1]) - dot3(Nv, Xv)) * geoA : fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
+            float geoB = c.ortho ? Nv.z * geoA : -dot3(Nv, Xv) * geoA;
             f3 T, B;
             basis3(Nv, T, B);
             T = mul3(T, worldRadius);
             B = mul3(B, worldRadius);
-            float inv = 1.0f / (c.pj[4] * z);
-            float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
-            float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
+            float inv = 1.0f, kuz = 0.0f, kvz = 0.0f; // pixel-space Jacobian of the projection (orthographic: no divide, no z terms)
+            if (!c.ortho) {
+                inv = 1.0f / (c.pj[4] * z);
+                float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
+                float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
+                kuz = c.pj[2] - nu * c.pj[4];
+                kvz = c.pj[3] - nv * c.pj[4];
+            }
             float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
-            float kuz = c.pj[2] - nu * c.pj[4], kvz = c.pj[3] - nv * c.pj[4];
             float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
             float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
             bool perPixel = pass == 0; // Blur rotates per pixel, PostBlur per frame
@@ -197,7 +202,7 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
                     if (!(absf(zs) <= c.denoisingRange))
                         continue;
                     float ga = fma_(gax, fpx, fma_(gay, fpy, ga0));
-                    float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(fma_(zs, ga, geoB)));
+                    float w = g_poisson8[t][2] * smoothstep01(1.0f - absf(c.ortho ? fma_(zs, geoB, ga) : fma_(zs, ga, geoB)));
                     float ps = ld_h(inPen, px, py);
                     bool lits = pass == 0 ? ps >= FP16_MAX : !(ps > 0.0f);
                     f4 sv = pass == 0 ? input_visibility(k, px, py, ps) : ld_h4(inSh, px, py);
@@ -296,7 +301,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             bool have = false;
             if (historyOk && uvOk) {
                 f3 NvPrev = rot3(c.w2vPrev, g.n);
-                float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * absf(XvPrev.z);
+                float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * (c.ortho ? 1.0f : absf(XvPrev.z));
                 float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
                 float fx0 = floorf(px), fy0 = floorf(py);
                 float fx = px - fx0, fy = py - fy0;
@@ -305,7 +310,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     int ix = (int)fx0, iy = (int)fy0;
                     float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
                     float planeRef = dot3(NvPrev, XvPrev);
-                    float g0 = fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+                    float g0 = c.ortho ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
                     float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
                     f4 sum = {0, 0, 0, 0};
                     float wsum = 0.0f;
@@ -316,7 +321,8 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                         Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
                         if (gp.sky)
                             continue;
-                        float plane = gp.z * fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+                        float lin = fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
+                        float plane = c.ortho ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin;
                         if (!(absf(plane - planeRef) <= threshold) || !(dot3(g.n, gp.n) > PREV_NORMAL_COS))
                             continue;
                         sum = fma4(decode_shadow(ld_u32(HP, tx, ty)), bw[i], sum);
