@@ -28,6 +28,9 @@ struct ReblurParams {
     float tapsPre[8][2], tapsPost[8][2]; // Poisson disk rotated for this frame (PrePass / PostBlur rotate per frame)
     uint32_t minMatDiff, minMatSpec;
     int clampEnabled;
+    int prepassTrackOnly; // usePrepassOnlyForSpecularMotionEstimation: the PrePass passes the specular signal through (hit distance tracking still filtered)
+    int returnHistLen;    // returnHistoryLengthInsteadOfOcclusion (OCCLUSION variants): OUT_*_HITDIST = accumulated frames * invMaxA
+    float invMaxA;
     int antiFirefly;    // HistoryFix: clamp the luma to the centre-less 5x5 moments of the incoming signal
     float fireflyScale; //   sigma scale of that clamp (ReblurSettings::fireflySuppressorMinRelativeScale)
     int hasDiff, hasSpec;

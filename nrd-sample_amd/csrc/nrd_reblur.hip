@@ -439,9 +439,16 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             }
         }
         float invw = rcp_(wsum);
-        st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum, invw)), sig * sb);
+        f4 res = mul4(sum, invw), res1 = mul4(sum1, invw);
+        if (VARIANT == 0 && isSpec && p.prepassTrackOnly) { // pass-through: the centre is fetched again instead of being kept live across the tap loop
+            res = load_signal(p, srcP, x, y, srcBpt, srcOff, occIn);
+            if (relaxIn)
+                res = rgb_to_ycocg4(res);
+            res1 = SH ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
+        }
+        st<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
         if (SH)
-            st<uint2>(outP, x, y, RBPT, pack_h4(mul4(sum1, invw)), sig * sb + 8);
+            st<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
         if (VARIANT == 0 && isSpec)
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit));
     }
@@ -1123,6 +1130,8 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         float Yout = lerpf(Y, Yclamped, wHist);
         float scale = (Yout + 1e-6f) * rcps_(Y + 1e-6f);
         f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
+        if (p.returnHistLen) // OCCLUSION variants: the single output channel reports the normalised history length instead
+            o.x = sat(Acur * p.invMaxA);
         st<uint16_t>(p.stab, x, y, LBPT, f2h(Yout), sig * 2);
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;

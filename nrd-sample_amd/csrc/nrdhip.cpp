@@ -513,6 +513,9 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.maxA = (float)std::min<uint32_t>(s.maxAccumulatedFrameNum, 63);
     p.maxFastA = (float)std::min<uint32_t>(s.maxFastAccumulatedFrameNum, 63);
     p.maxStab = (float)std::min<uint32_t>(s.maxStabilizedFrameNum, 63);
+    p.prepassTrackOnly = s.usePrepassOnlyForSpecularMotionEstimation ? 1 : 0;
+    p.returnHistLen = (d.occlusion && s.returnHistoryLengthInsteadOfOcclusion) ? 1 : 0;
+    p.invMaxA = 1.0f / std::max(p.maxA, 1.0f);
     p.historyFixFrameNum = (int)s.historyFixFrameNum;
     p.historyFixStride = (int)s.historyFixBasePixelStride;
     p.reachPre = (int)(std::max(s.diffusePrepassBlurRadius, s.specularPrepassBlurRadius) * 1.1f) + 3;

@@ -388,6 +388,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 if (relaxIn)
                     center = rgb_to_ycocg4(center);
                 f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
+                const f4 center1 = sum1;
                 float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
                 float hitDist = center.w * hitNorm;
                 float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
@@ -478,9 +479,15 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     }
                 }
                 float invw = rcp_(wsum);
-                st_h4(*io.out[sig], x, y, mul4(sum, invw), io.outOff[sig]);
+                f4 res = mul4(sum, invw), res1 = mul4(sum1, invw);
+                // usePrepassOnlyForSpecularMotionEstimation: the specular signal passes through, only the tracked hit distance is filtered
+                if (variant == PRE && isSpec && k.d.kind == Kind::REBLUR && s.usePrepassOnlyForSpecularMotionEstimation) {
+                    res = center;
+                    res1 = center1;
+                }
+                st_h4(*io.out[sig], x, y, res, io.outOff[sig]);
                 if (sh)
-                    st_h4(*io.out[sig], x, y, mul4(sum1, invw), io.outOff[sig] + 8);
+                    st_h4(*io.out[sig], x, y, res1, io.outOff[sig] + 8);
                 if (variant == PRE && isSpec)
                     st_h(HT, x, y, minHit);
             }
@@ -1119,6 +1126,9 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 float Yout = lerpf(Y, Yclamped, wHist);
                 float scale = (Yout + 1e-6f) * rcps_(Y + 1e-6f);
                 f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
+                // returnHistoryLengthInsteadOfOcclusion (OCCLUSION variants): the single output channel reports the normalised history length
+                if (d.occlusion && s.returnHistoryLengthInsteadOfOcclusion)
+                    o.x = sat(Acur * (1.0f / fmax2((float)std::min<uint32_t>(s.maxAccumulatedFrameNum, 63), 1.0f)));
                 st_h(STABC, x, y, Yout, sig * 2);
                 if (dirOcc) {
                     f4 c1 = ld_h4(HIST, x, y, sig * sb + 8);

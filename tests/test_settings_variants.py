@@ -67,6 +67,8 @@ CASES = [
                                                   "roughnessEdgeStoppingRelaxation": 0.4, "historyFixEdgeStoppingNormalPower": 3.0,
                                                   "antilagSettings.accelerationAmount": 0.8, "antilagSettings.spatialSigmaScale": 0.5,
                                                   "antilagSettings.temporalSigmaScale": 0.1, "antilagSettings.resetAmount": 1.0}, None, None),
+    ("prepass_track_only", ["REBLUR_DIFFUSE_SPECULAR_SH"], {"usePrepassOnlyForSpecularMotionEstimation": True}, None, None),
+    ("history_length_out", ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], {"returnHistoryLengthInsteadOfOcclusion": True}, None, None),
     ("relax_tuning_sh", ["RELAX_SPECULAR_SH"], {"luminanceEdgeStoppingRelaxation": 0.0, "normalEdgeStoppingRelaxation": 1.0,
                                                 "antilagSettings.resetAmount": 0.0, "antilagSettings.accelerationAmount": 0.0}, None, None),
 ]
@@ -196,3 +198,26 @@ def test_relax_antilag_reset_speeds_up_a_lighting_change(pkg, api, oracle):
         out[name] = float(hz.output("out_diff")[8:24, 8:40, 0].astype(np.float32).mean())
     assert out["on"] > out["off"] + 0.05, out
     assert out["on"] <= 1.0 + 1e-3
+
+
+def test_reblur_flags_semantics(pkg, api, oracle):
+    """usePrepassOnlyForSpecularMotionEstimation leaves the diffuse path alone and changes the specular one;
+    returnHistoryLengthInsteadOfOcclusion reports accumulated frames / maxAccumulatedFrameNum in OUT_*_HITDIST"""
+    D = api.Denoiser
+    w, h = 60, 44
+    scene = pkg.synth.Scene(w, h, dolly=0.0)
+    base = util.run_frames(api, pkg.harness, oracle, scene, [D.REBLUR_DIFFUSE_SPECULAR], 1, settings=settings_factory(api, [D.REBLUR_DIFFUSE_SPECULAR], {})(scene))
+    var = util.run_frames(api, pkg.harness, oracle, scene, [D.REBLUR_DIFFUSE_SPECULAR], 1,
+                          settings=settings_factory(api, [D.REBLUR_DIFFUSE_SPECULAR], {"usePrepassOnlyForSpecularMotionEstimation": True})(scene))
+    assert np.array_equal(base.output("out_diff").view(np.uint16), var.output("out_diff").view(np.uint16))
+    assert not np.array_equal(base.output("out_spec").view(np.uint16), var.output("out_spec").view(np.uint16))
+
+    den = D.REBLUR_DIFFUSE_SPECULAR_OCCLUSION
+    keep = []
+    st = settings_factory(api, [den], {"returnHistoryLengthInsteadOfOcclusion": True, "maxAccumulatedFrameNum": 20})(scene)
+    util.run_frames(api, pkg.harness, oracle, scene, [den], 6, settings=st, keep=keep)
+    z = np.asarray(scene.frame(0)["viewz"], dtype=np.float32)
+    m = z < 1e4
+    med = [float(np.median(np.asarray(k["out_diff_hitdist"]).view(np.uint16).reshape(h, w).astype(np.float32)[m] / 65535.0)) for k in keep]
+    assert med[0] == 0.0 and all(b > a for a, b in zip(med, med[1:])), med  # one more frame per frame, 0 on the first
+    assert abs(med[5] - 5.0 / 20.0) < 0.02, med
