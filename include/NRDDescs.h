@@ -123,6 +123,7 @@ enum class Format : uint32_t {
     R10_G10_B10_A2_UNORM,
     RGBA32_UINT, // 16-byte packed diff+spec radiance plane (2 x RGBA16F)
     R16_UNORM,   // OCCLUSION variants: normalised hit distance (Source/NRDSample.cpp:2934-2937)
+    RGBA16_SNORM, // DIRECTIONAL_OCCLUSION: {direction * hitDist, hitDist} (Source/NRDSample.cpp:2937)
     MAX_NUM
 };
 
@@ -188,6 +189,8 @@ inline bool IsFormatAllowed(ResourceType type, Format format) {
         case ResourceType::IN_TRANSLUCENCY:
         case ResourceType::OUT_VALIDATION: return format == Format::RGBA8_UNORM;
         case ResourceType::OUT_SHADOW_TRANSLUCENCY: return format == Format::RGBA8_UNORM || format == Format::R8_UNORM;
+        case ResourceType::IN_DIFF_DIRECTION_HITDIST:
+        case ResourceType::OUT_DIFF_DIRECTION_HITDIST: return format == Format::RGBA16_SFLOAT || format == Format::RGBA16_SNORM; // Source/NRDSample.cpp:2937
         default: return format == Format::RGBA16_SFLOAT; // motion vectors, radiance / SH / direction planes, confidence, REFERENCE signal
     }
 }

@@ -100,12 +100,14 @@ class Format(enum.IntEnum):
     R10_G10_B10_A2_UNORM = 11
     RGBA32_UINT = 12
     R16_UNORM = 13
+    RGBA16_SNORM = 14
 
 
 FORMAT_BYTES = {
     Format.R8_UNORM: 1, Format.R8_UINT: 1, Format.RGBA8_UNORM: 4, Format.R16_UINT: 2, Format.R16_SFLOAT: 2,
     Format.RG16_SFLOAT: 4, Format.RGBA16_SFLOAT: 8, Format.R32_UINT: 4, Format.R32_SFLOAT: 4, Format.RG32_UINT: 8,
     Format.RGBA32_SFLOAT: 16, Format.R10_G10_B10_A2_UNORM: 4, Format.RGBA32_UINT: 16, Format.R16_UNORM: 2,
+    Format.RGBA16_SNORM: 8,
 }
 
 

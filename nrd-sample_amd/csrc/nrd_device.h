@@ -147,6 +147,11 @@ NRD_DEV f3 normalize3(f3 a) {
 NRD_DEV float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 NRD_DEV uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)clampf(f, -NRD_FP16_MAX, NRD_FP16_MAX)); }
 NRD_DEV f4 unpack_h4(uint2 v) { return {h2f((uint16_t)(v.x & 0xffffu)), h2f((uint16_t)(v.x >> 16)), h2f((uint16_t)(v.y & 0xffffu)), h2f((uint16_t)(v.y >> 16))}; }
+// RGBA16_SNORM texel (the sample's DIRECTIONAL_OCCLUSION data format, Source/NRDSample.cpp:2937): v = max(int16 / 32767, -1)
+NRD_DEV float sn2f(uint32_t h) { return fmax2((float)(int16_t)(uint16_t)h * (1.0f / 32767.0f), -1.0f); }
+NRD_DEV uint32_t f2sn(float v) { return (uint32_t)(uint16_t)(int16_t)__builtin_floorf(fma_(fmin2(fmax2(v, -1.0f), 1.0f), 32767.0f, 0.5f)); }
+NRD_DEV f4 unpack_sn4(uint2 v) { return {sn2f(v.x & 0xffffu), sn2f(v.x >> 16), sn2f(v.y & 0xffffu), sn2f(v.y >> 16)}; }
+NRD_DEV uint2 pack_sn4(f4 v) { return {f2sn(v.x) | (f2sn(v.y) << 16), f2sn(v.z) | (f2sn(v.w) << 16)}; }
 NRD_DEV uint2 pack_h4(f4 v) { return {(uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16), (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16)}; }
 
 // ---- polynomial transcendentals (coefficients frozen) ------------------------------------------------

@@ -43,6 +43,7 @@ struct ReblurParams {
     PlaneRef rawDiff, rawSpec, rawDiff1, rawSpec1;
     int prepared, checker, phaseDiff, phaseSpec, reconRadius;
     int prepSh1; // PrepareInputs also writes the SH1 copies (checkerboarded SH inputs / DIRECTIONAL_OCCLUSION)
+    int dirInSnorm, dirOutSnorm; // ... whose planes are RGBA16_SNORM (1) or RGBA16_SFLOAT (0)
     int dirOcc;  // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: one {direction * h, h} texel in / out (split by PrepareInputs, merged by TS)
     // pools
     PlaneRef guide, guidePrev, data1, data1Prev, data1Tmp, data2, hist, fast, fastPrev, stab, stabPrev, tiles, tmp1, tmp2, hitTrack;

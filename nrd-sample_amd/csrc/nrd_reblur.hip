@@ -51,6 +51,8 @@ NRD_DEV f4 dir_pass(const ReblurParams& p, int x, int y) {
     f4 a = unpack_h4(ld<uint2>(p.inDiff, x, y, 8)), b = unpack_h4(ld<uint2>(p.inDiff1, x, y, 8));
     return {b.x, b.y, b.z, a.x};
 }
+// OUT_DIFF_DIRECTION_HITDIST texel in the bound format
+NRD_DEV uint2 pack_dir(const ReblurParams& p, f4 v) { return p.dirOutSnorm ? pack_sn4(v) : pack_h4(v); }
 // the same in two steps (gather now, decode later)
 NRD_DEV uint2 load_signal_raw(const PlaneRef& P, int x, int y, int bpt, int off, bool occlusion) {
     if (!occlusion)
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
         // one input position -> (SH0-like signal, SH1 texel)
         auto load_pair = [&](int sx, int sy, f4& a, f4& b) {
             if (dirOcc) { // {direction * h, h}
-                f4 t = unpack_h4(ld<uint2>(in, sx, sy, 8));
+                uint2 tr = ld<uint2>(in, sx, sy, 8);
+                f4 t = p.dirInSnorm ? unpack_sn4(tr) : unpack_h4(tr);
                 a = {t.w, 0.0f, 0.0f, t.w};
                 b = {t.x, t.y, t.z, 0.0f};
             } else {
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
             // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
             if (SH && p.dirOcc) // single {SH1.xyz, SH0.x} texel out
-                st<uint2>(o, x, y, 8, split ? pack_h4(dir_pass(p, x, y)) : uint2{0u, 0u});
+                st<uint2>(o, x, y, 8, split ? pack_dir(p, dir_pass(p, x, y)) : uint2{0u, 0u});
             else
                 store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : f4{0, 0, 0, 0});
             if (SH && !p.dirOcc)
@@ -1137,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
         if (SH && p.dirOcc) {
             f4 c1 = unpack_h4(ctex[sig * SW + S1]);
-            st<uint2>(op, x, y, 8, split ? pack_h4(dir_pass(p, x, y)) : pack_h4({c1.x * scale, c1.y * scale, c1.z * scale, Yout}));
+            st<uint2>(op, x, y, 8, pack_dir(p, split ? dir_pass(p, x, y) : f4{c1.x * scale, c1.y * scale, c1.z * scale, Yout}));
             continue;
         }
         store_signal(p, op, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : o);

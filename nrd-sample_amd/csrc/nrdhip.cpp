@@ -75,6 +75,7 @@ uint32_t format_bytes(uint32_t f) {
         case Format::R32_SFLOAT:
         case Format::R10_G10_B10_A2_UNORM: return 4;
         case Format::RGBA16_SFLOAT:
+        case Format::RGBA16_SNORM:
         case Format::RG32_UINT: return 8;
         case Format::RGBA32_SFLOAT:
         case Format::RGBA32_UINT: return 16;
@@ -552,6 +553,8 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.reconRadius = pm.radius;
     p.prepSh1 = pm.sh1 ? 1 : 0;
     p.dirOcc = d.dirOcc ? 1 : 0;
+    p.dirInSnorm = (d.dirOcc && I.slots[(size_t)nrd::ResourceType::IN_DIFF_DIRECTION_HITDIST].fmt == (uint32_t)nrd::Format::RGBA16_SNORM) ? 1 : 0;
+    p.dirOutSnorm = (d.dirOcc && I.slots[(size_t)nrd::ResourceType::OUT_DIFF_DIRECTION_HITDIST].fmt == (uint32_t)nrd::Format::RGBA16_SNORM) ? 1 : 0;
     if (pm.any) {
         p.inDiff = TP(rb::PREP_D);
         p.inSpec = TP(rb::PREP_S);

@@ -64,6 +64,9 @@ class Harness:
             if key not in self.outputs:  # SH0 outputs share the plain radiance output planes, like the sample's textures
                 self.outputs[key] = self._zeros(height, width * bpt)
         self.resident = {}
+        # plane key -> api.Format for slots bound in another allowed format of the same texel size (e.g. the sample's RGBA16_SNORM
+        # DIRECTIONAL_OCCLUSION planes, Source/NRDSample.cpp:2937: {"diff_dirocc": F.RGBA16_SNORM, "out_diff_dirocc": F.RGBA16_SNORM})
+        self.format_override = {}
 
     def _zeros(self, rows, rowbytes):
         if self.backend.is_device:
@@ -95,10 +98,11 @@ class Harness:
         for slot, (key, fmt) in INPUT_SLOTS.items():
             if key in planes:
                 buf = planes[key]
+                fmt = self.format_override.get(key, fmt)
                 bpt = api.FORMAT_BYTES[fmt]
                 self.nrd.set_resource(slot, buf, fmt, width=buf.shape[1] // bpt, height=buf.shape[0])
         for slot, (key, fmt, bpt) in OUTPUT_SLOTS.items():
-            self.nrd.set_resource(slot, self.outputs[key], fmt, width=self.w, height=self.h)
+            self.nrd.set_resource(slot, self.outputs[key], self.format_override.get(key, fmt), width=self.w, height=self.h)
         # REFERENCE runs in place: the sample binds the same texture to IN_SIGNAL and OUT_SIGNAL (NRDSample.cpp:484-485)
         if "signal" in planes:
             self.nrd.set_resource(RT.OUT_SIGNAL, planes["signal"], F.RGBA16_SFLOAT, width=self.w, height=self.h)

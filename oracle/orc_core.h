@@ -35,6 +35,7 @@ static inline uint32_t format_bytes(uint32_t f) {
         case Format::R32_SFLOAT:
         case Format::R10_G10_B10_A2_UNORM: return 4;
         case Format::RGBA16_SFLOAT:
+        case Format::RGBA16_SNORM:
         case Format::RG32_UINT: return 8;
         case Format::RGBA32_SFLOAT:
         case Format::RGBA32_UINT: return 16;
@@ -57,6 +58,20 @@ static inline void st_f32(const Plane& P, int x, int y, float v, int off = 0) { 
 static inline void st_u32(const Plane& P, int x, int y, uint32_t v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 4); }
 static inline void st_u16(const Plane& P, int x, int y, uint16_t v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 2); }
 static inline void st_h(const Plane& P, int x, int y, float v, int off = 0) { st_u16(P, x, y, f32_to_f16(clampf(v, -FP16_MAX, FP16_MAX)), off); }
+// RGBA16_SNORM texels (the sample's DIRECTIONAL_OCCLUSION data format, Source/NRDSample.cpp:2937): v = max(int16 / 32767, -1)
+static inline float sn2f(uint16_t h) { return fmax2((float)(int16_t)h * (1.0f / 32767.0f), -1.0f); }
+static inline uint16_t f2sn(float v) { return (uint16_t)(int16_t)floorf(fma_(fmin2(fmax2(v, -1.0f), 1.0f), 32767.0f, 0.5f)); }
+static inline f4 ld_sn4(const Plane& P, int x, int y) {
+    const uint16_t* t = reinterpret_cast<const uint16_t*>(P.p + (size_t)y * P.pitch + (size_t)x * 8);
+    return {sn2f(t[0]), sn2f(t[1]), sn2f(t[2]), sn2f(t[3])};
+}
+static inline void st_sn4(const Plane& P, int x, int y, f4 v) {
+    uint16_t* t = reinterpret_cast<uint16_t*>(P.p + (size_t)y * P.pitch + (size_t)x * 8);
+    t[0] = f2sn(v.x);
+    t[1] = f2sn(v.y);
+    t[2] = f2sn(v.z);
+    t[3] = f2sn(v.w);
+}
 static inline void st_h4(const Plane& P, int x, int y, f4 v, int off = 0) {
     uint16_t h[4] = {f32_to_f16(clampf(v.x, -FP16_MAX, FP16_MAX)), f32_to_f16(clampf(v.y, -FP16_MAX, FP16_MAX)),
                      f32_to_f16(clampf(v.z, -FP16_MAX, FP16_MAX)), f32_to_f16(clampf(v.w, -FP16_MAX, FP16_MAX))};

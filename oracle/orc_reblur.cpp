@@ -54,6 +54,13 @@ static inline f4 dir_pass(const Plane& sh0, const Plane& sh1, int x, int y) {
     f4 a = ld_h4(sh0, x, y), b = ld_h4(sh1, x, y);
     return {b.x, b.y, b.z, a.x};
 }
+// OUT_DIFF_DIRECTION_HITDIST texel in the bound format
+static inline void st_dir(const Plane& P, int x, int y, f4 v) {
+    if (P.fmt == (uint32_t)nrd::Format::RGBA16_SNORM)
+        st_sn4(P, x, y, v);
+    else
+        st_h4(P, x, y, v);
+}
 static inline nrd::ResourceType in_slot(const DenoiserState& d, bool spec) {
     using RT = nrd::ResourceType;
     if (d.dirOcc)
@@ -225,7 +232,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                 // one input position -> (SH0-like signal, SH1 texel)
                 auto load_pair = [&](int sx, int sy, f4& a, f4& b) {
                     if (d.dirOcc) { // {direction * h, h}
-                        f4 t = ld_h4(in, sx, sy, 0);
+                        f4 t = in.fmt == (uint32_t)nrd::Format::RGBA16_SNORM ? ld_sn4(in, sx, sy) : ld_h4(in, sx, sy, 0);
                         a = {t.w, 0.0f, 0.0f, t.w};
                         b = {t.x, t.y, t.z, 0.0f};
                     } else {
@@ -1036,7 +1043,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
                     if (dirOcc)
-                        st_h4(*outP[sig], x, y, split ? dir_pass(*inP[sig], *in1P[sig], x, y) : f4{0, 0, 0, 0});
+                        st_dir(*outP[sig], x, y, split ? dir_pass(*inP[sig], *in1P[sig], x, y) : f4{0, 0, 0, 0});
                     else
                         store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, occIn) : f4{0, 0, 0, 0}, d.occlusion);
                     if (d.sh && !dirOcc)
@@ -1132,7 +1139,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                 st_h(STABC, x, y, Yout, sig * 2);
                 if (dirOcc) {
                     f4 c1 = ld_h4(HIST, x, y, sig * sb + 8);
-                    st_h4(*outP[sig], x, y, split ? dir_pass(*inP[sig], *in1P[sig], x, y) : f4{c1.x * scale, c1.y * scale, c1.z * scale, Yout});
+                    st_dir(*outP[sig], x, y, split ? dir_pass(*inP[sig], *in1P[sig], x, y) : f4{c1.x * scale, c1.y * scale, c1.z * scale, Yout});
                     continue;
                 }
                 store_signal(*outP[sig], x, y, split ? load_signal(*inP[sig], x, y, 0, occIn) : o, d.occlusion);

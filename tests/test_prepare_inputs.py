@@ -130,3 +130,62 @@ def test_prepare_inputs_hip_bit_exact(pkg, api, oracle, hip, dens, checker, reco
     ho = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st, frame_hook=hooks(pkg, api, checker, recon is not None))
     hh = util.run_frames(api, pkg.harness, hip, scene, dd, 3, settings=st, frame_hook=hooks(pkg, api, checker, recon is not None))
     assert util.compare_all(ho, hh, exact=True) == []
+
+
+# ---- RGBA16_SNORM DIRECTIONAL_OCCLUSION planes (the sample's data format without DLSS, Source/NRDSample.cpp:2937) -----------------
+def to_snorm16(a):
+    """fp16 [H, W, 4] in [-1, 1] -> int16 snorm texels"""
+    f = np.clip(np.asarray(a, dtype=np.float32), -1.0, 1.0)
+    return np.floor(f * np.float32(32767.0) + np.float32(0.5)).astype(np.int16)
+
+
+def run_dirocc(pkg, api, backend, snorm, frames=3, w=56, h=40, split=0.0):
+    den = api.Denoiser.REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION
+    scene = pkg.synth.Scene(w, h, dolly=0.04)
+    hz = pkg.harness.Harness(backend, [den], w, h)
+    if snorm:
+        hz.format_override = {"diff_dirocc": api.Format.RGBA16_SNORM, "out_diff_dirocc": api.Format.RGBA16_SNORM}
+    st = settings(api, scene, [den], None, None)
+    for f in range(frames):
+        fr = scene.frame(f)
+        if snorm:
+            fr["diff_dirocc"] = to_snorm16(fr["diff_dirocc"])
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        cs.splitScreen = split
+        hz.frame(cs, hz.upload(fr), st)
+    return hz
+
+
+def test_dirocc_snorm_planes(pkg, api, oracle, emulated):
+    ho, he = run_dirocc(pkg, api, oracle, True), run_dirocc(pkg, api, emulated, True)
+    assert util.compare_all(ho, he, exact=True) == []
+    # same result as the RGBA16_SFLOAT run up to the quantisation of the two formats
+    hf = run_dirocc(pkg, api, oracle, False)
+    a = ho.output("out_diff_dirocc", dtype=np.int16).astype(np.float32) / 32767.0
+    b = hf.output("out_diff_dirocc").astype(np.float32)
+    assert float(np.abs(a - b).max()) < 4e-3
+    assert float(np.abs(b).max()) > 0.1
+    # split screen passes the snorm input through (via the fp16 prepared planes)
+    hs = run_dirocc(pkg, api, oracle, True, frames=1, split=1.0)
+    src = to_snorm16(pkg.synth.Scene(56, 40, dolly=0.04).frame(0)["diff_dirocc"]).astype(np.float32) / 32767.0
+    out = hs.output("out_diff_dirocc", dtype=np.int16).astype(np.float32) / 32767.0
+    z = np.asarray(pkg.synth.Scene(56, 40, dolly=0.04).frame(0)["viewz"], dtype=np.float32)
+    assert float(np.abs(out - src)[z < 1e4].max()) < 1e-3
+
+
+def test_dirocc_format_validation(pkg, api, oracle):
+    """RGBA16_SNORM is accepted on the DIRECTION_HITDIST slots only"""
+    den = api.Denoiser.REBLUR_DIFFUSE
+    w, h = 32, 32
+    scene = pkg.synth.Scene(w, h)
+    hz = pkg.harness.Harness(oracle, [den], w, h)
+    hz.format_override = {"diff": api.Format.RGBA16_SNORM}
+    fr = scene.frame(0)
+    with pytest.raises(api.NrdError):
+        hz.frame(scene.common_settings(api, fr, 0, reset=True), hz.upload(fr), {den: api.ReblurSettings()})
+
+
+@pytest.mark.gpu
+def test_dirocc_snorm_hip_bit_exact(pkg, api, oracle, hip):
+    ho, hh = run_dirocc(pkg, api, oracle, True, w=250, h=141), run_dirocc(pkg, api, hip, True, w=250, h=141)
+    assert util.compare_all(ho, hh, exact=True) == []
