@@ -58,6 +58,10 @@ struct AtrousParams {
     uint32_t minMatDiff, minMatSpec;
     int roughnessEdgeStopping;
     float lumRelax, normRelax, roughRelax; // {luminance, normal, roughness}EdgeStoppingRelaxation, saturated
+    float lobeSlack;                       // specularLobeAngleSlack in radians
+    int confDriven;                        // confidenceDrivenRelaxationMultiplier > 0 and confidence inputs available
+    float confMult, confLumRelax, confNormRelax;
+    PlaneRef confD, confS;
     int it, last, hasDiff, hasSpec, sh;
     PlaneRef guide, data1, data2, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec, inDiff1, inSpec1, outDiff1, outSpec1;
 };

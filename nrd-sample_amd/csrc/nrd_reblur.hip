@@ -1319,7 +1319,15 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         float sigma = sqrt_(var);
         invL[sig] = 0.3333f * rcp_(fma_(p.phi[si], sigma, 1e-4f));
         float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
+        if (isSpec)
+            angle += p.lobeSlack;
         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+        if (p.confDriven) { // confidenceDriven*: low history confidence relaxes the luminance / normal edge stopping of both signals
+            float conf = sample_confidence(isSpec ? p.confS : p.confD, u, ((float)gy0 + 0.5f) * c.invH);
+            float cd = sat(p.confMult * (1.0f - conf));
+            invL[sig] *= fma_(-cd, p.confLumRelax, 1.0f);
+            normalW *= fma_(-cd, p.confNormRelax, 1.0f);
+        }
         if (LS && isSpec) { // fine iterations: relax the edge stopping where the specular history was reprojected with low confidence
             float conf = (float)((ld<uint32_t>(p.data2, x, y, 4) >> 16) & 255u) * (1.0f / 255.0f);
             invL[sig] *= lerpf(1.0f, conf, p.lumRelax);

@@ -767,6 +767,13 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     a.normRelax = sat01(r.normalEdgeStoppingRelaxation);
     a.roughRelax = sat01(r.roughnessEdgeStoppingRelaxation);
     a.data2 = p.data2;
+    a.lobeSlack = r.specularLobeAngleSlack * 0.017453292f; // degrees -> radians
+    a.confDriven = (r.confidenceDrivenRelaxationMultiplier > 0.0f && c.confAvail) ? 1 : 0;
+    a.confMult = r.confidenceDrivenRelaxationMultiplier;
+    a.confLumRelax = sat01(r.confidenceDrivenLuminanceEdgeStoppingRelaxation);
+    a.confNormRelax = sat01(r.confidenceDrivenNormalEdgeStoppingRelaxation);
+    a.confD = p.confD;
+    a.confS = p.confS;
     a.hasDiff = d.hasDiff;
     a.hasSpec = d.hasSpec;
     a.sh = d.sh ? 1 : 0;

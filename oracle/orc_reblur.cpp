@@ -1256,7 +1256,16 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 float minLw = isSpec ? s.specularMinLuminanceWeight : s.diffuseMinLuminanceWeight;
                 float invL = 0.3333f * rcp_(fma_(phi, sigma, 1e-4f));
                 float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
+                if (isSpec)
+                    angle += s.specularLobeAngleSlack * 0.017453292f; // degrees
                 float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                // confidenceDriven*: low history confidence (IN_*_CONFIDENCE) relaxes the luminance / normal edge stopping of both signals
+                if (s.confidenceDrivenRelaxationMultiplier > 0.0f && c.confAvail) {
+                    float conf = sample_confidence(k.slot(isSpec ? nrd::ResourceType::IN_SPEC_CONFIDENCE : nrd::ResourceType::IN_DIFF_CONFIDENCE), u, ((float)gy0 + 0.5f) * c.invH);
+                    float cd = sat(s.confidenceDrivenRelaxationMultiplier * (1.0f - conf));
+                    invL *= fma_(-cd, sat(s.confidenceDrivenLuminanceEdgeStoppingRelaxation), 1.0f);
+                    normalW *= fma_(-cd, sat(s.confidenceDrivenNormalEdgeStoppingRelaxation), 1.0f);
+                }
                 // {luminance, normal, roughness}EdgeStoppingRelaxation (sample UI Source/NRDSample.cpp:1650): where the specular history
                 // was reprojected with low confidence (DATA2 bits 16..23) the three edge-stopping terms are relaxed toward "accept"
                 float roughRelax = 1.0f;

@@ -69,6 +69,8 @@ CASES = [
                                                   "antilagSettings.temporalSigmaScale": 0.1, "antilagSettings.resetAmount": 1.0}, None, None),
     ("prepass_track_only", ["REBLUR_DIFFUSE_SPECULAR_SH"], {"usePrepassOnlyForSpecularMotionEstimation": True}, None, None),
     ("history_length_out", ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], {"returnHistoryLengthInsteadOfOcclusion": True}, None, None),
+    ("relax_confidence_driven", ["RELAX_DIFFUSE_SPECULAR"], {"confidenceDrivenRelaxationMultiplier": 2.0, "confidenceDrivenLuminanceEdgeStoppingRelaxation": 0.8,
+                                                            "confidenceDrivenNormalEdgeStoppingRelaxation": 0.5, "specularLobeAngleSlack": 1.0}, conf_hook, conf_frames),
     ("relax_tuning_sh", ["RELAX_SPECULAR_SH"], {"luminanceEdgeStoppingRelaxation": 0.0, "normalEdgeStoppingRelaxation": 1.0,
                                                 "antilagSettings.resetAmount": 0.0, "antilagSettings.accelerationAmount": 0.0}, None, None),
 ]
@@ -161,7 +163,7 @@ def test_camera_jitter_is_a_pure_pixel_grid_shift(pkg, api, oracle):
 
 RELAX_FIELDS = [
     {"luminanceEdgeStoppingRelaxation": 0.0}, {"normalEdgeStoppingRelaxation": 1.0}, {"roughnessEdgeStoppingRelaxation": 0.0},
-    {"historyFixEdgeStoppingNormalPower": 1.0}, {"antilagSettings.accelerationAmount": 1.0},
+    {"historyFixEdgeStoppingNormalPower": 1.0}, {"antilagSettings.accelerationAmount": 1.0}, {"specularLobeAngleSlack": 3.0},
     {"antilagSettings.resetAmount": 1.0, "antilagSettings.spatialSigmaScale": 0.25, "antilagSettings.temporalSigmaScale": 0.0},
 ]
 
@@ -221,3 +223,14 @@ def test_reblur_flags_semantics(pkg, api, oracle):
     med = [float(np.median(np.asarray(k["out_diff_hitdist"]).view(np.uint16).reshape(h, w).astype(np.float32)[m] / 65535.0)) for k in keep]
     assert med[0] == 0.0 and all(b > a for a, b in zip(med, med[1:])), med  # one more frame per frame, 0 on the first
     assert abs(med[5] - 5.0 / 20.0) < 0.02, med
+
+
+def test_relax_confidence_driven_relaxation(pkg, api, oracle):
+    """confidenceDriven* only act with confidence inputs below 1; then they change the A-trous result"""
+    den = api.Denoiser.RELAX_DIFFUSE_SPECULAR
+    scene = pkg.synth.Scene(60, 44, dolly=0.06, denoiser="RELAX")
+    kw = {"confidenceDrivenRelaxationMultiplier": 2.0, "confidenceDrivenLuminanceEdgeStoppingRelaxation": 1.0, "confidenceDrivenNormalEdgeStoppingRelaxation": 1.0}
+    run = lambda k, ch, fh: util.run_frames(api, pkg.harness, oracle, scene, [den], 3, settings=settings_factory(api, [den], k)(scene), common_hook=ch, frame_hook=fh)
+    assert util.compare_all(run({}, None, None), run(kw, None, None), exact=True) == []  # no confidence inputs: no effect
+    assert util.compare_all(run({}, conf_hook, None), run(kw, conf_hook, None), exact=True) == []  # confidence == 1 everywhere: no effect
+    assert util.compare_all(run({}, conf_hook, conf_frames), run(kw, conf_hook, conf_frames), exact=True) != []
