@@ -61,6 +61,8 @@ struct FrameConsts {
     float mvScale[3];
     float viewZScale;
     uint32_t frameIndex;
+    uint32_t strandMat;    // CommonSettings::strandMaterialID (Source/NRDSample.cpp:3871), 0xffffffff = none
+    float strandThickness; // CommonSettings::strandThickness, world units
     int mvWorld, confAvail, historyOk;
     int ortho; // orthographic projection: view position of pixel (px, gy) = (pv0 + pv2 px, pv1 + pv3 gy, z); pj = {m0, m5, m12, m13, 1}
     int tilesX, tilesY; // tile grid covering the owned rows: tile row 0 starts at local row tileY0 * 16
@@ -366,6 +368,14 @@ NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, 
         p.geoB = -dot3(p.Nv, p.Xv) * geoA;
     }
     return p;
+}
+// Hair (CommonSettings::strandMaterialID / strandThickness, Source/NRDSample.cpp:3871-3872; the sample's own guide treatment:
+// Shaders/TraceOpaque.cs.hlsl:644-649): per-pixel normals of strands thinner than a pixel are unreliable, so the normal-weight
+// parameter of such pixels is scaled by lerp(0.25, 1, saturate(strandThickness / pixel world size))
+NRD_DEV float strand_normal_relax(const FrameConsts& c, uint32_t mat, float absZ) {
+    if (mat != c.strandMat)
+        return 1.0f;
+    return lerpf(0.25f, 1.0f, sat(c.strandThickness * rcp_(c.unproject * zpersp(absZ))));
 }
 // plane-distance term of a tap from its precomputed linear part ga = ga0 + gax px + gay gy
 NRD_DEV float geo_plane(const PixelGeo& p, float ga, float zs) { return ORTHO ? fma_(zs, p.geoB, ga) : fma_(zs, ga, p.geoB); }

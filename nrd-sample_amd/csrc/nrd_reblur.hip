@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
             float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
             float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+            normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
             float normalW2 = normalW * normalW;
             float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             float roughB = -rough * roughA;
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
             float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
             float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+            normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
             float normalW2 = normalW * normalW;
             const float m2w2 = -2.0f * normalW2;
             float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
@@ -907,6 +909,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                 }
                 float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, rcp_(1.0f + Acur));
                 float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                 float normalW2 = normalW * normalW;
                 float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
                 float roughB = -rough * roughA;
@@ -1322,6 +1325,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         if (isSpec)
             angle += p.lobeSlack;
         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+        normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
         if (p.confDriven) { // confidenceDriven*: low history confidence relaxes the luminance / normal edge stopping of both signals
             float conf = sample_confidence(isSpec ? p.confS : p.confD, u, ((float)gy0 + 0.5f) * c.invH);
             float cd = sat(p.confMult * (1.0f - conf));

@@ -138,6 +138,8 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
     for (int i = 0; i < 3; i++)
         c.mvScale[i] = cs.motionVectorScale[i];
     c.frameIndex = cs.frameIndex;
+    c.strandMat = (cs.strandMaterialID >= 0.0f && cs.strandMaterialID <= 3.0f) ? (uint32_t)cs.strandMaterialID : 0xffffffffu;
+    c.strandThickness = cs.strandThickness;
     c.mvWorld = cs.isMotionVectorInWorldSpace;
     c.confAvail = cs.isHistoryConfidenceAvailable;
     c.reset = cs.accumulationMode != nrd::AccumulationMode::CONTINUE;

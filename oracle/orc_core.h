@@ -98,6 +98,8 @@ struct Consts {
     float denoisingRange = 0, disocclusionThreshold = 0, splitScreen = 0;
     float mvScale[3] = {};
     uint32_t frameIndex = 0;
+    uint32_t strandMat = 0xffffffffu; // CommonSettings::strandMaterialID (Source/NRDSample.cpp:3871), 0xffffffff = none
+    float strandThickness = 0;        // CommonSettings::strandThickness, world units
     bool mvWorld = false, confAvail = false, reset = false;
     float rot[64][2] = {};
 };

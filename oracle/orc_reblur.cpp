@@ -169,6 +169,14 @@ static inline float geo_weight(const PixelGeo& p, float px, float gy, float zs) 
     float ga = fma_(p.gax, px, fma_(p.gay, gy, p.ga0));
     return smoothstep01(1.0f - absf(p.ortho ? fma_(zs, p.geoB, ga) : fma_(zs, ga, p.geoB)));
 }
+// Hair (CommonSettings::strandMaterialID / strandThickness, Source/NRDSample.cpp:3871-3872; the sample's own guide treatment:
+// Shaders/TraceOpaque.cs.hlsl:644-649): per-pixel normals of strands thinner than a pixel are unreliable, so the normal-weight
+// parameter of such pixels is scaled by lerp(0.25, 1, saturate(strandThickness / pixel world size))
+static inline float strand_normal_relax(const Consts& c, uint32_t mat, float absZ) {
+    if (mat != c.strandMat)
+        return 1.0f;
+    return lerpf(0.25f, 1.0f, sat(c.strandThickness * rcp_(c.unproject * (c.ortho ? 1.0f : absZ))));
+}
 // unit vector from the view-space point toward the viewer
 static inline f3 to_viewer(const Consts& c, f3 Xv) {
     if (c.ortho)
@@ -286,6 +294,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                     uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
                     float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
                     float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                    normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                     float normalW2 = normalW * normalW;
                     float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
@@ -440,6 +449,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
                     float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
                     float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                    normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                     float normalW2 = normalW * normalW;
                     float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
                     float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
@@ -879,6 +889,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                         }
                         float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, rcp_(1.0f + Acur));
                         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                        normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                         float normalW2 = normalW * normalW;
                         float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                         float roughB = -rough * roughA;
@@ -1259,6 +1270,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 if (isSpec)
                     angle += s.specularLobeAngleSlack * 0.017453292f; // degrees
                 float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                 // confidenceDriven*: low history confidence (IN_*_CONFIDENCE) relaxes the luminance / normal edge stopping of both signals
                 if (s.confidenceDrivenRelaxationMultiplier > 0.0f && c.confAvail) {
                     float conf = sample_confidence(k.slot(isSpec ? nrd::ResourceType::IN_SPEC_CONFIDENCE : nrd::ResourceType::IN_DIFF_CONFIDENCE), u, ((float)gy0 + 0.5f) * c.invH);

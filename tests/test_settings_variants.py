@@ -62,6 +62,8 @@ CASES = [
     ("confidence_relax", ["RELAX_DIFFUSE_SPECULAR"], {}, conf_hook, conf_frames),
     ("validation_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: setattr(cs, "enableValidation", True), None),
     ("jitter_reblur_sigma", ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW"], {}, lambda f, cs: jitter_hook(f, cs), None),
+    ("strand_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: strand_hook(f, cs), None),
+    ("strand_relax_sh", ["RELAX_DIFFUSE_SPECULAR_SH"], {}, lambda f, cs: strand_hook(f, cs), None),
     # RELAX tuning fields of the sample's UI (Source/NRDSample.cpp:1600-1606 antilag, :1626 history-fix normal power, :1650 relaxation)
     ("relax_tuning", ["RELAX_DIFFUSE_SPECULAR"], {"luminanceEdgeStoppingRelaxation": 1.0, "normalEdgeStoppingRelaxation": 0.8,
                                                   "roughnessEdgeStoppingRelaxation": 0.4, "historyFixEdgeStoppingNormalPower": 3.0,
@@ -74,6 +76,12 @@ CASES = [
     ("relax_tuning_sh", ["RELAX_SPECULAR_SH"], {"luminanceEdgeStoppingRelaxation": 0.0, "normalEdgeStoppingRelaxation": 1.0,
                                                 "antilagSettings.resetAmount": 0.0, "antilagSettings.accelerationAmount": 0.0}, None, None),
 ]
+
+
+def strand_hook(f, cs):
+    """the sample's hair settings (Source/NRDSample.cpp:3871-3872); material 1 plays the strand here (the scene's spheres carry it)"""
+    cs.strandMaterialID = 1.0
+    cs.strandThickness = 0.002
 
 
 def jitter_hook(f, cs):
@@ -234,3 +242,20 @@ def test_relax_confidence_driven_relaxation(pkg, api, oracle):
     assert util.compare_all(run({}, None, None), run(kw, None, None), exact=True) == []  # no confidence inputs: no effect
     assert util.compare_all(run({}, conf_hook, None), run(kw, conf_hook, None), exact=True) == []  # confidence == 1 everywhere: no effect
     assert util.compare_all(run({}, conf_hook, conf_frames), run(kw, conf_hook, conf_frames), exact=True) != []
+
+
+def test_strand_material_relaxes_only_its_pixels(pkg, api, oracle):
+    """strandMaterialID / strandThickness change the result on pixels of that material (and their filter neighbourhood) only"""
+    den = api.Denoiser.REBLUR_DIFFUSE_SPECULAR
+    scene = pkg.synth.Scene(96, 64, dolly=0.0)
+    st = settings_factory(api, [den], {})(scene)
+    base = util.run_frames(api, pkg.harness, oracle, scene, [den], 2, settings=st)
+    var = util.run_frames(api, pkg.harness, oracle, scene, [den], 2, settings=st, common_hook=strand_hook)
+    a, b = base.output("out_diff").view(np.uint16), var.output("out_diff").view(np.uint16)
+    changed = (a != b).any(-1)
+    nr = np.asarray(scene.frame(0)["normal_roughness"]).view(np.uint32).reshape(64, 96)
+    mat1 = (nr >> 30) == 1
+    assert changed.any() and changed[mat1].mean() > 0.5
+    from scipy.ndimage import binary_dilation
+    near = binary_dilation(mat1, iterations=60)  # farther than the widest filter reach from any strand pixel: bit-identical
+    assert not changed[~near].any()
