@@ -186,6 +186,7 @@ inline bool IsFormatAllowed(ResourceType type, Format format) {
         case ResourceType::OUT_DIFF_HITDIST:
         case ResourceType::OUT_SPEC_HITDIST: return format == Format::R16_UNORM || format == Format::R16_SFLOAT;
         case ResourceType::IN_PENUMBRA: return format == Format::R16_SFLOAT;
+        case ResourceType::IN_DISOCCLUSION_THRESHOLD_MIX: return format == Format::R8_UNORM;
         case ResourceType::IN_TRANSLUCENCY:
         case ResourceType::OUT_VALIDATION: return format == Format::RGBA8_UNORM;
         case ResourceType::OUT_SHADOW_TRANSLUCENCY: return format == Format::RGBA8_UNORM || format == Format::R8_UNORM;

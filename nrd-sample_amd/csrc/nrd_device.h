@@ -58,6 +58,8 @@ struct FrameConsts {
     float camDelta[3];
     float unproject, minRectDimMulUnproject;
     float denoisingRange, disocclusionThreshold, splitScreen;
+    float disoccAlt; // CommonSettings::disocclusionThresholdAlternate, blended in per pixel by IN_DISOCCLUSION_THRESHOLD_MIX when ...
+    int mixAvail;    // ... CommonSettings::isDisocclusionThresholdMixAvailable
     float mvScale[3];
     float viewZScale;
     uint32_t frameIndex;

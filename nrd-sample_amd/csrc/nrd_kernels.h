@@ -36,6 +36,7 @@ struct ReblurParams {
     int hasDiff, hasSpec;
     // resource slots
     PlaneRef inZ, inNR, inMV, inDiff, inSpec, confD, confS, outDiff, outSpec;
+    PlaneRef inMix; // IN_DISOCCLUSION_THRESHOLD_MIX (R8_UNORM), only with FrameConsts::mixAvail
     PlaneRef inDiff1, inSpec1, outDiff1, outSpec1; // SH mode: IN/OUT_*_SH1
     PlaneRef outValidation;                        // OUT_VALIDATION (RGBA8), only with CommonSettings::enableValidation
     // PrepareInputs (checkerboard resolve / hit distance reconstruction): reads the raw slots, writes the planes the PrePass
@@ -71,6 +72,7 @@ struct SigmaParams {
     float planeDistanceSensitivity, maxStab;
     int translucency, outBpt;
     PlaneRef inZ, inNR, inMV, inPen, inTransl, out;
+    PlaneRef inMix; // IN_DISOCCLUSION_THRESHOLD_MIX (R8_UNORM), only with FrameConsts::mixAvail
     PlaneRef guide, guidePrev, hist, histPrev, tiles, tilesSmooth, shadow1, pen1, shadow2;
 };
 

@@ -684,7 +684,10 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     float NoV = absf(dot3(Nv, V));
     Reproj r = reproject(c, Xv, u, v, mvRaw);
     f3 NvPrev = rot3(c.w2vPrev, g.n);
-    float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * zpersp(absf(r.zPrev));
+    float thrBase = c.disocclusionThreshold;
+    if (c.mixAvail) // per-pixel blend toward disocclusionThresholdAlternate
+        thrBase = lerpf(thrBase, c.disoccAlt, (float)ld<uint8_t>(p.inMix, x, y, 1) * (1.0f / 255.0f));
+    float threshold = thrBase * c.minRectDimMulUnproject * zpersp(absf(r.zPrev));
     uint32_t minMatAny = p.minMatDiff < p.minMatSpec ? p.minMatDiff : p.minMatSpec;
     const bool historyOk = c.historyOk != 0;
     // ---- both footprints: positions, then ALL their gathers, then validation

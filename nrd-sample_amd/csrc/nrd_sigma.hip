@@ -299,7 +299,10 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
     bool have = false;
     if (c.historyOk && uvOk) {
         f3 NvPrev = rot3(c.w2vPrev, g.n);
-        float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * zpersp(absf(XvPrev.z));
+        float thrBase = c.disocclusionThreshold;
+        if (c.mixAvail) // per-pixel blend toward disocclusionThresholdAlternate
+            thrBase = lerpf(thrBase, c.disoccAlt, (float)ld<uint8_t>(p.inMix, x, y, 1) * (1.0f / 255.0f));
+        float threshold = thrBase * c.minRectDimMulUnproject * zpersp(absf(XvPrev.z));
         float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
         float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
         float fx = px - fx0, fy = py - fy0;

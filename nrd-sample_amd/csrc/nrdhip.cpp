@@ -356,6 +356,8 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     c.minRectDimMulUnproject = (float)std::min(c.W, c.H) * c.unproject;
     c.denoisingRange = cs.denoisingRange;
     c.disocclusionThreshold = cs.disocclusionThreshold;
+    c.disoccAlt = cs.disocclusionThresholdAlternate;
+    c.mixAvail = cs.isDisocclusionThresholdMixAvailable ? 1 : 0;
     c.splitScreen = cs.splitScreen;
     for (int i = 0; i < 3; i++)
         c.mvScale[i] = cs.motionVectorScale[i];
@@ -537,6 +539,7 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.inZ = SP(RT::IN_VIEWZ);
     p.inNR = SP(RT::IN_NORMAL_ROUGHNESS);
     p.inMV = SP(RT::IN_MV);
+    p.inMix = SP(RT::IN_DISOCCLUSION_THRESHOLD_MIX);
     p.inDiff = SP(in_slot(d, false));
     p.inSpec = SP(in_slot(d, true));
     p.outValidation = SP(RT::OUT_VALIDATION);
@@ -632,6 +635,8 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
                    GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + sp + 8 * nr + 2 * n + 2 + 4, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST),
                   P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1)), T(rb::HITTRACK)};
+        if (c.mixAvail)
+            x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_accumulation(p, st); };
         d.dispatches.push_back(x);
@@ -738,6 +743,8 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
                    GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + 2 * n + sp + 8 * nr + 2 * n + 2 * n + 2 + 4, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)),
                   P(rb::DATA1_A + (cur ^ 1)), P(rb::STAB_A + (cur ^ 1)), T(rb::HITTRACK)};
+        if (c.mixAvail)
+            x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), P(rb::STAB_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_accumulation(p, st); };
         d.dispatches.push_back(x);
@@ -842,6 +849,7 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.inZ = SP(RT::IN_VIEWZ);
     p.inNR = SP(RT::IN_NORMAL_ROUGHNESS);
     p.inMV = SP(RT::IN_MV);
+    p.inMix = SP(RT::IN_DISOCCLUSION_THRESHOLD_MIX);
     p.inPen = SP(RT::IN_PENUMBRA);
     p.inTransl = SP(RT::IN_TRANSLUCENCY);
     p.out = SP(RT::OUT_SHADOW_TRANSLUCENCY);
@@ -891,6 +899,8 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.read = {P(sg::GUIDE_A + cur), P(sg::GUIDE_A + (cur ^ 1)), P(sg::HIST_A + (cur ^ 1)), T(sg::SHADOW2), T(sg::TILES_SMOOTH), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
         if (d.translucency)
             x.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
+        if (c.mixAvail)
+            x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {P(sg::HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};
         x.launch = [p](hipStream_t st) { launch_sigma_temporal_stabilization(p, st); };
         d.dispatches.push_back(x);

@@ -28,6 +28,7 @@ INPUT_SLOTS = {
     RT.IN_SPEC_SH0: ("spec", F.RGBA16_SFLOAT),
     RT.IN_SPEC_SH1: ("spec_sh1", F.RGBA16_SFLOAT),
     RT.IN_DIFF_DIRECTION_HITDIST: ("diff_dirocc", F.RGBA16_SFLOAT),  # DIRECTIONAL_OCCLUSION (Source/NRDSample.cpp:488-491)
+    RT.IN_DISOCCLUSION_THRESHOLD_MIX: ("disocclusion_mix", F.R8_UNORM),  # optional; the sample never binds it
 }
 OUTPUT_SLOTS = {
     RT.OUT_DIFF_RADIANCE_HITDIST: ("out_diff", F.RGBA16_SFLOAT, 8),

@@ -134,6 +134,8 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
     c.minRectDimMulUnproject = (float)std::min(c.W, c.H) * c.unproject;
     c.denoisingRange = cs.denoisingRange;
     c.disocclusionThreshold = cs.disocclusionThreshold;
+    c.disoccAlt = cs.disocclusionThresholdAlternate;
+    c.mixAvail = cs.isDisocclusionThresholdMixAvailable;
     c.splitScreen = cs.splitScreen;
     for (int i = 0; i < 3; i++)
         c.mvScale[i] = cs.motionVectorScale[i];

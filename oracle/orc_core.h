@@ -96,6 +96,8 @@ struct Consts {
     float camDelta[3] = {}; // camera position prev - current (world)
     float unproject = 0, minRectDimMulUnproject = 0;
     float denoisingRange = 0, disocclusionThreshold = 0, splitScreen = 0;
+    float disoccAlt = 0;   // CommonSettings::disocclusionThresholdAlternate, blended in per pixel by IN_DISOCCLUSION_THRESHOLD_MIX when ...
+    bool mixAvail = false; // ... CommonSettings::isDisocclusionThresholdMixAvailable
     float mvScale[3] = {};
     uint32_t frameIndex = 0;
     uint32_t strandMat = 0xffffffffu; // CommonSettings::strandMaterialID (Source/NRDSample.cpp:3871), 0xffffffff = none

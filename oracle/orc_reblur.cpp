@@ -714,7 +714,10 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
             float NoV = absf(dot3(Nv, V));
             Reproj r = reproject(c, Xv, u, v, ld_h4(MV, x, y));
             f3 NvPrev = rot3(c.w2vPrev, g.n);
-            float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * (c.ortho ? 1.0f : absf(r.zPrev));
+            float thrBase = c.disocclusionThreshold;
+            if (c.mixAvail) // per-pixel blend toward disocclusionThresholdAlternate (IN_DISOCCLUSION_THRESHOLD_MIX, R8_UNORM)
+                thrBase = lerpf(thrBase, c.disoccAlt, (float)*texel(k.slot(nrd::ResourceType::IN_DISOCCLUSION_THRESHOLD_MIX), x, y) * (1.0f / 255.0f));
+            float threshold = thrBase * c.minRectDimMulUnproject * (c.ortho ? 1.0f : absf(r.zPrev));
             uint32_t minMatAny = std::min<uint32_t>(s.minMaterialForDiffuse, s.minMaterialForSpecular);
             Footprint smb = footprint(k, r.su, r.sv, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
             bool smbOk = historyOk && smb.wsum > 0.0f;
@@ -1499,6 +1502,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.haloRows = 0; // previous-frame planes are read at motion-displaced rows: the tiler adds its motion margin
         p.bytesPerPixel = GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + (d.hasSpec ? 2 : 0) + 8 * nr + 2 * n + 2 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1)), T(T_HITTRACK)};
+        if (I.common.isDisocclusionThresholdMixAvailable)
+            p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
         p.run = temporal_accumulation;
         d.passes.push_back(p);
@@ -1732,6 +1737,8 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.bytesPerPixel = GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + 2 * n + sp + 8 * nr + 2 * n + 2 * n + 2 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(T_TMP1), P(P_HIST), P(P_FAST_A + (cur ^ 1)),
                   P(P_DATA1_A + (cur ^ 1)), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
+        if (I.common.isDisocclusionThresholdMixAvailable)
+            p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_TMP2), P(P_FAST_A + cur), P(P_STAB_A + cur), T(T_DATA1), T(T_DATA2)};
         p.run = temporal_accumulation;
         d.passes.push_back(p);

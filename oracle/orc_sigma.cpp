@@ -301,7 +301,10 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
             bool have = false;
             if (historyOk && uvOk) {
                 f3 NvPrev = rot3(c.w2vPrev, g.n);
-                float threshold = c.disocclusionThreshold * c.minRectDimMulUnproject * (c.ortho ? 1.0f : absf(XvPrev.z));
+                float thrBase = c.disocclusionThreshold;
+                if (c.mixAvail) // per-pixel blend toward disocclusionThresholdAlternate (IN_DISOCCLUSION_THRESHOLD_MIX, R8_UNORM)
+                    thrBase = lerpf(thrBase, c.disoccAlt, (float)*texel(k.slot(nrd::ResourceType::IN_DISOCCLUSION_THRESHOLD_MIX), x, y) * (1.0f / 255.0f));
+                float threshold = thrBase * c.minRectDimMulUnproject * (c.ortho ? 1.0f : absf(XvPrev.z));
                 float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
                 float fx0 = floorf(px), fy0 = floorf(py);
                 float fx = px - fx0, fy = py - fy0;
@@ -362,7 +365,7 @@ void sigma_describe(DenoiserState&, std::vector<PoolPlane>& perm, std::vector<Po
     trans.push_back({"SIGMA::Shadow2", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, 1});
 }
 
-void sigma_build(Instance&, DenoiserState& d) {
+void sigma_build(Instance& I, DenoiserState& d) {
     using RT = nrd::ResourceType;
     int cur = (int)(d.frameCounter & 1);
     uint32_t pb = d.permBase, tb = d.transBase;
@@ -425,6 +428,8 @@ void sigma_build(Instance&, DenoiserState& d) {
         p.haloRows = 2;
         p.bytesPerPixel = GB + GB + 8 + 8 + 4 + 4 + 4;
         p.read = {P(P_GUIDE_A + cur), P(P_GUIDE_A + (cur ^ 1)), P(P_HIST_A + (cur ^ 1)), T(T_SHADOW2), T(T_TILES_SMOOTH), enc_slot(RT::IN_MV), enc_slot(RT::IN_PENUMBRA)};
+        if (I.common.isDisocclusionThresholdMixAvailable)
+            p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         if (d.translucency)
             p.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
         p.written = {P(P_HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};

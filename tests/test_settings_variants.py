@@ -63,6 +63,8 @@ CASES = [
     ("validation_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: setattr(cs, "enableValidation", True), None),
     ("jitter_reblur_sigma", ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW"], {}, lambda f, cs: jitter_hook(f, cs), None),
     ("strand_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: strand_hook(f, cs), None),
+    ("disocclusion_mix", ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW"], {}, lambda f, cs: mix_hook(f, cs), lambda f, fr: mix_frames(f, fr)),
+    ("disocclusion_mix_relax", ["RELAX_DIFFUSE"], {}, lambda f, cs: mix_hook(f, cs), lambda f, fr: mix_frames(f, fr)),
     ("strand_relax_sh", ["RELAX_DIFFUSE_SPECULAR_SH"], {}, lambda f, cs: strand_hook(f, cs), None),
     # RELAX tuning fields of the sample's UI (Source/NRDSample.cpp:1600-1606 antilag, :1626 history-fix normal power, :1650 relaxation)
     ("relax_tuning", ["RELAX_DIFFUSE_SPECULAR"], {"luminanceEdgeStoppingRelaxation": 1.0, "normalEdgeStoppingRelaxation": 0.8,
@@ -82,6 +84,16 @@ def strand_hook(f, cs):
     """the sample's hair settings (Source/NRDSample.cpp:3871-3872); material 1 plays the strand here (the scene's spheres carry it)"""
     cs.strandMaterialID = 1.0
     cs.strandThickness = 0.002
+
+
+def mix_hook(f, cs):
+    cs.isDisocclusionThresholdMixAvailable = True
+    cs.disocclusionThresholdAlternate = 0.0005
+
+
+def mix_frames(f, fr):
+    h, w = np.asarray(fr["viewz"]).shape[:2]
+    fr["disocclusion_mix"] = np.tile((np.arange(w) * 255 // max(w - 1, 1)).astype(np.uint8)[None, :], (h, 1))  # 0 left .. 1 right
 
 
 def jitter_hook(f, cs):
@@ -259,3 +271,34 @@ def test_strand_material_relaxes_only_its_pixels(pkg, api, oracle):
     from scipy.ndimage import binary_dilation
     near = binary_dilation(mat1, iterations=60)  # farther than the widest filter reach from any strand pixel: bit-identical
     assert not changed[~near].any()
+
+
+def test_disocclusion_threshold_mix(pkg, api, oracle):
+    """IN_DISOCCLUSION_THRESHOLD_MIX blends disocclusionThreshold toward disocclusionThresholdAlternate per pixel: a very strict
+    alternate threshold on the right half of the image drops history there (moving camera), the left half keeps it; the slot is
+    required once isDisocclusionThresholdMixAvailable is set"""
+    den = api.Denoiser.REBLUR_DIFFUSE_SPECULAR
+    w, h = 96, 64
+    scene = pkg.synth.Scene(w, h, dolly=0.05)
+    st = settings_factory(api, [den], {})(scene)
+
+    def hook(f, cs):
+        cs.enableValidation = True
+        cs.isDisocclusionThresholdMixAvailable = True
+        cs.disocclusionThresholdAlternate = 0.0
+
+    def frames(f, fr):
+        m = np.zeros((h, w), dtype=np.uint8)
+        m[:, w // 2:] = 255
+        fr["disocclusion_mix"] = m
+
+    hz = util.run_frames(api, pkg.harness, oracle, scene, [den], 5, settings=st, common_hook=hook, frame_hook=frames)
+    val = hz.fetch(hz.outputs["out_validation"]).reshape(h, w, 4)[..., 0].astype(np.float32) / 255.0 * 63.0
+    z = np.asarray(scene.frame(4)["viewz"], dtype=np.float32)
+    hit = z < 1e4
+    left, right = hit.copy(), hit.copy()
+    left[:, w // 2 - 4:] = False
+    right[:, :w // 2 + 4] = False
+    assert float(np.median(val[left])) >= 3.0 and float(np.median(val[right])) <= 1.0, (np.median(val[left]), np.median(val[right]))
+    with pytest.raises(api.NrdError):
+        util.run_frames(api, pkg.harness, oracle, scene, [den], 1, settings=st, common_hook=hook)  # slot not bound
