@@ -307,7 +307,12 @@ def measured_traffic(workload, pass_name):
     import json
 
     prefix = PASS_KERNEL.get(pass_name)
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_%s.json" % workload)))
+    import re
+
+    def build_order(path):  # r01v6 < r01v8 < r01v10 < r02v1: numeric, not alphabetical
+        return [int(n) for n in re.findall(r"\d+", os.path.basename(path).split("_hbm_traffic_")[0])]
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_%s.json" % workload)), key=build_order)
     if not prefix or not files:
         return None
     table = json.load(open(files[-1]))
