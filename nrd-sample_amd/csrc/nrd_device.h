@@ -96,7 +96,7 @@ NRD_DEV float smoothstep01(float x) {
     x = sat(x);
     return x * x * fma_(x, -2.0f, 3.0f); // == 3 - 2x rounded once: 2x is exact, so this is bit-identical to "3.0f - 2.0f * x"
 }
-NRD_DEV float absf(float x) { return x < 0.0f ? -x : x; }
+NRD_DEV float absf(float x) { return __builtin_fabsf(x); } // a free source modifier (|x|) on the consuming instruction
 NRD_DEV int imin(int a, int b) { return a < b ? a : b; }
 NRD_DEV int imax(int a, int b) { return a > b ? a : b; }
 

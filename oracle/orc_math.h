@@ -64,7 +64,7 @@ static inline float rsqrt_(float x) {
 static inline float sqrt_(float x) { return x * rsqrt_(x); } // sqrt_(0) = 0
 static inline float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 static inline float smoothstep01(float x) { x = sat(x); return x * x * (3.0f - 2.0f * x); }
-static inline float absf(float x) { return x < 0.0f ? -x : x; }
+static inline float absf(float x) { return __builtin_fabsf(x); }
 
 static inline f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
