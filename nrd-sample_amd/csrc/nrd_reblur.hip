@@ -363,6 +363,14 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             B = mul3(B, worldRadius);
             float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
             float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
+            if (PER_PIXEL) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk, 4 fma per tap
+                const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
+                const float cc = fma_(rc, jty, rs * jby), d = fma_(rc, jby, -(rs * jty));
+                jtx = a;
+                jbx = b;
+                jty = cc;
+                jby = d;
+            }
             float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
             float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
             normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
@@ -390,8 +398,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     const int t = t0 + k;
                     float ox, oy;
                     if (PER_PIXEL) {
-                        ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
-                        oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                        ox = g_poisson8[t][0];
+                        oy = g_poisson8[t][1];
                     } else {
                         ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
                         oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
@@ -399,8 +407,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
                     float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
                     gaT[k] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
-                    inWin[k] = (fpx >= loXf) & (fpx <= hiXf) & (fpy >= loYf) & (fpy <= hiYf); // NaN positions fail every test
-                    int px = (int)__builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cpy = (int)__builtin_amdgcn_fmed3f(fpy, loYf, hiYf) - c.yOff;
+                    // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
+                    const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
+                    inWin[k] = (cxf == fpx) & (cyf == fpy);
+                    int px = (int)cxf, cpy = (int)cyf - c.yOff;
                     graw[k] = ld<uint4>(p.guide, px, cpy, 16);
                     sraw[k] = load_signal_raw(srcP, px, cpy, srcBpt, srcOff, occIn);
                     sraw1[k] = SH ? ld<uint2>(src1P, px, cpy, srcBpt, src1Off) : uint2{0u, 0u};

@@ -164,6 +164,14 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
     constexpr bool PER_PIXEL = PASS == 0; // Blur rotates per pixel, PostBlur per frame (coalesced gathers)
     uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x : 0u, PER_PIXEL ? (uint32_t)gy0 : 0u, c.frameIndex, 17u + (uint32_t)PASS);
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
+    { // rotation folded into the Jacobian (J . R): the taps then are the unrotated disk, 4 fma per tap
+        const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
+        const float cc = fma_(rc, jty, rs * jby), d = fma_(rc, jby, -(rs * jty));
+        jtx = a;
+        jbx = b;
+        jty = cc;
+        jby = d;
+    }
     f4 sum = center;
     float wsum = 1.0f;
     float penSum = lit ? 0.0f : pen, penW = lit ? 0.0f : 1.0f;
@@ -171,8 +179,7 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
         const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
 #pragma unroll 2
         for (int t = 0; t < 8; t++) {
-            float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
-            float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+            const float ox = g_poisson8[t][0], oy = g_poisson8[t][1];
             float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
             float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
             // loads first (clamped address), validation after: one memory round trip per tap

@@ -456,9 +456,17 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     float hitB = -center.w * hitA;
                     float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
+                    if (variant == BLUR) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk
+                        const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
+                        const float cc = fma_(rc, jty, rs * jby), d = fma_(rc, jby, -(rs * jty));
+                        jtx = a;
+                        jbx = b;
+                        jty = cc;
+                        jby = d;
+                    }
                     for (int t = 0; t < 8; t++) {
-                        float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
-                        float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                        float ox = variant == BLUR ? g_poisson8[t][0] : fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
+                        float oy = variant == BLUR ? g_poisson8[t][1] : fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
                         float fpx = floorf(fma_(ox, jtx, fma_(oy, jbx, (float)x + 0.5f)));
                         float fpy = floorf(fma_(ox, jty, fma_(oy, jby, (float)gy0 + 0.5f)));
                         // tap window: inside the frame, inside the held rows, within the hard reach of the pass

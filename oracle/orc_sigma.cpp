@@ -181,13 +181,20 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
             bool perPixel = pass == 0; // Blur rotates per pixel, PostBlur per frame
             uint32_t h = hash_px(perPixel ? (uint32_t)x : 0u, perPixel ? (uint32_t)gy0 : 0u, c.frameIndex, 17u + (uint32_t)pass);
             float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
+            { // rotation folded into the Jacobian (J . R): the taps then are the unrotated disk
+                const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
+                const float cc = fma_(rc, jty, rs * jby), d = fma_(rc, jby, -(rs * jty));
+                jtx = a;
+                jbx = b;
+                jty = cc;
+                jby = d;
+            }
             f4 sum = center;
             float wsum = 1.0f;
             float penSum = lit ? 0.0f : pen, penW = lit ? 0.0f : 1.0f;
             if (radiusPx > 0.0f)
                 for (int t = 0; t < 8; t++) {
-                    float ox = fma_(g_poisson8[t][0], rc, -(g_poisson8[t][1] * rs));
-                    float oy = fma_(g_poisson8[t][0], rs, g_poisson8[t][1] * rc);
+                    const float ox = g_poisson8[t][0], oy = g_poisson8[t][1]; // rotation folded into the Jacobian above
                     float fpx = floorf(fma_(ox, jtx, fma_(oy, jbx, (float)x + 0.5f)));
                     float fpy = floorf(fma_(ox, jty, fma_(oy, jby, (float)gy0 + 0.5f)));
                     if (!(fpx >= 0.0f && fpx < (float)c.W && fpy >= 0.0f && fpy < (float)c.H))
