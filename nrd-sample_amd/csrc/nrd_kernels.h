@@ -91,6 +91,7 @@ struct ReferenceParams {
     void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_validation(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); \
+    void launch_reblur_blur_radiance(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s); \

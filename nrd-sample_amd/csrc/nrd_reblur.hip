@@ -11,6 +11,13 @@
 // first RELAX A-trous iterations stage their tile (+ halo) in LDS.
 #include "nrd_kernels.h"
 
+// NRD_PART 0 (default): every launcher of this file except the non-SH Blur one; NRD_PART 1 (nrd_reblur_blur*.hip): only that one.
+// The split exists for the build flags: k_spatial<1, 0, ...> is the one kernel that is faster WITH the SLP vectorizer (its
+// divergent per-quad gathers like the finer vmcnt waits that schedule produces), everything else is faster without (Makefile).
+#ifndef NRD_PART
+#define NRD_PART 0
+#endif
+
 namespace nrdhip {
 
 NRD_KERNELS_BEGIN
@@ -1486,6 +1493,9 @@ namespace NRD_PROJ_NS {
             hipLaunchKernelGGL((KERNEL<false, true, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);      \
     } while (0)
 
+#if NRD_PART == 1
+void launch_reblur_blur_radiance(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_spatial, 1, 0, ); }
+#else
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }
@@ -1508,7 +1518,7 @@ void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
         if (p.sh)
             NRD_LAUNCH3(k_spatial, 1, 3, );
         else
-            NRD_LAUNCH3(k_spatial, 1, 0, );
+            launch_reblur_blur_radiance(p, s); // own translation unit (NRD_PART 1)
     } else {
         if (p.sh)
             NRD_LAUNCH3(k_spatial, 2, 3, );
@@ -1560,6 +1570,8 @@ void launch_relax_atrous(const AtrousParams& p, hipStream_t s) {
         }
     }
 }
+
+#endif // NRD_PART
 
 } // namespace NRD_PROJ_NS
 
