@@ -130,6 +130,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
+        # first communication of the group is one every rank takes part in (batched P2P between row neighbours comes later)
+        hello = torch.ones(1, device=dev)
+        dist.all_reduce(hello)
+        torch.cuda.synchronize()
+        if int(hello.item()) != world:
+            raise SystemExit("all_reduce over %d ranks returned %s" % (world, hello.item()))
 
     OPTIONS["checkerboard"], OPTIONS["atrous"] = args.checkerboard, args.atrous
     if args.checkerboard and (world > 1 or args.force_tiled):
@@ -197,7 +203,7 @@ def main():
                          "pipeline_frac": round(sum_bpp * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "passes_ms": {k: round(v[0], 4) for k, v in per_pass.items()},
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:  # reported on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of, dev)
             except Exception as e:  # the baseline is a reported extra; never fail the GPU number because of it

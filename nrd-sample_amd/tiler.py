@@ -60,6 +60,7 @@ class Tiler:
         self.bytes_exchanged = 0
         self.split_dispatches = 0  # dispatches run as boundary strips + interior with the exchange in flight
         self._plan_cache = {}
+        self._p2p_cache = {}  # dispatch todo -> (P2POp list, bytes sent): pool planes never move, so the row slices are built once
 
     def _as_tensor(self, buf):
         import torch
@@ -156,6 +157,28 @@ class Tiler:
             items.append((self._as_tensor(planes[key]), 1))
         self.exchange(items)
 
+    def exchange_start_cached(self, todo):
+        """exchange_start(items_of(todo)) with the P2POp list of a dispatch built once: the pool planes live as long as the
+        instance, so per frame only batch_isend_irecv itself runs on the host (seven exchanges per frame sit on the critical
+        path of the launch thread)"""
+        key = tuple(todo)
+        hit = self._p2p_cache.get(key)
+        if hit is None:
+            dist = self.dist
+            ops = self._ops(self.items_of(todo))
+            sent = sum(ten.numel() * ten.element_size() for fn, ten, _ in ops if fn is dist.isend)
+            hit = ([dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops], sent,
+                   bool(ops) and ops[0][1].is_cuda and dist.get_backend(self.group) != "nccl")
+            self._p2p_cache[key] = hit
+        p2p, sent, host_sync = hit
+        if not p2p:
+            return []
+        self.bytes_exchanged += sent
+        if host_sync:  # see exchange_start
+            import torch
+            torch.cuda.current_stream().synchronize()
+        return self.dist.batch_isend_irecv(p2p)
+
     def items_of(self, todo):
         local_h = self.band.layout["local_h"]
         items = []
@@ -175,7 +198,7 @@ class Tiler:
         up, down = b.rank > 0, b.rank < b.world - 1
         if not todo or not (up or down) or own_n < 4 * strip or own0 % 16:
             nrd.denoise_range(ids, i, 1)
-            for w in self.exchange_start(self.items_of(todo)):
+            for w in self.exchange_start_cached(todo):
                 w.wait()
             return
         self.split_dispatches += 1
@@ -187,7 +210,7 @@ class Tiler:
             first = False
         if down:
             nrd.denoise_rows(ids, i, hi, own0 + own_n - hi, part=1 if first else 0)
-        works = self.exchange_start(self.items_of(todo))
+        works = self.exchange_start_cached(todo)
         nrd.denoise_rows(ids, i, lo, hi - lo, part=2)
         for w in works:
             w.wait()
