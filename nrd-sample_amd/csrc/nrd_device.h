@@ -65,6 +65,7 @@ struct FrameConsts {
     uint32_t frameIndex;
     uint32_t strandMat;    // CommonSettings::strandMaterialID (Source/NRDSample.cpp:3871), 0xffffffff = none
     float strandThickness; // CommonSettings::strandThickness, world units
+    uint32_t camAttachMat; // CommonSettings::cameraAttachedReflectionMaterialID (Source/NRDSample.cpp:3869-3876), 0xffffffff = none
     int mvWorld, confAvail, historyOk;
     int ortho; // orthographic projection: view position of pixel (px, gy) = (pv0 + pv2 px, pv1 + pv3 gy, z); pj = {m0, m5, m12, m13, 1}
     int tilesX, tilesY; // tile grid covering the owned rows: tile row 0 starts at local row tileY0 * 16

@@ -521,13 +521,22 @@ struct Footprint {
     uint32_t bits;
 };
 
-NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
+// `mat` = material of the reflecting pixel: reflections seen in surfaces of CommonSettings::cameraAttachedReflectionMaterialID
+// (Source/NRDSample.cpp:3869-3876: objects that travel with the camera, e.g. a first-person weapon) keep their VIEW-space
+// position from frame to frame, so their virtual point is projected as it stands in the current view instead of being carried
+// back through the camera motion. The test is wave-uniform off when no material is named (the sample's setting, Shared.hlsli:44).
+NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float roughness, uint32_t mat, float& vu, float& vv) {
     f3 toCam = ORTHO ? rot3(c.v2w, f3{0.0f, 0.0f, r.zPrev >= 0.0f ? 1.0f : -1.0f}) : normalize3(r.Xw); // direction camera -> surface
     float f = spec_dominant_factor(roughness);
     f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
     f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
     f3 rel = sub3(XvirtPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
     f3 Xp = rot3(c.w2vPrev, rel);
+    if (c.camAttachMat != 0xffffffffu) {
+        f3 Xa = rot3(c.w2v, Xvirt);
+        bool attached = mat == c.camAttachMat;
+        Xp = {attached ? Xa.x : Xp.x, attached ? Xa.y : Xp.y, attached ? Xa.z : Xp.z};
+    }
     return project(c.pjPrev, Xp, vu, vv);
 }
 
@@ -715,7 +724,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     bool vOk = false;
     if (HAS_SPEC) {
         float tu, tv;
-        vOk = virtual_uv(c, r, hitDist, g.roughness, tu, tv) && historyOk;
+        vOk = virtual_uv(c, r, hitDist, g.roughness, g.mat, tu, tv) && historyOk;
         vu = vOk ? tu : -10.0f; // an unusable virtual position lands outside: no texel validates (bits 0, weight 0)
         vv = vOk ? tv : -10.0f;
     }
@@ -1127,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     FootPos vpos = spos;
     if (HAS_SPEC) {
         float tu, tv;
-        bool vOk = virtual_uv(c, r, hitDist, g.roughness, tu, tv) && amount > 0.0f;
+        bool vOk = virtual_uv(c, r, hitDist, g.roughness, g.mat, tu, tv) && amount > 0.0f;
         vpos = foot_pos(c, vOk ? tu : -10.0f, vOk ? tv : -10.0f); // unusable virtual position: lands outside, never validates
         load_stab(p, vpos, LBPT, vraw);
     }

@@ -365,6 +365,7 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     c.frameIndex = cs.frameIndex;
     c.strandMat = (cs.strandMaterialID >= 0.0f && cs.strandMaterialID <= 3.0f) ? (uint32_t)cs.strandMaterialID : 0xffffffffu; // 2-bit material IDs
     c.strandThickness = cs.strandThickness;
+    c.camAttachMat = (cs.cameraAttachedReflectionMaterialID >= 0.0f && cs.cameraAttachedReflectionMaterialID <= 3.0f) ? (uint32_t)cs.cameraAttachedReflectionMaterialID : 0xffffffffu;
     c.mvWorld = cs.isMotionVectorInWorldSpace ? 1 : 0;
     c.confAvail = cs.isHistoryConfidenceAvailable ? 1 : 0;
     for (int k = 0; k < 64; k++) {

@@ -142,6 +142,7 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
     c.frameIndex = cs.frameIndex;
     c.strandMat = (cs.strandMaterialID >= 0.0f && cs.strandMaterialID <= 3.0f) ? (uint32_t)cs.strandMaterialID : 0xffffffffu;
     c.strandThickness = cs.strandThickness;
+    c.camAttachMat = (cs.cameraAttachedReflectionMaterialID >= 0.0f && cs.cameraAttachedReflectionMaterialID <= 3.0f) ? (uint32_t)cs.cameraAttachedReflectionMaterialID : 0xffffffffu;
     c.mvWorld = cs.isMotionVectorInWorldSpace;
     c.confAvail = cs.isHistoryConfidenceAvailable;
     c.reset = cs.accumulationMode != nrd::AccumulationMode::CONTINUE;

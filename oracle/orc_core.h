@@ -102,6 +102,7 @@ struct Consts {
     uint32_t frameIndex = 0;
     uint32_t strandMat = 0xffffffffu; // CommonSettings::strandMaterialID (Source/NRDSample.cpp:3871), 0xffffffff = none
     float strandThickness = 0;        // CommonSettings::strandThickness, world units
+    uint32_t camAttachMat = 0xffffffffu; // CommonSettings::cameraAttachedReflectionMaterialID (Source/NRDSample.cpp:3869-3876), 0xffffffff = none
     bool mvWorld = false, confAvail = false, reset = false;
     float rot[64][2] = {};
 };

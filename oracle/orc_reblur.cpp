@@ -627,14 +627,18 @@ static inline void fetchA(const Ctx& k, const Plane& P, const Footprint& f, floa
     sA *= inv;
 }
 
-// virtual-motion previous uv of the specular reflection (shared by TA and TS)
-static inline bool virtual_uv(const Consts& c, const Reproj& r, float hitDist, float roughness, float& vu, float& vv) {
+// virtual-motion previous uv of the specular reflection (shared by TA and TS). Surfaces of
+// CommonSettings::cameraAttachedReflectionMaterialID (Source/NRDSample.cpp:3869-3876) reflect objects that travel with the
+// camera: their virtual point keeps its VIEW-space position, so it is projected as it stands in the current view.
+static inline bool virtual_uv(const Consts& c, const Reproj& r, float hitDist, float roughness, uint32_t mat, float& vu, float& vv) {
     f3 toCam = c.ortho ? rot3(c.v2w, f3{0.0f, 0.0f, r.zPrev >= 0.0f ? 1.0f : -1.0f}) : normalize3(r.Xw); // direction camera -> surface
     float f = spec_dominant_factor(roughness);
     f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
     f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
     f3 rel = sub3(XvirtPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
     f3 Xp = rot3(c.w2vPrev, rel);
+    if (c.camAttachMat != 0xffffffffu && mat == c.camAttachMat)
+        Xp = rot3(c.w2v, Xvirt);
     return project(c.pjPrev, Xp, vu, vv);
 }
 
@@ -784,7 +788,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 Footprint vmb;
                 vmb.bits = 0;
                 vmb.wsum = 0.0f;
-                if (historyOk && virtual_uv(c, r, hitDist, g.roughness, vu, vv)) {
+                if (historyOk && virtual_uv(c, r, hitDist, g.roughness, g.mat, vu, vv)) {
                     vmb = footprint(k, vu, vv, NvPrev, r.XvPrev, g.n, g.mat, s.minMaterialForSpecular, threshold);
                     if (vmb.wsum > 0.0f) {
                         // roughness similarity of the virtual footprint
@@ -1128,7 +1132,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     if (isSpec) {
                         float amount = (float)((data2 >> 8) & 255u) * (1.0f / 255.0f);
                         float vu, vv, vmbY = 0.0f;
-                        bool vmbOk = amount > 0.0f && virtual_uv(c, r, ld_h(HT, x, y), g.roughness, vu, vv) && fetchStab(vu, vv, (data2 >> 4) & 15u, vmbY);
+                        bool vmbOk = amount > 0.0f && virtual_uv(c, r, ld_h(HT, x, y), g.roughness, g.mat, vu, vv) && fetchStab(vu, vv, (data2 >> 4) & 15u, vmbY);
                         if (smbOk && vmbOk) {
                             Yhist = lerpf(smbY, vmbY, amount);
                             have = true;

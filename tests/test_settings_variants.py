@@ -75,6 +75,8 @@ CASES = [
     ("history_length_out", ["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], {"returnHistoryLengthInsteadOfOcclusion": True}, None, None),
     ("relax_confidence_driven", ["RELAX_DIFFUSE_SPECULAR"], {"confidenceDrivenRelaxationMultiplier": 2.0, "confidenceDrivenLuminanceEdgeStoppingRelaxation": 0.8,
                                                             "confidenceDrivenNormalEdgeStoppingRelaxation": 0.5, "specularLobeAngleSlack": 1.0}, conf_hook, conf_frames),
+    ("camera_attached_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: attach_hook(f, cs), None),
+    ("camera_attached_relax", ["RELAX_SPECULAR"], {}, lambda f, cs: attach_hook(f, cs), None),
     ("relax_tuning_sh", ["RELAX_SPECULAR_SH"], {"luminanceEdgeStoppingRelaxation": 0.0, "normalEdgeStoppingRelaxation": 1.0,
                                                 "antilagSettings.resetAmount": 0.0, "antilagSettings.accelerationAmount": 0.0}, None, None),
 ]
@@ -84,6 +86,12 @@ def strand_hook(f, cs):
     """the sample's hair settings (Source/NRDSample.cpp:3871-3872); material 1 plays the strand here (the scene's spheres carry it)"""
     cs.strandMaterialID = 1.0
     cs.strandThickness = 0.002
+
+
+def attach_hook(f, cs):
+    """CommonSettings::cameraAttachedReflectionMaterialID (Source/NRDSample.cpp:3869-3876); material 1 (the scene's spheres) plays
+    the surface that shows reflections of camera-attached objects"""
+    cs.cameraAttachedReflectionMaterialID = 1.0
 
 
 def mix_hook(f, cs):
@@ -271,6 +279,42 @@ def test_strand_material_relaxes_only_its_pixels(pkg, api, oracle):
     from scipy.ndimage import binary_dilation
     near = binary_dilation(mat1, iterations=60)  # farther than the widest filter reach from any strand pixel: bit-identical
     assert not changed[~near].any()
+
+
+def test_camera_attached_reflection_material(pkg, api, oracle):
+    """cameraAttachedReflectionMaterialID re-aims the virtual-motion reprojection of the specular signal on pixels of that
+    material only: with a moving camera those pixels (and what the spatial passes spread from them) change, the diffuse signal
+    does not; a material nobody carries and the default (999) leave every plane bit-identical; a static camera makes it a no-op
+    up to rounding"""
+    den = api.Denoiser.REBLUR_DIFFUSE_SPECULAR
+    w, h = 96, 64
+    scene = pkg.synth.Scene(w, h, dolly=0.05)
+    st = settings_factory(api, [den], {})(scene)
+    nr = np.asarray(scene.frame(0)["normal_roughness"]).view(np.uint32).reshape(h, w)
+    mats = set(np.unique(nr >> 30).tolist())
+    assert 1 in mats and 3 not in mats
+
+    def hook_of(v):
+        return lambda f, cs: setattr(cs, "cameraAttachedReflectionMaterialID", v)
+
+    base = util.run_frames(api, pkg.harness, oracle, scene, [den], 4, settings=st)
+    var = util.run_frames(api, pkg.harness, oracle, scene, [den], 4, settings=st, common_hook=hook_of(1.0))
+    assert util.compare_all(base, util.run_frames(api, pkg.harness, oracle, scene, [den], 4, settings=st, common_hook=hook_of(3.0)), exact=True) == []
+    assert util.compare_all(base, util.run_frames(api, pkg.harness, oracle, scene, [den], 4, settings=st, common_hook=hook_of(999.0)), exact=True) == []
+    a, b = base.output("out_spec").view(np.uint16), var.output("out_spec").view(np.uint16)
+    changed = (a != b).any(-1)
+    mat1 = (np.asarray(scene.frame(3)["normal_roughness"]).view(np.uint32).reshape(h, w) >> 30) == 1
+    assert changed[mat1].mean() > 0.25, changed[mat1].mean()
+    from scipy.ndimage import binary_dilation
+    assert not changed[~binary_dilation(mat1, iterations=60)].any()
+    assert (base.output("out_diff").view(np.uint16) == var.output("out_diff").view(np.uint16)).all()
+    # static camera: both aims are the same point up to the rounding of the reprojection chain
+    still = pkg.synth.Scene(w, h, dolly=0.0)
+    st0 = settings_factory(api, [den], {})(still)
+    s0 = util.run_frames(api, pkg.harness, oracle, still, [den], 4, settings=st0).output("out_spec").astype(np.float32)
+    s1 = util.run_frames(api, pkg.harness, oracle, still, [den], 4, settings=st0, common_hook=hook_of(1.0)).output("out_spec").astype(np.float32)
+    moving = np.abs(base.output("out_spec").astype(np.float32) - var.output("out_spec").astype(np.float32)).mean()
+    assert np.abs(s0 - s1).mean() < 0.02 * moving, (np.abs(s0 - s1).mean(), moving)
 
 
 def test_disocclusion_threshold_mix(pkg, api, oracle):
