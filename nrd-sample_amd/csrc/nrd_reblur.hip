@@ -394,6 +394,13 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             // one range test per axis. Phase 2 validates and accumulates: a rejected tap is SELECTED out (sums untouched),
             // exactly like an early "continue". The scheduling barrier keeps the compiler from serialising load -> use pairs
             // when registers get tight (one memory round trip per signal instead of eight).
+            // tap rows are GLOBAL rows: the band's first row is folded into the base pointers once (scalar unit) instead of
+            // one subtract per tap (denoise_parts checks that (first row + rows held) x pitch stays a 32-bit offset)
+            PlaneRef guideG = p.guide, srcG = srcP, src1G = src1P;
+            guideG.p -= (size_t)c.yOff * guideG.pitch;
+            srcG.p -= (size_t)c.yOff * srcG.pitch;
+            if (SH)
+                src1G.p -= (size_t)c.yOff * src1G.pitch;
             float gaT[NRD_TAP_BATCH]; // plane-equation term of geo_weight at the tap position
             bool inWin[NRD_TAP_BATCH];
             uint4 graw[NRD_TAP_BATCH];
@@ -417,10 +424,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                     // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
                     const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
                     inWin[k] = (cxf == fpx) & (cyf == fpy);
-                    int px = (int)cxf, cpy = (int)cyf - c.yOff;
-                    graw[k] = ld<uint4>(p.guide, px, cpy, 16);
-                    sraw[k] = load_signal_raw(srcP, px, cpy, srcBpt, srcOff, occIn);
-                    sraw1[k] = SH ? ld<uint2>(src1P, px, cpy, srcBpt, src1Off) : uint2{0u, 0u};
+                    int px = (int)cxf, gpy = (int)cyf;
+                    graw[k] = ld<uint4>(guideG, px, gpy, 16);
+                    sraw[k] = load_signal_raw(srcG, px, gpy, srcBpt, srcOff, occIn);
+                    sraw1[k] = SH ? ld<uint2>(src1G, px, gpy, srcBpt, src1Off) : uint2{0u, 0u};
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

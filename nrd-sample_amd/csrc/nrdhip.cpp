@@ -1199,6 +1199,16 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                     I.error = std::string("resource slot bound with an unsupported format for pass ") + x.name;
                     return (int)nrd::Result::INVALID_ARGUMENT;
                 }
+        // texel offsets are 32-bit, and the tap loops address band planes by GLOBAL row (the band's first row is folded into
+        // the base pointer): (first row + rows held) x pitch must stay below 4 GiB for every plane the pass touches
+        for (auto* lst : {&x.read, &x.written})
+            for (uint32_t s : *lst) {
+                const Plane* P = (s >> 16) == 0 ? &I.perm[s & 0xffff] : ((s >> 16) == 1 ? &I.trans[s & 0xffff] : ((s >> 16) == 2 ? &I.slots[s & 0xffff] : nullptr));
+                if (P && P->p && ((uint64_t)I.yOff + (uint64_t)I.resH) * (uint64_t)P->pitch > 0xffffffffull) {
+                    I.error = std::string("plane too large for 32-bit texel offsets in pass ") + x.name;
+                    return (int)nrd::Result::UNSUPPORTED;
+                }
+            }
         if ((part & NRDHIP_PART_FIRST) && fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
             for (uint32_t k = d.permBase; k < d.permEnd; k++)
                 (void)hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);

@@ -46,6 +46,12 @@ def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mo
     run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, "oracle")
 
 
+def test_row_tiling_emulated_kernels_bit_identical(tmp_path, pkg, api, oracle, emulated):
+    """the kernel sources themselves (compiled for the host) on two bands: rows stored at a band offset, nrdhip_denoise_rows strips,
+    halo rows owned by the neighbour - against the single-instance oracle run"""
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 448, "default", "emu")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,frame_h,mode", [(2, 640, "default"), (2, 704, "cb")])
 def test_row_tiling_hip_bit_identical(tmp_path, pkg, api, oracle, hip, world, frame_h, mode):

@@ -21,7 +21,11 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     use_hip = len(sys.argv) > 7 and sys.argv[7] == "hip"  # -m gpu variant: the real kernels on cuda:0 (all ranks share the one GPU of the box)
-    orc = pkg.hip_backend("cuda:0") if use_hip else graft.oracle_backend()
+    use_emu = len(sys.argv) > 7 and sys.argv[7] == "emu"  # the kernel sources compiled for the host (tests/hip_emu): band offsets through the kernels on CPU
+    if use_emu:
+        orc = api.Backend(graft.build_emulated(), "nrdhip_", "cpu")
+    else:
+        orc = pkg.hip_backend("cuda:0") if use_hip else graft.oracle_backend()
     D = api.Denoiser
     dens = [D.REBLUR_DIFFUSE_SPECULAR, D.SIGMA_SHADOW_TRANSLUCENCY]
     band = tiler.BandHarness(orc, dens, w, frame_h, rank, world, halo=halo)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B timing of library variants on ONE box: alternate the variants, print per-pass times
-for round in 1 2 3; do
+for round in $(seq 1 ${ROUNDS:-3}); do
   for v in "$@"; do
     cp _variants/$v.so nrd-sample_amd/csrc/libnrdhip.so
     timeout 200 python bench.py --workload ${WL:-reblur_ds_4k} --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
