@@ -23,7 +23,7 @@ namespace nrdhip {
 NRD_KERNELS_BEGIN
 
 // taps gathered per memory round trip in the spatial passes (8 = all taps of a signal; 4 or 2 were measured slower: more round
-// trips and no extra wave)
+// trips and no extra wave - also when software-pipelined, the next batch's gathers issued before this batch's arithmetic)
 #ifndef NRD_TAP_BATCH
 #define NRD_TAP_BATCH 8
 #endif
