@@ -243,10 +243,19 @@ NRD_DEV f3 oct_decode(float px, float py) {
     return normalize3({nx, ny, nz});
 }
 
+// v / 1023 for a 10-bit v, bit for bit the IEEE quotient the oracle computes with `/` (all 1024 inputs checked in exact arithmetic,
+// tests/test_oracle_math.py): product with the rounded reciprocal + one fma residual correction - 3 full-rate instructions
+// instead of the ~13 issue slots of the IEEE division expansion, three times per pixel in ClassifyTiles
+NRD_DEV float unorm10_(uint32_t v) {
+    const float x = (float)v, r = 1.0f / 1023.0f;
+    const float q = x * r;
+    return fma_(fma_(-q, 1023.0f, x), r, q);
+}
+
 // guide texel (16 bytes): {viewZ f32 | nx f16, ny f16 | nz f16, roughness f16 | materialID u32}
 NRD_DEV uint4 encode_guide(float z, uint32_t packedNR) {
-    f3 n = oct_decode((float)(packedNR & 1023u) / 1023.0f, (float)((packedNR >> 10) & 1023u) / 1023.0f);
-    float roughness = (float)((packedNR >> 20) & 1023u) / 1023.0f;
+    f3 n = oct_decode(unorm10_(packedNR & 1023u), unorm10_((packedNR >> 10) & 1023u));
+    float roughness = unorm10_((packedNR >> 20) & 1023u);
     return uint4{f2u(z), (uint32_t)f2h(n.x) | ((uint32_t)f2h(n.y) << 16), (uint32_t)f2h(n.z) | ((uint32_t)f2h(roughness) << 16), packedNR >> 30};
 }
 

@@ -105,3 +105,34 @@ def test_ycocg_roundtrip_and_hitdist_norm(lib, pkg):
     for z, r in ((1.0, 1.0), (10.0, 0.05), (55.0, 0.3), (0.2, 0.0)):
         ref = float(pkg.synth.reblur_hitdist_norm(np.float64(z), np.float64(r)))
         assert abs(lib.orc_hitdist_norm(z, hp, r) / ref - 1) < 1e-5
+
+
+def test_unorm10_decode_sequence_is_the_ieee_quotient():
+    """nrd_device.h unorm10_: q = x * r; q' = fma(fma(-q, 1023, x), r, q) with r = fl(1/1023) equals the correctly rounded x / 1023
+    (what the oracle's `/` computes) for every 10-bit x - checked in exact rational arithmetic with one rounding per operation"""
+    import math
+    from fractions import Fraction as F
+
+    def rnd32(v):
+        if v == 0:
+            return F(0)
+        sgn, v = (1 if v > 0 else -1), abs(v)
+        e = math.floor(math.log2(v))
+        while F(2) ** e > v:
+            e -= 1
+        while F(2) ** (e + 1) <= v:
+            e += 1
+        ulp = F(2) ** (max(e, -126) - 23)
+        n = v / ulp
+        fl = n.numerator // n.denominator
+        rem = n - fl
+        if rem > F(1, 2) or (rem == F(1, 2) and fl % 2 == 1):
+            fl += 1
+        return sgn * fl * ulp
+
+    r = F(float(np.float32(1.0) / np.float32(1023.0)))
+    for x in range(1024):
+        q = rnd32(F(x) * r)
+        q2 = rnd32(rnd32(-q * 1023 + x) * r + q)
+        assert q2 == rnd32(F(x, 1023)), x
+        assert float(q2) == float(np.float32(x) / np.float32(1023.0))
