@@ -166,6 +166,8 @@ def main():
     # ---- warm-up (untimed) ----
     for f in range(args.warmup):
         runner.step(f, reset=(f == 0))
+    if hasattr(runner, "finish"):
+        runner.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,6 +179,8 @@ def main():
     for f in range(args.warmup, args.warmup + args.steps):
         runner.enable_events((f - args.warmup) % stride == 0)
         runner.step(f, reset=False)
+    if hasattr(runner, "finish"):
+        runner.finish()  # row tiler: halo rows of the last frame's permanent planes still travelling
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -61,6 +61,7 @@ class Tiler:
         self.split_dispatches = 0  # dispatches run as boundary strips + interior with the exchange in flight
         self._plan_cache = {}
         self._p2p_cache = {}  # dispatch todo -> (P2POp list, bytes sent): pool planes never move, so the row slices are built once
+        self._deferred = []   # exchanges of planes only the NEXT frame reads: in flight until the next dispatch list starts
 
     def _as_tensor(self, buf):
         import torch
@@ -74,15 +75,19 @@ class Tiler:
         return self.band.nrd.pools[pool][index]
 
     def _plan(self, ids, dispatches):
-        """for every dispatch: [(plane code, rows)] - the pool planes it writes whose boundary rows a neighbour will read, and
-        how many rows: the largest halo of the dispatches that read the plane before it is written again; permanent planes
-        that survive the frame get the full halo (next frame's reprojection reads them at motion-displaced rows)"""
+        """for every dispatch: (now, later), two lists of (plane code, rows) over the pool planes it writes.
+        now: boundary rows a LATER DISPATCH OF THIS FRAME reads - the largest halo of the dispatches that read the plane before
+        it is written again; these are exchanged strips-first and waited for before the next dispatch.
+        later: permanent planes that survive the frame get the full halo (next frame's reprojection reads them at
+        motion-displaced rows), but nobody needs those rows before the next frame: their exchange is enqueued after the
+        dispatch and stays in flight behind the rest of the frame (no strips, no wait) - most dispatches end with such a plane
+        (history, fast history, stabilized luma, accumulation speeds), and an 80-row strip is two mostly empty workgroup rounds"""
         key = tuple((d["name"], tuple(d["written"]), tuple(d["read"]), d["halo_rows"]) for d in dispatches)
         if key in self._plan_cache:
             return self._plan_cache[key]
         plan = []
         for i, d in enumerate(dispatches):
-            todo = []
+            now, later = [], []
             for code in d["written"]:
                 if (code >> 16) > 1:
                     continue  # output slots are final
@@ -93,11 +98,12 @@ class Tiler:
                     if code in r["written"]:
                         rewritten = True
                         break
-                if (code >> 16) == 0 and not rewritten:
-                    rows = self.band.halo
+                rows = min(rows, self.band.halo)
+                if (code >> 16) == 0 and not rewritten and rows < self.band.halo:
+                    later.append((code, self.band.halo))
                 if rows > 0:
-                    todo.append((code, min(rows, self.band.halo)))
-            plan.append(todo)
+                    now.append((code, rows))
+            plan.append((now, later))
         self._plan_cache[key] = plan
         return plan
 
@@ -188,10 +194,25 @@ class Tiler:
             items.append((self._as_tensor(p["buf"]), div, rows))
         return items
 
-    def run_dispatch(self, ids, i, todo):
+    def finish(self):
+        """wait for the exchanges still in flight (rows only the next frame reads)"""
+        for w in self._deferred:
+            w.wait()
+        self._deferred = []
+
+    def run_dispatch(self, ids, i, plan_entry):
         """one dispatch + the halo exchange of what it wrote. When the band is tall enough the rows a neighbour needs are
         computed FIRST (boundary strips), their exchange is started, and the interior is computed while the rows travel -
-        the copies overlap the compute instead of serialising with it (nrdhip_denoise_rows)."""
+        the copies overlap the compute instead of serialising with it (nrdhip_denoise_rows). Rows that only the next frame
+        reads follow without strips and without a wait (see _plan)."""
+        if i == 0:
+            self.finish()  # a new dispatch list: last frame's permanent planes must have arrived
+        todo, later = plan_entry
+        self._run_dispatch_now(ids, i, todo)
+        if later:
+            self._deferred += self.exchange_start_cached(later)
+
+    def _run_dispatch_now(self, ids, i, todo):
         nrd, L, b = self.band.nrd, self.band.layout, self.band
         own0, own_n = L["own_first"], L["own_rows"]
         strip = (max([r for _, r in todo] + [0]) + 15) // 16 * 16
@@ -220,8 +241,8 @@ class Tiler:
         nrd = self.band.nrd
         dispatches = nrd.dispatches(ids)
         plan = self._plan(ids, dispatches)
-        for i, todo in enumerate(plan):
-            self.run_dispatch(ids, i, todo)
+        for i, entry in enumerate(plan):
+            self.run_dispatch(ids, i, entry)
 
 
 class TiledRunner:
@@ -284,13 +305,16 @@ class TiledRunner:
             self.names = [(x["name"], x["bytes_per_pixel"]) for x in dispatches]
         plan = self.tiler._plan(ids, dispatches)
         evs = []
-        for i, todo in enumerate(plan):
+        for i, entry in enumerate(plan):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            self.tiler.run_dispatch(ids, i, todo)
+            self.tiler.run_dispatch(ids, i, entry)
             b.record()
             evs.append((a, b))
         self.events.append(evs)
+
+    def finish(self):
+        self.tiler.finish()
 
     def pass_times_ms(self):
         import torch

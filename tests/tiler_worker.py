@@ -62,6 +62,7 @@ def main():
         t.denoise([int(d) for d in dens])
         for key in ("out_diff", "out_spec", "out_shadow"):
             blob["f%d_%s" % (f, key)] = band.own_rows(band.fetch(band.outputs[key])).copy()
+    t.finish()  # halo rows of the permanent planes written by the last frame are still travelling
     blob["history"] = band.own_rows(band.pool("REBLUR::History")).copy()
     blob["own0"] = np.array([band.layout["own0"], band.layout["own1"]])
     blob["bytes"] = np.array([t.bytes_exchanged])
