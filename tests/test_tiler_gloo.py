@@ -46,6 +46,36 @@ def test_row_tiling_bit_identical(tmp_path, pkg, api, oracle, world, frame_h, mo
     run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, "oracle")
 
 
+def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
+    """Tiler._plan: strips-first rows ("now") are bounded by the reach of the later dispatches of the same frame; every permanent
+    plane that survives the frame travels with the full halo in the deferred list ("later"), transient planes never do"""
+    from nrd_sample_amd import tiler
+
+    D = api.Denoiser
+    for den in (D.REBLUR_DIFFUSE_SPECULAR, D.RELAX_DIFFUSE_SPECULAR_SH, D.SIGMA_SHADOW_TRANSLUCENCY):
+        band = tiler.BandHarness(oracle, [den], 128, 1280, 1, 4)
+        t = tiler.Tiler(band, None)
+        disp = band.nrd.dispatches([int(den)])
+        plan = t._plan([int(den)], disp)
+        assert len(plan) == len(disp)
+        deferred = set()
+        for i, (now, later) in enumerate(plan):
+            reach = max([d["halo_rows"] for d in disp[i + 1:]] + [0])
+            assert all(0 < rows <= min(reach, band.halo) for _, rows in now), (disp[i]["name"], now, reach)
+            for code, rows in later:
+                assert code >> 16 == 0 and rows == band.halo and code in disp[i]["written"]
+                deferred.add(code)
+        assert plan[-1][0] == []  # nothing after the last dispatch reads its outputs this frame: no strips, no wait
+        written_last = {}  # permanent plane -> last dispatch that writes it
+        for i, d in enumerate(disp):
+            for c in d["written"]:
+                if c >> 16 == 0:
+                    written_last[c] = i
+        for c, i in written_last.items():  # its final version reaches the neighbours with the full halo, deferred or at once
+            assert (c, band.halo) in plan[i][1] or (c, band.halo) in plan[i][0], (disp[i]["name"], c)
+        assert deferred <= set(written_last)
+
+
 def test_row_tiling_emulated_kernels_bit_identical(tmp_path, pkg, api, oracle, emulated):
     """the kernel sources themselves (compiled for the host) on two bands: rows stored at a band offset, nrdhip_denoise_rows strips,
     halo rows owned by the neighbour - against the single-instance oracle run"""
