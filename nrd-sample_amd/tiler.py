@@ -100,7 +100,7 @@ class Tiler:
                         break
                 rows = min(rows, self.band.halo)
                 if (code >> 16) == 0 and not rewritten and rows < self.band.halo:
-                    later.append((code, self.band.halo))
+                    later.append((code, self.band.halo, rows))  # the `rows` nearest the band edge travel at once (below)
                 if rows > 0:
                     now.append((code, rows))
             plan.append((now, later))
@@ -108,26 +108,32 @@ class Tiler:
         return plan
 
     def _ops(self, bufs_rows):
-        """send / recv descriptors for [(2-D byte tensor [local rows, pitch], rows-per-texel-row divisor, rows)]"""
+        """send / recv descriptors for [(2-D byte tensor [local rows, pitch], rows-per-texel-row divisor, rows[, skip])]:
+        the `rows` owned rows next to each band edge go to that neighbour's halo; `skip` = how many of them (nearest the edge)
+        an earlier exchange already delivered"""
         dist, b = self.dist, self.band
         L = b.layout
         ops = []
-        for t, div, rows in bufs_rows:
+        for item in bufs_rows:
+            t, div, rows = item[:3]
+            hskip = (item[3] // div) if len(item) > 3 else 0
             hrows = max((rows + div - 1) // div, 1)
             first, n = L["own_first"] // div, max(L["own_rows"] // div, 1)
             total = t.shape[0]
             if b.rank > 0:  # upper neighbour: send my first owned rows, receive into my top halo
-                send = t[first:first + min(hrows, n)]
+                send = t[first + hskip:first + min(hrows, n)]
                 top = first - min(hrows, first)
-                recv = t[top:first]
-                ops.append((dist.isend, send, b.rank - 1))
+                recv = t[top:first - hskip]
+                if send.shape[0] > 0:
+                    ops.append((dist.isend, send, b.rank - 1))
                 if recv.shape[0] > 0:
                     ops.append((dist.irecv, recv, b.rank - 1))
             if b.rank < b.world - 1:  # lower neighbour
-                send = t[first + n - min(hrows, n):first + n]
+                send = t[first + n - min(hrows, n):first + n - hskip]
                 bot = min(first + n + hrows, total)
-                recv = t[first + n:bot]
-                ops.append((dist.isend, send, b.rank + 1))
+                recv = t[first + n + hskip:bot]
+                if send.shape[0] > 0:
+                    ops.append((dist.isend, send, b.rank + 1))
                 if recv.shape[0] > 0:
                     ops.append((dist.irecv, recv, b.rank + 1))
         return ops
@@ -188,10 +194,10 @@ class Tiler:
     def items_of(self, todo):
         local_h = self.band.layout["local_h"]
         items = []
-        for code, rows in todo:
+        for code, rows, *skip in todo:
             p = self._plane_of(code)
             div = max(int(round(local_h / p["height"])), 1)
-            items.append((self._as_tensor(p["buf"]), div, rows))
+            items.append((self._as_tensor(p["buf"]), div, rows, *skip))
         return items
 
     def finish(self):
@@ -215,7 +221,7 @@ class Tiler:
     def _run_dispatch_now(self, ids, i, todo):
         nrd, L, b = self.band.nrd, self.band.layout, self.band
         own0, own_n = L["own_first"], L["own_rows"]
-        strip = (max([r for _, r in todo] + [0]) + 15) // 16 * 16
+        strip = (max([t[1] for t in todo] + [0]) + 15) // 16 * 16
         up, down = b.rank > 0, b.rank < b.world - 1
         if not todo or not (up or down) or own_n < 4 * strip or own0 % 16:
             nrd.denoise_range(ids, i, 1)
