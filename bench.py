@@ -134,7 +134,10 @@ def main():
     dev = "cuda:%d" % local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+
+        # a stuck exchange should end the run with an error within minutes, not sit on the node for the default half hour
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         # first communication of the group is one every rank takes part in (batched P2P between row neighbours comes later)
         hello = torch.ones(1, device=dev)
         dist.all_reduce(hello)
