@@ -412,6 +412,38 @@ NRD_DEV void st(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
     *reinterpret_cast<T*>(P.p + texel_offset(P, x, y, bpt, off)) = v;
 }
 
+// Gathers of the spatial passes go through buffer instructions: a raw V# (base = the plane's first texel, no stride, no bounds -
+// the tap positions are clamped before they become offsets) + a 32-bit byte offset per lane ("buffer_load_dwordx4 v, voff, s[V#],
+// 0 offen"). Same texture-addresser cost as global_load (16 cycles per wave64 instruction of <= 16 B per lane when the lanes'
+// texels are row-contiguous, ~26 when scattered: tools/ubench/ta_rate.hip), but the base lives in 4 SGPRs shared by all taps.
+// `row0` = the global row held at local row 0 (row tiling): folded into the base once, so taps address GLOBAL rows
+// (nrdhip.cpp denoise_parts checks that (first row + rows held) x pitch stays a 32-bit offset).
+struct PlaneBuf {
+    __amdgpu_buffer_rsrc_t r;
+    uint32_t pitch;
+};
+NRD_DEV PlaneBuf plane_buf(const PlaneRef& P, int row0) {
+    return {__builtin_amdgcn_make_buffer_rsrc(P.p - (size_t)row0 * P.pitch, 0, 0xffffffffu, 0x00020000), P.pitch}; // gfx9 raw-buffer word 3
+}
+template <typename T>
+NRD_DEV T ldb(const PlaneBuf& B, int x, int y, int bpt, int off = 0) {
+    typedef unsigned int u4v __attribute__((__vector_size__(16)));
+    typedef unsigned int u2v __attribute__((__vector_size__(8)));
+    const int o = (int)(__umul24((uint32_t)y, B.pitch) + (uint32_t)x * (uint32_t)bpt + (uint32_t)off);
+    if constexpr (sizeof(T) == 16) {
+        u4v v = __builtin_amdgcn_raw_buffer_load_b128(B.r, o, 0, 0);
+        return T{v[0], v[1], v[2], v[3]};
+    } else if constexpr (sizeof(T) == 8) {
+        u2v v = __builtin_amdgcn_raw_buffer_load_b64(B.r, o, 0, 0);
+        return T{v[0], v[1]};
+    } else if constexpr (sizeof(T) == 4) {
+        return (T)__builtin_amdgcn_raw_buffer_load_b32(B.r, o, 0, 0);
+    } else {
+        static_assert(sizeof(T) == 2, "ldb: 2 / 4 / 8 / 16-byte texels");
+        return (T)__builtin_amdgcn_raw_buffer_load_b16(B.r, o, 0, 0);
+    }
+}
+
 // 8-tap Poisson disk + weight (same frozen table as the oracle)
 #define NRD_POISSON8_TABLE                                                                                          \
     {{-0.4706069f, -0.4427112f, 0.7592f}, {-0.9057375f, 0.3003471f, 0.5483f}, {-0.3487388f, 0.4037880f, 0.8287f},    \

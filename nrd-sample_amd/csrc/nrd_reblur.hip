@@ -27,6 +27,18 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_TAP_BATCH
 #define NRD_TAP_BATCH 8
 #endif
+// taps in flight per wave in the software-pipelined tap loop of the spatial passes (k_spatial)
+#ifndef NRD_PIPE_DEPTH
+#define NRD_PIPE_DEPTH 8
+#endif
+#ifndef NRD_PIPE_DEPTH_WIDE
+#define NRD_PIPE_DEPTH_WIDE 5
+#endif
+
+#if defined(NRD_DEBUG_COUNTERS) && !NRD_ORTHO // diagnosis build only (tools/tap_histogram.py): histogram of tap distances per spatial pass
+__device__ unsigned long long g_dbg_hist[3][8];
+#define NRD_DBG_HIST 1
+#endif
 
 constexpr float MAX_ACCUM = 63.0f;
 constexpr float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
@@ -271,8 +283,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     int x, y, tx, ty;
     if (!my_pixel(c, x, y, tx, ty))
         return;
-    const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
+    const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
     constexpr bool relaxIn = VARIANT == 0 && (MODE == 1 || MODE == 4); // RELAX inputs: linear RGB + world-space hit distance
     constexpr bool occIn = VARIANT == 0 && MODE == 2;
@@ -315,21 +327,31 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     const int loY = imax(gy0 - reach, imax(c.yOff, 0)), hiY = imin(gy0 + reach, imin(c.yOff + c.resH, c.H) - 1);
     const float loXf = (float)loX, hiXf = (float)hiX, loYf = (float)loY, hiYf = (float)hiY; // floored tap positions are compared / clamped as floats
 
+    // ---- per-signal set-up: everything the taps of a signal need, for BOTH signals, before the first gather is issued -------
+    // (a signal whose radius is 0 keeps its constants - its taps land on the centre and are selected out by `active`, which
+    // leaves sum = centre, wsum = 1 exactly as if they had never run)
+    const PlaneRef* srcPs[NSIG];
+    const PlaneRef* src1Ps[NSIG];
+    int srcOffs[NSIG];
+    uint32_t minMats[NSIG];
+    f4 sum[NSIG], sum1[NSIG];
+    float wsum[NSIG], minHit[NSIG], hitNormS[NSIG];
+    float jtx[NSIG], jty[NSIG], jbx[NSIG], jby[NSIG], m2w2[NSIG], hitA[NSIG], hitB[NSIG], roughA[NSIG], roughB[NSIG];
+    bool active[NSIG];
+    constexpr int srcBpt = VARIANT == 0 ? 8 : RBPT;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         float rough = isSpec ? g.roughness : 1.0f;
-        uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
-        const PlaneRef& srcP = VARIANT == 0 ? (isSpec ? p.inSpec : p.inDiff) : inP;
-        constexpr int srcBpt = VARIANT == 0 ? 8 : RBPT;
-        const int srcOff = VARIANT == 0 ? 0 : sig * sb;
-        f4 center = load_signal(p, srcP, x, y, srcBpt, srcOff, occIn);
+        minMats[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
+        srcPs[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec : &p.inDiff) : &inP;
+        srcOffs[sig] = VARIANT == 0 ? 0 : sig * sb;
+        f4 center = load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
         if (relaxIn)
             center = rgb_to_ycocg4(center);
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
-        const PlaneRef& src1P = VARIANT == 0 ? (isSpec ? p.inSpec1 : p.inDiff1) : inP;
-        const int src1Off = VARIANT == 0 ? 0 : srcOff + 8;
-        f4 sum1 = SH ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
+        src1Ps[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec1 : &p.inDiff1) : &inP;
+        sum1[sig] = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
         float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
@@ -345,141 +367,177 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             r *= smc;
             radius = p.maxBlurRadius != 0.0f ? r : 0.0f;
         }
-        f4 sum = center;
-        float wsum = 1.0f;
-        float minHit = hitDist;
-        if (radius > 0.0f) {
-            float worldRadius = radius * c.unproject * zpersp(pg.absZ);
-            f3 T, B;
-            basis3(pg.Nv, T, B);
-            if (isSpec) {
-                float NoV = dot3(pg.Nv, V);
-                f3 R = sub3(mul3(pg.Nv, 2.0f * NoV), V);
-                float df = spec_dominant_factor(rough);
-                f3 D = normalize3(add3(pg.Nv, mul3(sub3(R, pg.Nv), df)));
-                float NoD = dot3(pg.Nv, D);
-                if (NoD < 0.999f && rough < 0.95f) {
-                    f3 Dr = sub3(mul3(pg.Nv, 2.0f * NoD), D);
-                    T = normalize3(cross3(pg.Nv, Dr));
-                    B = cross3(Dr, T);
-                    float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
-                    T = mul3(T, skew);
-                }
-            }
-            T = mul3(T, worldRadius);
-            B = mul3(B, worldRadius);
-            float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
-            float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
-            if (PER_PIXEL) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk, 4 fma per tap
-                const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
-                const float cc = fma_(rc, jty, rs * jby), d = fma_(rc, jby, -(rs * jty));
-                jtx = a;
-                jbx = b;
-                jty = cc;
-                jby = d;
-            }
-            float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
-            float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
-            normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-            float normalW2 = normalW * normalW;
-            const float m2w2 = -2.0f * normalW2;
-            float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
-            float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
-            float hitB = -center.w * hitA;
-            float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
-            float roughB = -rough * roughA;
-            const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
-            // Phase 1: positions + ALL gathers of this signal's 8 taps (clamped, always valid addresses), nothing consumed yet.
-            // The tap window [lo, hi] folds the frame bounds, the rows this instance holds and the hard reach of the pass into
-            // one range test per axis. Phase 2 validates and accumulates: a rejected tap is SELECTED out (sums untouched),
-            // exactly like an early "continue". The scheduling barrier keeps the compiler from serialising load -> use pairs
-            // when registers get tight (one memory round trip per signal instead of eight).
-            // tap rows are GLOBAL rows: the band's first row is folded into the base pointers once (scalar unit) instead of
-            // one subtract per tap (denoise_parts checks that (first row + rows held) x pitch stays a 32-bit offset)
-            PlaneRef guideG = p.guide, srcG = srcP, src1G = src1P;
-            guideG.p -= (size_t)c.yOff * guideG.pitch;
-            srcG.p -= (size_t)c.yOff * srcG.pitch;
-            if (SH)
-                src1G.p -= (size_t)c.yOff * src1G.pitch;
-            float gaT[NRD_TAP_BATCH]; // plane-equation term of geo_weight at the tap position
-            bool inWin[NRD_TAP_BATCH];
-            uint4 graw[NRD_TAP_BATCH];
-            uint2 sraw[NRD_TAP_BATCH], sraw1[NRD_TAP_BATCH];
-#pragma unroll
-            for (int t0 = 0; t0 < 8; t0 += NRD_TAP_BATCH) {
-#pragma unroll
-                for (int k = 0; k < NRD_TAP_BATCH; k++) {
-                    const int t = t0 + k;
-                    float ox, oy;
-                    if (PER_PIXEL) {
-                        ox = g_poisson8[t][0];
-                        oy = g_poisson8[t][1];
-                    } else {
-                        ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
-                        oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
-                    }
-                    float fpx = __builtin_floorf(fma_(ox, jtx, fma_(oy, jbx, cx)));
-                    float fpy = __builtin_floorf(fma_(ox, jty, fma_(oy, jby, cy)));
-                    gaT[k] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
-                    // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
-                    const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
-                    inWin[k] = (cxf == fpx) & (cyf == fpy);
-                    int px = (int)cxf, gpy = (int)cyf;
-                    graw[k] = ld<uint4>(guideG, px, gpy, 16);
-                    sraw[k] = load_signal_raw(srcG, px, gpy, srcBpt, srcOff, occIn);
-                    sraw1[k] = SH ? ld<uint2>(src1G, px, gpy, srcBpt, src1Off) : uint2{0u, 0u};
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < NRD_TAP_BATCH; k++) {
-                    const int t = t0 + k;
-                    Guide gs = decode_guide(graw[k], c.denoisingRange);
-                    f4 sv = decode_signal(p, sraw[k], occIn);
-                    bool valid = inWin[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
-                    float w = g_poisson8[t][2];
-                    w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[k], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
-                    w *= normal_weight_m2(dot3(g.n, gs.n), m2w2);
-                    if (isSpec)
-                        w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                    if (relaxIn)
-                        sv = rgb_to_ycocg4(sv);
-                    w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
-                    if (VARIANT == 0) {
-                        // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): a rejected tap is
-                        // selected out component by component
-                        f4 acc = fma4(sv, w, sum);
-                        sum = {valid ? acc.x : sum.x, valid ? acc.y : sum.y, valid ? acc.z : sum.z, valid ? acc.w : sum.w};
-                        if (SH) {
-                            f4 acc1 = fma4(unpack_h4(sraw1[k]), w, sum1);
-                            sum1 = {valid ? acc1.x : sum1.x, valid ? acc1.y : sum1.y, valid ? acc1.z : sum1.z, valid ? acc1.w : sum1.w};
-                        }
-                        wsum = valid ? wsum + w : wsum;
-                        minHit = (valid && w > 0.0f) ? fmin2(minHit, sv.w * hitNorm) : minHit;
-                    } else {
-                        // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0 - one select
-                        w = valid ? w : 0.0f;
-                        sum = fma4(sv, w, sum);
-                        if (SH)
-                            sum1 = fma4(unpack_h4(sraw1[k]), w, sum1);
-                        wsum += w;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        sum[sig] = center;
+        wsum[sig] = 1.0f;
+        minHit[sig] = hitDist;
+        hitNormS[sig] = hitNorm;
+        active[sig] = radius > 0.0f;
+        float worldRadius = radius * c.unproject * zpersp(pg.absZ);
+        f3 T, B;
+        basis3(pg.Nv, T, B);
+        if (isSpec) {
+            float NoV = dot3(pg.Nv, V);
+            f3 R = sub3(mul3(pg.Nv, 2.0f * NoV), V);
+            float df = spec_dominant_factor(rough);
+            f3 D = normalize3(add3(pg.Nv, mul3(sub3(R, pg.Nv), df)));
+            float NoD = dot3(pg.Nv, D);
+            if (NoD < 0.999f && rough < 0.95f) {
+                f3 Dr = sub3(mul3(pg.Nv, 2.0f * NoD), D);
+                T = normalize3(cross3(pg.Nv, Dr));
+                B = cross3(Dr, T);
+                float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
+                T = mul3(T, skew);
             }
         }
-        float invw = rcp_(wsum);
-        f4 res = mul4(sum, invw), res1 = mul4(sum1, invw);
+        T = mul3(T, worldRadius);
+        B = mul3(B, worldRadius);
+        jtx[sig] = ju * fma_(c.pj[0], T.x, kuz * T.z), jty[sig] = jv * fma_(c.pj[1], T.y, kvz * T.z);
+        jbx[sig] = ju * fma_(c.pj[0], B.x, kuz * B.z), jby[sig] = jv * fma_(c.pj[1], B.y, kvz * B.z);
+        if (PER_PIXEL) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk, 4 fma per tap
+            const float a = fma_(rc, jtx[sig], rs * jbx[sig]), b = fma_(rc, jbx[sig], -(rs * jtx[sig]));
+            const float cc = fma_(rc, jty[sig], rs * jby[sig]), d = fma_(rc, jby[sig], -(rs * jty[sig]));
+            jtx[sig] = a;
+            jbx[sig] = b;
+            jty[sig] = cc;
+            jby[sig] = d;
+        }
+        float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
+        float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+        normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
+        float normalW2 = normalW * normalW;
+        m2w2[sig] = -2.0f * normalW2;
+        float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
+        hitA[sig] = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
+        hitB[sig] = -center.w * hitA[sig];
+        roughA[sig] = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
+        roughB[sig] = -rough * roughA[sig];
+    }
+
+    // ---- tap loop: ONE software pipeline over the 8 taps of every signal ----------------------------------------------------
+    // A tap has two halves: ISSUE (position on the linearised tangent plane, window test, the gathers of its guide and radiance
+    // texels - clamped, always valid addresses) and CONSUME (weights + accumulation). Measured on MI355X (diagnosis
+    // builds): the gathers of a pass cost ~0.17 ms of texture-addresser time and the arithmetic ~0.20 ms of VALU time, and with
+    // "all gathers of a signal, then all arithmetic" the waves of a CU march in step - everybody gathers, then everybody computes -
+    // so the two added up (0.30 ms). Here every wave keeps NRD_PIPE_DEPTH taps in flight and consumes tap T right after issuing
+    // tap T + DEPTH, across the signal boundary, so each wave feeds the addresser and the VALU all the time.
+    // The tap window [lo, hi] folds the frame bounds, the rows this instance holds and the hard reach of the pass into one range
+    // test per axis; a rejected tap is SELECTED out (sums untouched), exactly like an early "continue".
+    // tap rows are GLOBAL rows: the band's first row is folded into the base pointers once (scalar unit) instead of one
+    // subtract per tap (denoise_parts checks that (first row + rows held) x pitch stays a 32-bit offset)
+    const bool anyRadius = VARIANT == 0 ? (p.diffusePrepassBlurRadius > 0.0f || p.specularPrepassBlurRadius > 0.0f) : p.maxBlurRadius != 0.0f;
+    if (anyRadius) { // uniform (kernel argument)
+        constexpr int NT = 8 * NSIG;
+        // PrePass (hit-distance tracking state) and the SH flavours (a second radiance texel per tap) carry more registers per tap
+        constexpr int DEPTH_WANTED = (VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : NRD_PIPE_DEPTH;
+        constexpr int DEPTH = DEPTH_WANTED < NT ? DEPTH_WANTED : NT;
+        const PlaneBuf guideB = plane_buf(p.guide, c.yOff);
+        PlaneBuf srcB[NSIG], src1B[NSIG];
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            srcB[sig] = plane_buf(*srcPs[sig], c.yOff);
+            if (SH)
+                src1B[sig] = plane_buf(*src1Ps[sig], c.yOff);
+        }
+        const float cx = (float)x + 0.5f, cy = (float)gy0 + 0.5f;
+        float gaT[NT]; // plane-equation term of geo_weight at the tap position
+        bool inWin[NT];
+        uint4 graw[NT];
+        uint2 sraw[NT], sraw1[NT];
+        auto issue = [&](const int T) {
+            const int sig = T >> 3, t = T & 7;
+            float ox, oy;
+            if (PER_PIXEL) {
+                ox = g_poisson8[t][0];
+                oy = g_poisson8[t][1];
+            } else {
+                ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
+                oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
+            }
+            float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], cx)));
+            float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], cy)));
+            gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
+            // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
+            const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
+            inWin[T] = (cxf == fpx) & (cyf == fpy);
+            const int px = (int)cxf, gpy = (int)cyf;
+            graw[T] = ldb<uint4>(guideB, px, gpy, 16);
+            sraw[T] = occIn ? uint2{(uint32_t)ldb<uint16_t>(srcB[sig], px, gpy, 2), 0u} : ldb<uint2>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
+            sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8)) : uint2{0u, 0u};
+        };
+        auto consume = [&](const int T) {
+            const int sig = T >> 3, t = T & 7;
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            Guide gs = decode_guide(graw[T], c.denoisingRange);
+            f4 sv = decode_signal(p, sraw[T], occIn);
+            const bool valid = inWin[T] & active[sig] & !gs.sky & !material_mismatch(g.mat, gs.mat, minMats[sig]); // bitwise: one basic block
+#ifdef NRD_DBG_HIST
+            if (active[sig]) { // Chebyshev distance of the tap from the centre pixel, buckets <=2, 4, 8, 12, 16, 24, 32, more (taps of both signals)
+                const int t = T & 7;
+                float ox = PER_PIXEL ? g_poisson8[t][0] : (VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0]);
+                float oy = PER_PIXEL ? g_poisson8[t][1] : (VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1]);
+                float dx = absf(fma_(ox, jtx[sig], oy * jbx[sig])), dy = absf(fma_(ox, jty[sig], oy * jby[sig]));
+                float d = fmax2(dx, dy);
+                int b = d <= 2.f ? 0 : d <= 4.f ? 1 : d <= 8.f ? 2 : d <= 12.f ? 3 : d <= 16.f ? 4 : d <= 24.f ? 5 : d <= 32.f ? 6 : 7;
+                atomicAdd(&g_dbg_hist[VARIANT][b], 1ull);
+            }
+#endif
+            float w = g_poisson8[t][2];
+            w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
+            w *= normal_weight_m2(dot3(g.n, gs.n), m2w2[sig]);
+            if (isSpec)
+                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
+            if (relaxIn)
+                sv = rgb_to_ycocg4(sv);
+            w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA[sig], hitB[sig]))));
+            if (VARIANT == 0) {
+                // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): a rejected tap is
+                // selected out component by component
+                f4 acc = fma4(sv, w, sum[sig]);
+                sum[sig] = {valid ? acc.x : sum[sig].x, valid ? acc.y : sum[sig].y, valid ? acc.z : sum[sig].z, valid ? acc.w : sum[sig].w};
+                if (SH) {
+                    f4 acc1 = fma4(unpack_h4(sraw1[T]), w, sum1[sig]);
+                    sum1[sig] = {valid ? acc1.x : sum1[sig].x, valid ? acc1.y : sum1[sig].y, valid ? acc1.z : sum1[sig].z, valid ? acc1.w : sum1[sig].w};
+                }
+                wsum[sig] = valid ? wsum[sig] + w : wsum[sig];
+                minHit[sig] = (valid & (w > 0.0f)) ? fmin2(minHit[sig], sv.w * hitNormS[sig]) : minHit[sig];
+            } else {
+                // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0 - one select
+                w = valid ? w : 0.0f;
+                sum[sig] = fma4(sv, w, sum[sig]);
+                if (SH)
+                    sum1[sig] = fma4(unpack_h4(sraw1[T]), w, sum1[sig]);
+                wsum[sig] += w;
+            }
+        };
+#pragma unroll
+        for (int T = 0; T < DEPTH; T++)
+            issue(T);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int T = 0; T < NT; T++) {
+            if (T + DEPTH < NT)
+                issue(T + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(T);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++) {
+        const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+        float invw = rcp_(wsum[sig]);
+        f4 res = mul4(sum[sig], invw), res1 = mul4(sum1[sig], invw);
         if (VARIANT == 0 && isSpec && p.prepassTrackOnly) { // pass-through: the centre is fetched again instead of being kept live across the tap loop
-            res = load_signal(p, srcP, x, y, srcBpt, srcOff, occIn);
+            res = load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
             if (relaxIn)
                 res = rgb_to_ycocg4(res);
-            res1 = SH ? unpack_h4(ld<uint2>(src1P, x, y, srcBpt, src1Off)) : f4{0, 0, 0, 0};
+            res1 = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
         }
         st<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
         if (SH)
             st<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
         if (VARIANT == 0 && isSpec)
-            st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit));
+            st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig]));
     }
 }
 
@@ -1511,7 +1569,19 @@ namespace NRD_PROJ_NS {
 
 #if NRD_PART == 1
 void launch_reblur_blur_radiance(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_spatial, 1, 0, ); }
+#ifdef NRD_DBG_HIST
+extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p1(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_hist), sizeof(g_dbg_hist));
+}
+#endif
 #else
+#ifdef NRD_DBG_HIST
+extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_hist), sizeof(g_dbg_hist));
+}
+#endif
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }

@@ -132,6 +132,24 @@ inline float hipemu_fmed3f(float a, float b, float c) {
     return lo > m ? lo : m;    // max(min(a, b), .)
 }
 #define __builtin_amdgcn_fmed3f hipemu_fmed3f
+// raw buffer loads (V# = base pointer; stride / bounds unused by the product kernels)
+struct __amdgpu_buffer_rsrc_t {
+    const unsigned char* p;
+};
+inline __amdgpu_buffer_rsrc_t hipemu_make_rsrc(const void* p, int, unsigned, unsigned) { return {(const unsigned char*)p}; }
+typedef unsigned int hipemu_u4v __attribute__((__vector_size__(16)));
+typedef unsigned int hipemu_u2v __attribute__((__vector_size__(8)));
+template <typename T>
+inline T hipemu_buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    T v;
+    std::memcpy(&v, r.p + (unsigned)voff + (unsigned)soff, sizeof(T));
+    return v;
+}
+#define __builtin_amdgcn_make_buffer_rsrc hipemu_make_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) hipemu_buf_ld<hipemu_u4v>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) hipemu_buf_ld<hipemu_u2v>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) hipemu_buf_ld<unsigned int>(r, v, s)
+#define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, a) hipemu_buf_ld<unsigned short>(r, v, s)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 inline void __syncthreads() { hipemu::sync(); }
 inline int __syncthreads_or(int v) {
