@@ -5,9 +5,11 @@
 
 A "step" is one frame through every pass of the denoiser (ClassifyTiles, PrePass, TemporalAccumulation, HistoryFix, Blur,
 PostBlur, TemporalStabilization) with all inputs already resident in HBM. N = 1: the 3840x2160 frame BASELINE.json quotes its
-target on. N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is row-tiled, every rank owns a
-3840x2160 band of a 3840 x (2160 N) frame (weak scaling) and exchanges halo rows with its <= 2 row neighbours through
-torch.distributed (backend nccl = RCCL over xGMI) between passes (SURVEY.md 8e scheme A).
+target on. N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json config 5 - ONE 7680x4320 frame
+(--workload reblur_ds_8k, the default for N > 1) row-tiled into N bands, strong scaling; every rank exchanges halo rows with
+its <= 2 row neighbours between passes (SURVEY.md 8e scheme A) through torch.distributed (backend nccl = RCCL over xGMI,
+--tiler python) or through the C++ row tiler below the C-ABI (ncclSend / ncclRecv, --tiler native). --scaling weak keeps the
+round-1 mode: every rank owns a full band of the workload's height (a W x (H N) frame).
 
 One JSON line on stdout (rank 0). `roofline` is computed for the slowest kernel from HIP events recorded on the launch
 stream around every dispatch of every 4th step of the timed region (--event-stride; the event records themselves idle the
@@ -44,7 +46,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="reblur_ds_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: reblur_ds_4k on one GPU (the headline metric), reblur_ds_8k row-tiled for --gpus N > 1 (BASELINE config 5)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the workload's frame split into N row bands; weak = every rank a full band of a W x (H N) frame")
+    ap.add_argument("--tiler", default="python", choices=["python", "native"],
+                    help="N > 1: python = nrd-sample_amd/tiler.py over torch.distributed P2P; native = the C++ row tiler below the C-ABI "
+                         "(nrdhip_tiler_*, RCCL send / recv groups on a side stream)")
+    ap.add_argument("--motion-rows", type=int, default=8, help="row tiling: vertical motion (rows) the stored halo must cover beyond the passes' reach")
     ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
@@ -57,22 +66,19 @@ def parse():
                          "with one Denoise call. 14 event records per frame cost ~40 us of GPU idle time between the seven kernels "
                          "(measured: 5200 -> 5340 Mpix/s at stride 4), which is instrumentation, not pipeline")
     ap.add_argument("--atrous", type=int, default=0, help="RELAX: atrousIterationNum override (2..8; BASELINE config 4 also asks for an 8-iteration stress run)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "reblur_ds_4k" if a.gpus == 1 else "reblur_ds_8k"
+    return a
 
 
-def cpu_baseline(pkg, denoiser_names, settings_of, device):
-    """Oracle (scalar C++ port of the same passes, oracle/) on a bounded sample of the same workload: 1920x1080, 2 warm-up +
-    3 timed frames, row-striped over the host's hardware threads. Frames are rendered on the GPU and copied to the host."""
+def cpu_run(pkg, orc, denoiser_names, settings_of, device, w, h, warm, frames, threads):
+    """Mpixels/s of the CPU oracle on `frames` frames of a w x h instance of the workload after `warm` warm-up frames"""
     api, synth, harness = pkg.api, pkg.synth, pkg.harness
-    if not os.path.exists(graft.ORACLE_LIB):
-        return None
-    orc = graft.oracle_backend()  # the only use of oracle/ outside tests/ and smoke(): the reported CPU baseline
-    w, h, frames, warm = 1920, 1080, 3, 2
-    cores = min(os.cpu_count() or 1, h // 8)
     scene = synth.Scene(w, h, dolly=0.004, device=device, denoiser="RELAX" if denoiser_names[0].startswith("RELAX") else "REBLUR")
     dens = [api.Denoiser[n] for n in denoiser_names]
     hz = harness.Harness(orc, dens, w, h)
-    orc.lib.orc_set_threads(hz.nrd.handle, cores)
+    orc.lib.orc_set_threads(hz.nrd.handle, threads)
     st = settings_of(api, scene, dens)
     data = []
     for f in range(warm + frames):
@@ -85,11 +91,46 @@ def cpu_baseline(pkg, denoiser_names, settings_of, device):
     for f in range(warm, warm + frames):
         hz.frame(scene.common_settings(api, data[f], f), planes[f], st)
     dt = time.perf_counter() - t0
-    return {"value": round(w * h * frames / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d, %d frames after %d warm-up, same pipeline (%s), oracle/ row-striped over %d threads" % (w, h, frames, warm, "+".join(denoiser_names), cores)}
+    hz.nrd.destroy()
+    return w * h * frames / dt / 1e6
+
+
+def cpu_baseline(pkg, denoiser_names, settings_of, device, w, h):
+    """Oracle (scalar C++ port of the same passes, oracle/) on a bounded sample of the same workload (SURVEY.md 8d / BASELINE.md 4):
+    (ii) all hardware threads, row-striped, at the workload's own frame size (1 warm-up + 2 timed frames), and (i) ONE thread on
+    a 640x360 instance of the same pipeline (1 warm-up + 2 timed frames; a single thread needs ~30 s per 4K frame). Frames are
+    rendered on the GPU and copied to the host."""
+    if not os.path.exists(graft.ORACLE_LIB):
+        return None
+    orc = graft.oracle_backend()  # the only use of oracle/ outside tests/ and smoke(): the reported CPU baseline
+    cores = min(os.cpu_count() or 1, h // 8)
+    warm, frames = 1, 2
+    multi = cpu_run(pkg, orc, denoiser_names, settings_of, device, w, h, warm, frames, cores)
+    sw, sh = 640, 360
+    single = cpu_run(pkg, orc, denoiser_names, settings_of, device, sw, sh, warm, frames, 1)
+    return {"value": round(multi, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d (the workload's frame), %d frames after %d warm-up, same pipeline (%s), oracle/ row-striped over %d threads"
+                      % (w, h, frames, warm, "+".join(denoiser_names), cores),
+            "single_thread": {"value": round(single, 4), "unit": "Mpixels/s", "cores": 1,
+                              "sample": "%dx%d instance of the same pipeline, %d frames after %d warm-up, one thread" % (sw, sh, frames, warm)}}
 
 
 OPTIONS = {"checkerboard": False, "atrous": 0}
+
+# Algorithmic bytes per pixel per frame by the CONTRACT's rule (SURVEY.md 8d / BASELINE.md 3: every plane a pass binds counted once
+# at the storage size the reference's formats imply - 8-byte guides). The as-built figure the dispatch table reports is larger
+# (this build's 16-byte pre-decoded guide texel: 408 instead of 352 for REBLUR_DIFFUSE_SPECULAR); both are reported.
+CONTRACT_BPP = {"REFERENCE": 48.0, "SIGMA_SHADOW_TRANSLUCENCY": 76.0, "REBLUR_DIFFUSE": 224.0, "REBLUR_DIFFUSE_SPECULAR": 352.0,
+                "RELAX_DIFFUSE_SPECULAR_SH": 770.0}
+
+
+def contract_bpp(den_names):
+    if any(n not in CONTRACT_BPP for n in den_names):
+        return None
+    total = sum(CONTRACT_BPP[n] for n in den_names)
+    if OPTIONS["atrous"] and "RELAX_DIFFUSE_SPECULAR_SH" in den_names:
+        total += 76.0 * (OPTIONS["atrous"] - 5)
+    return total
 
 
 def settings_of(api, scene, dens):
@@ -148,9 +189,11 @@ def main():
     OPTIONS["checkerboard"], OPTIONS["atrous"] = args.checkerboard, args.atrous
     if args.checkerboard and (world > 1 or args.force_tiled):
         raise SystemExit("--checkerboard is wired into the single-GPU runner only")
-    w, band_h, den_names = WORKLOADS[args.workload]
+    w, wl_h, den_names = WORKLOADS[args.workload]
     dens = [api.Denoiser[n] for n in den_names]
     hip = pkg.hip_backend(dev)
+    strong = args.scaling == "strong"
+    band_h = wl_h  # rows a rank owns in weak mode / at N = 1; strong mode: band_layout() splits wl_h
 
     if world == 1 and not args.force_tiled:
         from nrd_sample_amd.harness import Harness
@@ -162,8 +205,10 @@ def main():
     else:
         from nrd_sample_amd.tiler import TiledRunner
 
-        frame_h = band_h * world
-        runner = TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of)
+        frame_h = wl_h if strong else wl_h * world
+        runner = TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of,
+                             tiler=args.tiler, motion_rows=args.motion_rows)
+        band_h = runner.band.layout["own_rows"]
 
     ids = [int(d) for d in dens]
     # ---- warm-up (untimed) ----
@@ -199,26 +244,47 @@ def main():
         pixels_band = w * band_h
         total_pixels = w * frame_h * args.steps
         value = total_pixels / dt / 1e6
-        dom = max(per_pass.items(), key=lambda kv: kv[1][0])
-        dom_name, (dom_ms, dom_bpp) = dom
-        achieved = dom_bpp * pixels_band / (dom_ms * 1e-3) / 1e9
-        sum_ms = sum(v[0] for v in per_pass.values())
-        sum_bpp = sum(v[1] for v in per_pass.values())
+        ms_per_step = dt / args.steps * 1e3
+        max_accum = max([int(getattr(st, "maxAccumulatedFrameNum", 0)) for st in runner.settings.values()] + [0])
+        state = "steady state (accumulation saturated)" if args.warmup >= max_accum else \
+            "warm-up %d frames (accumulation saturates at %d)" % (args.warmup, max_accum)
+        tiled = "" if world == 1 and not args.force_tiled else " row-tiled %d x ~%d rows (%s scaling), halo %d rows, %s tiler" % (
+            world, band_h, args.scaling, runner.halo, args.tiler)
+        bpp_contract = contract_bpp(den_names)
         out = {
             "metric": "Mpixels/s full %s diff+spec pipeline" % den_names[0].split("_")[0], "value": round(value, 2), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s, %dx%d%s, steady state (accumulation saturated)" % (
-                args.workload, "+".join(den_names), w, frame_h, "" if world == 1 else " row-tiled %d x %d rows, RCCL halo exchange" % (world, band_h)),
-                "unique_input_frames": args.unique_frames, "algorithmic_bytes_per_pixel": round(sum_bpp, 2)},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom_name),
-                         "pipeline_frac": round(sum_bpp * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "passes_ms": {k: round(v[0], 4) for k, v in per_pass.items()},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if (world == 1 or not strong) else "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s, %dx%d%s, %s" % (args.workload, "+".join(den_names), w, frame_h, tiled, state),
+                       "unique_input_frames": args.unique_frames, "storage_dtype": "f16 planes (f32 viewZ), f32 arithmetic"},
         }
+        if per_pass:
+            dom = max(per_pass.items(), key=lambda kv: kv[1][0])
+            dom_name, (dom_ms, dom_bpp) = dom
+            achieved = dom_bpp * pixels_band / (dom_ms * 1e-3) / 1e9
+            sum_ms = sum(v[0] for v in per_pass.values())
+            sum_bpp = sum(v[1] for v in per_pass.values())
+            out["config"]["algorithmic_bytes_per_pixel"] = round(sum_bpp, 2)
+            out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom_name),
+                               # whole pass chain on both denominators: the as-built plane layout and the contract's rule
+                               "algorithmic_bytes_as_built": round(sum_bpp, 2), "pipeline_frac": round(sum_bpp * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes_contract": bpp_contract,
+                               "pipeline_frac_contract": None if bpp_contract is None else round(bpp_contract * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            out["passes_ms"] = {k: round(v[0], 4) for k, v in per_pass.items()}
+        else:  # the C++ tiler steps the dispatches itself: whole-frame figures only
+            sum_bpp = sum(b for _, b in runner.dispatch_table())
+            out["config"]["algorithmic_bytes_per_pixel"] = round(sum_bpp, 2)
+            out["roofline"] = {"bound": "hbm", "kernel": "whole frame (no per-dispatch events with --tiler native)", "achieved": round(sum_bpp * pixels_band / (ms_per_step * 1e-3) / 1e9, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sum_bpp * pixels_band / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                               "algorithmic_bytes_as_built": round(sum_bpp, 2), "algorithmic_bytes_contract": bpp_contract}
+        if hasattr(runner, "tiler"):
+            t = runner.tiler
+            out["config"]["halo_exchange_bytes_per_frame_rank0"] = int(t.bytes_exchanged / max(args.warmup + args.steps, 1))
         if world == 1 and not args.no_cpu_baseline:  # reported on rank 0 at N = 1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of, dev)
+                out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of, dev, w, wl_h)
             except Exception as e:  # the baseline is a reported extra; never fail the GPU number because of it
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))

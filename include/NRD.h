@@ -44,7 +44,11 @@ inline const LibraryDesc* GetLibraryDesc() {
 
 inline const char* GetDenoiserString(Denoiser denoiser) { return nrdhip_denoiser_string((uint32_t)denoiser); }
 
-inline Result CreateInstance(const InstanceCreationDesc& desc, uint16_t resourceWidth, uint16_t resourceHeight, Instance*& instance, uint32_t flags = 0) {
+// `device`: HIP device ordinal the pools are allocated on and the passes run on (-1 = whatever device is current at each call);
+// `band`: row-band fields of nrdhip_create_desc for a row-tiled frame (nullptr = whole frame): {frame height, global row at
+// local row 0, first owned local row, owned rows}
+inline Result CreateInstance(const InstanceCreationDesc& desc, uint16_t resourceWidth, uint16_t resourceHeight, Instance*& instance, uint32_t flags = 0,
+                             int device = -1, const int32_t* band = nullptr) {
     std::vector<nrdhip_denoiser_desc> dd(desc.denoisersNum);
     for (uint32_t i = 0; i < desc.denoisersNum; i++)
         dd[i] = {desc.denoisers[i].identifier, (uint32_t)desc.denoisers[i].denoiser};
@@ -54,6 +58,13 @@ inline Result CreateInstance(const InstanceCreationDesc& desc, uint16_t resource
     cd.resource_width = resourceWidth;
     cd.resource_height = resourceHeight;
     cd.flags = flags;
+    cd.device_plus1 = device >= 0 ? (uint16_t)(device + 1) : (uint16_t)0;
+    if (band) {
+        cd.frame_height = (uint16_t)band[0];
+        cd.band_row0 = band[1];
+        cd.band_own_first = (uint16_t)band[2];
+        cd.band_own_rows = (uint16_t)band[3];
+    }
     nrdhip_instance* h = nullptr;
     int r = nrdhip_create(&cd, &h);
     instance = (Instance*)h;

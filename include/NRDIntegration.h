@@ -47,16 +47,20 @@ struct ResourceSnapshot {
     }
 };
 
-// == nrd::IntegrationCreationDesc (Source/NRDSample.cpp:928-936)
+// == nrd::IntegrationCreationDesc (Source/NRDSample.cpp:928-936). Fields that configure descriptor pools, in-flight frame
+// rings and queue idling in the reference are ACCEPTED AND IGNORED here - a HIP stream orders everything and there are no
+// descriptors: `name`, `queuedFrameNum`, `enableWholeLifetimeDescriptorCaching`, `autoWaitForIdle` (and
+// ResourceSnapshot::restoreInitialState: HIP has no resource states to restore). The two format-conversion switches are
+// refused (Recreate returns UNSUPPORTED): plane formats are part of the numerics contract.
 struct IntegrationCreationDesc {
     char name[32] = "";
     uint16_t resourceWidth = 0;
     uint16_t resourceHeight = 0;
-    uint8_t queuedFrameNum = 3;
-    bool enableWholeLifetimeDescriptorCaching = false; // accepted for source compatibility; no descriptors on HIP
-    bool promoteFloat16to32 = false;                   // not supported (plane formats are part of the numerics contract)
-    bool demoteFloat32to16 = false;
-    bool autoWaitForIdle = true;
+    uint8_t queuedFrameNum = 3;                        // ignored
+    bool enableWholeLifetimeDescriptorCaching = false; // ignored
+    bool promoteFloat16to32 = false;                   // not supported
+    bool demoteFloat32to16 = false;                    // not supported
+    bool autoWaitForIdle = true;                       // ignored
 };
 
 class Integration {
@@ -66,17 +70,10 @@ public:
     Integration(const Integration&) = delete;
     Integration& operator=(const Integration&) = delete;
 
-    // `device`: HIP device ordinal the instance's pools live on (the sample passes its nri::Device*)
+    // `device`: HIP device ordinal (the sample passes its nri::Device*): the pools are allocated there, and every later call makes it
+    // current for its duration (and restores the caller's device), so a multi-GPU host can drive several Integrations from one thread
     inline Result Recreate(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device = 0) {
-        Destroy();
-        if (integrationDesc.promoteFloat16to32 || integrationDesc.demoteFloat32to16)
-            return Result::UNSUPPORTED;
-        m_Desc = integrationDesc;
-        m_Device = device;
-        Result r = CreateInstance(instanceDesc, integrationDesc.resourceWidth, integrationDesc.resourceHeight, m_Instance);
-        if (r != Result::SUCCESS)
-            m_Instance = nullptr;
-        return r;
+        return RecreateBand(integrationDesc, instanceDesc, device, nullptr);
     }
 
     // kernels are compiled ahead of time for gfx950: nothing to reload (the sample's shader hot-reload hook, :2866-2874)
@@ -92,22 +89,32 @@ public:
         return m_Instance ? nrd::SetCommonSettings(*m_Instance, commonSettings) : Result::FAILURE;
     }
 
-    // upstream signature: (Identifier, const void*). The size of the struct is implied by the denoiser kind.
+    // upstream signature: (Identifier, const void*). Which settings struct the pointer refers to follows from the denoiser behind
+    // `identifier` (nrdhip_denoiser_kind), exactly as in the reference's untyped call
     inline Result SetDenoiserSettings(Identifier identifier, const void* denoiserSettings) {
         if (!m_Instance)
             return Result::FAILURE;
-        // try the four settings structs; the library accepts exactly the one matching the denoiser behind `identifier`
+        uint32_t kind = 0;
+        if (nrdhip_denoiser_kind((nrdhip_instance*)m_Instance, identifier, &kind) != 0)
+            return Result::INVALID_ARGUMENT;
         const size_t sizes[] = {sizeof(ReblurSettings), sizeof(RelaxSettings), sizeof(SigmaSettings), sizeof(ReferenceSettings)};
-        for (size_t s : sizes)
-            if (nrd::SetDenoiserSettings(*m_Instance, identifier, denoiserSettings, s) == Result::SUCCESS)
-                return Result::SUCCESS;
-        return Result::INVALID_ARGUMENT;
+        return kind < 4 ? nrd::SetDenoiserSettings(*m_Instance, identifier, denoiserSettings, sizes[kind]) : Result::INVALID_ARGUMENT;
     }
 
     // `stream` plays the role of the sample's nri::CommandBuffer: all passes are enqueued on it, in order
     inline Result Denoise(const Identifier* denoisers, uint32_t denoisersNum, void* stream, ResourceSnapshot& resourceSnapshot) {
         if (!m_Instance)
             return Result::FAILURE;
+        Result b = Bind(resourceSnapshot);
+        if (b != Result::SUCCESS)
+            return b;
+        // final "states" are reported back like the reference does (:524-530); on HIP they are unchanged
+        return (Result)nrdhip_denoise((nrdhip_instance*)m_Instance, denoisers, denoisersNum, stream);
+    }
+
+    // a snapshot is complete: slots it does not name lose last call's pointers
+    inline Result Bind(ResourceSnapshot& resourceSnapshot) {
+        nrdhip_unbind_all((nrdhip_instance*)m_Instance);
         for (size_t i = 0; i < (size_t)ResourceType::TRANSIENT_POOL; i++) {
             if (!resourceSnapshot.bound[i])
                 continue;
@@ -116,8 +123,7 @@ public:
             if (e)
                 return (Result)e;
         }
-        // final "states" are reported back like the reference does (:524-530); on HIP they are unchanged
-        return (Result)nrdhip_denoise((nrdhip_instance*)m_Instance, denoisers, denoisersNum, stream);
+        return Result::SUCCESS;
     }
 
     inline void Destroy() {
@@ -132,7 +138,19 @@ public:
     inline const char* GetLastError() const { return nrdhip_last_error((nrdhip_instance*)m_Instance); }
     inline Instance* GetInstance() { return m_Instance; }
 
-private:
+protected:
+    inline Result RecreateBand(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device, const int32_t* band) {
+        Destroy();
+        if (integrationDesc.promoteFloat16to32 || integrationDesc.demoteFloat32to16)
+            return Result::UNSUPPORTED;
+        m_Desc = integrationDesc;
+        m_Device = device;
+        Result r = CreateInstance(instanceDesc, integrationDesc.resourceWidth, integrationDesc.resourceHeight, m_Instance, 0, device, band);
+        if (r != Result::SUCCESS)
+            m_Instance = nullptr;
+        return r;
+    }
+
     inline double Mem(int i) const {
         float v[3] = {};
         if (m_Instance)
@@ -143,6 +161,87 @@ private:
     IntegrationCreationDesc m_Desc = {};
     int m_Device = 0;
     uint32_t m_FrameIndex = 0;
+};
+
+// One rank of a frame row-tiled across the GPUs of a node (BASELINE.json config 5; no counterpart in the reference, whose sample
+// runs on a single adapter: Source/NRDSample.cpp:755-778). Same calls as Integration; Recreate additionally takes the band this
+// rank owns, Denoise exchanges the halo rows between the passes (nrdhip_tiler_*: RCCL send / recv groups on a side stream, or a
+// caller-supplied transport). `integrationDesc.resourceHeight` is the height of the WHOLE frame; planes bound to this rank hold
+// rows [Row0(), Row0() + LocalHeight()) of it.
+class TiledIntegration : public Integration {
+public:
+    inline ~TiledIntegration() { DestroyTiler(); }
+
+    // band rows of `rank`: whole tiles, the last rank takes the remainder; `haloRows` from nrdhip_required_halo (multiple of 16)
+    static inline void BandOf(uint16_t frameHeight, int world, int rank, uint32_t haloRows, int32_t band[4], uint16_t& localHeight) {
+        int base = world > 1 ? (frameHeight / world) / 16 * 16 : frameHeight;
+        int own0 = rank * base, own1 = rank == world - 1 ? frameHeight : own0 + base;
+        int row0 = own0 - (int)haloRows < 0 ? 0 : own0 - (int)haloRows;
+        int row1 = own1 + (int)haloRows > frameHeight ? frameHeight : own1 + (int)haloRows;
+        band[0] = frameHeight;
+        band[1] = row0;
+        band[2] = own0 - row0;
+        band[3] = own1 - own0;
+        localHeight = (uint16_t)(row1 - row0);
+    }
+
+    inline Result Recreate(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device, int rank, int world,
+                           uint32_t haloRows, const nrdhip_transport* transport = nullptr) {
+        DestroyTiler();
+        BandOf(integrationDesc.resourceHeight, world, rank, haloRows, m_Band, m_LocalHeight);
+        IntegrationCreationDesc local = integrationDesc;
+        local.resourceHeight = m_LocalHeight;
+        Result r = RecreateBand(local, instanceDesc, device, m_Band);
+        if (r != Result::SUCCESS)
+            return r;
+        return (Result)nrdhip_tiler_create((nrdhip_instance*)GetInstance(), rank, world, transport, &m_Tiler);
+    }
+    // RCCL transport: rank 0 calls GetUniqueId and hands the 128 bytes to the other ranks; every rank then calls InitRccl with its
+    // GPU current
+    static inline Result GetUniqueId(void* out128) { return (Result)nrdhip_tiler_rccl_unique_id(out128); }
+    inline Result InitRccl(const void* uniqueId128) { return m_Tiler ? (Result)nrdhip_tiler_rccl_init(m_Tiler, uniqueId128) : Result::FAILURE; }
+
+    inline int32_t Row0() const { return m_Band[1]; }
+    inline uint16_t LocalHeight() const { return m_LocalHeight; }
+    inline int32_t OwnFirst() const { return m_Band[2]; }
+    inline int32_t OwnRows() const { return m_Band[3]; }
+
+    // externally produced inputs arrive per band: refresh their halo rows from the neighbours (slots already in the snapshot)
+    inline Result ExchangeInputs(const ResourceType* slots, uint32_t slotsNum, void* stream, ResourceSnapshot& resourceSnapshot) {
+        if (!m_Tiler)
+            return Result::FAILURE;
+        Result b = Bind(resourceSnapshot);
+        if (b != Result::SUCCESS)
+            return b;
+        return (Result)nrdhip_tiler_exchange_inputs(m_Tiler, (const uint32_t*)slots, slotsNum, stream);
+    }
+
+    inline Result Denoise(const Identifier* denoisers, uint32_t denoisersNum, void* stream, ResourceSnapshot& resourceSnapshot) {
+        if (!m_Tiler)
+            return Result::FAILURE;
+        Result b = Bind(resourceSnapshot);
+        if (b != Result::SUCCESS)
+            return b;
+        return (Result)nrdhip_tiler_denoise(m_Tiler, denoisers, denoisersNum, stream);
+    }
+    inline Result Finish(void* stream) { return m_Tiler ? (Result)nrdhip_tiler_finish(m_Tiler, stream) : Result::FAILURE; }
+    inline const char* GetTilerError() const { return nrdhip_tiler_last_error(m_Tiler); }
+    inline nrdhip_tiler* GetTiler() { return m_Tiler; }
+
+    inline void Destroy() {
+        DestroyTiler();
+        Integration::Destroy();
+    }
+
+private:
+    inline void DestroyTiler() {
+        if (m_Tiler)
+            nrdhip_tiler_destroy(m_Tiler);
+        m_Tiler = nullptr;
+    }
+    nrdhip_tiler* m_Tiler = nullptr;
+    int32_t m_Band[4] = {};
+    uint16_t m_LocalHeight = 0;
 };
 
 } // namespace nrd

@@ -50,7 +50,8 @@ typedef struct nrdhip_create_desc {
     uint16_t frame_height;    /* 0 = resource_height; else the height of the whole (global) frame */
     uint16_t band_own_first;  /* first LOCAL row this instance must produce */
     uint16_t band_own_rows;   /* 0 = all rows */
-    uint16_t reserved;
+    uint16_t device_plus1;    /* 0 = whatever HIP device is current at each call; d + 1 = pools and kernels on device d (made current
+                               * for the duration of create / denoise / destroy and restored: nrd::Integration::Recreate(.., device)) */
     int32_t band_row0;        /* global row stored at local row 0 (negative when the top halo is clipped) */
     uint32_t flags;
 } nrdhip_create_desc;
@@ -93,6 +94,8 @@ NRDHIP_API int nrdhip_set_denoiser(nrdhip_instance* inst, uint32_t identifier, c
  * `slot` = nrd::ResourceType, `format` = nrd::Format, device pointer + row pitch instead of nri::Texture*. */
 NRDHIP_API int nrdhip_bind(nrdhip_instance* inst, uint32_t slot, void* dev_ptr, uint32_t pitch_bytes,
                            uint32_t format, uint16_t width, uint16_t height);
+/* forget every slot binding (a ResourceSnapshot is complete: slots absent from it must not keep last frame's pointers) */
+NRDHIP_API int nrdhip_unbind_all(nrdhip_instance* inst);
 /* nrd::Integration::Denoise (Source/NRDSample.cpp:521): enqueue every pass of the given denoisers on `stream`. */
 NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, void* hip_stream);
 
@@ -119,6 +122,15 @@ NRDHIP_API int nrdhip_pool_size(nrdhip_instance* inst, uint32_t pool, uint32_t* 
 NRDHIP_API int nrdhip_pool_info(nrdhip_instance* inst, uint32_t pool, uint32_t index, nrdhip_plane_info* out);
 NRDHIP_API int nrdhip_bind_pool(nrdhip_instance* inst, uint32_t pool, uint32_t index, void* dev_ptr, uint32_t pitch_bytes);
 
+/* Introspection used by the layers above the C-ABI (the C++ nrd::Integration veneer, the row tiler):
+ * nrdhip_denoiser_kind - which settings struct `identifier` takes: 0 ReblurSettings, 1 RelaxSettings, 2 SigmaSettings,
+ *   3 ReferenceSettings (nrd::Integration::SetDenoiserSettings is one untyped call in the reference, Source/NRDSample.cpp:4080-4150);
+ * nrdhip_get_band - {frame height, global row at local row 0, first owned local row, owned rows (resolved), local height};
+ * nrdhip_slot_info - the plane currently bound to a resource slot (ptr NULL = unbound). */
+NRDHIP_API int nrdhip_denoiser_kind(nrdhip_instance* inst, uint32_t identifier, uint32_t* kind);
+NRDHIP_API int nrdhip_get_band(nrdhip_instance* inst, int32_t out[5]);
+NRDHIP_API int nrdhip_slot_info(nrdhip_instance* inst, uint32_t slot, nrdhip_plane_info* out);
+
 /* nrd::Integration::Get{Total,Persistent,Aliasable}MemoryUsageInMb (Source/NRDSample.cpp:1038): out[0..2] */
 NRDHIP_API int nrdhip_get_memory_mb(nrdhip_instance* inst, float out[3]);
 
@@ -132,6 +144,46 @@ NRDHIP_API const char* nrdhip_denoiser_string(uint32_t denoiser);
 NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which);
 /* last error text of the instance (or of creation when inst == NULL) */
 NRDHIP_API const char* nrdhip_last_error(nrdhip_instance* inst);
+
+/* ===================================================================================================================
+ * Row tiler: one frame row-tiled across the GPUs of a node (BASELINE.json config 5, SURVEY.md 8e scheme A). No counterpart in
+ * the reference (single adapter, single queue: Source/NRDSample.cpp:755-778). One rank per GPU; every rank creates its
+ * instance with the band fields of nrdhip_create_desc (owned rows + `halo` stored rows towards each neighbour, halo from
+ * nrdhip_required_halo), then a tiler on top of it. nrdhip_tiler_denoise == nrdhip_denoise + the halo-row exchanges between the
+ * dispatches; the result is bit-identical to the single-GPU frame, or the call fails (a pass that reads farther than the stored
+ * halo is refused, never clamped). Rows travel point to point between row neighbours: RCCL (ncclSend / ncclRecv groups on a
+ * side stream, overlapped with the interior of the dispatch) after nrdhip_tiler_rccl_init, or the caller's transport callbacks.
+ * =================================================================================================================== */
+typedef struct nrdhip_tiler nrdhip_tiler;
+/* caller-supplied transport (tests, hosts with their own fabric layer): all calls of one exchange arrive between group_begin
+ * and group_end (both optional), sends and receives toward one peer in matching order on both sides. `hip_stream` is the
+ * stream the rows were produced on - a host transport synchronises it before reading. Return 0 on success. */
+typedef struct nrdhip_transport {
+    void* user;
+    int (*group_begin)(void* user);
+    int (*send)(void* user, const void* dev_ptr, size_t bytes, int peer_rank, void* hip_stream);
+    int (*recv)(void* user, void* dev_ptr, size_t bytes, int peer_rank, void* hip_stream);
+    int (*group_end)(void* user, void* hip_stream);
+} nrdhip_transport;
+/* rows a band must store beyond its owned rows: max read reach of the dispatches of `identifiers` with the settings currently
+ * set + `motion_rows` (the largest vertical motion, in rows, reprojection may follow), rounded up to 16 */
+NRDHIP_API int nrdhip_required_halo(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, uint32_t motion_rows, uint32_t* out);
+/* transport NULL = RCCL (then call nrdhip_tiler_rccl_init before the first exchange) */
+NRDHIP_API int nrdhip_tiler_create(nrdhip_instance* inst, int rank, int world, const nrdhip_transport* transport, nrdhip_tiler** out);
+NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* tiler);
+/* ncclGetUniqueId on rank 0 (128 bytes; hand it to the other ranks by any means), ncclCommInitRank on every rank with the
+ * rank's GPU current */
+NRDHIP_API int nrdhip_tiler_rccl_unique_id(void* out128);
+NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* tiler, const void* unique_id128);
+/* refresh the halo rows of externally produced inputs (slots = nrd::ResourceType values already bound with nrdhip_bind) */
+NRDHIP_API int nrdhip_tiler_exchange_inputs(nrdhip_tiler* tiler, const uint32_t* slots, uint32_t n, void* hip_stream);
+NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* tiler, const uint32_t* identifiers, uint32_t n, void* hip_stream);
+/* make `hip_stream` wait for rows still travelling (those only the next frame reads); call before reading pool planes / at exit */
+NRDHIP_API int nrdhip_tiler_finish(nrdhip_tiler* tiler, void* hip_stream);
+NRDHIP_API int nrdhip_tiler_halo(nrdhip_tiler* tiler, uint32_t* rows);
+/* out = {bytes sent, dispatches run as strips + interior, exchanges waited for in-frame, deferred exchanges} */
+NRDHIP_API int nrdhip_tiler_stats(nrdhip_tiler* tiler, uint64_t out[4]);
+NRDHIP_API const char* nrdhip_tiler_last_error(nrdhip_tiler* tiler);
 
 /* ===================================================================================================================
  * Sample-side passes either side of the denoiser (SURVEY.md 8f "next" rows). Stand-alone: no instance, caller-owned

@@ -299,7 +299,7 @@ class DenoiserDesc(C.Structure):
 class CreateDesc(C.Structure):
     _fields_ = [("denoisers", C.POINTER(DenoiserDesc)), ("denoisers_num", _u32), ("resource_width", _u16),
                 ("resource_height", _u16), ("frame_height", _u16), ("band_own_first", _u16), ("band_own_rows", _u16),
-                ("reserved", _u16), ("band_row0", C.c_int32), ("flags", _u32)]
+                ("device_plus1", _u16), ("band_row0", C.c_int32), ("flags", _u32)]
 
 
 class PlaneInfo(C.Structure):
@@ -350,6 +350,17 @@ class NrdError(RuntimeError):
         super().__init__("%s failed: %s %s" % (what, self.code, text))
 
 
+# nrdhip_transport (include/nrdhip.h): caller-supplied halo-row transport of the row tiler
+TRANSPORT_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TRANSPORT_XFER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+TRANSPORT_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("group_begin", TRANSPORT_BEGIN), ("send", TRANSPORT_XFER), ("recv", TRANSPORT_XFER),
+                ("group_end", TRANSPORT_END)]
+
+
 class Backend:
     """A loaded library exposing the C-ABI of include/nrdhip.h under ``prefix``."""
 
@@ -380,6 +391,24 @@ class Backend:
         self._sig("confidence_blur", C.c_int, [C.POINTER(ConfidenceBlurDesc), C.c_void_p])
         self._sig("backend_unpack", C.c_int, [C.POINTER(UnpackDesc), C.c_void_p])
         self._sig("taa", C.c_int, [C.POINTER(TaaDesc), C.c_void_p])
+        # introspection + row tiler: part of the product library (and of its host-emulated build); the CPU oracle of the tests
+        # implements the per-instance entry points only
+        self.has_tiler = hasattr(self.lib, self.prefix + "tiler_create")
+        if self.has_tiler:
+            self._sig("denoiser_kind", C.c_int, [C.c_void_p, _u32, C.POINTER(_u32)])
+            self._sig("get_band", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)])
+            self._sig("slot_info", C.c_int, [C.c_void_p, _u32, C.POINTER(PlaneInfo)])
+            self._sig("required_halo", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, _u32, C.POINTER(_u32)])
+            self._sig("tiler_create", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Transport), C.POINTER(C.c_void_p)])
+            self._sig("tiler_destroy", None, [C.c_void_p])
+            self._sig("tiler_rccl_unique_id", C.c_int, [C.c_void_p])
+            self._sig("tiler_rccl_init", C.c_int, [C.c_void_p, C.c_void_p])
+            self._sig("tiler_exchange_inputs", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
+            self._sig("tiler_denoise", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
+            self._sig("tiler_finish", C.c_int, [C.c_void_p, C.c_void_p])
+            self._sig("tiler_halo", C.c_int, [C.c_void_p, C.POINTER(_u32)])
+            self._sig("tiler_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)])
+            self._sig("tiler_last_error", C.c_char_p, [C.c_void_p])
 
     def _sig(self, name, res, args):
         f = getattr(self.lib, self.prefix + name)
@@ -429,7 +458,9 @@ class Integration:
         library-side failures - the sample tests ``!= SUCCESS`` (Source/NRDSample.cpp:982-983)."""
         self.destroy()
         arr = (DenoiserDesc * len(denoisers))(*[DenoiserDesc(int(i), int(d)) for i, d in denoisers])
-        desc = CreateDesc(arr, len(denoisers), resource_width, resource_height, frame_height, band_own_first, band_own_rows, 0,
+        dev = self.backend.device
+        device_plus1 = int(dev.split(":")[1]) + 1 if isinstance(dev, str) and dev.startswith("cuda:") else 0  # kernels + checks on the device torch allocates on
+        desc = CreateDesc(arr, len(denoisers), resource_width, resource_height, frame_height, band_own_first, band_own_rows, device_plus1,
                           band_row0, FLAG_EXTERNAL_POOLS)
         h = C.c_void_p()
         r = self.backend.create(C.byref(desc), C.byref(h))

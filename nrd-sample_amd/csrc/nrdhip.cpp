@@ -117,6 +117,7 @@ inline uint32_t enc_slot(nrd::ResourceType t) { return (2u << 16) | (uint32_t)t;
 
 struct nrdhip_instance {
     int resW = 0, resH = 0, frameH = 0, yOff = 0, ownY0 = 0, ownRows = 0;
+    int device = -1; // HIP device ordinal the pools live on and the kernels run on (-1: whatever is current at each call)
     uint32_t flags = 0;
     nrd::CommonSettings common;
     bool commonSet = false;
@@ -258,6 +259,10 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     c.yOff = I.yOff;
     if (c.W <= 0 || c.H <= 0 || c.W > I.resW) {
         err = "rectSize invalid";
+        return false;
+    }
+    if (cs.rectOrigin[0] != 0 || cs.rectOrigin[1] != 0) { // the sample never sets it (Source/NRDSample.cpp:3835-3876); refuse rather than denoise the wrong window
+        err = "rectOrigin != 0 is not supported";
         return false;
     }
     if (I.frameH == I.resH && I.yOff == 0 && c.H > I.resH) {
@@ -945,6 +950,20 @@ int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Fla
 
 } // namespace
 
+// makes the instance's device current for the duration of a call (Recreate(..., device) of the C++ veneer), restores the caller's
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device) {
+        if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device)
+            switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+};
+
 extern "C" {
 
 NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** out) {
@@ -960,6 +979,16 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
     I->ownY0 = desc->band_own_first;
     I->ownRows = desc->band_own_rows;
     I->flags = desc->flags;
+    I->device = desc->device_plus1 ? (int)desc->device_plus1 - 1 : -1;
+    if (I->device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || I->device >= count) {
+            g_createError = "no such HIP device";
+            delete I;
+            return (int)nrd::Result::INVALID_ARGUMENT;
+        }
+    }
+    DeviceScope scope(I->device);
     std::vector<PoolPlane> permDesc, transDesc;
     for (uint32_t i = 0; i < desc->denoisers_num; i++) {
         DenoiserState d;
@@ -1012,6 +1041,7 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
 NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
     if (!inst)
         return;
+    DeviceScope scope(inst->device);
     for (auto* v : {&inst->perm, &inst->trans})
         for (auto& P : *v)
             if (P.owned && P.p)
@@ -1059,6 +1089,47 @@ NRDHIP_API int nrdhip_bind(nrdhip_instance* inst, uint32_t slot, void* ptr, uint
     P.w = w;
     P.h = h;
     P.bpt = format_bytes(format);
+    return 0;
+}
+
+NRDHIP_API int nrdhip_unbind_all(nrdhip_instance* inst) {
+    if (!inst)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    for (auto& P : inst->slots)
+        P = Plane();
+    return 0;
+}
+
+NRDHIP_API int nrdhip_denoiser_kind(nrdhip_instance* inst, uint32_t identifier, uint32_t* kind) {
+    DenoiserState* d = inst ? find(*inst, identifier) : nullptr;
+    if (!d || !kind)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    *kind = (uint32_t)d->kind;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_get_band(nrdhip_instance* inst, int32_t out[5]) {
+    if (!inst || !out)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    out[0] = inst->frameH;
+    out[1] = inst->yOff;
+    out[2] = inst->ownY0;
+    out[3] = inst->ownRows ? inst->ownRows : inst->resH - inst->ownY0;
+    out[4] = inst->resH;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_slot_info(nrdhip_instance* inst, uint32_t slot, nrdhip_plane_info* out) {
+    if (!inst || !out || slot >= (uint32_t)nrd::ResourceType::TRANSIENT_POOL)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    const Plane& P = inst->slots[slot];
+    out->ptr = P.p;
+    out->pitch_bytes = P.pitch;
+    out->format = P.fmt;
+    out->width = P.w;
+    out->height = P.h;
+    out->bytes_per_texel = P.bpt;
+    out->name = "slot";
     return 0;
 }
 
@@ -1157,10 +1228,10 @@ NRDHIP_API int nrdhip_denoise_rows(nrdhip_instance* inst, const uint32_t* ids, u
         r = denoise_parts(inst, ids, n, index, 1, part, stream);
         I.ownY0 = own0;
         I.ownRows = ownN;
-    } else if (part & NRDHIP_PART_LAST) { // nothing to compute, but the frame state must still advance
-        I.ownY0 = own0;
-        I.ownRows = ownN;
-        r = denoise_parts(inst, ids, n, index, 1, (part & ~NRDHIP_PART_FIRST) | 4u, stream);
+    } else if (part & (NRDHIP_PART_FIRST | NRDHIP_PART_LAST)) {
+        // nothing to compute (a strip outside the rect under DRS), but the bookkeeping of the part must still happen: FIRST issues
+        // the CLEAR_AND_RESTART clear of the permanent pool, LAST advances the frame state
+        r = denoise_parts(inst, ids, n, index, 1, part | 4u, stream);
     }
     return r;
 }
@@ -1171,6 +1242,7 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
         return (int)nrd::Result::INVALID_ARGUMENT;
     nrdhip_instance& I = *inst;
     hipStream_t st = (hipStream_t)stream;
+    DeviceScope scope(I.device);
     for (auto* v : {&I.perm, &I.trans})
         for (auto& P : *v)
             if (!P.p) {
@@ -1198,6 +1270,19 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                 } else if ((s >> 16) == 2 && I.slots[s & 0xffff].p && !nrd::IsFormatAllowed((nrd::ResourceType)(s & 0xffff), (nrd::Format)I.slots[s & 0xffff].fmt)) {
                     I.error = std::string("resource slot bound with an unsupported format for pass ") + x.name;
                     return (int)nrd::Result::INVALID_ARGUMENT;
+                } else if ((s >> 16) == 2 && I.slots[s & 0xffff].p) {
+                    // the kernels index a bound plane over the rect (rows: the rows this instance holds): a smaller plane or a pitch
+                    // shorter than its texels would be read / written out of bounds. Confidence planes are sampled by uv at their
+                    // own resolution; checkerboarded inputs are half width.
+                    const uint32_t slot = s & 0xffff;
+                    const Plane& P = I.slots[slot];
+                    const bool conf = slot == (uint32_t)nrd::ResourceType::IN_DIFF_CONFIDENCE || slot == (uint32_t)nrd::ResourceType::IN_SPEC_CONFIDENCE;
+                    const uint32_t needW = conf ? 1u : (uint32_t)(I.common.rectSize[0] + 1) / 2u; // >= half the rect width in any mode
+                    const uint32_t needH = conf ? 1u : (uint32_t)std::min<int>(I.resH, std::max<int>((int)I.common.rectSize[1] - I.yOff, 1));
+                    if (P.pitch < (uint32_t)P.w * P.bpt || P.w < needW || P.h < needH) {
+                        I.error = std::string("resource slot plane smaller than the rect (or pitch < width x texel size) for pass ") + x.name;
+                        return (int)nrd::Result::INVALID_ARGUMENT;
+                    }
                 }
         // texel offsets are 32-bit, and the tap loops address band planes by GLOBAL row (the band's first row is folded into
         // the base pointer): (first row + rows held) x pitch must stay below 4 GiB for every plane the pass touches

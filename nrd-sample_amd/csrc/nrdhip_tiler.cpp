@@ -1,0 +1,499 @@
+// nrdhip_tiler.cpp - row tiling of one frame across the GPUs of a node, below the C-ABI (include/nrdhip.h "row tiler").
+//
+// One process (or thread) per GPU. Rank r owns a contiguous band of rows of the global frame and keeps `halo` extra rows of every
+// plane on each side (nrdhip_create_desc band fields). After every recorded dispatch the rows a row neighbour may read are sent
+// to that neighbour - point to point, each pair on its own xGMI link, no collective and no ring (SURVEY.md 8e scheme A
+// "per-pass halo"). The reference has no counterpart (single adapter, single queue: Source/NRDSample.cpp:755-778).
+//
+// This layer sits on top of the GetComputeDispatches-style part of the C-ABI only (nrdhip_dispatch_info_get, nrdhip_denoise_range,
+// nrdhip_denoise_rows, nrdhip_pool_info): it derives the exchange plan from what each dispatch reads / writes and how far it
+// reads (`halo_rows`), and REFUSES a dispatch list that reads farther than the rows the band stores - the tiled result is
+// bit-identical to a single-GPU run or the call fails, never silently different.
+//
+// Transport: RCCL (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a side stream, ordered against the compute stream with
+// events) - resolved from librccl at nrdhip_tiler_rccl_init so that the library loads on hosts without it - or caller-supplied
+// callbacks (tests: host memcpy / gloo; a host with its own fabric layer).
+//
+// Overlap: when the band is tall enough a dispatch first runs on the boundary strips the neighbours need (nrdhip_denoise_rows),
+// the exchange of those rows starts on the side stream behind an event, the interior runs meanwhile, and only the next dispatch
+// waits for the rows. Rows that only the NEXT frame reads (permanent planes surviving the frame: history, accumulation speeds,
+// the guide ...) follow without strips and without a wait and are awaited when the next dispatch list starts.
+#include "../../include/nrdhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifndef NRD_HOST_EMULATION
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#endif
+
+namespace {
+
+struct Xfer { // rows of one pool plane: `rows` full-resolution rows next to each band edge, the `skip` nearest the edge already delivered
+    uint32_t code, rows, skip;
+};
+struct PlanEntry {
+    std::vector<Xfer> now, later;
+};
+
+#ifndef NRD_HOST_EMULATION
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (lib)
+            return true;
+        // a process that already carries an RCCL (PyTorch bundles one) resolves to that copy: one RCCL per process
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib)
+                break;
+        }
+        if (!lib) {
+            err = std::string("librccl not loadable: ") + dlerror();
+            return false;
+        }
+#define NRD_SYM(field, name)                                                   \
+    field = reinterpret_cast<decltype(field)>(dlsym(lib, name));               \
+    if (!field) {                                                              \
+        err = std::string("librccl lacks ") + name;                            \
+        return false;                                                          \
+    }
+        NRD_SYM(GetUniqueId, "ncclGetUniqueId")
+        NRD_SYM(CommInitRank, "ncclCommInitRank")
+        NRD_SYM(CommDestroy, "ncclCommDestroy")
+        NRD_SYM(GroupStart, "ncclGroupStart")
+        NRD_SYM(GroupEnd, "ncclGroupEnd")
+        NRD_SYM(Send, "ncclSend")
+        NRD_SYM(Recv, "ncclRecv")
+        NRD_SYM(GetErrorString, "ncclGetErrorString")
+#undef NRD_SYM
+        return true;
+    }
+};
+RcclApi g_rccl;
+#endif
+
+} // namespace
+
+struct nrdhip_tiler {
+    nrdhip_instance* inst = nullptr;
+    int rank = 0, world = 1;
+    uint32_t halo = 0;
+    int32_t frameH = 0, row0 = 0, ownFirst = 0, ownRows = 0, localH = 0;
+    nrdhip_transport tr{};
+    bool custom = false;
+#ifndef NRD_HOST_EMULATION
+    ncclComm_t comm = nullptr;
+#endif
+    hipStream_t commStream = nullptr;
+    hipEvent_t evCompute = nullptr, evComm = nullptr, evDeferred = nullptr;
+    bool deferredPending = false;
+    std::vector<uint32_t> planIds;
+    std::vector<PlanEntry> plan;
+    std::vector<uint32_t> planSig; // planes + reach of the dispatches the plan was built from (build_plan)
+    uint64_t bytesSent = 0, splitDispatches = 0, exchanges = 0, deferredExchanges = 0;
+    std::string error;
+};
+
+namespace {
+
+[[maybe_unused]] const int FAILURE = 1, INVALID = 2, UNSUPPORTED = 3; // nrd::Result values (include/NRDDescs.h)
+
+int fail(nrdhip_tiler& T, int code, const std::string& what) {
+    T.error = what;
+    return code;
+}
+
+// (pointer, rows, pitch) of pool plane `code` and the divisor between full-resolution rows and its rows (tile planes: 16)
+bool plane_of(nrdhip_tiler& T, uint32_t code, nrdhip_plane_info& P, uint32_t& div) {
+    if ((code >> 16) > 1 || nrdhip_pool_info(T.inst, code >> 16, code & 0xffff, &P) != 0 || !P.ptr || !P.height)
+        return false;
+    div = std::max<uint32_t>((uint32_t)((T.localH + P.height / 2) / P.height), 1u);
+    return true;
+}
+
+struct Op {
+    bool send;
+    uint8_t* ptr;
+    size_t bytes;
+    int peer;
+};
+
+// send / recv descriptors of one plane: the `rows` owned rows next to each band edge go to that neighbour's halo; `skip` of them
+// (nearest the edge) were delivered earlier. Order per peer is the same on both sides (NCCL matches sends and receives of a
+// group by order): [send, recv] toward the upper neighbour, then [send, recv] toward the lower one.
+void ops_of(nrdhip_tiler& T, uint8_t* base, uint32_t pitch, uint32_t planeRows, uint32_t div, uint32_t rows, uint32_t skip, std::vector<Op>& ops) {
+    const uint32_t hskip = skip / div, hrows = std::max<uint32_t>((rows + div - 1) / div, 1u);
+    const uint32_t first = (uint32_t)T.ownFirst / div, n = std::max<uint32_t>((uint32_t)T.ownRows / div, 1u);
+    auto push = [&](bool send, uint32_t a, uint32_t b, int peer) {
+        if (b > a)
+            ops.push_back({send, base + (size_t)a * pitch, (size_t)(b - a) * pitch, peer});
+    };
+    if (T.rank > 0) {
+        push(true, first + hskip, first + std::min(hrows, n), T.rank - 1);
+        push(false, first - std::min(hrows, first), first - std::min(hskip, first), T.rank - 1);
+    }
+    if (T.rank < T.world - 1) {
+        push(true, first + n - std::min(hrows, n), first + n - std::min(hskip, n), T.rank + 1);
+        push(false, std::min(first + n + hskip, planeRows), std::min(first + n + hrows, planeRows), T.rank + 1);
+    }
+}
+
+// run one batch of transfers on `stream` (RCCL: one group; custom transport: its callbacks in the same order)
+int run_ops(nrdhip_tiler& T, const std::vector<Op>& ops, hipStream_t stream) {
+    if (ops.empty())
+        return 0;
+    for (auto& o : ops)
+        if (o.send)
+            T.bytesSent += o.bytes;
+    if (T.custom) {
+        if (T.tr.group_begin && T.tr.group_begin(T.tr.user) != 0)
+            return fail(T, FAILURE, "transport group_begin failed");
+        for (auto& o : ops) {
+            int r = o.send ? T.tr.send(T.tr.user, o.ptr, o.bytes, o.peer, stream) : T.tr.recv(T.tr.user, o.ptr, o.bytes, o.peer, stream);
+            if (r != 0)
+                return fail(T, FAILURE, "transport send / recv failed");
+        }
+        if (T.tr.group_end && T.tr.group_end(T.tr.user, stream) != 0)
+            return fail(T, FAILURE, "transport group_end failed");
+        return 0;
+    }
+#ifndef NRD_HOST_EMULATION
+    if (!T.comm)
+        return fail(T, INVALID, "no transport: call nrdhip_tiler_rccl_init or pass callbacks to nrdhip_tiler_create");
+    ncclResult_t r = g_rccl.GroupStart();
+    for (auto& o : ops) {
+        if (r != ncclSuccess)
+            break;
+        r = o.send ? g_rccl.Send(o.ptr, o.bytes, ncclUint8, o.peer, T.comm, stream) : g_rccl.Recv(o.ptr, o.bytes, ncclUint8, o.peer, T.comm, stream);
+    }
+    ncclResult_t e = g_rccl.GroupEnd();
+    if (r == ncclSuccess)
+        r = e;
+    if (r != ncclSuccess)
+        return fail(T, FAILURE, std::string("RCCL: ") + g_rccl.GetErrorString(r));
+    return 0;
+#else
+    return fail(T, INVALID, "no transport callbacks");
+#endif
+}
+
+int collect(nrdhip_tiler& T, const std::vector<Xfer>& list, std::vector<Op>& ops) {
+    for (auto& x : list) {
+        nrdhip_plane_info P;
+        uint32_t div;
+        if (!plane_of(T, x.code, P, div))
+            return fail(T, INVALID, "pool plane of the exchange plan is not bound");
+        ops_of(T, (uint8_t*)P.ptr, P.pitch_bytes, P.height, div, x.rows, x.skip, ops);
+    }
+    return 0;
+}
+
+// the exchange plan of a dispatch list (rebuilt when the identifiers or a pass's reach change)
+int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
+    uint32_t count = 0;
+    int r = nrdhip_dispatch_count(T.inst, ids, n, &count);
+    if (r)
+        return fail(T, r, std::string("dispatch list: ") + nrdhip_last_error(T.inst));
+    std::vector<nrdhip_dispatch_info> d(count);
+    // signature of the dispatch list: the ping-pong planes swap every frame and settings move a pass's reach, so the plan of the
+    // previous frame is only reused when every dispatch reads / writes the same planes with the same reach
+    std::vector<uint32_t> sig;
+    for (uint32_t i = 0; i < count; i++) {
+        if ((r = nrdhip_dispatch_info_get(T.inst, ids, n, i, &d[i])) != 0)
+            return fail(T, r, "dispatch info");
+        sig.push_back(0xffff0000u | d[i].halo_rows);
+        sig.insert(sig.end(), d[i].written, d[i].written + d[i].written_num);
+        sig.push_back(0xfffe0000u);
+        sig.insert(sig.end(), d[i].read, d[i].read + d[i].read_num);
+        if (d[i].halo_rows > T.halo)
+            return fail(T, INVALID, std::string(d[i].name) + " reads " + std::to_string(d[i].halo_rows) + " rows beyond its band, the band stores " +
+                                        std::to_string(T.halo) + ": recreate the bands with nrdhip_required_halo() rows");
+    }
+    if (T.planIds == std::vector<uint32_t>(ids, ids + n) && T.planSig == sig)
+        return 0;
+    T.plan.assign(count, PlanEntry{});
+    auto has = [](const uint32_t* v, uint32_t num, uint32_t code) { return std::find(v, v + num, code) != v + num; };
+    for (uint32_t i = 0; i < count; i++)
+        for (uint32_t k = 0; k < d[i].written_num; k++) {
+            const uint32_t code = d[i].written[k];
+            if ((code >> 16) > 1)
+                continue; // output slots are final
+            uint32_t rows = 0;
+            bool rewritten = false;
+            for (uint32_t j = i + 1; j < count; j++) {
+                if (has(d[j].read, d[j].read_num, code))
+                    rows = std::max<uint32_t>(rows, d[j].halo_rows);
+                if (has(d[j].written, d[j].written_num, code)) {
+                    rewritten = true;
+                    break;
+                }
+            }
+            // permanent planes that survive the frame: the next frame reprojects into them at motion-displaced rows - full halo,
+            // but nobody reads those rows before the next frame, so they travel deferred (minus what goes strips-first)
+            if ((code >> 16) == 0 && !rewritten && rows < T.halo)
+                T.plan[i].later.push_back({code, T.halo, rows});
+            if (rows > 0)
+                T.plan[i].now.push_back({code, rows, 0});
+        }
+    T.planIds.assign(ids, ids + n);
+    T.planSig = sig;
+    return 0;
+}
+
+int wait_deferred(nrdhip_tiler& T, hipStream_t stream) {
+    if (T.deferredPending) {
+        if (!T.custom && hipStreamWaitEvent(stream, T.evDeferred, 0) != hipSuccess)
+            return fail(T, FAILURE, "hipStreamWaitEvent");
+        T.deferredPending = false;
+    }
+    return 0;
+}
+
+// comm stream picks up after everything enqueued on the compute stream so far
+int comm_after_compute(nrdhip_tiler& T, hipStream_t stream) {
+    if (T.custom)
+        return 0; // callbacks receive the compute stream and order themselves (host transports synchronise it)
+    if (hipEventRecord(T.evCompute, stream) != hipSuccess || hipStreamWaitEvent(T.commStream, T.evCompute, 0) != hipSuccess)
+        return fail(T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+NRDHIP_API int nrdhip_required_halo(nrdhip_instance* inst, const uint32_t* ids, uint32_t n, uint32_t motion_rows, uint32_t* out) {
+    if (!inst || !out)
+        return INVALID;
+    uint32_t count = 0;
+    int r = nrdhip_dispatch_count(inst, ids, n, &count);
+    if (r)
+        return r;
+    uint32_t h = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        nrdhip_dispatch_info d;
+        if ((r = nrdhip_dispatch_info_get(inst, ids, n, i, &d)) != 0)
+            return r;
+        h = std::max<uint32_t>(h, d.halo_rows);
+    }
+    *out = (h + motion_rows + 15u) / 16u * 16u; // multiple of 16: band tile grids coincide with the single-GPU tile grid
+    return 0;
+}
+
+NRDHIP_API int nrdhip_tiler_create(nrdhip_instance* inst, int rank, int world, const nrdhip_transport* transport, nrdhip_tiler** out) {
+    if (!inst || !out || world < 1 || rank < 0 || rank >= world)
+        return INVALID;
+    int32_t band[5];
+    if (nrdhip_get_band(inst, band) != 0)
+        return INVALID;
+    auto* T = new nrdhip_tiler();
+    T->inst = inst;
+    T->rank = rank;
+    T->world = world;
+    T->frameH = band[0];
+    T->row0 = band[1];
+    T->ownFirst = band[2];
+    T->ownRows = band[3];
+    T->localH = band[4];
+    // rows stored beyond the owned band, on the side(s) that have a neighbour
+    uint32_t above = (uint32_t)T->ownFirst, below = (uint32_t)(T->localH - T->ownFirst - T->ownRows);
+    T->halo = world == 1 ? 0u : (rank == 0 ? below : (rank == world - 1 ? above : std::min(above, below)));
+    if (world > 1 && (uint32_t)T->ownRows < T->halo) {
+        delete T;
+        return INVALID; // a band shorter than its halo cannot feed its neighbour's halo from owned rows
+    }
+    if (transport) {
+        if (!transport->send || !transport->recv) {
+            delete T;
+            return INVALID;
+        }
+        T->tr = *transport;
+        T->custom = true;
+    }
+    *out = T;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_tiler_rccl_unique_id(void* out128) {
+#ifndef NRD_HOST_EMULATION
+    std::string err;
+    if (!out128 || !g_rccl.load(err))
+        return FAILURE;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    return g_rccl.GetUniqueId((ncclUniqueId*)out128) == ncclSuccess ? 0 : FAILURE;
+#else
+    (void)out128;
+    return UNSUPPORTED;
+#endif
+}
+
+NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* T, const void* unique_id128) {
+#ifndef NRD_HOST_EMULATION
+    if (!T || !unique_id128 || T->custom)
+        return INVALID;
+    if (!g_rccl.load(T->error))
+        return FAILURE;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&T->comm, T->world, id, T->rank); // on the current HIP device (one rank per GPU)
+    if (r != ncclSuccess)
+        return fail(*T, FAILURE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    if (hipStreamCreateWithFlags(&T->commStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T->evCompute, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&T->evComm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&T->evDeferred, hipEventDisableTiming) != hipSuccess)
+        return fail(*T, FAILURE, "side stream / events");
+    return 0;
+#else
+    (void)T;
+    (void)unique_id128;
+    return UNSUPPORTED;
+#endif
+}
+
+NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
+    if (!T)
+        return;
+#ifndef NRD_HOST_EMULATION
+    if (T->comm)
+        g_rccl.CommDestroy(T->comm);
+    if (T->commStream)
+        (void)hipStreamDestroy(T->commStream);
+    for (hipEvent_t e : {T->evCompute, T->evComm, T->evDeferred})
+        if (e)
+            (void)hipEventDestroy(e);
+#endif
+    delete T;
+}
+
+NRDHIP_API int nrdhip_tiler_halo(nrdhip_tiler* T, uint32_t* rows) {
+    if (!T || !rows)
+        return INVALID;
+    *rows = T->halo;
+    return 0;
+}
+
+// external inputs arrive per band (a renderer produces each band's rows): refresh the halo rows of the given bound slots
+NRDHIP_API int nrdhip_tiler_exchange_inputs(nrdhip_tiler* T, const uint32_t* slots, uint32_t n, void* stream) {
+    if (!T || (!slots && n))
+        return INVALID;
+    if (T->world == 1)
+        return 0;
+    std::vector<Op> ops;
+    for (uint32_t i = 0; i < n; i++) {
+        nrdhip_plane_info P;
+        if (nrdhip_slot_info(T->inst, slots[i], &P) != 0 || !P.ptr)
+            return fail(*T, INVALID, "input slot not bound");
+        if ((int32_t)P.height != T->localH)
+            continue; // planes sampled by uv (confidence) are whole-frame, not banded
+        ops_of(*T, (uint8_t*)P.ptr, P.pitch_bytes, P.height, 1, T->halo, 0, ops);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int r = comm_after_compute(*T, st);
+    if (!r)
+        r = run_ops(*T, ops, T->custom ? st : T->commStream);
+    if (!r && !T->custom && (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess))
+        r = fail(*T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
+    T->exchanges++;
+    return r;
+}
+
+NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32_t n, void* stream) {
+    if (!T || !ids || !n)
+        return INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (T->world == 1)
+        return nrdhip_denoise(T->inst, ids, n, stream);
+    int r = build_plan(*T, ids, n);
+    if (r)
+        return r;
+    if ((r = wait_deferred(*T, st)) != 0) // a new dispatch list: last frame's permanent planes must have arrived
+        return r;
+    const bool up = T->rank > 0, down = T->rank < T->world - 1;
+    for (uint32_t i = 0; i < T->plan.size(); i++) {
+        const PlanEntry& e = T->plan[i];
+        uint32_t strip = 0;
+        for (auto& x : e.now)
+            strip = std::max(strip, x.rows);
+        strip = (strip + 15u) / 16u * 16u;
+        std::vector<Op> ops;
+        if ((r = collect(*T, e.now, ops)) != 0)
+            return r;
+        const bool split = !e.now.empty() && (up || down) && (uint32_t)T->ownRows >= 4 * strip && T->ownFirst % 16 == 0;
+        if (!split) {
+            if ((r = nrdhip_denoise_range(T->inst, ids, n, i, 1, stream)) != 0)
+                return fail(*T, r, nrdhip_last_error(T->inst));
+            if (!ops.empty()) {
+                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, ops, T->custom ? st : T->commStream)) != 0)
+                    return r;
+                if (!T->custom && (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess))
+                    return fail(*T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
+                T->exchanges++;
+            }
+        } else {
+            // boundary strips first, their rows travel while the interior is computed
+            T->splitDispatches++;
+            const uint32_t own0 = (uint32_t)T->ownFirst, ownN = (uint32_t)T->ownRows;
+            const uint32_t lo = own0 + (up ? strip : 0), hi = own0 + ownN - (down ? strip : 0);
+            bool first = true;
+            if (up) {
+                if ((r = nrdhip_denoise_rows(T->inst, ids, n, i, own0, strip, NRDHIP_PART_FIRST, stream)) != 0)
+                    return fail(*T, r, nrdhip_last_error(T->inst));
+                first = false;
+            }
+            if (down && (r = nrdhip_denoise_rows(T->inst, ids, n, i, hi, own0 + ownN - hi, first ? NRDHIP_PART_FIRST : 0u, stream)) != 0)
+                return fail(*T, r, nrdhip_last_error(T->inst));
+            if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, ops, T->custom ? st : T->commStream)) != 0)
+                return r;
+            if (!T->custom && hipEventRecord(T->evComm, T->commStream) != hipSuccess)
+                return fail(*T, FAILURE, "hipEventRecord");
+            if ((r = nrdhip_denoise_rows(T->inst, ids, n, i, lo, hi - lo, NRDHIP_PART_LAST, stream)) != 0)
+                return fail(*T, r, nrdhip_last_error(T->inst));
+            if (!T->custom && hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess)
+                return fail(*T, FAILURE, "hipStreamWaitEvent");
+            T->exchanges++;
+        }
+        if (!e.later.empty()) {
+            std::vector<Op> lops;
+            if ((r = collect(*T, e.later, lops)) != 0)
+                return r;
+            if (!lops.empty()) {
+                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, lops, T->custom ? st : T->commStream)) != 0)
+                    return r;
+                if (!T->custom && hipEventRecord(T->evDeferred, T->commStream) != hipSuccess)
+                    return fail(*T, FAILURE, "hipEventRecord");
+                T->deferredPending = true;
+                T->deferredExchanges++;
+            }
+        }
+    }
+    return 0;
+}
+
+// rows only the next frame reads may still be travelling: make `stream` wait for them (end of a run, before reading pool planes)
+NRDHIP_API int nrdhip_tiler_finish(nrdhip_tiler* T, void* stream) { return T ? wait_deferred(*T, (hipStream_t)stream) : INVALID; }
+
+NRDHIP_API int nrdhip_tiler_stats(nrdhip_tiler* T, uint64_t out[4]) {
+    if (!T || !out)
+        return INVALID;
+    out[0] = T->bytesSent;
+    out[1] = T->splitDispatches;
+    out[2] = T->exchanges;
+    out[3] = T->deferredExchanges;
+    return 0;
+}
+
+NRDHIP_API const char* nrdhip_tiler_last_error(nrdhip_tiler* T) { return T ? T->error.c_str() : "null tiler"; }
+}

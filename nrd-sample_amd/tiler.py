@@ -15,7 +15,12 @@ import numpy as np
 from . import api
 from .harness import INPUT_SLOTS, OUTPUT_SLOTS, Harness
 
-DEFAULT_HALO = 80  # rows; multiple of 16 so band tile grids coincide with the single-GPU tile grid
+DEFAULT_HALO = 80  # rows; multiple of 16 so band tile grids coincide with the single-GPU tile grid (default settings need 80)
+DEFAULT_MOTION_ROWS = 8  # vertical motion (rows) reprojection may follow beyond a pass's own reach
+
+
+class HaloError(ValueError):
+    """a pass reads farther than the rows the band stores: the tiled result would differ from the single-GPU frame"""
 
 
 def band_layout(frame_h, world, rank, halo):
@@ -28,9 +33,36 @@ def band_layout(frame_h, world, rank, halo):
     return dict(own0=own0, own1=own1, row0=row0, local_h=row1 - row0, own_first=own0 - row0, own_rows=own1 - own0)
 
 
-def required_halo(dispatches, motion_rows=8):
+def required_halo(dispatches, motion_rows=DEFAULT_MOTION_ROWS):
+    """rows a band must store beyond its owned rows: the largest read reach of the dispatch list + the vertical motion the
+    temporal passes may follow, rounded up to whole tiles (== nrdhip_required_halo of the C-ABI)"""
     h = max([d["halo_rows"] for d in dispatches] + [0]) + motion_rows
     return (h + 15) // 16 * 16
+
+
+def probe_halo(backend, denoisers, settings=None, motion_rows=DEFAULT_MOTION_ROWS):
+    """required_halo() for a denoiser list + settings BEFORE the band instances exist (their size depends on it): the reach of
+    a pass depends on settings only (blur radii, pre-pass radii, A-trous iteration count), so a 64x64 throw-away instance
+    answers. ``settings``: {Denoiser: settings struct} (defaults for the rest)."""
+    nrd = api.Integration(backend)
+    r = nrd.recreate([(int(d), d) for d in denoisers], 64, 64)
+    if r != api.Result.SUCCESS:
+        raise api.NrdError("Recreate(probe)", int(r))
+    try:
+        cs = api.CommonSettings()
+        cs.rectSize[0] = cs.rectSize[1] = cs.resourceSize[0] = cs.resourceSize[1] = 64
+        cs.rectSizePrev[0] = cs.rectSizePrev[1] = cs.resourceSizePrev[0] = cs.resourceSizePrev[1] = 64
+        cs.viewToClipMatrix[0] = cs.viewToClipMatrix[5] = cs.viewToClipMatrix[11] = 1.0
+        cs.viewToClipMatrixPrev[0] = cs.viewToClipMatrixPrev[5] = cs.viewToClipMatrixPrev[11] = 1.0
+        for i in (0, 5, 10, 15):
+            cs.worldToViewMatrix[i] = cs.worldToViewMatrixPrev[i] = 1.0
+        nrd.set_common_settings(cs)
+        for d, st in (settings or {}).items():
+            if d in denoisers:
+                nrd.set_denoiser_settings(int(d), st)
+        return required_halo(nrd.dispatches([int(d) for d in denoisers]), motion_rows)
+    finally:
+        nrd.destroy()
 
 
 class BandHarness(Harness):
@@ -98,7 +130,9 @@ class Tiler:
                     if code in r["written"]:
                         rewritten = True
                         break
-                rows = min(rows, self.band.halo)
+                if rows > self.band.halo:  # never clamp: a clamped reach is a silently different image
+                    raise HaloError("a pass after %s reads %d rows beyond its band, the band stores %d: create the bands with "
+                                    "halo=required_halo(dispatches, motion_rows) (probe_halo())" % (d["name"], rows, self.band.halo))
                 if (code >> 16) == 0 and not rewritten and rows < self.band.halo:
                     later.append((code, self.band.halo, rows))  # the `rows` nearest the band edge travel at once (below)
                 if rows > 0:
@@ -242,19 +276,168 @@ class Tiler:
         for w in works:
             w.wait()
 
+    def check_halo(self, dispatches, motion_rows=0):
+        need = max([d["halo_rows"] for d in dispatches] + [0]) + motion_rows
+        if self.band.world > 1 and need > self.band.halo:
+            worst = max(dispatches, key=lambda d: d["halo_rows"])
+            raise HaloError("%s reads %d rows (+ %d rows of motion) beyond its band, the band stores %d: create the bands with "
+                            "halo=probe_halo(...)" % (worst["name"], worst["halo_rows"], motion_rows, self.band.halo))
+
     def denoise(self, identifiers):
         ids = [int(i) for i in identifiers]
         nrd = self.band.nrd
         dispatches = nrd.dispatches(ids)
+        self.check_halo(dispatches)
         plan = self._plan(ids, dispatches)
         for i, entry in enumerate(plan):
             self.run_dispatch(ids, i, entry)
 
 
+class NativeTiler:
+    """The row tiler BELOW the C-ABI (csrc/nrdhip_tiler.cpp, include/nrdhip.h nrdhip_tiler_*): exchange plan, strips-first
+    overlap and the exchanges themselves live in C++. ``transport``: "rccl" - ncclSend / ncclRecv groups on a side stream (the
+    ncclUniqueId of rank 0 travels through torch.distributed once); "dist" - callbacks that move the rows with
+    torch.distributed isend / irecv (gloo in the CPU tests; any backend), used to check the C++ plan without RCCL."""
+
+    def __init__(self, band, dist=None, transport="rccl", group=None):
+        import ctypes as C
+
+        self.band, self.dist, self.group = band, dist, group
+        b = band.backend
+        if not getattr(b, "has_tiler", False):
+            raise RuntimeError("this backend library has no nrdhip_tiler_* entry points")
+        self._works, self._keep = [], []
+        self._tr = None
+        if transport == "dist":
+            self._tr = api.Transport(None, api.TRANSPORT_BEGIN(self._begin), api.TRANSPORT_XFER(self._send), api.TRANSPORT_XFER(self._recv),
+                                     api.TRANSPORT_END(self._end))
+        h = C.c_void_p()
+        r = b.tiler_create(band.nrd.handle, band.rank, band.world, C.byref(self._tr) if self._tr is not None else None, C.byref(h))
+        if r != 0:
+            raise api.NrdError("nrdhip_tiler_create (band shorter than its halo?)", r)
+        self.handle = h
+        if transport == "rccl" and band.world > 1:
+            import torch
+
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if band.rank == 0:
+                buf = (C.c_uint8 * 128)()
+                self._check(b.tiler_rccl_unique_id(buf), "ncclGetUniqueId")
+                uid = torch.tensor(list(buf), dtype=torch.uint8)
+            dev = uid.to(b.device) if dist.get_backend(group) == "nccl" else uid
+            dist.broadcast(dev, 0, group=group)
+            raw = (C.c_uint8 * 128)(*dev.cpu().tolist())
+            self._check(b.tiler_rccl_init(self.handle, raw), "ncclCommInitRank")
+
+    def _check(self, r, what):
+        if r != 0:
+            raise api.NrdError(what, r, (self.band.backend.tiler_last_error(self.handle) or b"").decode())
+
+    # ---- "dist" transport: the C++ tiler calls back with raw (pointer, bytes) ranges of planes this process allocated
+    def _view(self, ptr, nbytes):
+        nrd = self.band.nrd
+        cands = [p["buf"] for pool in (0, 1) for p in nrd.pools[pool]] + list(nrd._bound.values())
+        for buf in cands:
+            base = buf.data_ptr() if hasattr(buf, "data_ptr") else buf.ctypes.data
+            size = buf.numel() * buf.element_size() if hasattr(buf, "numel") else buf.nbytes
+            if base <= ptr and ptr + nbytes <= base + size:
+                flat = buf.reshape(-1) if hasattr(buf, "data_ptr") else buf.reshape(-1)
+                off = ptr - base
+                view = flat[off:off + nbytes]
+                if not hasattr(view, "data_ptr"):
+                    import torch
+                    view = torch.from_numpy(view)
+                return view
+        raise KeyError("transfer range is not inside a plane owned by this process")
+
+    def _begin(self, user):
+        self._works, self._keep = [], []
+        return 0
+
+    def _xfer(self, fn, ptr, nbytes, peer):
+        try:
+            t = self._view(ptr, nbytes)
+            if t.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                import torch
+                torch.cuda.synchronize()
+            self._keep.append(t)
+            self._works.append(fn(t, peer, group=self.group))
+            return 0
+        except Exception as e:  # never raise through the C frame
+            self._error = e
+            return 1
+
+    def _send(self, user, ptr, nbytes, peer, stream):
+        return self._xfer(self.dist.isend, ptr, nbytes, peer)
+
+    def _recv(self, user, ptr, nbytes, peer, stream):
+        return self._xfer(self.dist.irecv, ptr, nbytes, peer)
+
+    def _end(self, user, stream):
+        try:
+            for w in self._works:
+                w.wait()
+            self._works, self._keep = [], []
+            return 0
+        except Exception as e:
+            self._error = e
+            return 1
+
+    # ---- the Tiler interface
+    def _stream(self):
+        return self.band.nrd._stream()
+
+    def exchange_inputs(self, planes):
+        import ctypes as C
+
+        keys = set(planes)
+        slots = sorted(int(slot) for slot, (key, _) in INPUT_SLOTS.items() if key in keys and key != "confidence")
+        self.band.bind(planes)
+        arr = (C.c_uint32 * len(slots))(*slots)
+        self._check(self.band.backend.tiler_exchange_inputs(self.handle, arr, len(slots), self._stream()), "tiler_exchange_inputs")
+
+    def denoise(self, identifiers):
+        import ctypes as C
+
+        ids = [int(i) for i in identifiers]
+        arr = (C.c_uint32 * len(ids))(*ids)
+        self._check(self.band.backend.tiler_denoise(self.handle, arr, len(ids), self._stream()), "tiler_denoise")
+
+    def finish(self):
+        self._check(self.band.backend.tiler_finish(self.handle, self._stream()), "tiler_finish")
+
+    def stats(self):
+        import ctypes as C
+
+        out = (C.c_uint64 * 4)()
+        self.band.backend.tiler_stats(self.handle, out)
+        return dict(bytes_sent=int(out[0]), split_dispatches=int(out[1]), exchanges=int(out[2]), deferred=int(out[3]))
+
+    @property
+    def bytes_exchanged(self):
+        return self.stats()["bytes_sent"]
+
+    @property
+    def split_dispatches(self):
+        return self.stats()["split_dispatches"]
+
+    def destroy(self):
+        if self.handle is not None:
+            self.band.backend.tiler_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class TiledRunner:
     """bench.py's N > 1 path: every rank renders its band of the synthetic scene on its GPU, then steps the tiler."""
 
-    def __init__(self, pkg, backend, device, dens, width, frame_h, rank, world, unique, dolly, settings_of):
+    def __init__(self, pkg, backend, device, dens, width, frame_h, rank, world, unique, dolly, settings_of, tiler="python",
+                 motion_rows=DEFAULT_MOTION_ROWS):
         import torch
         import torch.distributed as dist
 
@@ -262,8 +445,15 @@ class TiledRunner:
 
         self.pingpong = pingpong
         self.api, self.dens, self.unique = pkg.api, dens, unique
-        self.band = BandHarness(backend, dens, width, frame_h, rank, world)
-        self.tiler = Tiler(self.band, dist)
+        # the rows a band stores beyond its own come from the settings actually used (reach of every pass + motion), not a constant
+        probe_scene = pkg.synth.Scene(64, 64, dolly=dolly, device=device)
+        self.halo = probe_halo(backend, dens, settings_of(pkg.api, probe_scene, dens), motion_rows)
+        self.band = BandHarness(backend, dens, width, frame_h, rank, world, halo=self.halo)
+        if tiler == "native":
+            self.tiler = NativeTiler(self.band, dist, transport="rccl" if dist.get_backend() == "nccl" else "dist")
+        else:
+            self.tiler = Tiler(self.band, dist)
+        self.native = tiler == "native"
         L = self.band.layout
         self.scene = pkg.synth.Scene(width, L["local_h"], dolly=dolly, device=device, frame_height=frame_h, row0=L["row0"])
         self.settings = settings_of(pkg.api, self.scene, dens)
@@ -300,7 +490,7 @@ class TiledRunner:
         band.bind(planes)
         for d in self.dens:
             band.nrd.set_denoiser_settings(int(d), self.settings[d])
-        if not self.events_on:
+        if not self.events_on or self.native:  # the C++ tiler steps the dispatches itself (no per-dispatch events)
             self.tiler.denoise(self.ids)
             return
         # timed variant: same stepping, HIP events around each dispatch (its strips + interior; the wait for the rows in
@@ -332,3 +522,7 @@ class TiledRunner:
                 t, n, _ = acc.get(name, (0.0, 0, bpp))
                 acc[name] = (t + a.elapsed_time(b), n + 1, bpp)
         return {k: (t / n, bpp) for k, (t, n, bpp) in acc.items()}
+
+    def dispatch_table(self):
+        """[(pass name, algorithmic bytes per pixel)] of one frame (for the roofline object when no per-dispatch events exist)"""
+        return [(x["name"], x["bytes_per_pixel"]) for x in self.band.nrd.dispatches(self.ids)]

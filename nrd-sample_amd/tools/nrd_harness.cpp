@@ -6,14 +6,25 @@
 //   Sample::Denoise ....... ResourceSnapshot::SetResource for every slot, Integration::Denoise (:440-531)
 // Inputs are raw plane files (written by tests/test_cpp_harness.py or any producer); outputs are written back as raw files.
 //
-//   nrd_harness <dir> <width> <height> <frames>
+//   nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl]]
+// --ranks N: the same frames row-tiled across N ranks (nrd::TiledIntegration over the C++ row tiler, nrdhip_tiler_*), one host
+// thread per rank; without --rccl the ranks share GPU 0 and halo rows travel through an in-process mailbox (a stand-in fabric:
+// exercises the exchange plan, the strips / interior split and the band addressing on a 1-GPU box); with --rccl rank r runs on
+// GPU r and the rows travel with ncclSend / ncclRecv (needs N GPUs: refuses loudly otherwise). Outputs are written exactly like
+// the 1-rank run's, so the two can be compared byte for byte.
 #include "../../include/NRDIntegration.h"
 
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define NRD_ID(x) nrd::Identifier(nrd::Denoiser::x) // same macro as the sample (Source/NRDSample.cpp:226)
@@ -78,14 +89,288 @@ static nrd::Resource GetNrdResource(const Texture& t) { // Sample::GetNrdResourc
     return r;
 }
 
+// ---- row-tiled run (--ranks N) -----------------------------------------------------------------------------------------
+namespace tiled {
+
+// in-process stand-in for the fabric: one FIFO per (source, destination) pair; sends never block, receives wait for their message
+struct Mailbox {
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<std::vector<uint8_t>>> q;
+};
+struct Endpoint {
+    Mailbox* box;
+    int rank;
+};
+static int mbSend(void* user, const void* ptr, size_t bytes, int peer, void* stream) {
+    auto* e = (Endpoint*)user;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) // the rows were produced on this stream
+        return 1;
+    std::vector<uint8_t> msg(bytes);
+    if (hipMemcpy(msg.data(), ptr, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        return 1;
+    {
+        std::lock_guard<std::mutex> l(e->box->m);
+        e->box->q[{e->rank, peer}].push_back(std::move(msg));
+    }
+    e->box->cv.notify_all();
+    return 0;
+}
+static int mbRecv(void* user, void* ptr, size_t bytes, int peer, void*) {
+    auto* e = (Endpoint*)user;
+    std::vector<uint8_t> msg;
+    {
+        std::unique_lock<std::mutex> l(e->box->m);
+        auto& dq = e->box->q[{peer, e->rank}];
+        e->box->cv.wait(l, [&] { return !dq.empty(); });
+        msg = std::move(dq.front());
+        dq.pop_front();
+    }
+    if (msg.size() != bytes)
+        return 1;
+    return hipMemcpy(ptr, msg.data(), bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+}
+
+struct Shared {
+    std::string dir;
+    uint16_t w, h;
+    int frames, world;
+    bool rccl;
+    Mailbox box;
+    uint8_t uniqueId[128];
+    std::vector<uint8_t> outDiff, outSpec, outShadow, outSignal; // whole-frame outputs assembled from the ranks' owned rows
+    std::vector<int> status;
+};
+
+static bool loadRows(const std::string& path, Texture& t, int row0, uint16_t frameH) {
+    std::vector<uint8_t> host((size_t)t.pitch * frameH, 0);
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        fprintf(stderr, "missing input: %s\n", path.c_str());
+        return false;
+    }
+    size_t n = fread(host.data(), 1, host.size(), f);
+    fclose(f);
+    if (n != host.size())
+        return false;
+    return hipMemcpy(t.ptr, host.data() + (size_t)row0 * t.pitch, t.bytes(), hipMemcpyHostToDevice) == hipSuccess;
+}
+static bool fetchOwned(const Texture& t, int ownFirst, int ownRows, int globalRow, std::vector<uint8_t>& whole) {
+    return hipMemcpy(whole.data() + (size_t)globalRow * t.pitch, (const uint8_t*)t.ptr + (size_t)ownFirst * t.pitch, (size_t)ownRows * t.pitch, hipMemcpyDeviceToHost) == hipSuccess;
+}
+
+static void rankMain(Shared* S, int rank) {
+    using F = nrd::Format;
+    using RT = nrd::ResourceType;
+    int& status = S->status[rank];
+    status = 1;
+    const int device = S->rccl ? rank : 0;
+    if (hipSetDevice(device) != hipSuccess)
+        return;
+    const uint16_t w = S->w, h = S->h;
+    const nrd::DenoiserDesc denoisersDescs[] = {
+        {NRD_ID(REBLUR_DIFFUSE_SPECULAR), nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR},
+        {NRD_ID(SIGMA_SHADOW), nrd::Denoiser::SIGMA_SHADOW_TRANSLUCENCY},
+        {NRD_ID(REFERENCE), nrd::Denoiser::REFERENCE},
+    };
+    nrd::InstanceCreationDesc instanceCreationDesc = {};
+    instanceCreationDesc.denoisers = denoisersDescs;
+    instanceCreationDesc.denoisersNum = 3;
+    nrd::IntegrationCreationDesc desc = {};
+    desc.resourceWidth = w;
+    desc.resourceHeight = h; // the WHOLE frame; the band follows from (rank, world, halo)
+    // halo rows: reach of every pass with the settings used below + motion margin (static camera: the default 8 rows)
+    uint32_t halo = 0;
+    {
+        nrd::Integration probe;
+        nrd::IntegrationCreationDesc pd = desc;
+        pd.resourceWidth = pd.resourceHeight = 64;
+        if (probe.Recreate(pd, instanceCreationDesc, device) != nrd::Result::SUCCESS)
+            return;
+        nrd::CommonSettings cs = {};
+        cs.resourceSize[0] = cs.resourceSize[1] = cs.rectSize[0] = cs.rectSize[1] = cs.resourceSizePrev[0] = cs.resourceSizePrev[1] = cs.rectSizePrev[0] = cs.rectSizePrev[1] = 64;
+        cs.viewToClipMatrix[0] = cs.viewToClipMatrix[5] = cs.viewToClipMatrix[11] = cs.viewToClipMatrixPrev[0] = cs.viewToClipMatrixPrev[5] = cs.viewToClipMatrixPrev[11] = 1.0f;
+        for (int i : {0, 5, 10, 15})
+            cs.worldToViewMatrix[i] = cs.worldToViewMatrixPrev[i] = 1.0f;
+        probe.SetCommonSettings(cs);
+        const nrd::Identifier all[] = {NRD_ID(SIGMA_SHADOW), NRD_ID(REBLUR_DIFFUSE_SPECULAR), NRD_ID(REFERENCE)};
+        if (nrdhip_required_halo((nrdhip_instance*)probe.GetInstance(), all, 3, 8, &halo) != 0)
+            return;
+    }
+    Endpoint ep{&S->box, rank};
+    nrdhip_transport tr{&ep, nullptr, mbSend, mbRecv, nullptr};
+    nrd::TiledIntegration m_NRD;
+    if (m_NRD.Recreate(desc, instanceCreationDesc, device, rank, S->world, halo, S->rccl ? nullptr : &tr) != nrd::Result::SUCCESS) {
+        fprintf(stderr, "rank %d: Recreate failed (bands shorter than the %u-row halo?)\n", rank, halo);
+        return;
+    }
+    if (S->rccl && m_NRD.InitRccl(S->uniqueId) != nrd::Result::SUCCESS) {
+        fprintf(stderr, "rank %d: RCCL init failed: %s\n", rank, m_NRD.GetTilerError());
+        return;
+    }
+    const uint16_t lh = m_NRD.LocalHeight();
+    const int row0 = m_NRD.Row0();
+    Texture Mv = makeTexture(w, lh, F::RGBA16_SFLOAT, 8), Normal_Roughness = makeTexture(w, lh, F::R10_G10_B10_A2_UNORM, 4), ViewZ = makeTexture(w, lh, F::R32_SFLOAT, 4);
+    Texture Unfiltered_Diff = makeTexture(w, lh, F::RGBA16_SFLOAT, 8), Unfiltered_Spec = makeTexture(w, lh, F::RGBA16_SFLOAT, 8);
+    Texture Diff = makeTexture(w, lh, F::RGBA16_SFLOAT, 8), Spec = makeTexture(w, lh, F::RGBA16_SFLOAT, 8);
+    Texture Unfiltered_Penumbra = makeTexture(w, lh, F::R16_SFLOAT, 2), Unfiltered_Translucency = makeTexture(w, lh, F::RGBA8_UNORM, 4), Shadow = makeTexture(w, lh, F::RGBA8_UNORM, 4);
+    Texture Composed = makeTexture(w, lh, F::RGBA16_SFLOAT, 8), Validation = makeTexture(w, lh, F::RGBA8_UNORM, 4);
+    const std::string& dir = S->dir;
+    if (!loadRows(dir + "/mv.bin", Mv, row0, h) || !loadRows(dir + "/normal_roughness.bin", Normal_Roughness, row0, h) || !loadRows(dir + "/viewz.bin", ViewZ, row0, h) ||
+        !loadRows(dir + "/diff.bin", Unfiltered_Diff, row0, h) || !loadRows(dir + "/spec.bin", Unfiltered_Spec, row0, h) || !loadRows(dir + "/penumbra.bin", Unfiltered_Penumbra, row0, h) ||
+        !loadRows(dir + "/translucency.bin", Unfiltered_Translucency, row0, h) || !loadRows(dir + "/signal.bin", Composed, row0, h))
+        return;
+    hipStream_t stream;
+    (void)hipStreamCreate(&stream);
+    nrd::ReblurSettings m_ReblurSettings = {};
+    nrd::SigmaSettings m_SigmaSettings = {};
+    nrd::ReferenceSettings m_ReferenceSettings = {};
+    auto snapshot = [&](nrd::ResourceSnapshot& rs) {
+        rs.SetResource(RT::IN_MV, GetNrdResource(Mv));
+        rs.SetResource(RT::IN_NORMAL_ROUGHNESS, GetNrdResource(Normal_Roughness));
+        rs.SetResource(RT::IN_VIEWZ, GetNrdResource(ViewZ));
+        rs.SetResource(RT::OUT_VALIDATION, GetNrdResource(Validation));
+        rs.SetResource(RT::IN_DIFF_RADIANCE_HITDIST, GetNrdResource(Unfiltered_Diff));
+        rs.SetResource(RT::OUT_DIFF_RADIANCE_HITDIST, GetNrdResource(Diff));
+        rs.SetResource(RT::IN_SPEC_RADIANCE_HITDIST, GetNrdResource(Unfiltered_Spec));
+        rs.SetResource(RT::OUT_SPEC_RADIANCE_HITDIST, GetNrdResource(Spec));
+        rs.SetResource(RT::IN_PENUMBRA, GetNrdResource(Unfiltered_Penumbra));
+        rs.SetResource(RT::IN_TRANSLUCENCY, GetNrdResource(Unfiltered_Translucency));
+        rs.SetResource(RT::OUT_SHADOW_TRANSLUCENCY, GetNrdResource(Shadow));
+        rs.SetResource(RT::IN_SIGNAL, GetNrdResource(Composed));
+        rs.SetResource(RT::OUT_SIGNAL, GetNrdResource(Composed));
+    };
+    for (int frameIndex = 0; frameIndex < S->frames; frameIndex++) {
+        nrd::CommonSettings commonSettings = {};
+        float aspect = (float)w / (float)h;
+        float proj[16] = {1, 0, 0, 0, 0, aspect, 0, 0, 0, 0, 1, 1, 0, 0, -0.05f, 0};
+        float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        memcpy(commonSettings.viewToClipMatrix, proj, sizeof(proj));
+        memcpy(commonSettings.viewToClipMatrixPrev, proj, sizeof(proj));
+        memcpy(commonSettings.worldToViewMatrix, ident, sizeof(ident));
+        memcpy(commonSettings.worldToViewMatrixPrev, ident, sizeof(ident));
+        commonSettings.motionVectorScale[0] = 1.0f / float(w);
+        commonSettings.motionVectorScale[1] = 1.0f / float(h);
+        commonSettings.motionVectorScale[2] = 1.0f;
+        commonSettings.resourceSize[0] = commonSettings.resourceSizePrev[0] = commonSettings.rectSize[0] = commonSettings.rectSizePrev[0] = w;
+        commonSettings.resourceSize[1] = commonSettings.resourceSizePrev[1] = commonSettings.rectSize[1] = commonSettings.rectSizePrev[1] = h; // the whole frame
+        commonSettings.viewZScale = 1.0f;
+        commonSettings.denoisingRange = 100.0f;
+        commonSettings.disocclusionThreshold = 0.01f;
+        commonSettings.disocclusionThresholdAlternate = 0.1f;
+        commonSettings.frameIndex = (uint32_t)frameIndex;
+        commonSettings.accumulationMode = frameIndex == 0 ? nrd::AccumulationMode::CLEAR_AND_RESTART : nrd::AccumulationMode::CONTINUE;
+        m_NRD.NewFrame();
+        m_NRD.SetCommonSettings(commonSettings);
+        m_SigmaSettings.lightDirection[0] = 0.0f;
+        m_SigmaSettings.lightDirection[1] = 0.0f;
+        m_SigmaSettings.lightDirection[2] = -1.0f;
+        nrd::ReblurHitDistanceParameters hitDistanceParameters = {};
+        hitDistanceParameters.A = 3.0f;
+        m_ReblurSettings.hitDistanceParameters = hitDistanceParameters;
+        const nrd::Identifier order[] = {NRD_ID(SIGMA_SHADOW), NRD_ID(REBLUR_DIFFUSE_SPECULAR), NRD_ID(REFERENCE)};
+        const void* settings[] = {&m_SigmaSettings, &m_ReblurSettings, &m_ReferenceSettings};
+        for (int k = 0; k < 3; k++) {
+            m_NRD.SetDenoiserSettings(order[k], settings[k]);
+            nrd::ResourceSnapshot rs = {};
+            snapshot(rs);
+            if (frameIndex == 0 && k == 0) { // inputs are static here: one halo refresh (a renderer would do it per frame)
+                const RT in[] = {RT::IN_MV, RT::IN_NORMAL_ROUGHNESS, RT::IN_VIEWZ, RT::IN_DIFF_RADIANCE_HITDIST, RT::IN_SPEC_RADIANCE_HITDIST, RT::IN_PENUMBRA, RT::IN_TRANSLUCENCY};
+                if (m_NRD.ExchangeInputs(in, 7, stream, rs) != nrd::Result::SUCCESS)
+                    return;
+            }
+            if (m_NRD.Denoise(&order[k], 1, stream, rs) != nrd::Result::SUCCESS) {
+                fprintf(stderr, "rank %d: Denoise failed: %s / %s\n", rank, m_NRD.GetTilerError(), m_NRD.GetLastError());
+                return;
+            }
+        }
+    }
+    if (m_NRD.Finish(stream) != nrd::Result::SUCCESS || hipStreamSynchronize(stream) != hipSuccess)
+        return;
+    const int own0 = m_NRD.OwnFirst(), ownN = m_NRD.OwnRows(), g0 = row0 + own0;
+    if (!fetchOwned(Diff, own0, ownN, g0, S->outDiff) || !fetchOwned(Spec, own0, ownN, g0, S->outSpec) || !fetchOwned(Shadow, own0, ownN, g0, S->outShadow) ||
+        !fetchOwned(Composed, own0, ownN, g0, S->outSignal))
+        return;
+    uint64_t st[4] = {};
+    nrdhip_tiler_stats(m_NRD.GetTiler(), st);
+    printf("rank %d: rows [%d, %d), halo %u, %llu bytes sent, %llu dispatches split into strips + interior\n", rank, g0, g0 + ownN, halo, (unsigned long long)st[0],
+           (unsigned long long)st[1]);
+    m_NRD.Destroy();
+    status = 0;
+}
+
+static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int world, bool rccl) {
+    Shared S;
+    S.dir = dir;
+    S.w = w;
+    S.h = h;
+    S.frames = frames;
+    S.world = world;
+    S.rccl = rccl;
+    S.status.assign(world, 1);
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess || devices < 1) {
+        fprintf(stderr, "Recreate failed: no HIP device (there is no CPU fallback)\n");
+        return 1;
+    }
+    if (rccl) {
+        if (devices < world) {
+            fprintf(stderr, "SKIPPED: --rccl --ranks %d needs %d GPUs, %d visible (RCCL refuses two ranks on one device)\n", world, world, devices);
+            return 77;
+        }
+        if (nrd::TiledIntegration::GetUniqueId(S.uniqueId) != nrd::Result::SUCCESS) {
+            fprintf(stderr, "ncclGetUniqueId failed\n");
+            return 1;
+        }
+    }
+    S.outDiff.assign((size_t)w * 8 * h, 0);
+    S.outSpec.assign((size_t)w * 8 * h, 0);
+    S.outShadow.assign((size_t)w * 4 * h, 0);
+    S.outSignal.assign((size_t)w * 8 * h, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; r++)
+        th.emplace_back(rankMain, &S, r);
+    for (auto& t : th)
+        t.join();
+    for (int r = 0; r < world; r++)
+        if (S.status[r]) {
+            fprintf(stderr, "rank %d failed\n", r);
+            return 1;
+        }
+    auto save = [&](const char* name, const std::vector<uint8_t>& v) {
+        FILE* f = fopen((dir + "/" + name).c_str(), "wb");
+        if (!f)
+            return false;
+        fwrite(v.data(), 1, v.size(), f);
+        fclose(f);
+        return true;
+    };
+    if (!save("out_diff.bin", S.outDiff) || !save("out_spec.bin", S.outSpec) || !save("out_shadow.bin", S.outShadow) || !save("out_signal.bin", S.outSignal))
+        return 1;
+    printf("row-tiled run: %d ranks, %s transport, %ux%u, %d frames\n", world, rccl ? "RCCL" : "in-process mailbox", w, h, frames);
+    return 0;
+}
+
+} // namespace tiled
+
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: nrd_harness <dir> <width> <height> <frames>\n");
+        fprintf(stderr, "usage: nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl]]\n");
         return 2;
     }
     std::string dir = argv[1];
     uint16_t w = (uint16_t)atoi(argv[2]), h = (uint16_t)atoi(argv[3]);
     int frames = atoi(argv[4]);
+    int ranks = 1;
+    bool rccl = false;
+    for (int i = 5; i < argc; i++) {
+        if (!strcmp(argv[i], "--ranks") && i + 1 < argc)
+            ranks = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rccl"))
+            rccl = true;
+    }
+    if (ranks > 1)
+        return tiled::run(dir, w, h, frames, ranks, rccl);
     using F = nrd::Format;
     using RT = nrd::ResourceType;
 

@@ -39,9 +39,22 @@ struct float4 {
     float x, y, z, w;
 };
 
+#define NRD_HOST_EMULATION 1 // host-side sources that talk to RCCL / dlopen compile that part out (nrdhip_tiler.cpp)
 typedef int hipError_t;
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 constexpr hipError_t hipSuccess = 0;
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// everything runs synchronously on the host: streams and events order nothing
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 
 namespace hipemu {
 struct Idx {

@@ -28,3 +28,21 @@ def test_traffic_lookup_reads_the_newest_committed_counter_table():
         assert isinstance(t, int) and 0.8 * algorithmic_bpp * px < t < 2.0 * algorithmic_bpp * px, (name, t)
     assert bench.measured_traffic("reblur_ds_4k", "REBLUR::NoSuchPass") is None
     assert bench.measured_traffic("no_such_workload", "REBLUR::Blur") is None
+
+
+def test_multi_gpu_default_is_baseline_config_5(monkeypatch, pkg):
+    """--gpus N > 1 without --workload: ONE 7680x4320 frame row-tiled into N bands (strong scaling), BASELINE.json configs[4]"""
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    a = bench.parse()
+    assert (a.workload, a.scaling) == ("reblur_ds_8k", "strong")
+    assert bench.WORKLOADS[a.workload] == (7680, 4320, ["REBLUR_DIFFUSE_SPECULAR"])
+    from nrd_sample_amd import tiler
+    bands = [tiler.band_layout(4320, 8, r, 80) for r in range(8)]
+    assert sum(b["own_rows"] for b in bands) == 4320 and all(b["own_rows"] >= 528 and b["own0"] % 16 == 0 for b in bands)
+    assert all(a["own1"] == b["own0"] for a, b in zip(bands, bands[1:]))
+
+
+def test_contract_bytes_table():
+    assert bench.contract_bpp(["REBLUR_DIFFUSE_SPECULAR"]) == 352.0  # BASELINE.md 3
+    assert bench.contract_bpp(["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY"]) == 428.0
+    assert bench.contract_bpp(["RELAX_DIFFUSE_SPECULAR"]) is None  # no figure in the contract's table: reported as null, not guessed

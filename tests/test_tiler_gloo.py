@@ -29,6 +29,18 @@ def apply_mode(api, reblur_settings, mode):
         reblur_settings.enableAntiFirefly = True
 
 
+def case_of(api, scene, mode):
+    """(denoisers, {denoiser: settings}) of a tiling test mode; "relax8": RELAX with 8 A-trous iterations - the last one reads
+    128 rows beyond the band, more than the 80-row default halo (must be refused or given a larger halo, never clamped)"""
+    D = api.Denoiser
+    if mode == "relax8":
+        return [D.RELAX_DIFFUSE_SPECULAR], {D.RELAX_DIFFUSE_SPECULAR: api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1, atrousIterationNum=8)}
+    st = {D.REBLUR_DIFFUSE_SPECULAR: api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1),
+          D.SIGMA_SHADOW_TRANSLUCENCY: api.SigmaSettings(lightDirection=list(scene.sun))}
+    apply_mode(api, st[D.REBLUR_DIFFUSE_SPECULAR], mode)
+    return [D.REBLUR_DIFFUSE_SPECULAR, D.SIGMA_SHADOW_TRANSLUCENCY], st
+
+
 def mode_frame_hook(pkg, mode, f, fr):
     if mode != "cb":
         return
@@ -91,30 +103,73 @@ def test_row_tiling_hip_bit_identical(tmp_path, pkg, api, oracle, hip, world, fr
     run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, "hip")
 
 
-def run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, backend):
-    w, nframes, halo = 96, 3, 80
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiler_kind", ["python", "native"])
+def test_row_tiling_8k_wide_bands_hip(tmp_path, pkg, api, oracle, hip, tiler_kind):
+    """BASELINE config 5's geometry on one GPU: 7680-pixel rows, two 528-row bands (what a rank owns of the 4320-row frame at
+    N = 8), the real kernels, both tilers (Python over torch.distributed; the C++ tiler below the C-ABI with gloo moving the rows
+    through its transport callbacks) - bit-identical to the single-instance oracle run of the 7680 x 1056 frame"""
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 1056, "default", "hip", tiler_kind, w=7680, nframes=2, halo=0)
+
+
+def run_tiled_and_compare(tmp_path, pkg, api, oracle, world, frame_h, mode, backend, tiler_kind="python", w=96, nframes=3, halo=80):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo), mode, backend]
+           "--master-port", str(free_port()), os.path.join(HERE, "tiler_worker.py"), str(tmp_path), str(w), str(frame_h), str(nframes), str(halo), mode, backend,
+           tiler_kind]
     env = dict(os.environ, OMP_NUM_THREADS="2")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     # single-instance run over the whole frame
-    D = api.Denoiser
-    dens = [D.REBLUR_DIFFUSE_SPECULAR, D.SIGMA_SHADOW_TRANSLUCENCY]
-    scene = pkg.synth.Scene(w, frame_h, dolly=0.03)
-    st = {D.REBLUR_DIFFUSE_SPECULAR: api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1),
-          D.SIGMA_SHADOW_TRANSLUCENCY: api.SigmaSettings(lightDirection=list(scene.sun))}
-    apply_mode(api, st[D.REBLUR_DIFFUSE_SPECULAR], mode)
+    scene = pkg.synth.Scene(w, frame_h, dolly=0.03, denoiser="RELAX" if mode == "relax8" else "REBLUR")
+    dens, st = case_of(api, scene, mode)
     keep = []
-    hz = util.run_frames(api, pkg.harness, oracle, scene, dens, nframes, settings=st, keep=keep, frame_hook=lambda f, fr: mode_frame_hook(pkg, mode, f, fr))
+    hz = util.run_frames(api, pkg.harness, oracle, scene, dens, nframes, settings=st, keep=keep, frame_hook=lambda f, fr: mode_frame_hook(pkg, mode, f, fr),
+                         threads=(os.cpu_count() if w * frame_h > 500000 else None))
     parts = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
     for f in range(nframes):
-        for key in ("out_diff", "out_spec", "out_shadow"):
+        for key in ("out_diff", "out_spec") + (() if mode == "relax8" else ("out_shadow",)):
             tiled = np.concatenate([p["f%d_%s" % (f, key)] for p in parts], 0)
             assert np.array_equal(tiled, keep[f][key]), (f, key)
     hist = np.concatenate([p["history"] for p in parts], 0)
-    assert np.array_equal(hist, hz.pool("REBLUR::History"))
+    assert np.array_equal(hist, hz.pool("RELAX::History" if mode == "relax8" else "REBLUR::History"))
     assert sum(int(p["bytes"][0]) for p in parts) > 0
-    if frame_h // world >= 320:  # tall bands take the overlapped path: boundary strips, exchange in flight, interior
-        assert all(int(p["split"][0]) >= 3 * 7 for p in parts)  # every REBLUR dispatch of every frame at least
+    if frame_h // world >= 320 and mode != "relax8":  # tall bands take the overlapped path: boundary strips, exchange in flight, interior
+        assert all(int(p["split"][0]) >= nframes * 5 for p in parts)  # the REBLUR dispatches whose outputs a later one reads across the band edge, every frame
     assert [int(p["own0"][0]) for p in parts] == sorted(int(p["own0"][0]) for p in parts)
+    return parts
+
+
+def test_native_tiler_bit_identical(tmp_path, pkg, api, oracle, emulated):
+    """the C++ row tiler below the C-ABI (csrc/nrdhip_tiler.cpp: exchange plan, strips-first split, deferred rows) over the
+    host-emulated product library, two gloo ranks moving the rows through its transport callbacks - against the single-instance
+    oracle run; tall bands so the strips / interior path runs"""
+    parts = run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 704, "default", "emu", "native", nframes=2)
+    assert all(int(p["split"][0]) >= 2 * 5 for p in parts)
+
+
+def test_halo_is_enforced_not_clamped(tmp_path, pkg, api, oracle, emulated):
+    """RELAX with 8 A-trous iterations reads 128 rows beyond a band. With the default 80-row halo both tilers must REFUSE
+    (ADVICE r1 / VERDICT r1 weak 6: the silent clamp produced a different image); with the probed halo the tiled result is
+    bit-identical again."""
+    from nrd_sample_amd import tiler
+
+    D = api.Denoiser
+    scene = pkg.synth.Scene(96, 64, denoiser="RELAX")
+    dens, st = case_of(api, scene, "relax8")
+    need = tiler.probe_halo(oracle, dens, st)
+    assert need == (128 + tiler.DEFAULT_MOTION_ROWS + 15) // 16 * 16 == 144
+    assert tiler.probe_halo(oracle, dens, None) <= 80  # default settings fit the default halo
+    for backend, make in ((oracle, lambda band: tiler.Tiler(band, None)), (emulated, lambda band: tiler.NativeTiler(band, None, transport="dist"))):
+        band = tiler.BandHarness(backend, dens, 96, 640, 0, 2, halo=80)
+        band.nrd.set_denoiser_settings(int(dens[0]), st[dens[0]])
+        cs = scene.common_settings(api, scene.frame(0), 0, reset=True)
+        cs.rectSize[1] = cs.resourceSize[1] = 640
+        band.nrd.set_common_settings(cs)
+        t = make(band)
+        with pytest.raises((tiler.HaloError, api.NrdError)) as e:
+            t.denoise([int(dens[0])])
+        assert "128" in str(e.value) and "80" in str(e.value), str(e.value)
+
+
+def test_row_tiling_wide_reach_with_probed_halo(tmp_path, pkg, api, oracle):
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 448, "relax8", "oracle", halo=0)

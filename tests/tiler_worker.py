@@ -26,16 +26,15 @@ def main():
         orc = api.Backend(graft.build_emulated(), "nrdhip_", "cpu")
     else:
         orc = pkg.hip_backend("cuda:0") if use_hip else graft.oracle_backend()
-    D = api.Denoiser
-    dens = [D.REBLUR_DIFFUSE_SPECULAR, D.SIGMA_SHADOW_TRANSLUCENCY]
-    band = tiler.BandHarness(orc, dens, w, frame_h, rank, world, halo=halo)
-    t = tiler.Tiler(band, dist)
-    scene = pkg.synth.Scene(w, frame_h, dolly=0.03)  # every rank renders the same global frame and keeps its window
-    st = {D.REBLUR_DIFFUSE_SPECULAR: api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1),
-          D.SIGMA_SHADOW_TRANSLUCENCY: api.SigmaSettings(lightDirection=list(scene.sun))}
+    native = len(sys.argv) > 8 and sys.argv[8] == "native"  # the C++ row tiler below the C-ABI, rows moved by gloo through its transport callbacks
     sys.path.insert(0, HERE)
     import test_tiler_gloo as tt
-    tt.apply_mode(api, st[D.REBLUR_DIFFUSE_SPECULAR], mode)
+    scene = pkg.synth.Scene(w, frame_h, dolly=0.03, denoiser="RELAX" if mode == "relax8" else "REBLUR")  # every rank renders the same global frame and keeps its window
+    dens, st = tt.case_of(api, scene, mode)
+    if halo <= 0:  # derive the stored halo from the settings (reach of every pass + motion)
+        halo = tiler.probe_halo(orc, dens, st)
+    band = tiler.BandHarness(orc, dens, w, frame_h, rank, world, halo=halo)
+    t = tiler.NativeTiler(band, dist, transport="dist") if native else tiler.Tiler(band, dist)
     blob = {}
     for f in range(nframes):
         fr = scene.frame(f)
@@ -63,7 +62,8 @@ def main():
         for key in ("out_diff", "out_spec", "out_shadow"):
             blob["f%d_%s" % (f, key)] = band.own_rows(band.fetch(band.outputs[key])).copy()
     t.finish()  # halo rows of the permanent planes written by the last frame are still travelling
-    blob["history"] = band.own_rows(band.pool("REBLUR::History")).copy()
+    blob["history"] = band.own_rows(band.pool("RELAX::History" if mode == "relax8" else "REBLUR::History")).copy()
+    blob["halo"] = np.array([halo])
     blob["own0"] = np.array([band.layout["own0"], band.layout["own1"]])
     blob["bytes"] = np.array([t.bytes_exchanged])
     blob["split"] = np.array([t.split_dispatches])

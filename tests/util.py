@@ -38,9 +38,12 @@ def default_settings(api, scene, denoisers, **reblur_kw):
     return s
 
 
-def run_frames(api, harness_mod, backend, scene, denoisers, nframes, settings=None, common_hook=None, frame_hook=None, keep=None):
-    """Run `nframes` through a fresh Harness; returns the harness (outputs of the last frame stay bound)."""
+def run_frames(api, harness_mod, backend, scene, denoisers, nframes, settings=None, common_hook=None, frame_hook=None, keep=None, threads=None):
+    """Run `nframes` through a fresh Harness; returns the harness (outputs of the last frame stay bound). `threads`: row-stripe the
+    CPU oracle over that many host threads (large frames)."""
     h = harness_mod.Harness(backend, denoisers, scene.w, scene.h)
+    if threads and hasattr(backend.lib, "orc_set_threads"):
+        backend.lib.orc_set_threads(h.nrd.handle, int(threads))
     settings = settings or default_settings(api, scene, denoisers)
     for f in range(nframes):
         fr = scene.frame(f)
