@@ -140,7 +140,8 @@ NRDHIP_API int nrdhip_library_desc(uint32_t out[5]);
 NRDHIP_API const char* nrdhip_denoiser_string(uint32_t denoiser);
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 CommonSettings, 1 ReblurSettings, 2 RelaxSettings, 3 SigmaSettings, 4 ReferenceSettings,
- * 5 nrdhip_create_desc, 6 nrdhip_plane_info, 7 nrdhip_dispatch_info, 8 nrdhip_confidence_blur_desc, 9 nrdhip_unpack_desc */
+ * 5 nrdhip_create_desc, 6 nrdhip_plane_info, 7 nrdhip_dispatch_info, 8 nrdhip_confidence_blur_desc, 9 nrdhip_unpack_desc,
+ * 10 nrdhip_taa_desc, 11 nrdhip_frontend_pack_desc, 12 nrdhip_compose_desc */
 NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which);
 /* last error text of the instance (or of creation when inst == NULL) */
 NRDHIP_API const char* nrdhip_last_error(nrdhip_instance* inst);
@@ -234,6 +235,61 @@ typedef struct nrdhip_unpack_desc {
     float inv_rect_size[2];
 } nrdhip_unpack_desc;
 NRDHIP_API int nrdhip_backend_unpack(const nrdhip_unpack_desc* desc, void* hip_stream);
+
+/* Producer side = what Shaders/TraceOpaque.cs.hlsl does with a path-tracing result before it becomes denoiser input (:421 hit
+ * distance normalisation, :657 normal / roughness / materialID pack, :738-757 radiance texels per NRD_MODE for REBLUR / RELAX,
+ * :800-801 SIGMA inputs), built on the host+device helper API include/nrd_frontend.h. Raw fp32 planes in (RGBA32F unless noted),
+ * NRD input planes out; NULL skips a plane. */
+enum { NRDHIP_PACK_DIRECTIONAL_OCCLUSION = 3 }; /* `mode` = NRDHIP_UNPACK_NORMAL / _OCCLUSION / _SH or this */
+typedef struct nrdhip_frontend_pack_desc {
+    uint16_t width, height;
+    uint32_t mode;
+    uint32_t relax;                      /* RELAX_FrontEnd_* (linear RGB, world-space hit distance) instead of REBLUR_FrontEnd_* */
+    uint32_t sanitize;                   /* USE_SANITIZATION: non-finite radiance / hit distance -> 0 */
+    float hit_distance_parameters[4];    /* nrd::ReblurHitDistanceParameters {A, B, C, D} (gHitDistSettings) */
+    float tan_of_light_angular_radius;   /* gTanSunAngularRadius */
+    const void* normal; uint32_t normal_pitch;                 /* {world normal xyz, linear roughness} */
+    const void* material_id; uint32_t material_id_pitch;       /* R32F, 0..3 (optional) */
+    const void* viewz; uint32_t viewz_pitch;                   /* R32F linear view depth (REBLUR hit distance normalisation) */
+    const void* diff; uint32_t diff_pitch;                     /* {diffuse radiance rgb (demodulated), hit distance in world units} */
+    const void* spec; uint32_t spec_pitch;
+    const void* diff_direction; uint32_t diff_direction_pitch; /* SH / DIRECTIONAL_OCCLUSION: unit vector toward the light sample */
+    const void* spec_direction; uint32_t spec_direction_pitch;
+    const void* shadow; uint32_t shadow_pitch;                 /* {distance to occluder (>= 65504: miss), translucency rgb} */
+    void* out_normal_roughness; uint32_t out_normal_roughness_pitch; /* IN_NORMAL_ROUGHNESS R10_G10_B10_A2_UNORM */
+    void* out_diff; uint32_t out_diff_pitch;                   /* IN_DIFF_RADIANCE_HITDIST | _SH0 | _DIRECTION_HITDIST RGBA16F; OCCLUSION: IN_DIFF_HITDIST R16_UNORM */
+    void* out_spec; uint32_t out_spec_pitch;
+    void* out_diff_sh1; uint32_t out_diff_sh1_pitch;           /* SH mode: IN_DIFF_SH1 / IN_SPEC_SH1 RGBA16F */
+    void* out_spec_sh1; uint32_t out_spec_sh1_pitch;
+    void* out_penumbra; uint32_t out_penumbra_pitch;           /* IN_PENUMBRA R16F */
+    void* out_translucency; uint32_t out_translucency_pitch;   /* IN_TRANSLUCENCY RGBA8 */
+} nrdhip_frontend_pack_desc;
+NRDHIP_API int nrdhip_frontend_pack(const nrdhip_frontend_pack_desc* desc, void* hip_stream);
+
+/* Consumer side after the NRD decode = Shaders/Composition.cs.hlsl:92-107 (SH mode: NRD_SG_ReJitter against the 4 neighbours'
+ * normals / depths) and :183-188 (material re-modulation: NRD_MaterialFactors from base colour / metalness; hair keeps factor 1,
+ * Shaders/RaytracingShared.hlsli:925-936). Input = the planes nrdhip_backend_unpack wrote. */
+typedef struct nrdhip_compose_desc {
+    uint16_t width, height;
+    uint32_t sh;                         /* 1: apply the re-jitter scales computed from the OUT_*_SH0 / SH1 planes below */
+    uint32_t relax;
+    uint32_t hair_material_id;           /* materialID whose factors stay 1 (MATERIAL_ID_HAIR); 0xffffffff = none */
+    const void* diff; uint32_t diff_pitch;                     /* RGBA16F {linear radiance, hit distance term} from nrdhip_backend_unpack */
+    const void* spec; uint32_t spec_pitch;
+    const void* diff_sh0; uint32_t diff_sh0_pitch;             /* SH mode: the denoiser's OUT_DIFF_SH0 / SH1, OUT_SPEC_SH0 / SH1 */
+    const void* diff_sh1; uint32_t diff_sh1_pitch;
+    const void* spec_sh0; uint32_t spec_sh0_pitch;
+    const void* spec_sh1; uint32_t spec_sh1_pitch;
+    const void* normal_roughness; uint32_t normal_roughness_pitch;         /* IN_NORMAL_ROUGHNESS */
+    const void* viewz; uint32_t viewz_pitch;                               /* IN_VIEWZ (re-jitter depth test) */
+    const void* base_color_metalness; uint32_t base_color_metalness_pitch; /* RGBA8: sRGB base colour, metalness (gIn_BaseColor_Metalness); NULL = factors 1 */
+    void* out_diff; uint32_t out_diff_pitch;                   /* RGBA16F Ldiff = diff x diffFactor (w passes through) */
+    void* out_spec; uint32_t out_spec_pitch;
+    float view_to_world[9];
+    float camera_frustum[4];
+    float inv_rect_size[2];
+} nrdhip_compose_desc;
+NRDHIP_API int nrdhip_compose(const nrdhip_compose_desc* desc, void* hip_stream);
 
 /* Temporal anti-aliasing = Shaders/Taa.cs.hlsl:11-159 (one 16x16-group dispatch over the rect): 20x20 LDS tiles of the tonemapped
  * colour and of the motion vectors, 3x3 / 5x5 Gaussian moments, closest-depth motion vector, bicubic (5-tap "no corners")

@@ -340,7 +340,29 @@ class TaaDesc(C.Structure):
                 ("render_width", _u16), ("render_height", _u16), ("tonemap", _u32), ("hdr_scale", _f), ("taa", _f)]
 
 
-UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH = 0, 1, 2
+def _plane_fields(*names):
+    out = []
+    for n in names:
+        out += [(n, C.c_void_p), (n + "_pitch", _u32)]
+    return out
+
+
+class FrontendPackDesc(C.Structure):
+    """nrdhip_frontend_pack_desc (producer side, Shaders/TraceOpaque.cs.hlsl:421, :657, :738-757, :800-801 over include/nrd_frontend.h)"""
+    _fields_ = [("width", _u16), ("height", _u16), ("mode", _u32), ("relax", _u32), ("sanitize", _u32), ("hit_distance_parameters", _f * 4),
+                ("tan_of_light_angular_radius", _f)] + _plane_fields(
+        "normal", "material_id", "viewz", "diff", "spec", "diff_direction", "spec_direction", "shadow", "out_normal_roughness", "out_diff", "out_spec",
+        "out_diff_sh1", "out_spec_sh1", "out_penumbra", "out_translucency")
+
+
+class ComposeDesc(C.Structure):
+    """nrdhip_compose_desc (Shaders/Composition.cs.hlsl:92-107 re-jitter, :183-188 material re-modulation)"""
+    _fields_ = [("width", _u16), ("height", _u16), ("sh", _u32), ("relax", _u32), ("hair_material_id", _u32)] + _plane_fields(
+        "diff", "spec", "diff_sh0", "diff_sh1", "spec_sh0", "spec_sh1", "normal_roughness", "viewz", "base_color_metalness", "out_diff", "out_spec") + [
+        ("view_to_world", _f * 9), ("camera_frustum", _f * 4), ("inv_rect_size", _f * 2)]
+
+
+UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH, PACK_DIRECTIONAL_OCCLUSION = 0, 1, 2, 3
 FLAG_EXTERNAL_POOLS = 1
 
 
@@ -393,6 +415,10 @@ class Backend:
         self._sig("taa", C.c_int, [C.POINTER(TaaDesc), C.c_void_p])
         # introspection + row tiler: part of the product library (and of its host-emulated build); the CPU oracle of the tests
         # implements the per-instance entry points only
+        self.has_frontend = hasattr(self.lib, self.prefix + "frontend_pack")
+        if self.has_frontend:
+            self._sig("frontend_pack", C.c_int, [C.POINTER(FrontendPackDesc), C.c_void_p])
+            self._sig("compose", C.c_int, [C.POINTER(ComposeDesc), C.c_void_p])
         self.has_tiler = hasattr(self.lib, self.prefix + "tiler_create")
         if self.has_tiler:
             self._sig("denoiser_kind", C.c_int, [C.c_void_p, _u32, C.POINTER(_u32)])
@@ -423,7 +449,7 @@ class Backend:
 
     def check_abi(self):
         want = [CommonSettings, ReblurSettings, RelaxSettings, SigmaSettings, ReferenceSettings, CreateDesc, PlaneInfo, DispatchInfo,
-                ConfidenceBlurDesc, UnpackDesc, TaaDesc]
+                ConfidenceBlurDesc, UnpackDesc, TaaDesc] + ([FrontendPackDesc, ComposeDesc] if self.has_frontend else [])
         for i, cls in enumerate(want):
             got = self.sizeof(i)
             if got != C.sizeof(cls):

@@ -1365,6 +1365,8 @@ NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which) {
         case 8: return sizeof(nrdhip_confidence_blur_desc);
         case 9: return sizeof(nrdhip_unpack_desc);
         case 10: return sizeof(nrdhip_taa_desc);
+        case 11: return sizeof(nrdhip_frontend_pack_desc);
+        case 12: return sizeof(nrdhip_compose_desc);
     }
     return 0;
 }

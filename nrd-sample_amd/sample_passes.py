@@ -75,6 +75,42 @@ def backend_unpack(backend, width, height, mode=api.UNPACK_NORMAL, relax=False, 
         raise api.NrdError("backend_unpack", int(r))
 
 
+def frontend_pack(backend, width, height, mode=api.UNPACK_NORMAL, relax=False, sanitize=True, hit_distance_parameters=(3.0, 0.1, 20.0, -25.0),
+                  tan_of_light_angular_radius=0.0, **planes):
+    """nrdhip_frontend_pack: raw fp32 planes -> NRD input planes. `planes`: normal, material_id, viewz, diff, spec, diff_direction,
+    spec_direction, shadow (inputs) and out_normal_roughness, out_diff, out_spec, out_diff_sh1, out_spec_sh1, out_penumbra,
+    out_translucency (outputs); byte views [rows, pitch] (numpy or torch), absent = skipped"""
+    d = api.FrontendPackDesc()
+    d.width, d.height, d.mode, d.relax, d.sanitize = width, height, int(mode), 1 if relax else 0, 1 if sanitize else 0
+    d.hit_distance_parameters[:] = [float(v) for v in hit_distance_parameters]
+    d.tan_of_light_angular_radius = float(tan_of_light_angular_radius)
+    for name, buf in planes.items():
+        ptr, pitch = _pp(buf)
+        setattr(d, name, ptr)
+        setattr(d, name + "_pitch", pitch)
+    r = backend.frontend_pack(C.byref(d), _stream(backend))
+    if r != 0:
+        raise api.NrdError("frontend_pack", int(r))
+
+
+def compose(backend, width, height, sh=False, relax=False, hair_material_id=0xFFFFFFFF, view_to_world=None, camera_frustum=(0, 0, 0, 0), **planes):
+    """nrdhip_compose: re-jitter (SH mode) + material re-modulation of the planes nrdhip_backend_unpack wrote. `planes`: diff, spec,
+    diff_sh0, diff_sh1, spec_sh0, spec_sh1, normal_roughness, viewz, base_color_metalness, out_diff, out_spec"""
+    d = api.ComposeDesc()
+    d.width, d.height, d.sh, d.relax, d.hair_material_id = width, height, 1 if sh else 0, 1 if relax else 0, int(hair_material_id)
+    for name, buf in planes.items():
+        ptr, pitch = _pp(buf)
+        setattr(d, name, ptr)
+        setattr(d, name + "_pitch", pitch)
+    v2w = np.eye(3, dtype=np.float32) if view_to_world is None else np.asarray(view_to_world, dtype=np.float32).reshape(3, 3)
+    d.view_to_world[:] = [float(v) for v in v2w.reshape(-1)]
+    d.camera_frustum[:] = [float(v) for v in camera_frustum]
+    d.inv_rect_size[:] = [float(np.float32(1.0) / np.float32(width)), float(np.float32(1.0) / np.float32(height))]
+    r = backend.compose(C.byref(d), _stream(backend))
+    if r != 0:
+        raise api.NrdError("compose", int(r))
+
+
 def taa(backend, mv, composed, history, result, rect_width, rect_height, render_width=None, render_height=None, rect_width_prev=0,
         rect_height_prev=0, tonemap=True, hdr_scale=1.0, taa_min_mix=0.1):
     """Shaders/Taa.cs.hlsl: one dispatch; `history` is last frame's `result` (ping-pong by the caller, Source/NRDSample.cpp TAA pass)"""

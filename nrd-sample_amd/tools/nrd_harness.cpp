@@ -369,6 +369,10 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--rccl"))
             rccl = true;
     }
+    bool synthesize = false;
+    for (int i = 5; i < argc; i++)
+        if (!strcmp(argv[i], "--synthesize"))
+            synthesize = true;
     if (ranks > 1)
         return tiled::run(dir, w, h, frames, ranks, rccl);
     using F = nrd::Format;
@@ -405,9 +409,73 @@ int main(int argc, char** argv) {
     Texture Diff = makeTexture(w, h, F::RGBA16_SFLOAT, 8), Spec = makeTexture(w, h, F::RGBA16_SFLOAT, 8);
     Texture Unfiltered_Penumbra = makeTexture(w, h, F::R16_SFLOAT, 2), Unfiltered_Translucency = makeTexture(w, h, F::RGBA8_UNORM, 4), Shadow = makeTexture(w, h, F::RGBA8_UNORM, 4);
     Texture Composed = makeTexture(w, h, F::RGBA16_SFLOAT, 8), Validation = makeTexture(w, h, F::RGBA8_UNORM, 4);
-    if (!loadPlane(dir + "/mv.bin", Mv) || !loadPlane(dir + "/normal_roughness.bin", Normal_Roughness) || !loadPlane(dir + "/viewz.bin", ViewZ) ||
-        !loadPlane(dir + "/diff.bin", Unfiltered_Diff) || !loadPlane(dir + "/spec.bin", Unfiltered_Spec) || !loadPlane(dir + "/penumbra.bin", Unfiltered_Penumbra) ||
-        !loadPlane(dir + "/translucency.bin", Unfiltered_Translucency) || !loadPlane(dir + "/signal.bin", Composed))
+    if (synthesize) {
+        // --synthesize: no input files. A small analytic "path tracer" runs on the host (tilted floor + back wall, hashed noise on
+        // radiance and hit distances) and its raw fp32 results go through the producer kernel nrdhip_frontend_pack - the HIP twin of
+        // what Shaders/TraceOpaque.cs.hlsl:421, :657, :738-757, :800-801 do - straight into the slots the denoisers read.
+        const size_t n = (size_t)w * h;
+        std::vector<float> normal(n * 4), mat(n), viewz(n), diff(n * 4), spec(n * 4), shadow(n * 4);
+        auto hash = [](uint32_t x) {
+            x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            return (float)(x >> 8) * (1.0f / 16777216.0f);
+        };
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < w; x++) {
+                size_t i = (size_t)y * w + x;
+                bool floor = y > h / 2u;
+                float z = floor ? 3.0f + 30.0f * (float)(h - y) / (float)h : 20.0f;
+                viewz[i] = z;
+                float nx = 0.0f, ny = floor ? 0.8f : 0.0f, nz = floor ? -0.6f : -1.0f;
+                normal[4 * i + 0] = nx, normal[4 * i + 1] = ny, normal[4 * i + 2] = nz;
+                normal[4 * i + 3] = floor ? 0.3f + 0.4f * (float)((x / 32u) & 1u) : 0.6f;
+                mat[i] = floor ? 0.0f : 1.0f;
+                float n0 = hash((uint32_t)i * 4u + 0u), n1 = hash((uint32_t)i * 4u + 1u), n2 = hash((uint32_t)i * 4u + 2u), n3 = hash((uint32_t)i * 4u + 3u);
+                float d = 0.2f + 1.6f * n0 * n0, sp = 0.1f + 2.5f * n1 * n1 * n1;
+                diff[4 * i + 0] = 0.45f * d, diff[4 * i + 1] = 0.55f * d, diff[4 * i + 2] = 0.75f * d, diff[4 * i + 3] = 0.5f + 4.0f * n2;
+                spec[4 * i + 0] = 0.9f * sp, spec[4 * i + 1] = 0.8f * sp, spec[4 * i + 2] = 0.7f * sp, spec[4 * i + 3] = 1.0f + 30.0f * n3;
+                bool lit = ((x / 48u + y / 48u) & 1u) != 0u;
+                shadow[4 * i + 0] = lit ? 65504.0f : 2.0f + 6.0f * n2;
+                shadow[4 * i + 1] = 0.9f, shadow[4 * i + 2] = 0.6f, shadow[4 * i + 3] = 0.3f;
+            }
+        auto upload = [&](const std::vector<float>& v) {
+            void* p = nullptr;
+            if (hipMalloc(&p, v.size() * 4) != hipSuccess || hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return (void*)nullptr;
+            return p;
+        };
+        nrdhip_frontend_pack_desc pd = {};
+        pd.width = w;
+        pd.height = h;
+        pd.mode = NRDHIP_UNPACK_NORMAL;
+        pd.sanitize = 1;
+        const float hp[4] = {3.0f, 0.1f, 20.0f, -25.0f};
+        memcpy(pd.hit_distance_parameters, hp, sizeof(hp));
+        pd.tan_of_light_angular_radius = 0.00465f;
+        pd.normal = upload(normal), pd.normal_pitch = w * 16u;
+        pd.material_id = upload(mat), pd.material_id_pitch = w * 4u;
+        pd.viewz = upload(viewz), pd.viewz_pitch = w * 4u;
+        pd.diff = upload(diff), pd.diff_pitch = w * 16u;
+        pd.spec = upload(spec), pd.spec_pitch = w * 16u;
+        pd.shadow = upload(shadow), pd.shadow_pitch = w * 16u;
+        pd.out_normal_roughness = Normal_Roughness.ptr, pd.out_normal_roughness_pitch = Normal_Roughness.pitch;
+        pd.out_diff = Unfiltered_Diff.ptr, pd.out_diff_pitch = Unfiltered_Diff.pitch;
+        pd.out_spec = Unfiltered_Spec.ptr, pd.out_spec_pitch = Unfiltered_Spec.pitch;
+        pd.out_penumbra = Unfiltered_Penumbra.ptr, pd.out_penumbra_pitch = Unfiltered_Penumbra.pitch;
+        pd.out_translucency = Unfiltered_Translucency.ptr, pd.out_translucency_pitch = Unfiltered_Translucency.pitch;
+        if (!pd.normal || !pd.material_id || !pd.viewz || !pd.diff || !pd.spec || !pd.shadow || nrdhip_frontend_pack(&pd, nullptr) != 0 ||
+            hipMemcpy(ViewZ.ptr, viewz.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(Composed.ptr, Unfiltered_Diff.ptr, Composed.bytes(), hipMemcpyDeviceToDevice) != hipSuccess) {
+            fprintf(stderr, "synthesize / nrdhip_frontend_pack failed\n");
+            return 1;
+        }
+        // the packed inputs are written out so that another driver can be fed the very same planes (tests/test_cpp_harness.py)
+        if (!savePlane(dir + "/mv.bin", Mv) || !savePlane(dir + "/normal_roughness.bin", Normal_Roughness) || !savePlane(dir + "/viewz.bin", ViewZ) ||
+            !savePlane(dir + "/diff.bin", Unfiltered_Diff) || !savePlane(dir + "/spec.bin", Unfiltered_Spec) || !savePlane(dir + "/penumbra.bin", Unfiltered_Penumbra) ||
+            !savePlane(dir + "/translucency.bin", Unfiltered_Translucency) || !savePlane(dir + "/signal.bin", Composed))
+            return 1;
+        printf("synthesized inputs through nrdhip_frontend_pack\n");
+    } else if (!loadPlane(dir + "/mv.bin", Mv) || !loadPlane(dir + "/normal_roughness.bin", Normal_Roughness) || !loadPlane(dir + "/viewz.bin", ViewZ) ||
+               !loadPlane(dir + "/diff.bin", Unfiltered_Diff) || !loadPlane(dir + "/spec.bin", Unfiltered_Spec) || !loadPlane(dir + "/penumbra.bin", Unfiltered_Penumbra) ||
+               !loadPlane(dir + "/translucency.bin", Unfiltered_Translucency) || !loadPlane(dir + "/signal.bin", Composed))
         return 1;
 
     nrd::ReblurSettings m_ReblurSettings = {};

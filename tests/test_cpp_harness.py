@@ -115,3 +115,27 @@ def test_harness_rccl_ranks(tmp_path, pkg):
     assert r1.returncode == 0
     for name in ("out_diff.bin", "out_spec.bin", "out_shadow.bin", "out_signal.bin"):
         assert np.array_equal(np.fromfile(one / name, np.uint8), np.fromfile(two / name, np.uint8)), name
+
+
+@pytest.mark.gpu
+def test_harness_synthesizes_its_own_inputs_through_the_pack_kernel(tmp_path, pkg, api, hip):
+    """--synthesize: no Python-made planes. The C++ host produces raw fp32 path-tracer results, nrdhip_frontend_pack turns them
+    into the NRD input planes, the denoisers run. The packed planes it saves, fed to a second (file-driven)
+    run, must reproduce the outputs byte for byte, and the packed normals / radiance must decode to sane values."""
+    w, h, frames = 256, 160, 3
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(), b.mkdir()
+    r = _run([a, w, h, frames, "--synthesize"])
+    assert r.returncode == 0 and "synthesized inputs through nrdhip_frontend_pack" in r.stdout, r.stdout + r.stderr
+    for name in ("mv", "normal_roughness", "viewz", "diff", "spec", "penumbra", "translucency", "signal"):
+        (b / (name + ".bin")).write_bytes((a / (name + ".bin")).read_bytes())
+    r2 = _run([b, w, h, frames])
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    for name in ("out_diff.bin", "out_spec.bin", "out_shadow.bin", "out_signal.bin"):
+        assert np.array_equal(np.fromfile(a / name, np.uint8), np.fromfile(b / name, np.uint8)), name
+    nr = np.fromfile(a / "normal_roughness.bin", np.uint32).reshape(h, w)
+    assert set(np.unique(nr >> 30)) == {0, 1} and (nr[0, 0] & 1023) == 512  # wall: material 1, normal (0, 0, -1) -> oct x = 0.5
+    diff = np.fromfile(a / "diff.bin", np.float16).reshape(h, w, 4)
+    assert np.isfinite(diff).all() and (diff[..., 3] >= 0).all() and (diff[..., 3] <= 1).all() and diff[..., 0].mean() > 0.1
+    out = np.fromfile(a / "out_diff.bin", np.float16).reshape(h, w, 4)
+    assert np.isfinite(out).all() and out[..., 0].std() < diff[..., 0].std()  # denoised: less luma variance than the noisy input
