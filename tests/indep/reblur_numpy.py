@@ -1,0 +1,189 @@
+"""TEST INFRASTRUCTURE - an INDEPENDENT restatement (numpy, float64, vectorised; shares no code with oracle/orc_math.h or the
+kernels) of three pieces of the frozen algorithm: REFERENCE accumulation, the guide decode of ClassifyTiles and the REBLUR PrePass
+(8-tap Poisson bilateral filter of both signals). tests/test_independent.py holds the oracle to it at <= 1 fp16 ULP, and uses its
+switches to MEASURE the known deviations from the recalled upstream formulas listed in oracle/README.md ("deviation ledger").
+
+Switches (all False = the frozen algorithm):
+  exp_hit_weight ...... hit-distance weight exp(-3 |x|) instead of the compact-support stand-in (1 - |x|)^2
+  angle_normal_weight . normal weight on the angle itself, smoothstep(1 - acos(cos) / angleMax), instead of the squared-angle form
+  no_reach ............ no hard tap reach (the reach exists for row tiling: it bounds what a pass may read beyond a band)
+  f32_guide ........... normals / roughness of the guide kept at decode precision instead of being stored as fp16
+"""
+import numpy as np
+
+POISSON8 = np.array([[-0.4706069, -0.4427112, 0.7592], [-0.9057375, 0.3003471, 0.5483], [-0.3487388, 0.4037880, 0.8287], [0.1023042, 0.6439373, 0.7554],
+                     [0.5699277, 0.3513750, 0.7439], [0.2939128, -0.1131226, 0.9366], [0.7836658, -0.4208784, 0.5932], [0.1564120, -0.8198990, 0.6314]], np.float32).astype(np.float64)
+NORMAL_ANGLE_MIN = 0.02
+
+
+def f16(a):
+    return np.clip(a, -65504.0, 65504.0).astype(np.float16)
+
+
+def hash_px(x, y, frame, salt):
+    m = 0xFFFFFFFF
+    h = ((x * 73856093) & m) ^ ((y * 19349663) & m) ^ ((frame * 83492791) & m) ^ ((salt * 2654435761) & m)
+    h ^= h >> 13
+    h = (h * 0x5BD1E995) & m
+    h ^= h >> 15
+    return h
+
+
+def smoothstep01(x):
+    x = np.clip(x, 0.0, 1.0)
+    return x * x * (3.0 - 2.0 * x)
+
+
+def decode_guide(viewz, packed, viewz_scale=1.0, f32_guide=False):
+    """ClassifyTiles: viewZ * scale; octahedral normal (10 + 10 bits), linear roughness (10 bits), materialID (2 bits); the
+    guide plane stores the decoded normal and roughness as fp16"""
+    ox, oy = (packed & 1023) / 1023.0, ((packed >> 10) & 1023) / 1023.0
+    fx, fy = ox * 2.0 - 1.0, oy * 2.0 - 1.0
+    nz = 1.0 - np.abs(fx) - np.abs(fy)
+    t = np.clip(-nz, 0.0, 1.0)
+    n = np.stack([fx + np.where(fx >= 0, -t, t), fy + np.where(fy >= 0, -t, t), nz], -1)
+    n /= np.sqrt((n * n).sum(-1, keepdims=True))
+    rough = ((packed >> 20) & 1023) / 1023.0
+    if not f32_guide:
+        n = f16(n).astype(np.float64)
+        rough = f16(rough).astype(np.float64)
+    return viewz.astype(np.float64) * viewz_scale, n, rough, (packed >> 30).astype(np.int64)
+
+
+def reference_accumulate(history, signal, frames_since_reset, max_accum, restart):
+    """REFERENCE: fp32 running mean; returns (new history fp32, output fp16)"""
+    x = signal.astype(np.float32)
+    if restart:
+        h = x
+    else:
+        w = np.float32(1.0) / np.float32(1.0 + min(frames_since_reset, max_accum))
+        h = (history.astype(np.float64) + (x.astype(np.float64) - history.astype(np.float64)) * np.float64(w)).astype(np.float32)
+    return h, f16(h.astype(np.float64))
+
+
+def basis(n):
+    sz = np.where(n[..., 2] >= 0, 1.0, -1.0)
+    a = -1.0 / (sz + n[..., 2])
+    bb = n[..., 0] * n[..., 1] * a
+    t = np.stack([1.0 + sz * n[..., 0] * n[..., 0] * a, sz * bb, -sz * n[..., 0]], -1)
+    b = np.stack([bb, sz + n[..., 1] * n[..., 1] * a, -n[..., 1]], -1)
+    return t, b
+
+
+def normalize(v):
+    return v / np.sqrt(np.maximum((v * v).sum(-1, keepdims=True), 1e-30))
+
+
+def spec_magic_curve(r):
+    return (1.0 - np.exp2(-200.0 * r * r)) * np.sqrt(np.clip(r, 0, 1))
+
+
+def hitdist_norm(absz, hp, r):
+    return (hp[0] + absz * hp[1]) * (1.0 + (hp[2] - 1.0) * np.exp2(hp[3] * r * r))
+
+
+def spec_dominant_factor(r):
+    s = np.clip(1.0 - r, 0, 1)
+    return s * (np.sqrt(s) + r)
+
+
+def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_index, denoising_range, s, exp_hit_weight=False,
+            angle_normal_weight=False, no_reach=False, f32_guide=False):
+    """REBLUR_DIFFUSE_SPECULAR PrePass of one frame (perspective, no jitter, radiance mode, full frame). `s`: dict of the
+    ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16)."""
+    H, W = viewz.shape
+    M = np.asarray(view_to_clip, np.float64)
+    sgn = 1.0 if M[11] > 0 else -1.0
+    pj = np.array([M[0], M[5], M[8], M[9], sgn])
+    fr = np.array([(-sgn - M[8]) / M[0], (sgn - M[9]) / M[5], 2.0 * sgn / M[0], -2.0 * sgn / M[5]])
+    pv = np.array([fr[0] + 0.5 * fr[2] / W, fr[1] + 0.5 * fr[3] / H, fr[2] / W, fr[3] / H])
+    w2v = np.asarray(world_to_view, np.float64).reshape(4, 4).T[:3, :3]  # column-major -> rotation rows
+    unproject = 1.0 / (0.5 * H * abs(pj[1]))
+    min_dim_unproject = min(W, H) * unproject
+    z, n, rough_g, mat = decode_guide(viewz, packed_nr, f32_guide=f32_guide)
+    sky = ~(np.abs(z) <= denoising_range)
+    yy, xx = np.mgrid[0:H, 0:W]
+    Xv = np.stack([z * (pv[2] * xx + pv[0]), z * (pv[3] * yy + pv[1]), z], -1)
+    Nv = n @ w2v.T
+    absz = np.abs(z)
+    frustum = min_dim_unproject * absz
+    geoA = 1.0 / (s["planeDistanceSensitivity"] * frustum)
+    gax, gay = Nv[..., 0] * pv[2] * geoA, Nv[..., 1] * pv[3] * geoA
+    ga0 = (Nv[..., 0] * pv[0] + Nv[..., 1] * pv[1] + Nv[..., 2]) * geoA
+    geoB = -(Nv * Xv).sum(-1) * geoA
+    V = -normalize(Xv)
+    inv = 1.0 / (pj[4] * z)
+    nu = (pj[0] * Xv[..., 0] + pj[2] * z) * inv
+    nv_ = (pj[1] * Xv[..., 1] + pj[3] * z) * inv
+    kuz, kvz = pj[2] - nu * pj[4], pj[3] - nv_ * pj[4]
+    ju, jv = 0.5 * W * inv, -0.5 * H * inv
+    # per-frame rotation of the Poisson disk (PrePass: salt 1)
+    k = hash_px(0, 0, frame_index, 1) & 63
+    ang = 2.0 * np.pi * k / 64.0
+    rc, rs = np.float64(np.float32(np.cos(ang))), np.float64(np.float32(np.sin(ang)))
+    taps = np.stack([POISSON8[:, 0] * rc - POISSON8[:, 1] * rs, POISSON8[:, 0] * rs + POISSON8[:, 1] * rc], -1).astype(np.float32).astype(np.float64)
+    reach = 10 ** 9 if no_reach else int(max(s["diffusePrepassBlurRadius"], s["specularPrepassBlurRadius"]) * 1.1) + 3
+    out = np.zeros((H, W, 2, 4), np.float64)
+    track = np.zeros((H, W), np.float64)
+    hp = s["hitDistanceParameters"]
+    for sig, (plane, is_spec) in enumerate(((diff, False), (spec, True))):
+        center = plane.astype(np.float64)
+        rough = rough_g if is_spec else np.ones_like(rough_g)
+        min_mat = s["minMaterialForSpecular"] if is_spec else s["minMaterialForDiffuse"]
+        hn = hitdist_norm(absz, hp, rough)
+        hit = center[..., 3] * hn
+        hdf = np.clip(hit / frustum, 0, 1)
+        smc = spec_magic_curve(rough) if is_spec else np.ones_like(rough)
+        radius = (s["specularPrepassBlurRadius"] if is_spec else s["diffusePrepassBlurRadius"]) * hdf * smc
+        active = radius > 0
+        world_radius = radius * unproject * absz
+        T, B = basis(Nv)
+        if is_spec:
+            NoV = (Nv * V).sum(-1, keepdims=True)
+            R = Nv * 2.0 * NoV - V
+            D = normalize(Nv + (R - Nv) * spec_dominant_factor(rough)[..., None])
+            NoD = (Nv * D).sum(-1, keepdims=True)
+            skewed = (NoD[..., 0] < 0.999) & (rough < 0.95)
+            Dr = Nv * 2.0 * NoD - D
+            T2 = normalize(np.cross(Nv, Dr))
+            B2 = np.cross(Dr, T2)
+            T2 = T2 * ((0.5 + 0.5 * rough)[..., None] + (1.0 - (0.5 + 0.5 * rough)[..., None]) * NoD)
+            T, B = np.where(skewed[..., None], T2, T), np.where(skewed[..., None], B2, B)
+        T, B = T * world_radius[..., None], B * world_radius[..., None]
+        jtx, jty = ju * (pj[0] * T[..., 0] + kuz * T[..., 2]), jv * (pj[1] * T[..., 1] + kvz * T[..., 2])
+        jbx, jby = ju * (pj[0] * B[..., 0] + kuz * B[..., 2]), jv * (pj[1] * B[..., 1] + kvz * B[..., 2])
+        angle = np.arctan(3.0 * np.clip(rough, 0, 1) ** 2)  # lerp(lobeAngleFraction, 1, nonLinearAccumSpeed = 1) = 1 in the PrePass
+        normal_w = 1.0 / np.maximum(angle, NORMAL_ANGLE_MIN)
+        hitA = 1.0 / (1e-6 + (1.0 - 1e-6) * np.minimum(1.0, smc))
+        hitB = -center[..., 3] * hitA
+        roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
+        roughB = -rough * roughA
+        acc, wsum, min_hit = center.copy(), np.ones((H, W)), hit.copy()
+        for t in range(8):
+            fpx = np.floor(taps[t, 0] * jtx + taps[t, 1] * jbx + xx + 0.5)
+            fpy = np.floor(taps[t, 0] * jty + taps[t, 1] * jby + yy + 0.5)
+            in_win = (fpx >= np.maximum(xx - reach, 0)) & (fpx <= np.minimum(xx + reach, W - 1)) & (fpy >= np.maximum(yy - reach, 0)) & (fpy <= np.minimum(yy + reach, H - 1))
+            px, py = np.clip(fpx, 0, W - 1).astype(np.int64), np.clip(fpy, 0, H - 1).astype(np.int64)
+            zs, ns, rs_, ms = z[py, px], n[py, px], rough_g[py, px], mat[py, px]
+            sv = plane[py, px].astype(np.float64)
+            valid = in_win & active & ~sky[py, px] & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
+            w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
+            cosa = (n * ns).sum(-1)
+            if angle_normal_weight:
+                w = w * smoothstep01(1.0 - np.arccos(np.clip(cosa, -1, 1)) * normal_w)
+            else:
+                w = w * smoothstep01(1.0 - 2.0 * np.clip(1.0 - cosa, 0, 1) * normal_w * normal_w)
+            if is_spec:
+                w = w * smoothstep01(1.0 - np.abs(rs_ * roughA + roughB))
+            ax = np.abs(sv[..., 3] * hitA + hitB)
+            e = np.exp(-3.0 * ax) if exp_hit_weight else np.clip(1.0 - ax, 0, 1) ** 2
+            w = w * (s["minHitDistanceWeight"] + (1.0 - s["minHitDistanceWeight"]) * e)
+            w = np.where(valid, w, 0.0)
+            acc = acc + np.where(valid[..., None], sv, 0.0) * w[..., None]
+            wsum = wsum + w
+            min_hit = np.where(valid & (w > 0), np.minimum(min_hit, sv[..., 3] * hn), min_hit)
+        res = acc / wsum[..., None]
+        out[:, :, sig] = np.where(sky[..., None], 0.0, res)
+        if is_spec:
+            track = np.where(sky, 0.0, min_hit)
+    return f16(out), f16(track)
