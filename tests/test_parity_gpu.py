@@ -198,3 +198,41 @@ def test_4k_against_oracle(pkg, api, oracle, hip, den):
         ho.frame(cs, ho.upload(fr), st)
         hg.frame(cs, hg.upload(fr), st)
     assert util.compare_all(ho, hg, exact=True) == []
+
+
+def test_1080p_config2_against_oracle(pkg, api, oracle, hip):
+    """BASELINE.json configs[1] at FULL size: REBLUR_DIFFUSE, 1920x1080, 3 frames of the moving-camera scene with the bench's
+    operating point - every output and every pool plane of the HIP path equals the CPU oracle bit for bit"""
+    w, h = 1920, 1080
+    scene = pkg.synth.Scene(w, h, dolly=0.01)
+    dd = [api.Denoiser.REBLUR_DIFFUSE]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1, fastHistoryClampingSigmaScale=1.5)
+    ho = pkg.harness.Harness(oracle, dd, w, h)
+    oracle.lib.orc_set_threads(ho.nrd.handle, 128)
+    hg = pkg.harness.Harness(hip, dd, w, h)
+    for f in range(3):
+        fr = scene.frame(f)
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        ho.frame(cs, ho.upload(fr), st)
+        hg.frame(cs, hg.upload(fr), st)
+    assert util.compare_all(ho, hg, exact=True) == []
+
+
+def test_8k_config5_frame_against_oracle(pkg, api, oracle, hip):
+    """BASELINE.json configs[4]'s frame (7680x4320, REBLUR_DIFFUSE_SPECULAR) on one GPU, 2 frames: the 8K planes (33 Mpixel, 32-bit
+    texel offsets up to 1 GiB) against the CPU oracle, bit for bit"""
+    w, h = 7680, 4320
+    scene = pkg.synth.Scene(w, h, dolly=0.01, device="cuda:0")
+    dd = [api.Denoiser.REBLUR_DIFFUSE_SPECULAR]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    ho = pkg.harness.Harness(oracle, dd, w, h)
+    oracle.lib.orc_set_threads(ho.nrd.handle, 256)
+    hg = pkg.harness.Harness(hip, dd, w, h)
+    for f in range(2):
+        fr = scene.frame(f)
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in fr.items()}
+        host["normal_roughness"] = host["normal_roughness"].view(np.uint32)
+        ho.frame(cs, ho.upload(host), st)
+        hg.frame(cs, hg.upload(fr), st)
+    assert util.compare_all(ho, hg, exact=True) == []
