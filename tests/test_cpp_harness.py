@@ -134,7 +134,7 @@ def test_harness_synthesizes_its_own_inputs_through_the_pack_kernel(tmp_path, pk
     for name in ("out_diff.bin", "out_spec.bin", "out_shadow.bin", "out_signal.bin"):
         assert np.array_equal(np.fromfile(a / name, np.uint8), np.fromfile(b / name, np.uint8)), name
     nr = np.fromfile(a / "normal_roughness.bin", np.uint32).reshape(h, w)
-    assert set(np.unique(nr >> 30)) == {0, 1} and (nr[0, 0] & 1023) == 512  # wall: material 1, normal (0, 0, -1) -> oct x = 0.5
+    assert set(int(v) for v in np.unique(nr >> 30)) == {0, 1} and (nr[0, 0] & 1023) == 1023 and (nr[0, 0] >> 30) == 1  # wall: material 1, normal (0, 0, -1) -> octahedral corner (1, 1)
     diff = np.fromfile(a / "diff.bin", np.float16).reshape(h, w, 4)
     assert np.isfinite(diff).all() and (diff[..., 3] >= 0).all() and (diff[..., 3] <= 1).all() and diff[..., 0].mean() > 0.1
     out = np.fromfile(a / "out_diff.bin", np.float16).reshape(h, w, 4)
