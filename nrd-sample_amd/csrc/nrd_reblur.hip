@@ -894,6 +894,29 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
 // =====================================================================================================================
 // 5x5 luma tile in LDS: 20x20 floats, NaN marks "sky / outside" (the consumer substitutes its own centre value)
 // =====================================================================================================================
+// The 400 texels of a 20x20 tile are staged by the 256 threads of the workgroup in two sweeps without a divide: sweep 0 = the
+// thread's own pixel moved to tile position (tx + 0..15, ty + 0..15) of the 20x20 window [-2, 18)^2 ... i.e. window column
+// threadIdx.x, row threadIdx.y; sweep 1 (threads 0..143) = the 4 remaining columns of rows 0..15 and the 4 remaining rows
+NRD_DEV bool tile_pos(int sweep, int tid, int& lx, int& ly) {
+    if (sweep == 0) {
+        lx = tid & 15;
+        ly = tid >> 4;
+        return true;
+    }
+    if (tid >= 144)
+        return false;
+    if (tid < 64) { // columns 16..19 of rows 0..15
+        lx = 16 + (tid & 3);
+        ly = tid >> 2;
+    } else { // rows 16..19, all 20 columns
+        const int k = tid - 64;
+        ly = (k >= 20 ? 1 : 0) + (k >= 40 ? 1 : 0) + (k >= 60 ? 1 : 0);
+        lx = k - ly * 20;
+        ly += 16;
+    }
+    return true;
+}
+
 // `holes` is block-uniform: false when every texel of the staged 20x20 tile is valid (the common case), and the per-tap NaN test
 // of the substitution is dropped - the sums are the same either way
 NRD_DEV void moments5x5(const float* tile, int lx, int ly, float centre, bool holes, float& m1, float& m2) {
@@ -939,13 +962,27 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
+    // the centre loads of the pixel do not depend on the staged tiles: issued first, they travel with the staging loads (this
+    // kernel spent 72 % of its wave time in s_waitcnt: staging round trip, barrier, then the centre round trip)
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    const bool live = x < c.W && y >= c.ownY0 && y < c.ownY1;
+    const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
+    const uint4 graw = ld<uint4>(p.guide, cxp, cyp, 16);
+    const uint16_t data1Raw = ld<uint16_t>(p.data1Tmp, cxp, cyp, 2);
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.tmp2, cxp, cyp, ctex);
+    const uint32_t fastRaw = p.clampEnabled ? load_luma(p.fast, cxp, cyp, LBPT) : 0u;
     bool holes = false; // some texel of the staged tiles is sky / outside (block-uniform)
     if (p.clampEnabled || p.antiFirefly) {
-        // 20x20 luma tiles of all signals in one sweep (depth + one luma texel per position, clamped unconditional loads)
+        // 20x20 luma tiles of all signals (depth + one luma texel per position, clamped unconditional loads)
         int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
         int bad = 0;
-        for (int i = tid; i < 400; i += 256) {
-            int lx = i % 20, ly = i / 20;
+#pragma unroll
+        for (int sweep = 0; sweep < 2; sweep++) {
+            int lx, ly;
+            if (!tile_pos(sweep, tid, lx, ly))
+                continue;
+            const int i = ly * 20 + lx;
             int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
             bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
             int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
@@ -964,11 +1001,10 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         }
         holes = __syncthreads_or(bad) != 0;
     }
-    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
-    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+    if (!live)
         return;
     const PlaneRef& outP = p.relax ? p.hist : p.tmp1; // RELAX: the fixed + clamped signal IS the next frame's history
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(graw, c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
@@ -980,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     }
     const int gy0 = y + c.yOff;
     float A[2];
-    unpack_data1(ld<uint16_t>(p.data1Tmp, x, y, 2), A[0], A[1]);
+    unpack_data1(data1Raw, A[0], A[1]);
     float outA[2] = {A[0], A[1]};
     bool geoReady = false;
     PixelGeo pg;
@@ -990,8 +1026,8 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         const int ai = isSpec ? 1 : 0;
         float rough = isSpec ? g.roughness : 1.0f;
         uint32_t minMat = isSpec ? p.minMatSpec : p.minMatDiff;
-        f4 val = unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb));
-        f4 val1 = SH ? unpack_h4(ld<uint2>(p.tmp2, x, y, RBPT, sig * sb + 8)) : f4{0, 0, 0, 0};
+        f4 val = unpack_h4(ctex[sig * (sb / 8)]);
+        f4 val1 = SH ? unpack_h4(ctex[sig * (sb / 8) + 1]) : f4{0, 0, 0, 0};
         float Acur = A[ai];
         if (Acur < (float)p.historyFixFrameNum && p.historyFixFrameNum > 0) {
             float normA = sat(Acur / (float)p.historyFixFrameNum);
@@ -1038,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             }
         }
         if (p.clampEnabled) {
-            float fc = h2f(ld<uint16_t>(p.fast, x, y, LBPT, sig * 2));
+            float fc = h2f((uint16_t)(fastRaw >> (16 * sig)));
             float m1, m2;
             moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, holes, m1, m2);
             float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fastHistoryClampingSigmaScale;
@@ -1138,13 +1174,30 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
-    // 20x20 luma tiles of all signals in one sweep: guide depth + whole radiance texel per position, fetched unconditionally
-    // at clamped coordinates (NaN marks "sky / outside")
+    // Memory round trips are what this kernel waits for (64 % of its wave time sat in s_waitcnt): the centre loads of the pixel do
+    // not depend on the staged tile, so they are issued FIRST and travel together with the staging loads - one round trip, then
+    // the barrier; the history footprints (which need the centre's motion vector) travel while the 5x5 moments are read from LDS.
+    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    const bool live = x < c.W && y >= c.ownY0 && y < c.ownY1;
+    const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
+    const uint4 graw = ld<uint4>(p.guide, cxp, cyp, 16);
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.hist, cxp, cyp, ctex);
+    const uint2 mvTexel = ld<uint2>(p.inMV, cxp, cyp, 8);
+    const uint32_t data2 = ld<uint32_t>(p.data2, cxp, cyp, 4);
+    const uint16_t data1Raw = ld<uint16_t>(p.data1, cxp, cyp, 2);
+    const uint16_t hitRaw = HAS_SPEC ? ld<uint16_t>(p.hitTrack, cxp, cyp, 2) : (uint16_t)0;
+    // 20x20 luma tiles of all signals: guide depth + whole radiance texel per position, fetched unconditionally at clamped
+    // coordinates (NaN marks "sky / outside")
     int bad = 0;
     {
-        int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-        for (int i = tid; i < 400; i += 256) {
-            int lx = i % 20, ly = i / 20;
+        const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+#pragma unroll
+        for (int sweep = 0; sweep < 2; sweep++) {
+            int lx, ly;
+            if (!tile_pos(sweep, tid, lx, ly))
+                continue;
+            const int i = ly * 20 + lx;
             int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
             bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
             int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
@@ -1159,13 +1212,34 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         }
     }
     const bool holes = __syncthreads_or(bad) != 0; // some texel of the staged tiles is sky / outside (block-uniform)
-    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
-    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+#ifdef NRD_SEP_MOMENTS
+    __shared__ float rows1[NSIG][320], rows2[NSIG][320];
+    if (!holes) { // 16 columns x 20 rows of horizontal 5-sums: 320 per signal over 256 threads
+        const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+        for (int k = tid; k < 320; k += 256) {
+            const int lx = k & 15, ly = k >> 4;
+#pragma unroll
+            for (int sig = 0; sig < NSIG; sig++) {
+                float a = 0.0f, b = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    float f = tile[sig][ly * 20 + lx + i];
+                    a += f;
+                    b = fma_(f, f, b);
+                }
+                rows1[sig][k] = a;
+                rows2[sig][k] = b;
+            }
+        }
+        __syncthreads();
+    }
+#endif
+    if (!live)
         return;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     bool split = u < c.splitScreen;
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(graw, c.denoisingRange);
     if (g.sky) {
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
@@ -1183,14 +1257,11 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         }
         return;
     }
-    // ---- centre loads, then both history footprints in one round trip
-    uint2 ctex[RBPT / 8];
-    load_texel<RBPT>(p.hist, x, y, ctex);
-    f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
-    uint32_t data2 = ld<uint32_t>(p.data2, x, y, 4);
+    // ---- both history footprints in one round trip (the centre loads came in with the staging)
+    f4 mvRaw = unpack_h4(mvTexel);
     float A[2];
-    unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
-    float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
+    unpack_data1(data1Raw, A[0], A[1]);
+    float hitDist = HAS_SPEC ? h2f(hitRaw) : 0.0f;
     f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
     Reproj r = reproject(c, Xv, u, v, mvRaw);
     const bool historyOk = c.historyOk != 0;
@@ -1205,12 +1276,33 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         vpos = foot_pos(c, vOk ? tu : -10.0f, vOk ? tv : -10.0f); // unusable virtual position: lands outside, never validates
         load_stab(p, vpos, LBPT, vraw);
     }
+    // the 5x5 moments come from LDS: computed while the footprints travel
+    float m1s[NSIG], m2s[NSIG];
+#ifdef NRD_SEP_MOMENTS // timing prototype: row sums shared through LDS (no-holes tiles), column sums per pixel
+    if (!holes) {
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            m1s[sig] = 0.0f;
+            m2s[sig] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                m1s[sig] += rows1[sig][((int)threadIdx.y + j) * 16 + (int)threadIdx.x];
+                m2s[sig] += rows2[sig][((int)threadIdx.y + j) * 16 + (int)threadIdx.x];
+            }
+            m1s[sig] *= 1.0f / 25.0f;
+            m2s[sig] *= 1.0f / 25.0f;
+        }
+    } else
+#endif
+#pragma unroll
+    for (int sig = 0; sig < NSIG; sig++)
+        moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, h2f((uint16_t)ctex[sig * SW].x), holes, m1s[sig], m2s[sig]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         f4 cur = unpack_h4(ctex[sig * SW]);
-        float m1, m2;
-        moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, cur.x, holes, m1, m2);
+        const float m1 = m1s[sig], m2 = m2s[sig];
         float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f));
         float smbY, vmbY = 0.0f;
         bool smbOk = blend_stab(spos, sraw, sig, data2 & 15u, smbY) && historyOk;
