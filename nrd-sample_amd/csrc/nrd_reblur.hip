@@ -1188,76 +1188,30 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     const uint16_t data1Raw = ld<uint16_t>(p.data1, cxp, cyp, 2);
     const uint16_t hitRaw = HAS_SPEC ? ld<uint16_t>(p.hitTrack, cxp, cyp, 2) : (uint16_t)0;
     // 20x20 luma tiles of all signals: guide depth + whole radiance texel per position, fetched unconditionally at clamped
-    // coordinates (NaN marks "sky / outside")
-    int bad = 0;
-    {
-        const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    // coordinates (NaN marks "sky / outside"). The loads go to registers first: the history footprints below only need the
+    // centre loads (issued earlier, so they return earlier) and are issued BEFORE the staged texels are waited for and written to
+    // LDS - centre, staging and footprint traffic overlap instead of forming three dependent round trips.
+    const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    float stZ[2];
+    uint2 stT[2][RBPT / 8];
+    bool stIn[2], stOn[2];
+    int stI[2];
 #pragma unroll
-        for (int sweep = 0; sweep < 2; sweep++) {
-            int lx, ly;
-            if (!tile_pos(sweep, tid, lx, ly))
-                continue;
-            const int i = ly * 20 + lx;
-            int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
-            bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
-            int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
-            float zt = ld<float>(p.guide, cx, cy, 16, 0);
-            uint2 t[RBPT / 8];
-            load_texel<RBPT>(p.hist, cx, cy, t);
-            bool ok = inside && absf(zt) <= c.denoisingRange;
-            bad |= ok ? 0 : 1;
-#pragma unroll
-            for (int sig = 0; sig < NSIG; sig++)
-                tile[sig][i] = ok ? h2f((uint16_t)t[sig * SW].x) : u2f(0x7fc00000u);
-        }
+    for (int sweep = 0; sweep < 2; sweep++) {
+        int lx = 0, ly = 0;
+        stOn[sweep] = tile_pos(sweep, tid, lx, ly);
+        stI[sweep] = ly * 20 + lx;
+        int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
+        stIn[sweep] = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
+        int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
+        stZ[sweep] = ld<float>(p.guide, cx, cy, 16, 0);
+        load_texel<RBPT>(p.hist, cx, cy, stT[sweep]);
     }
-    const bool holes = __syncthreads_or(bad) != 0; // some texel of the staged tiles is sky / outside (block-uniform)
-#ifdef NRD_SEP_MOMENTS
-    __shared__ float rows1[NSIG][320], rows2[NSIG][320];
-    if (!holes) { // 16 columns x 20 rows of horizontal 5-sums: 320 per signal over 256 threads
-        const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-        for (int k = tid; k < 320; k += 256) {
-            const int lx = k & 15, ly = k >> 4;
-#pragma unroll
-            for (int sig = 0; sig < NSIG; sig++) {
-                float a = 0.0f, b = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    float f = tile[sig][ly * 20 + lx + i];
-                    a += f;
-                    b = fma_(f, f, b);
-                }
-                rows1[sig][k] = a;
-                rows2[sig][k] = b;
-            }
-        }
-        __syncthreads();
-    }
-#endif
-    if (!live)
-        return;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     bool split = u < c.splitScreen;
     Guide g = decode_guide(graw, c.denoisingRange);
-    if (g.sky) {
-#pragma unroll
-        for (int sig = 0; sig < NSIG; sig++) {
-            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
-            const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-            // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
-            if (SH && p.dirOcc) // single {SH1.xyz, SH0.x} texel out
-                st<uint2>(o, x, y, 8, split ? pack_dir(p, dir_pass(p, x, y)) : uint2{0u, 0u});
-            else
-                store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : f4{0, 0, 0, 0});
-            if (SH && !p.dirOcc)
-                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
-            st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
-        }
-        return;
-    }
-    // ---- both history footprints in one round trip (the centre loads came in with the staging)
+    // ---- both history footprints (positions from the centre's motion vector; a sky / outside pixel computes harmless clamped ones)
     f4 mvRaw = unpack_h4(mvTexel);
     float A[2];
     unpack_data1(data1Raw, A[0], A[1]);
@@ -1276,24 +1230,40 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         vpos = foot_pos(c, vOk ? tu : -10.0f, vOk ? tv : -10.0f); // unusable virtual position: lands outside, never validates
         load_stab(p, vpos, LBPT, vraw);
     }
-    // the 5x5 moments come from LDS: computed while the footprints travel
-    float m1s[NSIG], m2s[NSIG];
-#ifdef NRD_SEP_MOMENTS // timing prototype: row sums shared through LDS (no-holes tiles), column sums per pixel
-    if (!holes) {
+    __builtin_amdgcn_sched_barrier(0);
+    int bad = 0;
+#pragma unroll
+    for (int sweep = 0; sweep < 2; sweep++) {
+        if (!stOn[sweep])
+            continue;
+        bool ok = stIn[sweep] && absf(stZ[sweep]) <= c.denoisingRange;
+        bad |= ok ? 0 : 1;
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++)
+            tile[sig][stI[sweep]] = ok ? h2f((uint16_t)stT[sweep][sig * SW].x) : u2f(0x7fc00000u);
+    }
+    const bool holes = __syncthreads_or(bad) != 0; // some texel of the staged tiles is sky / outside (block-uniform)
+    if (!live)
+        return;
+    if (g.sky) {
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
-            m1s[sig] = 0.0f;
-            m2s[sig] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                m1s[sig] += rows1[sig][((int)threadIdx.y + j) * 16 + (int)threadIdx.x];
-                m2s[sig] += rows2[sig][((int)threadIdx.y + j) * 16 + (int)threadIdx.x];
-            }
-            m1s[sig] *= 1.0f / 25.0f;
-            m2s[sig] *= 1.0f / 25.0f;
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
+            const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+            // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
+            if (SH && p.dirOcc) // single {SH1.xyz, SH0.x} texel out
+                st<uint2>(o, x, y, 8, split ? pack_dir(p, dir_pass(p, x, y)) : uint2{0u, 0u});
+            else
+                store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : f4{0, 0, 0, 0});
+            if (SH && !p.dirOcc)
+                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
+            st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
         }
-    } else
-#endif
+        return;
+    }
+    // the 5x5 moments come from LDS: computed while the footprints travel
+    float m1s[NSIG], m2s[NSIG];
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++)
         moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, h2f((uint16_t)ctex[sig * SW].x), holes, m1s[sig], m2s[sig]);
