@@ -11,10 +11,15 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
+
+#ifndef NRD_HOST_EMULATION
+#include <dlfcn.h>
+#endif
 
 using namespace nrdhip;
 
@@ -950,6 +955,45 @@ int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Fla
 
 } // namespace
 
+// Stage annotations, like the reference's nri Annotation scopes around every stage (Source/NRDSample.cpp:4070, :4087, :4214): one roctx
+// range per recorded dispatch, named after the pass ("REBLUR::Blur" ...), visible in `rocprofv3 --marker-trace`. libroctx64 is
+// resolved on first use (no link dependency); NRDHIP_MARKERS=0 turns the ranges off.
+struct Markers {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Markers() {
+#ifndef NRD_HOST_EMULATION
+        const char* env = std::getenv("NRDHIP_MARKERS");
+        if (env && env[0] == '0')
+            return;
+        void* lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib)
+            lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib)
+            return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop)
+            push = nullptr, pop = nullptr;
+#endif
+    }
+};
+struct MarkerScope {
+    const Markers& m;
+    MarkerScope(const Markers& markers, const char* name) : m(markers) {
+        if (m.push)
+            m.push(name);
+    }
+    ~MarkerScope() {
+        if (m.pop)
+            m.pop();
+    }
+};
+const Markers& markers() {
+    static Markers m;
+    return m;
+}
+
 // makes the instance's device current for the duration of a call (Recreate(..., device) of the C++ veneer), restores the caller's
 struct DeviceScope {
     int prev = -1;
@@ -1297,8 +1341,10 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
         if ((part & NRDHIP_PART_FIRST) && fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
             for (uint32_t k = d.permBase; k < d.permEnd; k++)
                 (void)hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);
-        if (!(part & 4u))
+        if (!(part & 4u)) {
+            MarkerScope scope(markers(), x.name);
             x.launch(st);
+        }
         if ((part & NRDHIP_PART_LAST) && fl[i].index + 1 == d.dispatches.size()) {
             d.framesSinceReset = (reset || !d.historyValid) ? 1 : d.framesSinceReset + 1;
             d.frameCounter++;
