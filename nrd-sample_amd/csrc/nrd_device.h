@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #define NRD_DEV static __device__ __forceinline__
 #define NRD_HD static __host__ __device__ __forceinline__
 #ifndef NRD_WAVES_PER_EU // occupancy target of a kernel (the host emulation of the tests defines it away)
@@ -98,6 +100,8 @@ NRD_DEV float smoothstep01(float x) {
     return x * x * fma_(x, -2.0f, 3.0f); // == 3 - 2x rounded once: 2x is exact, so this is bit-identical to "3.0f - 2.0f * x"
 }
 NRD_DEV float absf(float x) { return __builtin_fabsf(x); } // a free source modifier (|x|) on the consuming instruction
+// true when `pred` holds on every active lane of the wave (wave-uniform: usable as a branch condition that costs no divergence)
+NRD_DEV bool nrd_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(!pred) == 0ull; }
 NRD_DEV int imin(int a, int b) { return a < b ? a : b; }
 NRD_DEV int imax(int a, int b) { return a > b ? a : b; }
 

@@ -164,6 +164,9 @@ inline T hipemu_buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 #define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) hipemu_buf_ld<unsigned int>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, a) hipemu_buf_ld<unsigned short>(r, v, s)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+// wave vote: threads run one at a time here, so a "wave" is the thread itself - valid wherever both sides of a wave-uniform
+// branch compute the same result (the only way the product kernels use it)
+#define __builtin_amdgcn_ballot_w64(pred) ((pred) ? 1ull : 0ull)
 inline void __syncthreads() { hipemu::sync(); }
 inline int __syncthreads_or(int v) {
     hipemu::sync();
