@@ -38,6 +38,9 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_LDS_HALO
 #define NRD_LDS_HALO 8
 #endif
+#ifndef NRD_LDS_POST // 1: PostBlur stages its guide window too (measured: its taps reach farther, too few waves qualify)
+#define NRD_LDS_POST 0
+#endif
 
 #if defined(NRD_DEBUG_COUNTERS) && !NRD_ORTHO // diagnosis build only (tools/tap_histogram.py): histogram of tap distances per spatial pass
 __device__ unsigned long long g_dbg_hist[3][8];
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     // runs the global-gather pipeline. Both read the same bits. In steady state no Blur tap reaches beyond 8 pixels
     // (profiles/r02_tap_distance_histogram.txt); PostBlur (5 % beyond 8, staging gain 0.016 ms measured) and the PrePass (16-32
     // pixels) stay on global gathers.
-    constexpr bool USE_LDS = VARIANT == 1 && NRD_LDS_HALO > 0;
+    constexpr bool USE_LDS = (VARIANT == 1 || (VARIANT == 2 && NRD_LDS_POST)) && NRD_LDS_HALO > 0;
     constexpr int LH = NRD_LDS_HALO, WW = 16 + 2 * LH;
     static_assert(!USE_LDS || WW == 32, "the staging index math assumes a 32 x 32 window");
     __shared__ uint4 ldsG[USE_LDS ? WW * WW : 1];
@@ -828,7 +831,8 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     float confD = (HAS_DIFF && c.confAvail) ? sample_confidence(p.confD, u, v) : 1.0f;
-    float confS = (HAS_SPEC && c.confAvail) ? sample_confidence(p.confS, u, v) : 1.0f;
+    // the sample binds ONE texture to both confidence slots (Source/NRDSample.cpp:457, :462): fetch it once then
+    float confS = (HAS_SPEC && c.confAvail) ? ((HAS_DIFF && p.confS.p == p.confD.p) ? confD : sample_confidence(p.confS, u, v)) : 1.0f;
     f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
     f3 Nv = rot3(c.w2v, g.n);
     f3 V = to_viewer(Xv);
