@@ -502,8 +502,14 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                 graw[T] = ldsG[(int)fma_(cyf - wy0f, (float)WW, cxf - wx0f)];
             else
                 graw[T] = ldb<uint4>(guideB, px, gpy, 16);
-            sraw[T] = occIn ? uint2{(uint32_t)ldb<uint16_t>(srcB[sig], px, gpy, 2), 0u} : ldb<uint2>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
-            sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8)) : uint2{0u, 0u};
+            if constexpr (SH && VARIANT != 0) { // SH0 | SH1 of a signal sit side by side in the internal planes: ONE 16-byte gather
+                const uint4 both = ldb<uint4>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
+                sraw[T] = uint2{both.x, both.y};
+                sraw1[T] = uint2{both.z, both.w};
+            } else {
+                sraw[T] = occIn ? uint2{(uint32_t)ldb<uint16_t>(srcB[sig], px, gpy, 2), 0u} : ldb<uint2>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
+                sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig]) : uint2{0u, 0u};
+            }
         };
         auto consume = [&](const int T) {
             const int sig = T >> 3, t = T & 7;
