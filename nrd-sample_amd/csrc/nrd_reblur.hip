@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     // runs the global-gather pipeline. Both read the same bits. In steady state no Blur tap reaches beyond 8 pixels
     // (profiles/r02_tap_distance_histogram.txt); PostBlur (5 % beyond 8, staging gain 0.016 ms measured) and the PrePass (16-32
     // pixels) stay on global gathers.
-    constexpr bool USE_LDS = (VARIANT == 1 || (VARIANT == 2 && NRD_LDS_POST)) && NRD_LDS_HALO > 0;
+    constexpr bool USE_LDS = (VARIANT == 1 || (VARIANT == 2 && NRD_LDS_POST)) && NSIG == 2 && NRD_LDS_HALO > 0; // one signal = 8 taps per pixel: staging 4 texels per thread then costs more than it saves (measured)
     constexpr int LH = NRD_LDS_HALO, WW = 16 + 2 * LH;
     static_assert(!USE_LDS || WW == 32, "the staging index math assumes a 32 x 32 window");
     __shared__ uint4 ldsG[USE_LDS ? WW * WW : 1];
