@@ -128,6 +128,8 @@ struct nrdhip_instance {
     bool commonSet = false;
     std::vector<DenoiserState> denoisers;
     std::vector<Plane> perm, trans;
+    uint8_t* transArena = nullptr; // library-owned pools: the one allocation all transient planes alias into
+    size_t transArenaBytes = 0;
     Plane slots[(size_t)nrd::ResourceType::MAX_NUM];
     std::string error;
 };
@@ -1073,7 +1075,47 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
         }
         return true;
     };
-    if (!make(permDesc, I->perm) || !make(transDesc, I->trans)) {
+    // Transient planes do not survive a frame and the denoisers of an instance run one after the other on one stream, so the
+    // library-owned transient pool is ONE arena sized for the hungriest denoiser and every denoiser's transient planes alias into it
+    // (what Get AliasableMemoryUsageInMb of the reference reports as aliasable IS aliased here). Callers that own the pools
+    // (NRDHIP_FLAG_EXTERNAL_POOLS) get one description per plane and may alias them the same way.
+    auto make_transient_arena = [&]() -> bool {
+        const bool owned = !(I->flags & NRDHIP_FLAG_EXTERNAL_POOLS);
+        size_t arena = 0;
+        std::vector<size_t> offsets(transDesc.size(), 0);
+        for (size_t di = 0; di < I->denoisers.size(); di++) {
+            const uint32_t b = I->denoisers[di].transBase, e = di + 1 < I->denoisers.size() ? I->denoisers[di + 1].transBase : (uint32_t)transDesc.size();
+            size_t off = 0;
+            for (uint32_t k = b; k < e; k++) {
+                const PoolPlane& pd = transDesc[k];
+                size_t w = (size_t)(I->resW + pd.downsample - 1) / pd.downsample, h = (size_t)(I->resH + pd.downsample - 1) / pd.downsample;
+                offsets[k] = off;
+                off += (w * pd.bpt * h + 255) / 256 * 256; // 256-byte aligned planes
+            }
+            arena = std::max(arena, off);
+        }
+        I->transArenaBytes = arena;
+        if (owned && arena) {
+            if (hipMalloc((void**)&I->transArena, arena) != hipSuccess)
+                return false;
+            (void)hipMemset(I->transArena, 0, arena);
+        }
+        for (size_t k = 0; k < transDesc.size(); k++) {
+            const PoolPlane& pd = transDesc[k];
+            Plane P;
+            P.fmt = (uint32_t)pd.fmt;
+            P.bpt = pd.bpt;
+            P.name = pd.name;
+            P.w = (uint16_t)((I->resW + pd.downsample - 1) / pd.downsample);
+            P.h = (uint16_t)((I->resH + pd.downsample - 1) / pd.downsample);
+            P.pitch = P.w * P.bpt;
+            if (owned)
+                P.p = I->transArena + offsets[k]; // not `owned`: the arena is freed as a whole
+            I->trans.push_back(P);
+        }
+        return true;
+    };
+    if (!make(permDesc, I->perm) || !make_transient_arena()) {
         g_createError = "hipMalloc failed (is a HIP device visible?)";
         nrdhip_destroy(I);
         return (int)nrd::Result::FAILURE;
@@ -1090,6 +1132,8 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
         for (auto& P : *v)
             if (P.owned && P.p)
                 (void)hipFree(P.p);
+    if (inst->transArena)
+        (void)hipFree(inst->transArena);
     delete inst;
 }
 
@@ -1205,7 +1249,7 @@ NRDHIP_API int nrdhip_bind_pool(nrdhip_instance* inst, uint32_t pool, uint32_t i
     if (!inst || pool > 1)
         return (int)nrd::Result::INVALID_ARGUMENT;
     auto& v = pool == 0 ? inst->perm : inst->trans;
-    if (index >= v.size() || pitch < v[index].w * v[index].bpt || v[index].owned)
+    if (index >= v.size() || pitch < v[index].w * v[index].bpt || v[index].owned || !(inst->flags & NRDHIP_FLAG_EXTERNAL_POOLS))
         return (int)nrd::Result::INVALID_ARGUMENT;
     v[index].p = (uint8_t*)ptr;
     v[index].pitch = pitch;
@@ -1373,8 +1417,12 @@ NRDHIP_API int nrdhip_get_memory_mb(nrdhip_instance* inst, float out[3]) {
     double p = 0, t = 0;
     for (auto& P : inst->perm)
         p += (double)P.pitch * P.h;
-    for (auto& P : inst->trans)
-        t += (double)P.pitch * P.h;
+    if (!(inst->flags & NRDHIP_FLAG_EXTERNAL_POOLS)) {
+        t = (double)inst->transArenaBytes; // aliased: one arena for the hungriest denoiser
+    } else {
+        for (auto& P : inst->trans)
+            t += (double)P.pitch * P.h;
+    }
     out[0] = (float)((p + t) / 1048576.0);
     out[1] = (float)(p / 1048576.0);
     out[2] = (float)(t / 1048576.0);

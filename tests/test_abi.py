@@ -177,3 +177,41 @@ def test_rccl_entry_points_do_not_take_the_library_down_without_a_gpu(pkg):
     code = ("import ctypes as C; l = C.CDLL(%r); b = (C.c_uint8 * 128)(); r = l.nrdhip_tiler_rccl_unique_id(b); print('rc', r)" % pkg.HIP_LIB)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "rc 1" in r.stdout, r.stdout + r.stderr
+
+
+def test_library_owned_transient_pool_is_one_aliased_arena(api, emulated):
+    """with library-owned pools (the C++ path) the transient planes of all denoisers alias into ONE arena sized for the
+    hungriest denoiser - the "aliasable" figure of Get*MemoryUsageInMb is real, and an all-denoiser instance like the sample's does
+    not pay the sum"""
+    import ctypes as C
+
+    D = api.Denoiser
+
+    def mem(dens, flags):
+        arr = (api.DenoiserDesc * len(dens))(*[api.DenoiserDesc(int(d), int(d)) for d in dens])
+        h = C.c_void_p()
+        desc = api.CreateDesc(arr, len(dens), 256, 128, 0, 0, 0, 0, 0, flags)
+        assert emulated.create(C.byref(desc), C.byref(h)) == 0
+        out = (C.c_float * 3)()
+        emulated.get_memory_mb(h, out)
+        infos = []
+        n = C.c_uint32()
+        emulated.pool_size(h, 1, C.byref(n))
+        for i in range(n.value):
+            info = api.PlaneInfo()
+            emulated.pool_info(h, 1, i, C.byref(info))
+            infos.append((info.ptr, info.pitch_bytes * info.height))
+        emulated.destroy(h)
+        return list(out), infos
+
+    one, _ = mem([D.REBLUR_DIFFUSE_SPECULAR], 0)
+    two, infos = mem([D.REBLUR_DIFFUSE_SPECULAR, D.RELAX_DIFFUSE_SPECULAR, D.SIGMA_SHADOW], 0)
+    relax, _ = mem([D.RELAX_DIFFUSE_SPECULAR], 0)
+    assert abs(two[2] - max(one[2], relax[2])) < 1e-3  # aliasable = the hungriest denoiser, not the sum
+    assert two[1] > one[1] + relax[1] - 1e-3           # persistent planes are never shared
+    ext, _ = mem([D.REBLUR_DIFFUSE_SPECULAR, D.RELAX_DIFFUSE_SPECULAR, D.SIGMA_SHADOW], api.FLAG_EXTERNAL_POOLS)
+    assert ext[2] > two[2] * 1.5                       # caller-owned pools are described plane by plane (the caller may alias them)
+    ptrs = [p for p, _ in infos]
+    assert len(set(ptrs)) < len(ptrs) and all(p for p in ptrs)  # planes of different denoisers share addresses
+    lo, hi = min(ptrs), max(p + b for p, b in infos)
+    assert hi - lo <= int(two[2] * 1048576) + 256
