@@ -3,7 +3,7 @@
 // Numerics contract: every float expression is a sequence of separately rounded IEEE binary32 operations
 // (-ffp-contract=off, IEEE divide/sqrt); fusion happens ONLY where the source says fma_() (v_fma_f32). That makes results
 // reproducible bit for bit run to run, 1 GPU vs N GPUs, and against the CPU oracle of the tests. Transcendentals are fixed
-// polynomials (no ocml calls on the pixel path). The kernels are VALU-bound, so the per-tap arithmetic avoids IEEE
+// polynomials (no ocml calls on the pixel path). Instruction count matters, so the per-tap arithmetic avoids IEEE
 // divisions and square roots: guides are pre-decoded once per pixel into a 16-byte texel, the normal weight works on the
 // squared angle, the hit-distance weight has compact support, and taps are placed with the pixel-space Jacobian of the
 // projection instead of a perspective divide per tap.

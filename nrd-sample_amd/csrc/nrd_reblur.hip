@@ -7,13 +7,12 @@
 // pixel so a bilateral tap costs ONE 16-byte gather and four converts for all guides; diffuse+specular radiance interleaved
 // in one 16-byte texel; accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles, assigned to XCDs
 // in contiguous runs (nrd_device.h xcd_tile) so stencil / gather overlap between neighbouring tiles is served by one XCD's
-// L2. These are gather / stencil filters (VALU-issue / gather-latency bound, profiles/): no MFMA. 5x5 moment stencils and the
+// L2. These are gather / stencil filters (bound by the texture addresser's gather rate and by VALU issue): no MFMA. 5x5 moment stencils, Blur's tap guides and the
 // first RELAX A-trous iterations stage their tile (+ halo) in LDS.
 #include "nrd_kernels.h"
 
-// NRD_PART 0 (default): every launcher of this file except the non-SH Blur one; NRD_PART 1 (nrd_reblur_blur*.hip): only that one.
-// The split exists for the build flags: k_spatial<1, 0, ...> is the one kernel that is faster WITH the SLP vectorizer (its
-// divergent per-quad gathers like the finer vmcnt waits that schedule produces), everything else is faster without (Makefile).
+// NRD_PART 0 (default): every launcher of this file except the non-SH Blur one; NRD_PART 1 (nrd_reblur_blur*.hip): only that one -
+// the largest kernel family of the file compiles in its own translation unit (parallel build; round 1 also gave it its own flags).
 #ifndef NRD_PART
 #define NRD_PART 0
 #endif
@@ -22,11 +21,6 @@ namespace nrdhip {
 
 NRD_KERNELS_BEGIN
 
-// taps gathered per memory round trip in the spatial passes (8 = all taps of a signal; 4 or 2 were measured slower: more round
-// trips and no extra wave - also when software-pipelined, the next batch's gathers issued before this batch's arithmetic)
-#ifndef NRD_TAP_BATCH
-#define NRD_TAP_BATCH 8
-#endif
 // taps in flight per wave in the software-pipelined tap loop of the spatial passes (k_spatial)
 #ifndef NRD_PIPE_DEPTH
 #define NRD_PIPE_DEPTH 8
