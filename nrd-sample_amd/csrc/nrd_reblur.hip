@@ -1662,11 +1662,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     }
 }
 
-dim3 grid_for(const FrameConsts& c) {
-    int total = c.tilesX * c.tilesY;
-    int chunk = (total + 7) / 8;
-    return dim3((unsigned)(chunk * 8), 1, 1);
-}
+dim3 grid_for(const FrameConsts& c) { return dim3((unsigned)xcd_grid_blocks(c.tilesX, c.tilesY), 1, 1); }
 
 NRD_KERNELS_END
 

@@ -377,11 +377,7 @@ __global__ __launch_bounds__(256) void k_reference_accumulate(const ReferencePar
     st<uint2>(p.out, x, y, 8, pack_h4(u < c.splitScreen ? s : h));
 }
 
-dim3 grid_for(const FrameConsts& c) {
-    int total = c.tilesX * c.tilesY;
-    int chunk = (total + 7) / 8;
-    return dim3((unsigned)(chunk * 8), 1, 1);
-}
+dim3 grid_for(const FrameConsts& c) { return dim3((unsigned)xcd_grid_blocks(c.tilesX, c.tilesY), 1, 1); }
 
 NRD_KERNELS_END
 
