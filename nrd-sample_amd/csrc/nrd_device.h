@@ -470,12 +470,13 @@ NRD_HD void rotate_taps(const float (*rot)[2], uint32_t frameIndex, uint32_t sal
 // (workgroup b runs on XCD b % 8), each XCD has its own 4 MiB L2, and every pass reads neighbours of its pixels (taps reach 8-58
 // pixels, 5x5 stencils, motion-displaced footprints). So:
 //  * XCD k owns a contiguous band of tile COLUMNS [k cols, (k + 1) cols), cols = ceil(tilesX / 8): neighbour reads stay in one L2;
-//  * inside its band the XCD walks column STRIPS ~10 tiles wide (the band split evenly), row-major inside a strip: the ~128-256
-//    workgroups an XCD has in flight then cover a compact ~10 x 13 tile block instead of half a tile row of the frame, and the rows
-//    above / below that the taps reach are still in L2 when the next tile row of the strip runs.
-// Measured at 4K (profiles/r02_ab_tile_traversal.txt): row-major over the whole width 5870 Mpix/s, strips 6700-7060 (best when the
-// strips divide the XCD's band evenly: 10 tiles of its 30). The three spatial passes and TemporalAccumulation gain 17-22 % each -
-// what looked like a texture-addresser bound was to a good part the addresser stalling on L1 / L2 misses.
+//  * inside its band the XCD walks row-major, in column strips of at most ~NRD_STRIP_TARGET tiles (one strip at 4K, where a band
+//    is 30 tiles wide; two at 8K): the ~128-256 workgroups an XCD has in flight then cover a compact 30 x 4..8 tile block instead of
+//    half a tile row of the whole frame, and the rows above / below that the taps reach are still in L2 when the next rows run.
+// Measured at 4K (profiles/r02_ab_tile_traversal.txt): round 1's mapping (XCD k = a run of full-width tile rows) 5870 Mpix/s;
+// column bands 7060-7130 (strips of 5 / 6 / 8 / 10 / 15 / 30 tiles inside the band: 6870 / 6810 / 6780 / 7060 / 7050 / 7120). The
+// three spatial passes and TemporalAccumulation gain 17-25 % each - what looked like a pure texture-addresser bound was to a good
+// part the addresser stalling on L1 / L2 misses (TA_ADDR_STALLED_BY_TC).
 NRD_HD int xcd_cols(int tilesX) { return (tilesX + 7) >> 3; }
 NRD_HD int xcd_grid_blocks(int tilesX, int tilesY) { return xcd_cols(tilesX) * tilesY * 8; } // launch size: 8 x the largest band
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
@@ -484,7 +485,10 @@ NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
     const int wk = imin(c.tilesX - x0, cols); // width of this XCD's band (the last ones may be narrower or empty)
     if (wk <= 0 || j >= wk * c.tilesY)
         return false;
-    const int nStrips = imax((wk + 5) / 10, 1), S = (wk + nStrips - 1) / nStrips;
+#ifndef NRD_STRIP_TARGET // widest column strip inside an XCD's band (tiles)
+#define NRD_STRIP_TARGET 30
+#endif
+    const int nStrips = imax((wk + NRD_STRIP_TARGET / 2) / NRD_STRIP_TARGET, 1), S = (wk + nStrips - 1) / nStrips;
     const int perStrip = S * c.tilesY;
     const int s = j / perStrip, r = j - s * perStrip;
     const int w = imin(S, wk - s * S);
