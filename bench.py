@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
+    ap.add_argument("--roll", type=float, default=0.0, help="camera roll in degrees (1-GPU runs): 90 puts the sky at one SIDE of the frame - "
+                    "a layout probe for the XCD tile traversal, not the headline scene")
     ap.add_argument("--checkerboard", action="store_true",
                     help="the sample's default operating point (tracingMode RESOLUTION_HALF): half-width checkerboarded inputs, "
                          "CheckerboardMode::WHITE -> the PrepareInputs pass runs (single-GPU runner)")
@@ -198,7 +200,8 @@ def main():
     if world == 1 and not args.force_tiled:
         from nrd_sample_amd.harness import Harness
 
-        scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR")
+        scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
+                            roll_deg=args.roll)
         hz = Harness(hip, dens, w, band_h)
         runner = SingleRunner(api, hz, scene, dens, args.unique_frames, settings_of(api, scene, dens))
         frame_h = band_h
@@ -256,7 +259,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak" if (world == 1 or not strong) else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s, %dx%d%s, %s" % (args.workload, "+".join(den_names), w, frame_h, tiled, state),
+            "config": {"workload": "%s: %s, %dx%d%s, %s" % (args.workload, "+".join(den_names), w, frame_h, tiled, state) +
+                       (" [camera rolled %g deg: layout probe]" % args.roll if args.roll else ""),
                        "unique_input_frames": args.unique_frames, "storage_dtype": "f16 planes (f32 viewZ), f32 arithmetic"},
         }
         if per_pass:

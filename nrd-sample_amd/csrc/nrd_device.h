@@ -473,28 +473,44 @@ NRD_HD void rotate_taps(const float (*rot)[2], uint32_t frameIndex, uint32_t sal
 //  * inside its band the XCD walks row-major, in column strips of at most ~NRD_STRIP_TARGET tiles (one strip at 4K, where a band
 //    is 30 tiles wide; two at 8K): the ~128-256 workgroups an XCD has in flight then cover a compact 30 x 4..8 tile block instead of
 //    half a tile row of the whole frame, and the rows above / below that the taps reach are still in L2 when the next rows run.
+//  * the band an XCD works on ROTATES every ceil(tilesY / 8) tile rows (block (band, by) -> XCD (band + 3 by) mod 8): every XCD
+//    visits every column band and every block row once, so content that is cheap in whole rows (sky above a horizon: those
+//    tiles exit at once) or in whole columns costs every XCD the same. A fixed assignment of frame regions to XCDs does not: round
+//    1's mapping (XCD k = the k-th run of full-width tile rows) left the XCDs that owned the sky rows of the bench scene (28 % of
+//    the frame) idle while the others worked - CUs 70 % busy (SQ_BUSY_CU_CYCLES), now 92 %.
 // Measured at 4K (profiles/r02_ab_tile_traversal.txt): round 1's mapping (XCD k = a run of full-width tile rows) 5870 Mpix/s;
 // column bands 7060-7130 (strips of 5 / 6 / 8 / 10 / 15 / 30 tiles inside the band: 6870 / 6810 / 6780 / 7060 / 7050 / 7120). The
 // three spatial passes and TemporalAccumulation gain 17-25 % each - what looked like a pure texture-addresser bound was to a good
 // part the addresser stalling on L1 / L2 misses (TA_ADDR_STALLED_BY_TC).
 NRD_HD int xcd_cols(int tilesX) { return (tilesX + 7) >> 3; }
-NRD_HD int xcd_grid_blocks(int tilesX, int tilesY) { return xcd_cols(tilesX) * tilesY * 8; } // launch size: 8 x the largest band
+#ifndef NRD_BAND_ROTATE // 1: the band an XCD works on rotates every xcd_rows() tile rows (load balance for any scene layout)
+#define NRD_BAND_ROTATE 1
+#endif
+NRD_HD int xcd_rows(int tilesY) { return NRD_BAND_ROTATE ? (tilesY + 7) >> 3 : tilesY; } // tile rows per block row (<= 8 block rows)
+NRD_HD int xcd_grid_blocks(int tilesX, int tilesY) { // launch size: 8 x (largest band x block rows, rounded up)
+    const int rows = xcd_rows(tilesY);
+    return xcd_cols(tilesX) * rows * ((tilesY + rows - 1) / rows) * 8;
+}
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
     const int b = (int)blockIdx.x, k = b & 7, j = b >> 3;
-    const int cols = xcd_cols(c.tilesX), x0 = k * cols;
-    const int wk = imin(c.tilesX - x0, cols); // width of this XCD's band (the last ones may be narrower or empty)
-    if (wk <= 0 || j >= wk * c.tilesY)
+    const int cols = xcd_cols(c.tilesX), rows = xcd_rows(c.tilesY);
+    const int perBlock = cols * rows;
+    const int by = j / perBlock, jb = j - by * perBlock;
+    const int band = (k + 5 * by) & 7; // 5 = -3 mod 8: block (band, by) belongs to XCD (band + 3 by) mod 8
+    const int x0 = band * cols, y0 = by * rows;
+    const int wk = imin(c.tilesX - x0, cols), hk = imin(c.tilesY - y0, rows); // the last band / block row may be smaller (or empty)
+    if (wk <= 0 || jb >= wk * hk)
         return false;
-#ifndef NRD_STRIP_TARGET // widest column strip inside an XCD's band (tiles)
+#ifndef NRD_STRIP_TARGET // widest column strip inside a block (tiles)
 #define NRD_STRIP_TARGET 30
 #endif
     const int nStrips = imax((wk + NRD_STRIP_TARGET / 2) / NRD_STRIP_TARGET, 1), S = (wk + nStrips - 1) / nStrips;
-    const int perStrip = S * c.tilesY;
-    const int s = j / perStrip, r = j - s * perStrip;
+    const int perStrip = S * hk;
+    const int s = jb / perStrip, r = jb - s * perStrip;
     const int w = imin(S, wk - s * S);
-    ty = r / w;
-    tx = x0 + s * S + (r - ty * w);
-    ty += c.tileY0;
+    const int tyl = r / w;
+    tx = x0 + s * S + (r - tyl * w);
+    ty = y0 + tyl + c.tileY0;
     return true;
 }
 

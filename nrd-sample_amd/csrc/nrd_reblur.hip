@@ -28,13 +28,6 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_PIPE_DEPTH_WIDE
 #define NRD_PIPE_DEPTH_WIDE 5
 #endif
-// pixels of guide texels staged around the 16 x 16 tile of Blur / PostBlur (0 = no staging, all taps gather from global memory)
-#ifndef NRD_LDS_HALO
-#define NRD_LDS_HALO 8
-#endif
-#ifndef NRD_LDS_POST // 1: PostBlur stages its guide window too (measured: its taps reach farther, too few waves qualify)
-#define NRD_LDS_POST 0
-#endif
 
 #if defined(NRD_DEBUG_COUNTERS) && !NRD_ORTHO // diagnosis build only (tools/tap_histogram.py): histogram of tap distances per spatial pass
 __device__ unsigned long long g_dbg_hist[3][8];
@@ -282,36 +275,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
-    // Blur: the guide texels of the tile and NRD_LDS_HALO pixels around it are staged in LDS (32 x 32 texels, 16 KB, every texel
-    // fetched once per workgroup, coalesced). A wave whose taps all stay inside the staged window (decided once per wave from the
-    // extent of each lane's tap footprint) reads its tap guides from there: the texture addresser, which bounds these passes
-    //  and suffers most from Blur's per-quad rotation, then serves 16 gathers per pixel instead of 32. Any other wave
-    // runs the global-gather pipeline. Both read the same bits. In steady state no Blur tap reaches beyond 8 pixels
-    // (profiles/r02_tap_distance_histogram.txt); PostBlur (5 % beyond 8, staging gain 0.016 ms measured) and the PrePass (16-32
-    // pixels) stay on global gathers.
-    constexpr bool USE_LDS = (VARIANT == 1 || (VARIANT == 2 && NRD_LDS_POST)) && NSIG == 2 && NRD_LDS_HALO > 0; // one signal = 8 taps per pixel: staging 4 texels per thread then costs more than it saves (measured)
-    constexpr int LH = NRD_LDS_HALO, WW = 16 + 2 * LH;
-    static_assert(!USE_LDS || WW == 32, "the staging index math assumes a 32 x 32 window");
-    __shared__ uint4 ldsG[USE_LDS ? WW * WW : 1];
-    bool live;
-    if (USE_LDS) {
-        if (!xcd_tile(c, tx, ty))
-            return;
-        x = tx * 16 + (int)threadIdx.x;
-        y = ty * 16 + (int)threadIdx.y;
-        live = x < c.W && y >= c.ownY0 && y < c.ownY1;
-        const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { // 1024 texels over 256 threads; rows of 32 texels = 512 contiguous bytes
-            const int i = tid + 256 * k, wy = i >> 5, wx = i & 31;
-            const int lx = imin(imax(tx * 16 - LH + wx, 0), c.W - 1), ly = imin(imax(ty * 16 - LH + wy, 0), c.resH - 1);
-            ldsG[i] = ld<uint4>(p.guide, lx, ly, 16);
-        }
-        __syncthreads();
-    } else {
-        live = my_pixel(c, x, y, tx, ty);
-    }
-    if (!live)
+    if (!my_pixel(c, x, y, tx, ty))
         return;
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
     const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
@@ -356,8 +320,6 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     const int loX = imax(x - reach, 0), hiX = imin(x + reach, c.W - 1);
     const int loY = imax(gy0 - reach, imax(c.yOff, 0)), hiY = imin(gy0 + reach, imin(c.yOff + c.resH, c.H) - 1);
     const float loXf = (float)loX, hiXf = (float)hiX, loYf = (float)loY, hiYf = (float)hiY; // floored tap positions are compared / clamped as floats
-    // the staged window in global pixel coordinates
-    const float wx0f = (float)(tx * 16 - LH), wy0f = (float)(ty * 16 + c.yOff - LH);
 
     // ---- per-signal set-up: everything the taps of a signal need, for BOTH signals, before the first gather is issued -------
     // (a signal whose radius is 0 keeps its constants - its taps land on the centre and are selected out by `active`, which
@@ -452,6 +414,9 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     // "all gathers of a signal, then all arithmetic" the waves of a CU march in step - everybody gathers, then everybody computes -
     // so the two added up (0.30 ms). Here every wave keeps NRD_PIPE_DEPTH taps in flight and consumes tap T right after issuing
     // tap T + DEPTH, across the signal boundary, so each wave feeds the addresser and the VALU all the time.
+    // Guide texels are NOT staged in LDS: with the XCD column-band tile traversal (nrd_device.h, xcd_tile) the gathers hit in L1 /
+    // L2 and a staged 32 x 32 guide window measures the same 0.217 ms as global gathers (profiles/r02_ab_tile_traversal.txt; it was
+    // worth 0.05 ms under the old round-robin traversal, profiles/r02_ab_blur_lds_postblur_waveshape.txt).
     // The tap window [lo, hi] folds the frame bounds, the rows this instance holds and the hard reach of the pass into one range
     // test per axis; a rejected tap is SELECTED out (sums untouched), exactly like an early "continue".
     // tap rows are GLOBAL rows: the band's first row is folded into the base pointers once (scalar unit) instead of one
@@ -475,7 +440,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
         bool inWin[NT];
         uint4 graw[NT];
         uint2 sraw[NT], sraw1[NT];
-        auto issue = [&](const int T, auto fast) {
+        auto issue = [&](const int T) {
             const int sig = T >> 3, t = T & 7;
             float ox, oy;
             if (PER_PIXEL) {
@@ -492,10 +457,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
             inWin[T] = (cxf == fpx) & (cyf == fpy);
             const int px = (int)cxf, gpy = (int)cyf;
-            if constexpr (decltype(fast)::value) // the clamped position lies between the tap and the centre: inside the staged window
-                graw[T] = ldsG[(int)fma_(cyf - wy0f, (float)WW, cxf - wx0f)];
-            else
-                graw[T] = ldb<uint4>(guideB, px, gpy, 16);
+            graw[T] = ldb<uint4>(guideB, px, gpy, 16);
             if constexpr (SH && VARIANT != 0) { // SH0 | SH1 of a signal sit side by side in the internal planes: ONE 16-byte gather
                 const uint4 both = ldb<uint4>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
                 sraw[T] = uint2{both.x, both.y};
@@ -550,39 +512,17 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                 wsum[sig] += w;
             }
         };
-        auto pipeline = [&](auto fast) {
 #pragma unroll
-            for (int T = 0; T < DEPTH; T++)
-                issue(T, fast);
+        for (int T = 0; T < DEPTH; T++)
+            issue(T);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int T = 0; T < NT; T++) {
+            if (T + DEPTH < NT)
+                issue(T + DEPTH);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int T = 0; T < NT; T++) {
-                if (T + DEPTH < NT)
-                    issue(T + DEPTH, fast);
-                __builtin_amdgcn_sched_barrier(0);
-                consume(T);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if constexpr (USE_LDS) {
-            // does every tap of this lane stay inside the staged window? |J . o| <= |a| max|o.x| + |b| max|o.y| over the disk (+ 1
-            // for the floor); a signal without taps (radius 0) fits trivially. One decision per WAVE: a single far lane sends it
-            // down the global path.
-            const float wx1f = wx0f + (float)(WW - 1), wy1f = wy0f + (float)(WW - 1);
-            bool fits = true;
-#pragma unroll
-            for (int sig = 0; sig < NSIG; sig++) {
-                const float ex = fma_(0.9057375f, absf(jtx[sig]), fma_(0.8198990f, absf(jbx[sig]), 1.0f));
-                const float ey = fma_(0.9057375f, absf(jty[sig]), fma_(0.8198990f, absf(jby[sig]), 1.0f));
-                const bool in = (cx - ex >= wx0f) & (cx + ex <= wx1f) & (cy - ey >= wy0f) & (cy + ey <= wy1f);
-                fits = fits & (in | !active[sig]);
-            }
-            if (nrd_wave_all(fits))
-                pipeline(std::true_type{});
-            else
-                pipeline(std::false_type{});
-        } else {
-            pipeline(std::false_type{});
+            consume(T);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll

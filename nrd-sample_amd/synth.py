@@ -84,11 +84,14 @@ def orthographic(half_width, aspect):
     return m
 
 
-def world_to_view(pos, yaw=0.0, pitch=0.0):
+def world_to_view(pos, yaw=0.0, pitch=0.0, roll=0.0):
     cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
     ry = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
     rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
     r = rx @ ry
+    if roll != 0.0:  # camera rolled about its view axis (roll = pi / 2 puts the sky at one side of the frame)
+        cr, sr = math.cos(roll), math.sin(roll)
+        r = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]]) @ r
     t = -r @ np.asarray(pos, dtype=np.float64)
     m = np.zeros((4, 4))
     m[:3, :3] = r
@@ -102,9 +105,10 @@ class Scene:
     on a GPU so that large (4K/8K) frames are produced where the denoiser consumes them."""
 
     def __init__(self, width, height, seed=0x9E3779B9, hfov=90.0, dolly=0.01, denoiser="REBLUR", rough_bands=True,
-                 translucent_sphere=True, device="cpu", frame_height=None, row0=0, ortho=False):
+                 translucent_sphere=True, device="cpu", frame_height=None, row0=0, ortho=False, roll_deg=0.0):
         self.w, self.h, self.seed = width, height, seed
         self.ortho = ortho
+        self.roll = math.radians(roll_deg)
         self.hfov, self.dolly = hfov, dolly
         self.relax = denoiser == "RELAX"
         self.rough_bands = rough_bands
@@ -132,7 +136,7 @@ class Scene:
 
     def matrices(self, frame, prev_frame=None):
         prev_frame = max(frame - 1, 0) if prev_frame is None else prev_frame
-        return world_to_view(self.cam_pos(frame), 0.0, 0.12), world_to_view(self.cam_pos(prev_frame), 0.0, 0.12)
+        return world_to_view(self.cam_pos(frame), 0.0, 0.12, self.roll), world_to_view(self.cam_pos(prev_frame), 0.0, 0.12, self.roll)
 
     @staticmethod
     def _rot_pos(m):
