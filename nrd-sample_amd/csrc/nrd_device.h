@@ -491,8 +491,7 @@ NRD_HD int xcd_grid_blocks(int tilesX, int tilesY) { // launch size: 8 x (larges
     const int rows = xcd_rows(tilesY);
     return xcd_cols(tilesX) * rows * ((tilesY + rows - 1) / rows) * 8;
 }
-NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
-    const int b = (int)blockIdx.x, k = b & 7, j = b >> 3;
+NRD_DEV bool xcd_tile_kj(const FrameConsts& c, const int k, const int j, int& tx, int& ty) { // j-th tile of XCD k
     const int cols = xcd_cols(c.tilesX), rows = xcd_rows(c.tilesY);
     const int perBlock = cols * rows;
     const int by = j / perBlock, jb = j - by * perBlock;
@@ -512,6 +511,10 @@ NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
     tx = x0 + s * S + (r - tyl * w);
     ty = y0 + tyl + c.tileY0;
     return true;
+}
+NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) { // one 16 x 16 workgroup per tile
+    const int b = (int)blockIdx.x;
+    return xcd_tile_kj(c, b & 7, b >> 3, tx, ty);
 }
 
 } // namespace nrdhip

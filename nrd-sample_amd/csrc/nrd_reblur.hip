@@ -110,6 +110,25 @@ NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
     return x < c.W && y >= c.ownY0 && y < c.ownY1;
 }
 
+// TemporalAccumulation runs one WAVE per workgroup (16 x 4 pixels, a quarter of a tile; the four quarters of a tile are consecutive
+// workgroups of one XCD): a finished wave is replaced at once instead of waiting for the other three of a 256-thread workgroup
+// (-4 % on that kernel; its footprint gathers follow the motion vectors and share little inside a tile anyway).
+#ifndef NRD_WG64
+#define NRD_WG64 1
+#endif
+NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
+#if NRD_WG64
+    const int b = (int)blockIdx.x, jj = b >> 3;
+    if (!xcd_tile_kj(c, b & 7, jj >> 2, tx, ty))
+        return false;
+    x = tx * 16 + (int)threadIdx.x;
+    y = ty * 16 + (jj & 3) * 4 + (int)threadIdx.y;
+    return x < c.W && y >= c.ownY0 && y < c.ownY1;
+#else
+    return my_pixel(c, x, y, tx, ty);
+#endif
+}
+
 // =====================================================================================================================
 // K0 ClassifyTiles + guide packing
 // =====================================================================================================================
@@ -275,8 +294,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
-    if (!my_pixel(c, x, y, tx, ty))
-        return;
+    if (!my_pixel(c, x, y, tx, ty)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
+        return;                     // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
     const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
@@ -747,7 +766,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
-    if (!my_pixel(c, x, y, tx, ty))
+    if (!my_pixel_w(c, x, y, tx, ty))
         return;
     Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
@@ -1608,26 +1627,40 @@ NRD_KERNELS_END
 
 namespace NRD_PROJ_NS {
 
-#define NRD_LAUNCH3(KERNEL, ...)                                                                                 \
+// GRID / BLOCK: grid_for(p.c), NRD_BLK256 for kernels with barriers (one workgroup per tile), NRD_WAVE_GRID(p.c), NRD_BLK64 for the
+// barrier-free ones that take their pixel from my_pixel_w (one wave per workgroup)
+#define NRD_BLK256 dim3(16, 16, 1)
+#if NRD_WG64
+#define NRD_BLK64 dim3(16, 4, 1)
+#define NRD_WAVE_GRID(c) dim3(grid_for(c).x * 4u, 1, 1)
+#else
+#define NRD_BLK64 dim3(16, 16, 1)
+#define NRD_WAVE_GRID(c) grid_for(c)
+#endif
+#define NRD_LAUNCH3G(GRID, BLK, KERNEL, ...)                                                                      \
     do {                                                                                                          \
         if (p.hasDiff && p.hasSpec)                                                                               \
-            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);        \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, true>), GRID, BLK, 0, s, p);                             \
         else if (p.hasDiff)                                                                                       \
-            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ true, false>), GRID, BLK, 0, s, p);                            \
         else                                                                                                      \
-            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
+            hipLaunchKernelGGL((KERNEL<__VA_ARGS__ false, true>), GRID, BLK, 0, s, p);                            \
     } while (0)
+#define NRD_LAUNCH3(KERNEL, ...) NRD_LAUNCH3G(grid_for(p.c), NRD_BLK256, KERNEL, __VA_ARGS__)
+#define NRD_LAUNCH3W(KERNEL, ...) NRD_LAUNCH3G(NRD_WAVE_GRID(p.c), NRD_BLK64, KERNEL, __VA_ARGS__)
 
 // same, flags AFTER the signal pair
-#define NRD_LAUNCH4(KERNEL, ...)                                                                                 \
+#define NRD_LAUNCH4G(GRID, BLK, KERNEL, ...)                                                                      \
     do {                                                                                                          \
         if (p.hasDiff && p.hasSpec)                                                                               \
-            hipLaunchKernelGGL((KERNEL<true, true, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);       \
+            hipLaunchKernelGGL((KERNEL<true, true, __VA_ARGS__>), GRID, BLK, 0, s, p);                            \
         else if (p.hasDiff)                                                                                       \
-            hipLaunchKernelGGL((KERNEL<true, false, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);      \
+            hipLaunchKernelGGL((KERNEL<true, false, __VA_ARGS__>), GRID, BLK, 0, s, p);                           \
         else                                                                                                      \
-            hipLaunchKernelGGL((KERNEL<false, true, __VA_ARGS__>), grid_for(p.c), dim3(16, 16, 1), 0, s, p);      \
+            hipLaunchKernelGGL((KERNEL<false, true, __VA_ARGS__>), GRID, BLK, 0, s, p);                           \
     } while (0)
+#define NRD_LAUNCH4(KERNEL, ...) NRD_LAUNCH4G(grid_for(p.c), NRD_BLK256, KERNEL, __VA_ARGS__)
+#define NRD_LAUNCH4W(KERNEL, ...) NRD_LAUNCH4G(NRD_WAVE_GRID(p.c), NRD_BLK64, KERNEL, __VA_ARGS__)
 
 #if NRD_PART == 1
 void launch_reblur_blur_radiance(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_spatial, 1, 0, ); }
@@ -1678,14 +1711,14 @@ void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
 void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) {
     if (p.sh) {
         if (p.relax)
-            NRD_LAUNCH4(k_temporal_accumulation, true, true);
+            NRD_LAUNCH4W(k_temporal_accumulation, true, true);
         else
-            NRD_LAUNCH4(k_temporal_accumulation, true, false);
+            NRD_LAUNCH4W(k_temporal_accumulation, true, false);
     } else {
         if (p.relax)
-            NRD_LAUNCH4(k_temporal_accumulation, false, true);
+            NRD_LAUNCH4W(k_temporal_accumulation, false, true);
         else
-            NRD_LAUNCH4(k_temporal_accumulation, false, false);
+            NRD_LAUNCH4W(k_temporal_accumulation, false, false);
     }
 }
 void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s) {
