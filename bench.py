@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
+    ap.add_argument("--preset", default="", help="FILE:INDEX - one of the sample's recorded test presets (tests/golden/sample_tests/*.bin, "
+                    "Source/NRDSample.cpp:1787-1901) as operating point of a 1-GPU run: field of view, sun, hit-distance scale, accumulation "
+                    "lengths as Sample::PrepareFrame derives them, view direction (the G-buffer stays procedural)")
     ap.add_argument("--roll", type=float, default=0.0, help="camera roll in degrees (1-GPU runs): 90 puts the sky at one SIDE of the frame - "
                     "a layout probe for the XCD tile traversal, not the headline scene")
     ap.add_argument("--checkerboard", action="store_true",
@@ -200,10 +203,18 @@ def main():
     if world == 1 and not args.force_tiled:
         from nrd_sample_amd.harness import Harness
 
+        preset, scene_kw = None, {}
+        if args.preset:
+            from nrd_sample_amd import sample_tests
+
+            path, _, index = args.preset.rpartition(":")
+            preset = sample_tests.load_presets(path)[int(index)]
+            scene_kw = sample_tests.scene_kwargs(preset)
         scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
-                            roll_deg=args.roll)
+                            roll_deg=args.roll, **scene_kw)
         hz = Harness(hip, dens, w, band_h)
-        runner = SingleRunner(api, hz, scene, dens, args.unique_frames, settings_of(api, scene, dens))
+        st = settings_of(api, scene, dens) if preset is None else sample_tests.denoiser_settings(api, preset, scene, dens, first_frame=False)
+        runner = SingleRunner(api, hz, scene, dens, args.unique_frames, st)
         frame_h = band_h
     else:
         from nrd_sample_amd.tiler import TiledRunner
@@ -260,7 +271,8 @@ def main():
             "higher_is_better": True, "scaling": "weak" if (world == 1 or not strong) else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s, %dx%d%s, %s" % (args.workload, "+".join(den_names), w, frame_h, tiled, state) +
-                       (" [camera rolled %g deg: layout probe]" % args.roll if args.roll else ""),
+                       (" [camera rolled %g deg: layout probe]" % args.roll if args.roll else "") +
+                       (" [recorded preset %s]" % os.path.basename(args.preset) if args.preset else ""),
                        "unique_input_frames": args.unique_frames, "storage_dtype": "f16 planes (f32 viewZ), f32 arithmetic"},
         }
         if per_pass:

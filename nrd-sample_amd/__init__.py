@@ -10,7 +10,7 @@ The directory name carries a hyphen, so import it through ``__graft_entry__.load
 """
 import os
 
-from . import api, harness, synth  # noqa: F401
+from . import api, harness, sample_tests, synth  # noqa: F401
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)

@@ -84,6 +84,21 @@ def orthographic(half_width, aspect):
     return m
 
 
+def look_along(pos, forward):
+    """world-to-view matrix of a camera at `pos` looking along `forward` (y-up, no roll, left-handed: +z = forward)"""
+    f = np.asarray(forward, dtype=np.float64)
+    f = f / np.linalg.norm(f)
+    right = np.cross(np.array([0.0, 1.0, 0.0]), f)
+    right = right / max(np.linalg.norm(right), 1e-9)
+    up = np.cross(f, right)
+    r = np.stack([right, up, f])
+    m = np.zeros((4, 4))
+    m[:3, :3] = r
+    m[:3, 3] = -r @ np.asarray(pos, dtype=np.float64)
+    m[3, 3] = 1
+    return m.T.reshape(16).astype(np.float32)  # column-major
+
+
 def world_to_view(pos, yaw=0.0, pitch=0.0, roll=0.0):
     cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
     ry = np.array([[cy, 0, -sy], [0, 1, 0], [sy, 0, cy]])
@@ -105,10 +120,14 @@ class Scene:
     on a GPU so that large (4K/8K) frames are produced where the denoiser consumes them."""
 
     def __init__(self, width, height, seed=0x9E3779B9, hfov=90.0, dolly=0.01, denoiser="REBLUR", rough_bands=True,
-                 translucent_sphere=True, device="cpu", frame_height=None, row0=0, ortho=False, roll_deg=0.0):
+                 translucent_sphere=True, device="cpu", frame_height=None, row0=0, ortho=False, roll_deg=0.0, forward=None,
+                 sun_deg=(-147.0, 45.0, 0.533), hit_dist_scale=3.0):
         self.w, self.h, self.seed = width, height, seed
         self.ortho = ortho
         self.roll = math.radians(roll_deg)
+        # view direction override (y-up world, +z = the default heading): a recorded preset's camera orientation (sample_tests.py)
+        self.forward = None if forward is None else np.asarray(forward, dtype=np.float64) / np.linalg.norm(forward)
+        self.hit_dist_scale = float(hit_dist_scale)  # ReblurHitDistanceParameters::A (the sample's "HitT scale", NRDSample.cpp:3675)
         self.hfov, self.dolly = hfov, dolly
         self.relax = denoiser == "RELAX"
         self.rough_bands = rough_bands
@@ -121,13 +140,13 @@ class Scene:
         # spheres: centre, radius, roughness, materialID
         self.spheres = [((-1.6, 0.7, 4.0), 0.7, 0.05, 1), ((0.3, 1.0, 5.5), 1.0, 0.3, 0), ((2.2, 0.6, 3.5), 0.6, 0.7, 1)]
         self.wall_z = 9.0
-        az, el = math.radians(-147.0), math.radians(45.0)
+        az, el = math.radians(sun_deg[0]), math.radians(sun_deg[1])
         # the sample's sun direction is z-up (Source/NRDSample.cpp:587-594); this scene is y-up: swap
         sun = np.array([math.cos(az) * math.cos(el), math.sin(el), math.sin(az) * math.cos(el)])
         sun = -sun if sun[2] > 0 else sun  # keep the sun behind the camera so shadows fall into view
         sun[1] = abs(sun[1])
         self.sun = sun / np.linalg.norm(sun)
-        self.tan_sun = math.tan(math.radians(0.533) * 0.5)
+        self.tan_sun = math.tan(math.radians(sun_deg[2]) * 0.5)
         self.scene_radius = 12.0
 
     # ---- camera ---------------------------------------------------------------------------------
@@ -136,6 +155,8 @@ class Scene:
 
     def matrices(self, frame, prev_frame=None):
         prev_frame = max(frame - 1, 0) if prev_frame is None else prev_frame
+        if self.forward is not None:
+            return look_along(self.cam_pos(frame), self.forward), look_along(self.cam_pos(prev_frame), self.forward)
         return world_to_view(self.cam_pos(frame), 0.0, 0.12, self.roll), world_to_view(self.cam_pos(prev_frame), 0.0, 0.12, self.roll)
 
     @staticmethod
@@ -286,7 +307,7 @@ class Scene:
             return torch.stack([0.25 * r_ + 0.5 * g_ + 0.25 * b_, 0.5 * r_ - 0.5 * b_, -0.25 * r_ + 0.5 * g_ - 0.25 * b_], -1)
 
         def hitnorm(z, r_):
-            return (3.0 + torch.abs(z) * 0.1) * (1.0 + 19.0 * torch.exp2(-25.0 * r_ * r_))
+            return (self.hit_dist_scale + torch.abs(z) * 0.1) * (1.0 + 19.0 * torch.exp2(-25.0 * r_ * r_))
 
         out = {}
         out["viewz"] = view_z.to(torch.float32)
