@@ -1386,32 +1386,55 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     // rows / columns a tap may land on: inside the frame and inside the rows this instance holds
     const int loY = imax(0, -c.yOff), hiY = imin(c.resH, c.H - c.yOff) - 1;
     int x, y, tx, ty;
+    uint16_t d1raw = 0;
+    uint32_t d2raw = 0;
     if (LS) {
         if (!xcd_tile(c, tx, ty))
             return;
+        // ALL staging loads of this thread go out before the first LDS write (one memory round trip for the window instead of one
+        // per 256 texels), together with the pixel's own data1 / data2 words
         const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-        for (int i = tid; i < T * T; i += 256) {
-            int lx = i % T, ly = i / T;
-            int px = tx * 16 + lx - LS, py = ty * 16 + ly - LS;
-            bool inside = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
-            int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
-            uint4 gq = ld<uint4>(p.guide, cpx, cpy, 16);
-            gq.x = inside ? gq.x : 0x7fc00000u;
-            sG[i] = gq;
-            uint2 t[TW];
-            load_texel<RBPT>(p.in, cpx, cpy, t);
-#pragma unroll
-            for (int w = 0; w < TW; w++)
-                sT[i * TW + w] = t[w];
-            if (FIRST)
-                sM[i] = load_luma(p.mom, cpx, cpy, LBPT);
-        }
-        __syncthreads();
         x = tx * 16 + (int)threadIdx.x;
         y = ty * 16 + (int)threadIdx.y;
+        const int sx = imin(x, c.W - 1), sy = imin(y, c.resH - 1);
+        if (FIRST)
+            d1raw = ld<uint16_t>(p.data1, sx, sy, 2);
+        if (HAS_SPEC)
+            d2raw = ld<uint32_t>(p.data2, sx, sy, 4);
+        constexpr int TRIPS = (T * T + 255) / 256;
+        uint4 gq[TRIPS];
+        uint2 tq[TRIPS][TW];
+        uint32_t mq[TRIPS];
+        bool ins[TRIPS];
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = imin(tid + 256 * k, T * T - 1); // (the last trip's surplus threads re-load the last texel and do not store it)
+            const int lx = i % T, ly = i / T;
+            const int px = tx * 16 + lx - LS, py = ty * 16 + ly - LS;
+            ins[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+            const int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
+            gq[k] = ld<uint4>(p.guide, cpx, cpy, 16);
+            load_texel<RBPT>(p.in, cpx, cpy, tq[k]);
+            mq[k] = FIRST ? load_luma(p.mom, cpx, cpy, LBPT) : 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = tid + 256 * k;
+            if (i < T * T) {
+                gq[k].x = ins[k] ? gq[k].x : 0x7fc00000u;
+                sG[i] = gq[k];
+#pragma unroll
+                for (int w = 0; w < TW; w++)
+                    sT[i * TW + w] = tq[k][w];
+                if (FIRST)
+                    sM[i] = mq[k];
+            }
+        }
+        __syncthreads();
         if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
             return;
-    } else if (!my_pixel(c, x, y, tx, ty))
+    } else if (!my_pixel_w(c, x, y, tx, ty)) // no barrier in the gather flavour: one wave per workgroup
         return;
     const int ci = ((int)threadIdx.y + LS) * T + (int)threadIdx.x + LS; // this pixel in the staged window
     const int it = p.it;
@@ -1442,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.depthSens);
     float A[2] = {0.0f, 0.0f};
     if (FIRST)
-        unpack_data1(ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
+        unpack_data1(LS ? d1raw : ld<uint16_t>(p.data1, x, y, 2), A[0], A[1]);
     uint2 ctex[RBPT / 8];
     if (LS) {
 #pragma unroll
@@ -1512,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
             normalW *= fma_(-cd, p.confNormRelax, 1.0f);
         }
         if (LS && isSpec) { // fine iterations: relax the edge stopping where the specular history was reprojected with low confidence
-            float conf = (float)((ld<uint32_t>(p.data2, x, y, 4) >> 16) & 255u) * (1.0f / 255.0f);
+            float conf = (float)((d2raw >> 16) & 255u) * (1.0f / 255.0f);
             invL[sig] *= lerpf(1.0f, conf, p.lumRelax);
             normalW *= lerpf(1.0f, conf, p.normRelax);
             roughRelax = lerpf(1.0f, conf, p.roughRelax);
@@ -1527,77 +1550,99 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         wsum[sig] = 1.0f;
     }
     const bool roughStop = p.roughnessEdgeStopping != 0;
-    // the 8 taps in row-major order; gathered in batches (all loads of a batch in flight, then a scheduling barrier, then the
-    // arithmetic - one memory round trip per batch instead of one per tap)
+    // the 8 taps in row-major order as a software pipeline (like k_spatial): DEPTH taps in flight, tap k is consumed right after tap
+    // k + DEPTH is issued, so the arithmetic of a tap runs under the loads of the next ones (LDS flavours: the reads of a batch)
     constexpr int TI[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, TJ[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-    constexpr int AB = SH ? 4 : 8; // 32-byte SH texels: half batches keep the kernel within its registers
+#ifndef NRD_ATROUS_DEPTH
+#define NRD_ATROUS_DEPTH 4
+#endif
+    constexpr int DEPTH = LS ? (SH ? 4 : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
+    uint4 graw[8];
+    uint2 stex[8][RBPT / 8];
+    uint16_t mraw[8][NSIG];
+    bool inside[8];
+    auto issue = [&](const int k) {
+        const int i = TI[k], j = TJ[k];
+        if (LS) {
+            const int q = ci + (j * T + i) * LS;
+            inside[k] = true; // outside texels were staged as sky
+            graw[k] = sG[q];
 #pragma unroll
-    for (int t0 = 0; t0 < 8; t0 += AB) {
-        uint4 graw[AB];
-        uint2 stex[AB][RBPT / 8];
-        uint16_t mraw[AB][NSIG];
-        bool inside[AB];
-#pragma unroll
-        for (int k = 0; k < AB; k++) {
-            const int i = TI[t0 + k], j = TJ[t0 + k];
-            if (LS) {
-                const int q = ci + (j * T + i) * LS;
-                inside[k] = true; // outside texels were staged as sky
-                graw[k] = sG[q];
-#pragma unroll
-                for (int w = 0; w < TW; w++)
-                    stex[k][w] = sT[q * TW + w];
-#pragma unroll
-                for (int sig = 0; sig < NSIG; sig++)
-                    mraw[k][sig] = FIRST ? (uint16_t)(sM[q] >> (16 * sig)) : (uint16_t)0;
-                continue;
-            }
-            int px = x + i * stride, py = y + j * stride;
-            inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
-            int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
-            graw[k] = ld<uint4>(p.guide, cpx, cpy, 16);
-            load_texel<RBPT>(p.in, cpx, cpy, stex[k]);
+            for (int w = 0; w < TW; w++)
+                stex[k][w] = sT[q * TW + w];
 #pragma unroll
             for (int sig = 0; sig < NSIG; sig++)
-                mraw[k][sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+                mraw[k][sig] = FIRST ? (uint16_t)(sM[q] >> (16 * sig)) : (uint16_t)0;
+            return;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        int px = x + i * stride, py = y + j * stride;
+        inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+        int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
+        graw[k] = ld<uint4>(p.guide, cpx, cpy, 16);
+        load_texel<RBPT>(p.in, cpx, cpy, stex[k]);
 #pragma unroll
-        for (int k = 0; k < AB; k++) {
-            const int i = TI[t0 + k], j = TJ[t0 + k];
-            int px = x + i * stride, gy = y + j * stride + c.yOff;
-            Guide gs = decode_guide(graw[k], c.denoisingRange);
-            float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
-            float nDot = dot3(g.n, gs.n);
+        for (int sig = 0; sig < NSIG; sig++)
+            mraw[k][sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+    };
+    auto consume = [&](const int k) {
+        const int i = TI[k], j = TJ[k];
+        int px = x + i * stride, gy = y + j * stride + c.yOff;
+        Guide gs = decode_guide(graw[k], c.denoisingRange);
+        float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
+        float nDot = dot3(g.n, gs.n);
 #pragma unroll
-            for (int sig = 0; sig < NSIG; sig++) {
-                const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-                bool valid = inside[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
-                float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
-                w *= geoW;
-                w *= normal_weight_m2(nDot, normalW2[sig]);
-                if (isSpec) {
-                    float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                    if (LS)
-                        rw = lerpf(1.0f, rw, roughRelax);
-                    w *= roughStop ? rw : 1.0f;
-                }
-                f4 sv = unpack_h4(stex[k][sig * SW]);
-                float vs = sv.w;
-                if (FIRST)
-                    vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[k][sig])), 0.0f);
-                w *= fmax2(exp_weight(absf(sv.x - c0[sig].x) * invL[sig]), minLw[sig]);
-                // a rejected tap enters with weight 0 (its texel is a finite value of an internal plane, fetched at the clamped
-                // position): one select on the weight instead of one per accumulated component
-                w = valid ? w : 0.0f;
-                sum[sig] = {fma_(sv.x, w, sum[sig].x), fma_(sv.y, w, sum[sig].y), fma_(sv.z, w, sum[sig].z)};
-                if (SH)
-                    sum1[sig] = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
-                sumVar[sig] = fma_(vs, w * w, sumVar[sig]);
-                wsum[sig] += w;
+        for (int sig = 0; sig < NSIG; sig++) {
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            bool valid = inside[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
+            float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
+            w *= geoW;
+            w *= normal_weight_m2(nDot, normalW2[sig]);
+            if (isSpec) {
+                float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                if (LS)
+                    rw = lerpf(1.0f, rw, roughRelax);
+                w *= roughStop ? rw : 1.0f;
             }
+            f4 sv = unpack_h4(stex[k][sig * SW]);
+            float vs = sv.w;
+            if (FIRST)
+                vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[k][sig])), 0.0f);
+            w *= fmax2(exp_weight(absf(sv.x - c0[sig].x) * invL[sig]), minLw[sig]);
+            // a rejected tap enters with weight 0 (its texel is a finite value of an internal plane, fetched at the clamped
+            // position): one select on the weight instead of one per accumulated component
+            w = valid ? w : 0.0f;
+            sum[sig] = {fma_(sv.x, w, sum[sig].x), fma_(sv.y, w, sum[sig].y), fma_(sv.z, w, sum[sig].z)};
+            if (SH)
+                sum1[sig] = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
+            sumVar[sig] = fma_(vs, w * w, sumVar[sig]);
+            wsum[sig] += w;
         }
+    };
+    if constexpr (LS) { // batches of DEPTH LDS reads, then their arithmetic
+#pragma unroll
+        for (int t0 = 0; t0 < 8; t0 += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++)
+                issue(t0 + k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++)
+                consume(t0 + k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++)
+            issue(k);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k + DEPTH < 8)
+                issue(k + DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
@@ -1740,14 +1785,14 @@ void launch_relax_atrous(const AtrousParams& p, hipStream_t s) {
         case 0: NRD_LAUNCH4(k_relax_atrous, true, true, 1); break;
         case 1: NRD_LAUNCH4(k_relax_atrous, true, false, 2); break;
         case 2: NRD_LAUNCH4(k_relax_atrous, true, false, 4); break;
-        default: NRD_LAUNCH4(k_relax_atrous, true, false, 0); break;
+        default: NRD_LAUNCH4W(k_relax_atrous, true, false, 0); break;
         }
     } else {
         switch (p.it) {
         case 0: NRD_LAUNCH4(k_relax_atrous, false, true, 1); break;
         case 1: NRD_LAUNCH4(k_relax_atrous, false, false, 2); break;
         case 2: NRD_LAUNCH4(k_relax_atrous, false, false, 4); break;
-        default: NRD_LAUNCH4(k_relax_atrous, false, false, 0); break;
+        default: NRD_LAUNCH4W(k_relax_atrous, false, false, 0); break;
         }
     }
 }
