@@ -1725,6 +1725,19 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(u
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }
+#if defined(NRD_HOST_EMULATION) && !NRD_ORTHO
+// test hook, host-emulated build only (tests/test_tile_traversal.py): the tile that workgroup `block` of a launch over tilesX x
+// tilesY tiles works on (returns 0 when the workgroup is a spare one), and the launch size
+extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of(int tilesX, int tilesY, int tileY0, unsigned block, int* tx, int* ty) {
+    FrameConsts c = {};
+    c.tilesX = tilesX;
+    c.tilesY = tilesY;
+    c.tileY0 = tileY0;
+    hipemu::t_blockIdx = {block, 0u, 0u};
+    return xcd_tile(c, *tx, *ty) ? 1 : 0;
+}
+extern "C" __attribute__((visibility("default"))) unsigned nrdhip_debug_grid_blocks(int tilesX, int tilesY) { return (unsigned)xcd_grid_blocks(tilesX, tilesY); }
+#endif
 
 void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_prepare_inputs, ); }
 void launch_reblur_validation(const ReblurParams& p, hipStream_t s) { hipLaunchKernelGGL(k_validation, grid_for(p.c), dim3(16, 16, 1), 0, s, p); }
