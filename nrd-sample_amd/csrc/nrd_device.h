@@ -90,11 +90,11 @@ struct f4 {
 };
 
 NRD_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-NRD_DEV float fmin2(float a, float b) { return a < b ? a : b; }
-NRD_DEV float fmax2(float a, float b) { return a > b ? a : b; }
-NRD_DEV float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
-NRD_DEV float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
-NRD_DEV float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
+NRD_HD float fmin2(float a, float b) { return a < b ? a : b; }
+NRD_HD float fmax2(float a, float b) { return a > b ? a : b; }
+NRD_HD float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
+NRD_HD float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
+NRD_HD float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 NRD_DEV float smoothstep01(float x) {
     x = sat(x);
     return x * x * fma_(x, -2.0f, 3.0f); // == 3 - 2x rounded once: 2x is exact, so this is bit-identical to "3.0f - 2.0f * x"
@@ -117,8 +117,8 @@ NRD_DEV f4 mul4(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
 NRD_DEV f4 fma4(f4 a, float s, f4 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z), fma_(a.w, s, c.w)}; }
 NRD_DEV f4 lerp4(f4 a, f4 b, float t) { return {lerpf(a.x, b.x, t), lerpf(a.y, b.y, t), lerpf(a.z, b.z, t), lerpf(a.w, b.w, t)}; }
 
-NRD_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
-NRD_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+NRD_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+NRD_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
 // ---- software reciprocal / reciprocal square root (numerics contract) ---------------------------------------------
 // IEEE a / b and sqrt() expand to ~10 instructions around a quarter-rate v_rcp_f32 / v_sqrt_f32 on gfx950 (~13 issue slots); the
@@ -164,7 +164,7 @@ NRD_DEV uint2 pack_sn4(f4 v) { return {f2sn(v.x) | (f2sn(v.y) << 16), f2sn(v.z) 
 NRD_DEV uint2 pack_h4(f4 v) { return {(uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16), (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16)}; }
 
 // ---- polynomial transcendentals (coefficients frozen) ------------------------------------------------
-NRD_DEV float exp2_poly(float x) {
+NRD_HD float exp2_poly(float x) {
     x = clampf(x, -126.0f, 126.0f);
     float fi = __builtin_floorf(x + 0.5f);
     float f = x - fi;
@@ -301,9 +301,11 @@ NRD_DEV float spec_magic_curve(float roughness) {
     return f * sqrt_(sat(roughness));
 }
 
+// roughness-dependent factor of the hit-distance normalisation; for the diffuse signal (roughness 1) it depends on the settings
+// only and arrives precomputed from the host (ReblurParams::hitFactorDiff - same function, same roundings)
+NRD_HD float reblur_hitdist_factor(const float* hp, float roughness) { return lerpf(1.0f, hp[2], exp2_poly(hp[3] * roughness * roughness)); }
 NRD_DEV float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
-    float e = exp2_poly(hp[3] * roughness * roughness);
-    return fma_(absViewZ, hp[1], hp[0]) * lerpf(1.0f, hp[2], e);
+    return fma_(absViewZ, hp[1], hp[0]) * reblur_hitdist_factor(hp, roughness);
 }
 
 NRD_DEV float spec_lobe_half_angle(float roughness) {

@@ -10,6 +10,7 @@ struct ReblurParams {
     FrameConsts c;
     // nrd::ReblurSettings (Source/NRDSample.cpp:563-585 defaults, :4090-4124 per frame)
     float hp[4];
+    float hitFactorDiff; // reblur_hitdist_factor(hp, 1): the diffuse signal's factor is uniform
     float planeDistanceSensitivity, lobeAngleFraction, roughnessFraction, minHitDistanceWeight;
     float minBlurRadius, maxBlurRadius, diffusePrepassBlurRadius, specularPrepassBlurRadius;
     float fastHistoryClampingSigmaScale, antilagSigmaScale, antilagSensitivity;

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
         src1Ps[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec1 : &p.inDiff1) : &inP;
         sum1[sig] = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
-        float hitNorm = reblur_hitdist_norm(pg.absZ, p.hp, rough);
+        float hitNorm = isSpec ? reblur_hitdist_norm(pg.absZ, p.hp, rough) : fma_(pg.absZ, p.hp[1], p.hp[0]) * p.hitFactorDiff;
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
         float A = isSpec ? specA : diffA;

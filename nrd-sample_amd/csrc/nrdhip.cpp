@@ -515,6 +515,7 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.hp[1] = s.hitDistanceParameters.B;
     p.hp[2] = s.hitDistanceParameters.C;
     p.hp[3] = s.hitDistanceParameters.D;
+    p.hitFactorDiff = reblur_hitdist_factor(p.hp, 1.0f);
     p.planeDistanceSensitivity = s.planeDistanceSensitivity;
     p.lobeAngleFraction = s.lobeAngleFraction;
     p.roughnessFraction = s.roughnessFraction;

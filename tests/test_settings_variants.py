@@ -77,6 +77,10 @@ CASES = [
                                                             "confidenceDrivenNormalEdgeStoppingRelaxation": 0.5, "specularLobeAngleSlack": 1.0}, conf_hook, conf_frames),
     ("camera_attached_reblur", ["REBLUR_DIFFUSE_SPECULAR"], {}, lambda f, cs: attach_hook(f, cs), None),
     ("camera_attached_relax", ["RELAX_SPECULAR"], {}, lambda f, cs: attach_hook(f, cs), None),
+    # non-default hit-distance normalisation (the sample's "HitT scale" slider feeds A, Source/NRDSample.cpp:3675; C / D shape the
+    # roughness term whose diffuse value the host precomputes: ReblurParams::hitFactorDiff)
+    ("hit_distance_parameters", ["REBLUR_DIFFUSE_SPECULAR"], {"hitDistanceParameters.A": 1.7, "hitDistanceParameters.B": 0.25,
+                                                              "hitDistanceParameters.C": 12.0, "hitDistanceParameters.D": -13.5}, None, None),
     ("relax_tuning_sh", ["RELAX_SPECULAR_SH"], {"luminanceEdgeStoppingRelaxation": 0.0, "normalEdgeStoppingRelaxation": 1.0,
                                                 "antilagSettings.resetAmount": 0.0, "antilagSettings.accelerationAmount": 0.0}, None, None),
 ]
