@@ -94,6 +94,7 @@ class Tiler:
         self._plan_cache = {}
         self._p2p_cache = {}  # dispatch todo -> (P2POp list, bytes sent): pool planes never move, so the row slices are built once
         self._deferred = []   # exchanges of planes only the NEXT frame reads: in flight until the next dispatch list starts
+        self._later_todo = []  # ... and their (plane, rows, skip) items while a dispatch list is still running
 
     def _as_tensor(self, buf):
         import torch
@@ -240,17 +241,23 @@ class Tiler:
             w.wait()
         self._deferred = []
 
-    def run_dispatch(self, ids, i, plan_entry):
+    def run_dispatch(self, ids, i, plan_entry, last=None):
         """one dispatch + the halo exchange of what it wrote. When the band is tall enough the rows a neighbour needs are
         computed FIRST (boundary strips), their exchange is started, and the interior is computed while the rows travel -
         the copies overlap the compute instead of serialising with it (nrdhip_denoise_rows). Rows that only the next frame
         reads follow without strips and without a wait (see _plan)."""
         if i == 0:
             self.finish()  # a new dispatch list: last frame's permanent planes must have arrived
+            self._later_todo = []
         todo, later = plan_entry
         self._run_dispatch_now(ids, i, todo)
-        if later:
-            self._deferred += self.exchange_start_cached(later)
+        # rows only the NEXT frame reads: collected over the dispatch list and sent as ONE batch behind its last dispatch (`last`
+        # known: five batch calls per frame become one - the launch thread is the bottleneck when a band is a fraction of a
+        # millisecond of GPU work); `last` unknown: sent right away
+        self._later_todo += later
+        if (last is None or last) and self._later_todo:
+            self._deferred += self.exchange_start_cached(self._later_todo)
+            self._later_todo = []
 
     def _run_dispatch_now(self, ids, i, todo):
         nrd, L, b = self.band.nrd, self.band.layout, self.band
@@ -290,7 +297,7 @@ class Tiler:
         self.check_halo(dispatches)
         plan = self._plan(ids, dispatches)
         for i, entry in enumerate(plan):
-            self.run_dispatch(ids, i, entry)
+            self.run_dispatch(ids, i, entry, last=(i == len(plan) - 1))
 
 
 class NativeTiler:
@@ -504,7 +511,7 @@ class TiledRunner:
         for i, entry in enumerate(plan):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            self.tiler.run_dispatch(ids, i, entry)
+            self.tiler.run_dispatch(ids, i, entry, last=(i == len(plan) - 1))
             b.record()
             evs.append((a, b))
         self.events.append(evs)
