@@ -101,6 +101,12 @@ NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) 
     }
 }
 
+// REBLUR / RELAX::Tiles (written by ClassifyTiles): 1 = no pixel of the 16x16 tile has geometry. One byte per tile, same address for
+// the whole workgroup: a scalar value
+NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty) {
+    return __builtin_amdgcn_readfirstlane((int)ld<uint8_t>(p.tiles, tx, ty, 1)) != 0;
+}
+
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
 NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
     if (!xcd_tile(c, tx, ty))
@@ -989,6 +995,21 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     // kernel spent 72 % of its wave time in s_waitcnt: staging round trip, barrier, then the centre round trip)
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     const bool live = x < c.W && y >= c.ownY0 && y < c.ownY1;
+    const PlaneRef& outP = p.relax ? p.hist : p.tmp1; // RELAX: the fixed + clamped signal IS the next frame's history
+    auto sky_out = [&]() {
+        for (int sig = 0; sig < NSIG; sig++) {
+            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+            if (SH)
+                st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
+        }
+        st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
+    };
+    // a tile without geometry (ClassifyTiles: Tiles = 1; block-uniform): every pixel takes the sky path - no staging, no barrier
+    if (tile_is_sky(p, tx, ty)) {
+        if (live)
+            sky_out();
+        return;
+    }
     const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
     const uint4 graw = ld<uint4>(p.guide, cxp, cyp, 16);
     const uint16_t data1Raw = ld<uint16_t>(p.data1Tmp, cxp, cyp, 2);
@@ -1026,15 +1047,9 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     }
     if (!live)
         return;
-    const PlaneRef& outP = p.relax ? p.hist : p.tmp1; // RELAX: the fixed + clamped signal IS the next frame's history
     Guide g = decode_guide(graw, c.denoisingRange);
     if (g.sky) {
-        for (int sig = 0; sig < NSIG; sig++) {
-            st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-            if (SH)
-                st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
-        }
-        st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
+        sky_out();
         return;
     }
     const int gy0 = y + c.yOff;
@@ -1202,6 +1217,29 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     // the barrier; the history footprints (which need the centre's motion vector) travel while the 5x5 moments are read from LDS.
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     const bool live = x < c.W && y >= c.ownY0 && y < c.ownY1;
+    auto sky_out = [&]() {
+        const bool split = ((float)x + 0.5f) * c.invW < c.splitScreen;
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
+            const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+            // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
+            if (SH && p.dirOcc) // single {SH1.xyz, SH0.x} texel out
+                st<uint2>(o, x, y, 8, split ? pack_dir(p, dir_pass(p, x, y)) : uint2{0u, 0u});
+            else
+                store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : f4{0, 0, 0, 0});
+            if (SH && !p.dirOcc)
+                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
+            st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
+        }
+    };
+    // a tile without geometry (ClassifyTiles: Tiles = 1; block-uniform): every pixel takes the sky path - no staging, no barrier
+    if (tile_is_sky(p, tx, ty)) {
+        if (live)
+            sky_out();
+        return;
+    }
     const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
     const uint4 graw = ld<uint4>(p.guide, cxp, cyp, 16);
     uint2 ctex[RBPT / 8];
@@ -1269,20 +1307,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     if (!live)
         return;
     if (g.sky) {
-#pragma unroll
-        for (int sig = 0; sig < NSIG; sig++) {
-            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
-            const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-            // split screen shows the noisy input: the slot itself, or its dense PrepareInputs copy when that pass ran
-            if (SH && p.dirOcc) // single {SH1.xyz, SH0.x} texel out
-                st<uint2>(o, x, y, 8, split ? pack_dir(p, dir_pass(p, x, y)) : uint2{0u, 0u});
-            else
-                store_signal(p, o, x, y, split ? load_signal(p, in, x, y, 8, 0, p.occlusion != 0 && !p.prepared) : f4{0, 0, 0, 0});
-            if (SH && !p.dirOcc)
-                st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
-            st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
-        }
+        sky_out();
         return;
     }
     // the 5x5 moments come from LDS: computed while the footprints travel

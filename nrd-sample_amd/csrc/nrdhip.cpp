@@ -658,6 +658,8 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     {
         Dispatch x{"REBLUR::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
                    GB + 2 + 8 * nr + 2 * n + 8 * nr + 2, {}, {}, nullptr};
+        // (HistoryFix / TemporalStabilization also look up the Tiles flag of their OWN tile - no reach across tiles or bands, so it
+        // is not part of the exchange plan's read sets)
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
         x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };

@@ -167,6 +167,7 @@ inline T hipemu_buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 // wave vote: threads run one at a time here, so a "wave" is the thread itself - valid wherever both sides of a wave-uniform
 // branch compute the same result (the only way the product kernels use it)
 #define __builtin_amdgcn_ballot_w64(pred) ((pred) ? 1ull : 0ull)
+#define __builtin_amdgcn_readfirstlane(v) (v) // only used on values that are uniform by construction
 inline void __syncthreads() { hipemu::sync(); }
 inline int __syncthreads_or(int v) {
     hipemu::sync();
