@@ -42,3 +42,21 @@ def test_emulated_dispatch_lists_match(pkg, api, oracle, emulated):
     # REBLUR_DIFFUSE_SPECULAR algorithmic bytes / pixel / frame: SURVEY.md 8d estimated ~352 with 8-byte guides; this build
     # keeps a 16-byte pre-decoded guide texel (+8 B in each of the 8 guide accesses), DESIGN.md "byte accounting"
     assert 400 < total < 416
+
+
+@pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["RELAX_DIFFUSE_SPECULAR_SH"]])
+def test_emulated_kernels_sky_tiles(pkg, api, oracle, emulated, dens):
+    """a frame tall enough that whole tiles are sky: HistoryFix / TemporalStabilization skip their staging on tiles ClassifyTiles
+    marked (the Tiles mask), every thread taking the per-pixel sky path - outputs and pools must still equal the oracle's, which
+    knows no such shortcut; camera rolled too, so that the sky tiles form a column band instead of rows"""
+    import numpy as np
+
+    for roll, (w, h) in ((0.0, (40, 104)), (90.0, (104, 40))):  # 3 x 7 / 7 x 3 tiles, partial ones on both axes
+        scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR", roll_deg=roll)
+        dd = [api.Denoiser[x] for x in dens]
+        st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+        ho = util.run_frames(api, pkg.harness, oracle, scene, dd, 2, settings=st)
+        he = util.run_frames(api, pkg.harness, emulated, scene, dd, 2, settings=st)
+        assert util.compare_all(ho, he, exact=True) == []
+        tiles = np.asarray(he.pool(("RELAX" if dens[0].startswith("RELAX") else "REBLUR") + "::Tiles"))
+        assert tiles.max() == 1 and tiles.min() == 0  # the run had sky tiles and geometry tiles
