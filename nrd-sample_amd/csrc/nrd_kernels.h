@@ -66,6 +66,7 @@ struct AtrousParams {
     PlaneRef confD, confS;
     int it, last, hasDiff, hasSpec, sh;
     PlaneRef guide, data1, data2, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec, inDiff1, inSpec1, outDiff1, outSpec1;
+    PlaneRef tiles; // RELAX::Tiles (ClassifyTiles): 1 = the tile has no geometry
 };
 
 struct SigmaParams {

@@ -103,9 +103,8 @@ NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) 
 
 // REBLUR / RELAX::Tiles (written by ClassifyTiles): 1 = no pixel of the 16x16 tile has geometry. One byte per tile, same address for
 // the whole workgroup: a scalar value
-NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty) {
-    return __builtin_amdgcn_readfirstlane((int)ld<uint8_t>(p.tiles, tx, ty, 1)) != 0;
-}
+NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty) { return __builtin_amdgcn_readfirstlane((int)ld<uint8_t>(tiles, tx, ty, 1)) != 0; }
+NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty) { return tile_is_sky(p.tiles, tx, ty); }
 
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
 NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
@@ -1413,9 +1412,35 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     int x, y, tx, ty;
     uint16_t d1raw = 0;
     uint32_t d2raw = 0;
+    const bool last = p.last != 0;
+    auto sky_out = [&]() { // what a sky pixel stores
+        const bool split = last && ((float)x + 0.5f) * c.invW < c.splitScreen;
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            if (last) {
+                const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
+                const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
+                st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
+                if (SH)
+                    st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
+            } else {
+                st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+                if (SH)
+                    st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
+            }
+        }
+    };
     if (LS) {
         if (!xcd_tile(c, tx, ty))
             return;
+        if (tile_is_sky(p.tiles, tx, ty)) { // a tile without geometry (block-uniform): the per-pixel sky stores, no staging, no barrier
+            x = tx * 16 + (int)threadIdx.x;
+            y = ty * 16 + (int)threadIdx.y;
+            if (x < c.W && y >= c.ownY0 && y < c.ownY1)
+                sky_out();
+            return;
+        }
         // ALL staging loads of this thread go out before the first LDS write (one memory round trip for the window instead of one
         // per 256 texels), together with the pixel's own data1 / data2 words
         const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
@@ -1463,28 +1488,13 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         return;
     const int ci = ((int)threadIdx.y + LS) * T + (int)threadIdx.x + LS; // this pixel in the staged window
     const int it = p.it;
-    const bool last = p.last != 0;
     const int stride = LS ? LS : 1 << it;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW;
     bool split = last && u < c.splitScreen;
     Guide g = decode_guide(LS ? sG[ci] : ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
-#pragma unroll
-        for (int sig = 0; sig < NSIG; sig++) {
-            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            if (last) {
-                const PlaneRef& o = isSpec ? p.outSpec : p.outDiff;
-                const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
-                st<uint2>(o, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(in, x, y, 8))) : uint2{0u, 0u});
-                if (SH)
-                    st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : uint2{0u, 0u});
-            } else {
-                st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-                if (SH)
-                    st<uint2>(p.out, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
-            }
-        }
+        sky_out();
         return;
     }
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.depthSens);

@@ -807,6 +807,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     a.outDiff1 = p.outDiff1;
     a.outSpec1 = p.outSpec1;
     a.guide = p.guide;
+    a.tiles = p.tiles;
     a.data1 = p.data1;
     a.hist = p.hist;
     a.mom = p.stab;
