@@ -5,10 +5,12 @@
 //   ClassifyTiles(+guide packing) -> PrePass -> TemporalAccumulation -> HistoryFix -> Blur -> PostBlur -> TemporalStabilization
 // Data layout (DESIGN.md "HBM layout"): one 16-byte guide texel {viewZ f32, normal 3 x f16, roughness f16, materialID} per
 // pixel so a bilateral tap costs ONE 16-byte gather and four converts for all guides; diffuse+specular radiance interleaved
-// in one 16-byte texel; accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles, assigned to XCDs
-// in contiguous runs (nrd_device.h xcd_tile) so stencil / gather overlap between neighbouring tiles is served by one XCD's
-// L2. These are gather / stencil filters (bound by the texture addresser's gather rate and by VALU issue): no MFMA. 5x5 moment stencils, Blur's tap guides and the
-// first RELAX A-trous iterations stage their tile (+ halo) in LDS.
+// in one 16-byte texel; accumulation speeds 2 x u8 in one 16-bit texel. Workgroups are 16x16 pixel tiles; every XCD walks
+// compact blocks of them (column bands that rotate every 1/8 of the frame height, nrd_device.h xcd_tile), so stencil / gather
+// overlap between neighbouring tiles is served by one XCD's L2 and every XCD gets the same mix of sky and geometry. These are
+// gather / stencil filters (bound by the texture addresser's gather rate and by VALU issue): no MFMA. The 5x5 moment
+// stencils and the first RELAX A-trous iterations stage their tile (+ halo) in LDS; tiles without geometry (ClassifyTiles'
+// Tiles mask) skip that staging.
 #include "nrd_kernels.h"
 
 // NRD_PART 0 (default): every launcher of this file except the non-SH Blur one; NRD_PART 1 (nrd_reblur_blur*.hip): only that one -
