@@ -68,12 +68,7 @@ NRD_DEV f4 dir_pass(const ReblurParams& p, int x, int y) {
 }
 // OUT_DIFF_DIRECTION_HITDIST texel in the bound format
 NRD_DEV uint2 pack_dir(const ReblurParams& p, f4 v) { return p.dirOutSnorm ? pack_sn4(v) : pack_h4(v); }
-// the same in two steps (gather now, decode later)
-NRD_DEV uint2 load_signal_raw(const PlaneRef& P, int x, int y, int bpt, int off, bool occlusion) {
-    if (!occlusion)
-        return ld<uint2>(P, x, y, bpt, off);
-    return uint2{(uint32_t)ld<uint16_t>(P, x, y, 2), 0u};
-}
+// decode of a gathered signal texel (the tap loops gather the raw words first and decode them when the tap is consumed)
 NRD_DEV f4 decode_signal(const ReblurParams& p, uint2 raw, bool occlusion) {
     if (!occlusion)
         return unpack_h4(raw);
