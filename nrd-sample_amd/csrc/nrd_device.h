@@ -100,8 +100,6 @@ NRD_DEV float smoothstep01(float x) {
     return x * x * fma_(x, -2.0f, 3.0f); // == 3 - 2x rounded once: 2x is exact, so this is bit-identical to "3.0f - 2.0f * x"
 }
 NRD_DEV float absf(float x) { return __builtin_fabsf(x); } // a free source modifier (|x|) on the consuming instruction
-// true when `pred` holds on every active lane of the wave (wave-uniform: usable as a branch condition that costs no divergence)
-NRD_DEV bool nrd_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(!pred) == 0ull; }
 NRD_DEV int imin(int a, int b) { return a < b ? a : b; }
 NRD_DEV int imax(int a, int b) { return a > b ? a : b; }
 
@@ -416,6 +414,42 @@ NRD_DEV T ld(const PlaneRef& P, int x, int y, int bpt, int off = 0) {
 template <typename T>
 NRD_DEV void st(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
     *reinterpret_cast<T*>(P.p + texel_offset(P, x, y, bpt, off)) = v;
+}
+// Streaming accesses (the "nt" bit of the memory instruction): lines without reuse inside the kernel - an output nobody reads before
+// the launch is over, a plane read at the thread's own pixel only - should not evict the lines the tap gathers live on. Measured per
+// kernel (profiles/r03_ab_setup_planes.txt): a win where the data is not wanted again soon, a loss where the NEXT kernel reads it at
+// once (the Infinity Cache carries planes from one pass to the next), so it is applied case by case.
+template <typename T>
+struct nt_native {
+    typedef T type;
+};
+#ifndef NRD_HOST_EMULATION
+template <>
+struct nt_native<uint2> {
+    typedef unsigned int type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct nt_native<uint4> {
+    typedef unsigned int type __attribute__((ext_vector_type(4)));
+};
+#endif
+template <typename T>
+NRD_DEV T ld_stream(const PlaneRef& P, int x, int y, int bpt, int off = 0) {
+#ifdef NRD_HOST_EMULATION
+    return ld<T>(P, x, y, bpt, off);
+#else
+    typedef typename nt_native<T>::type N;
+    return __builtin_bit_cast(T, __builtin_nontemporal_load(reinterpret_cast<const N*>(P.p + texel_offset(P, x, y, bpt, off))));
+#endif
+}
+template <typename T>
+NRD_DEV void st_stream(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
+#ifdef NRD_HOST_EMULATION
+    st<T>(P, x, y, bpt, v, off);
+#else
+    typedef typename nt_native<T>::type N;
+    __builtin_nontemporal_store(__builtin_bit_cast(N, v), reinterpret_cast<N*>(P.p + texel_offset(P, x, y, bpt, off)));
+#endif
 }
 
 // Gathers of the spatial passes go through buffer instructions: a raw V# (base = the plane's first texel, no stride, no bounds -

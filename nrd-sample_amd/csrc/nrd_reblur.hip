@@ -136,9 +136,9 @@ NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) 
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     const FrameConsts& c = p.c;
-    int tx, ty;
-    if (!xcd_tile(c, tx, ty))
-        return;
+    // a streaming pass without neighbour reads: plain 2-D grid of tiles (the XCD traversal of the other passes costs a wave ~700
+    // cycles of scalar index arithmetic and buys this pass nothing: 0.0485 -> 0.0462 ms, profiles/r03_ab_setup_planes.txt)
+    const int tx = (int)blockIdx.x, ty = (int)blockIdx.y + c.tileY0;
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     bool valid = x < c.W && y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
     int notSky = 0;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)
-        unpack_data1(ld<uint16_t>(p.data1, x, y, 2), diffA, specA);
+        unpack_data1(ld_stream<uint16_t>(p.data1, x, y, 2), diffA, specA);
     // tap window (global pixel coordinates): within `reach` of the centre, inside the frame and inside the held rows
     const int loX = imax(x - reach, 0), hiX = imin(x + reach, c.W - 1);
     const int loY = imax(gy0 - reach, imax(c.yOff, 0)), hiY = imin(gy0 + reach, imin(c.yOff + c.resH, c.H) - 1);
@@ -557,9 +557,18 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
                 res = rgb_to_ycocg4(res);
             res1 = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
         }
-        st<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
-        if (SH)
-            st<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
+        // Blur / PostBlur results are not read again before the gathers of this launch are done (PostBlur's only by the next frame):
+        // streamed past the caches, they stop evicting the tap texels (PostBlur -8 %, Blur -4 %). The PrePass result is read by the
+        // next kernel at once and travels through the Infinity Cache: a plain store (profiles/r03_ab_setup_planes.txt)
+        if (VARIANT == 0) {
+            st<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
+            if (SH)
+                st<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
+        } else {
+            st_stream<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
+            if (SH)
+                st_stream<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
+        }
         if (VARIANT == 0 && isSpec)
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig]));
     }
@@ -1755,7 +1764,7 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(u
 }
 #endif
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+    hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)p.c.tilesX, (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
 }
 #if defined(NRD_HOST_EMULATION) && !NRD_ORTHO
 // test hook, host-emulated build only (tests/test_tile_traversal.py): the tile that workgroup `block` of a launch over tilesX x
