@@ -279,6 +279,33 @@ NRD_DEV Guide decode_guide(uint4 g, float range) {
     return r;
 }
 
+// ---- tap texels of REBLUR's Blur / PostBlur (radiance flavours) -------------------------------------------------------------
+// What a tap needs - depth, normal, roughness, material and the signal - in ONE 16-byte texel per signal, so a tap is one gather
+// instead of two (guide + radiance): the spatial passes are bound by what moves through the texture path, not by arithmetic
+// (profiles/r03_ab_setup_planes.txt).
+//   .x = viewZ rounded to 22 bits | roughness as the 10-bit code of IN_NORMAL_ROUGHNESS   (read back AS A FLOAT it is the depth, the
+//        roughness code perturbing it by < 2^-13 relative - every consumer reads it that way, centre and taps alike)
+//   .y = normal x | y << 10 | z << 20, 10 bits per component (n = code * 2/1023 - 1, not re-normalised) | materialID << 30
+//   .z .w = the signal {Y, Co | Cg, hitT} as 4 x fp16
+// HistoryFix packs the guide part from the 16-byte guide texel, Blur copies it through, and both passes take their CENTRE pixel's
+// guide from the texel too (no guide plane access). The normal arrives in IN_NORMAL_ROUGHNESS as a 10 + 10 bit octahedron and the
+// roughness as 10 bits: the texel is as fine as the input; only the depth loses its 10 low mantissa bits.
+NRD_DEV uint32_t qn10(float v) { return (uint32_t)__builtin_floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
+NRD_DEV uint2 pack_tap_guide(const Guide& g) {
+    const uint32_t rc = (uint32_t)__builtin_floorf(fma_(sat(g.roughness), 1023.0f, 0.5f));
+    return uint2{((f2u(g.z) + 0x200u) & 0xFFFFFC00u) | rc, qn10(g.n.x) | (qn10(g.n.y) << 10) | (qn10(g.n.z) << 20) | (g.mat << 30)};
+}
+NRD_DEV Guide unpack_tap_guide(uint32_t w0, uint32_t w1, float range) {
+    Guide g;
+    g.z = u2f(w0);
+    g.roughness = (float)(w0 & 1023u) * (1.0f / 1023.0f);
+    const float s = 2.0f / 1023.0f;
+    g.n = {fma_((float)(w1 & 1023u), s, -1.0f), fma_((float)((w1 >> 10) & 1023u), s, -1.0f), fma_((float)((w1 >> 20) & 1023u), s, -1.0f)};
+    g.mat = w1 >> 30;
+    g.sky = !(absf(g.z) <= range);
+    return g;
+}
+
 NRD_DEV f3 linear_to_ycocg(f3 c) {
     float Y = c.x * 0.25f + c.y * 0.5f + c.z * 0.25f;
     float Co = c.x * 0.5f - c.z * 0.5f;

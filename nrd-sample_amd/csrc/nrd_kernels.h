@@ -49,6 +49,10 @@ struct ReblurParams {
     int dirOcc;  // REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION: one {direction * h, h} texel in / out (split by PrepareInputs, merged by TS)
     // pools
     PlaneRef guide, guidePrev, data1, data1Prev, data1Tmp, data2, hist, fast, fastPrev, stab, stabPrev, tiles, tmp1, tmp2, hitTrack;
+    // REBLUR flavours without SH: tap texels of Blur / PostBlur (nrd_device.h), [0] diffuse, [1] specular.
+    // tapA: HistoryFix -> Blur, tapB: Blur -> PostBlur
+    int tapTex;
+    PlaneRef tapA[2], tapB[2];
 };
 
 // one RELAX A-trous iteration (nrd_reblur.hip k_relax_atrous)

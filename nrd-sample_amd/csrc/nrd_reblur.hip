@@ -30,6 +30,13 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_PIPE_DEPTH_WIDE
 #define NRD_PIPE_DEPTH_WIDE 5
 #endif
+// Blur / PostBlur on tap texels (one 16-byte gather per tap): taps in flight and waves per SIMD
+#ifndef NRD_TAP_DEPTH
+#define NRD_TAP_DEPTH NRD_PIPE_DEPTH
+#endif
+#ifndef NRD_TAP_WAVES // 104 VGPRs at 4 waves; capped at 102 for a fifth wave: Blur 0.202 -> 0.198 ms, PostBlur 0.179 -> 0.1705
+#define NRD_TAP_WAVES 5  // (depth 6 / 8 at 5 waves: equal; depth 12 / 16 at 4 waves: slower - profiles/r03_ab_tap_texels.txt)
+#endif
 
 #if defined(NRD_DEBUG_COUNTERS) && !NRD_ORTHO // diagnosis build only (tools/tap_histogram.py): histogram of tap distances per spatial pass
 __device__ unsigned long long g_dbg_hist[3][8];
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
 template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
 // 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
 // carry 16 more registers of tap data and stay at 3
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spatial(const ReblurParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 0 && MODE == 0) ? NRD_TAP_WAVES : 4)) void k_spatial(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr bool SH = MODE == 3 || MODE == 4;
     constexpr int sb = SH ? 16 : 8;   // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
@@ -304,9 +311,23 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     constexpr bool relaxIn = VARIANT == 0 && (MODE == 1 || MODE == 4); // RELAX inputs: linear RGB + world-space hit distance
     constexpr bool occIn = VARIANT == 0 && MODE == 2;
 
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    // REBLUR radiance Blur / PostBlur run on tap texels (nrd_device.h): guide part and signal of a pixel in one 16-byte texel per signal
+    // (Blur: tapA -> tapB, PostBlur: tapB -> History) - one gather per tap, and the centre's guide comes from its own texel
+    constexpr bool TAP = VARIANT != 0 && MODE == 0;
+    const PlaneRef* tapIn = VARIANT == 1 ? p.tapA : p.tapB;
+    uint4 ctap[NSIG];
+    if (TAP) {
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++)
+            ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
+    }
+    Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
+            if (TAP && VARIANT == 1) { // the guide part travels on (PostBlur takes its sky test from it)
+                st_stream<uint4>(p.tapB[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16, uint4{ctap[sig].x, ctap[sig].y, 0u, 0u});
+                continue;
+            }
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
             if (SH)
                 st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
@@ -317,6 +338,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     }
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
+    // tap texels: the tap's normal and roughness stay 10-bit codes; scale and offset of their decode are folded into per-pixel
+    // constants (N . Ns = sum (2/1023 N_i) code_i - sum N_i; roughness likewise)
+    const f3 nsc = mul3(g.n, 2.0f / 1023.0f);
+    const float nb = -((g.n.x + g.n.y) + g.n.z);
     f3 V = to_viewer(pg.Xv);
     // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic: no
     // perspective divide and no z terms
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
         minMats[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
         srcPs[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec : &p.inDiff) : &inP;
         srcOffs[sig] = VARIANT == 0 ? 0 : sig * sb;
-        f4 center = load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
+        f4 center = TAP ? unpack_h4(uint2{ctap[sig].z, ctap[sig].w}) : load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
         if (relaxIn)
             center = rgb_to_ycocg4(center);
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
@@ -426,6 +451,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
         hitB[sig] = -center.w * hitA[sig];
         roughA[sig] = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
         roughB[sig] = -rough * roughA[sig];
+        if (TAP)
+            roughA[sig] = roughA[sig] * (1.0f / 1023.0f); // applies to the tap's roughness CODE
     }
 
     // ---- tap loop: ONE software pipeline over the 8 taps of every signal ----------------------------------------------------
@@ -446,13 +473,13 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
     if (anyRadius) { // uniform (kernel argument)
         constexpr int NT = 8 * NSIG;
         // PrePass (hit-distance tracking state) and the SH flavours (a second radiance texel per tap) carry more registers per tap
-        constexpr int DEPTH_WANTED = (VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : NRD_PIPE_DEPTH;
+        constexpr int DEPTH_WANTED = (VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? NRD_TAP_DEPTH : NRD_PIPE_DEPTH);
         constexpr int DEPTH = DEPTH_WANTED < NT ? DEPTH_WANTED : NT;
         const PlaneBuf guideB = plane_buf(p.guide, c.yOff);
         PlaneBuf srcB[NSIG], src1B[NSIG];
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
-            srcB[sig] = plane_buf(*srcPs[sig], c.yOff);
+            srcB[sig] = plane_buf(TAP ? tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0] : *srcPs[sig], c.yOff);
             if (SH)
                 src1B[sig] = plane_buf(*src1Ps[sig], c.yOff);
         }
@@ -478,6 +505,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
             inWin[T] = (cxf == fpx) & (cyf == fpy);
             const int px = (int)cxf, gpy = (int)cyf;
+            if constexpr (TAP) { // ONE gather: {guide part | signal}
+                graw[T] = ldb<uint4>(srcB[sig], px, gpy, 16);
+                return;
+            }
             graw[T] = ldb<uint4>(guideB, px, gpy, 16);
             if constexpr (SH && VARIANT != 0) { // SH0 | SH1 of a signal sit side by side in the internal planes: ONE 16-byte gather
                 const uint4 both = ldb<uint4>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
@@ -491,8 +522,17 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
         auto consume = [&](const int T) {
             const int sig = T >> 3, t = T & 7;
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            Guide gs = decode_guide(graw[T], c.denoisingRange);
-            f4 sv = decode_signal(p, sraw[T], occIn);
+            Guide gs;
+            f4 sv;
+            if constexpr (TAP) {
+                gs.z = u2f(graw[T].x);
+                gs.mat = graw[T].y >> 30;
+                gs.sky = !(absf(gs.z) <= c.denoisingRange);
+                sv = unpack_h4(uint2{graw[T].z, graw[T].w});
+            } else {
+                gs = decode_guide(graw[T], c.denoisingRange);
+                sv = decode_signal(p, sraw[T], occIn);
+            }
             const bool valid = inWin[T] & active[sig] & !gs.sky & !material_mismatch(g.mat, gs.mat, minMats[sig]); // bitwise: one basic block
 #ifdef NRD_DBG_HIST
             if (active[sig]) { // Chebyshev distance of the tap from the centre pixel, buckets <=2, 4, 8, 12, 16, 24, 32, more (taps of both signals)
@@ -507,9 +547,17 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
 #endif
             float w = g_poisson8[t][2];
             w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
-            w *= normal_weight_m2(dot3(g.n, gs.n), m2w2[sig]);
-            if (isSpec)
-                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
+            if constexpr (TAP) {
+                const uint32_t nw = graw[T].y;
+                const float cosn = fma_(nsc.x, (float)(nw & 1023u), fma_(nsc.y, (float)((nw >> 10) & 1023u), fma_(nsc.z, (float)((nw >> 20) & 1023u), nb)));
+                w *= normal_weight_m2(cosn, m2w2[sig]);
+                if (isSpec)
+                    w *= smoothstep01(1.0f - absf(fma_((float)(graw[T].x & 1023u), roughA[sig], roughB[sig])));
+            } else {
+                w *= normal_weight_m2(dot3(g.n, gs.n), m2w2[sig]);
+                if (isSpec)
+                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
+            }
             if (relaxIn)
                 sv = rgb_to_ycocg4(sv);
             w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA[sig], hitB[sig]))));
@@ -564,6 +612,9 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : 4) void k_spa
             st<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
             if (SH)
                 st<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
+        } else if (TAP && VARIANT == 1) {
+            const uint2 rv = pack_h4(res);
+            st_stream<uint4>(p.tapB[isSpec ? 1 : 0], x, y, 16, uint4{ctap[sig].x, ctap[sig].y, rv.x, rv.y});
         } else {
             st_stream<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
             if (SH)
@@ -1001,8 +1052,14 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     const bool live = x < c.W && y >= c.ownY0 && y < c.ownY1;
     const PlaneRef& outP = p.relax ? p.hist : p.tmp1; // RELAX: the fixed + clamped signal IS the next frame's history
-    auto sky_out = [&]() {
+    // REBLUR radiance flavours: the result goes out as tap texels {guide part | signal} for the Blur (nrd_device.h), one plane per signal
+    const bool tapTex = !SH && p.tapTex != 0;
+    auto sky_out = [&](const uint2 tg) {
         for (int sig = 0; sig < NSIG; sig++) {
+            if (tapTex) {
+                st<uint4>(p.tapA[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16, uint4{tg.x, tg.y, 0u, 0u});
+                continue;
+            }
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
             if (SH)
                 st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
@@ -1012,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     // a tile without geometry (ClassifyTiles: Tiles = 1; block-uniform): every pixel takes the sky path - no staging, no barrier
     if (tile_is_sky(p, tx, ty)) {
         if (live)
-            sky_out();
+            sky_out(tapTex ? pack_tap_guide(decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange)) : uint2{0u, 0u});
         return;
     }
     const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
@@ -1053,8 +1110,9 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     if (!live)
         return;
     Guide g = decode_guide(graw, c.denoisingRange);
+    const uint2 tapGuide = tapTex ? pack_tap_guide(g) : uint2{0u, 0u};
     if (g.sky) {
-        sky_out();
+        sky_out(tapGuide);
         return;
     }
     const int gy0 = y + c.yOff;
@@ -1169,7 +1227,11 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             val1.y *= scale;
             val1.z *= scale;
         }
-        st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * sb);
+        if (tapTex) {
+            const uint2 sv = pack_h4(val);
+            st<uint4>(p.tapA[isSpec ? 1 : 0], x, y, 16, uint4{tapGuide.x, tapGuide.y, sv.x, sv.y});
+        } else
+            st<uint2>(outP, x, y, RBPT, pack_h4(val), sig * sb);
         if (SH)
             st<uint2>(outP, x, y, RBPT, pack_h4(val1), sig * sb + 8);
     }

@@ -177,12 +177,17 @@ bool classify(nrd::Denoiser dn, DenoiserState& d) {
 // ---- pool descriptions (indices must match the enums used by the builders below) ----------------------------------
 namespace rb { // REBLUR
 enum Perm { GUIDE_A, GUIDE_B, DATA1_A, DATA1_B, HIST, FAST_A, FAST_B, STAB_A, STAB_B };
-enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK, PREP_D, PREP_S, PREP_D1, PREP_S1, AT_A, AT_B }; // PREP_*: PrepareInputs outputs; AT_*: RELAX only
+enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK, PREP_D, PREP_S, PREP_D1, PREP_S1, AT_A, AT_B, // PREP_*: PrepareInputs outputs; AT_*: RELAX only
+             // REBLUR only: tap texels of Blur / PostBlur (nrd_device.h), _A HistoryFix -> Blur, _B Blur -> PostBlur, one plane per signal
+             TAP_D_A = AT_A, TAP_S_A, TAP_D_B, TAP_S_B };
 } // namespace rb
 namespace sg { // SIGMA
 enum Perm { GUIDE_A, GUIDE_B, HIST_A, HIST_B };
 enum Trans { TILES, TILES_SMOOTH, SHADOW1, PEN1, SHADOW2 };
 } // namespace sg
+
+// REBLUR radiance flavours run Blur / PostBlur on tap texels (guide + signal in one 16-byte texel, nrd_device.h)
+bool tap_texels(const DenoiserState& d) { return d.kind == Kind::REBLUR && !d.sh; } // (OCCLUSION signals travel as {h, 0, 0, h} internally: same kernels)
 
 void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
     using F = nrd::Format;
@@ -211,6 +216,12 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"REBLUR::Prepared_Spec", F::RGBA16_SFLOAT, 8, 1});
         trans.push_back({"REBLUR::Prepared_DiffSh1", F::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
         trans.push_back({"REBLUR::Prepared_SpecSh1", F::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
+        // tap texels of Blur / PostBlur (radiance flavours only): _A HistoryFix -> Blur, _B Blur -> PostBlur
+        const bool tap = tap_texels(d);
+        trans.push_back({"REBLUR::Tap_Diff_A", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
+        trans.push_back({"REBLUR::Tap_Spec_A", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
+        trans.push_back({"REBLUR::Tap_Diff_B", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
+        trans.push_back({"REBLUR::Tap_Spec_B", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
     } else if (d.kind == Kind::RELAX) { // same slot order as REBLUR for the shared front half; moments live in the STAB slots
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
@@ -499,6 +510,14 @@ void push_signal_slots(const DenoiserState& d, std::vector<uint32_t>& list, bool
     }
 }
 
+// the tap planes of the signals present, diffuse first (base = rb::TAP_D_A or rb::TAP_D_B)
+void push_tap_planes(const DenoiserState& d, uint32_t tb, int base, std::vector<uint32_t>& list) {
+    if (d.hasDiff)
+        list.push_back(enc_trans(tb + base));
+    if (d.hasSpec)
+        list.push_back(enc_trans(tb + base + 1));
+}
+
 // parameter block of the REBLUR kernels; RELAX reuses them for its front half (ClassifyTiles, PrePass, TA, HistoryFix)
 ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c, const nrd::ReblurSettings& s) {
     using RT = nrd::ResourceType;
@@ -606,6 +625,12 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.data1Tmp = TP(rb::DATA1_TMP);
     p.data2 = TP(rb::DATA2);
     p.hitTrack = TP(rb::HITTRACK);
+    p.tapTex = tap_texels(d) ? 1 : 0;
+    if (p.tapTex)
+        for (int sgl = 0; sgl < 2; sgl++) {
+            p.tapA[sgl] = TP(rb::TAP_D_A + sgl);
+            p.tapB[sgl] = TP(rb::TAP_D_B + sgl);
+        }
     p.maxASpec = p.maxA;
     p.maxFastASpec = p.maxFastA;
     p.relax = 0;
@@ -626,6 +651,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     float sp = d.hasSpec ? 2.0f : 0.0f;
     uint16_t blurHalo = (uint16_t)p.reachBlur, postHalo = (uint16_t)p.reachPost, preHalo = (uint16_t)p.reachPre;
     const float GB = 16.0f; // guide texel bytes
+    const bool tap = tap_texels(d);
     {
         Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
@@ -657,24 +683,38 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     {
         Dispatch x{"REBLUR::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
-                   GB + 2 + 8 * nr + 2 * n + 8 * nr + 2, {}, {}, nullptr};
+                   GB + 2 + 8 * nr + 2 * n + (tap ? 16 * n : 8 * nr) + 2, {}, {}, nullptr};
         // (HistoryFix / TemporalStabilization also look up the Tiles flag of their OWN tile - no reach across tiles or bands, so it
         // is not part of the exchange plan's read sets)
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
-        x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
+        if (tap) {
+            push_tap_planes(d, tb, rb::TAP_D_A, x.written);
+            x.written.push_back(P(rb::DATA1_A + cur));
+        } else
+            x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
-        x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
-        x.written = {T(rb::TMP2)};
+        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, tap ? 2 + 16 * n + 16 * n : GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
+        if (tap) { // the tap texels carry the guide: no guide plane access
+            x.read = {P(rb::DATA1_A + cur)};
+            push_tap_planes(d, tb, rb::TAP_D_A, x.read);
+            push_tap_planes(d, tb, rb::TAP_D_B, x.written);
+        } else {
+            x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
+            x.written = {T(rb::TMP2)};
+        }
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 1, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
-        x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
+        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, tap ? 2 + 16 * n + 8 * nr : GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
+        if (tap) {
+            x.read = {P(rb::DATA1_A + cur)};
+            push_tap_planes(d, tb, rb::TAP_D_B, x.read);
+        } else
+            x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
         x.written = {P(rb::HIST)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 2, st); };
         d.dispatches.push_back(x);

@@ -19,7 +19,10 @@ namespace {
 
 // pool plane indices relative to permBase / transBase
 enum Perm { P_GUIDE_A, P_GUIDE_B, P_DATA1_A, P_DATA1_B, P_HIST, P_FAST_A, P_FAST_B, P_STAB_A, P_STAB_B, P_NUM };
-enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_PREP_D, T_PREP_S, T_PREP_D1, T_PREP_S1, T_NUM };
+enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_PREP_D, T_PREP_S, T_PREP_D1, T_PREP_S1, T_NUM,
+             // REBLUR only (RELAX keeps its A-trous ping-pong at these indices): tap texels of Blur / PostBlur, see TapTexel below.
+             // _A: HistoryFix -> Blur, _B: Blur -> PostBlur; one plane per signal
+             T_TAP_D_A = T_NUM, T_TAP_S_A, T_TAP_D_B, T_TAP_S_B };
 
 const float MAX_ACCUM = 63.0f;
 const float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
@@ -351,6 +354,55 @@ static inline f4 load_sh1(const SpatialIO& io, int sig, int x, int y, bool pre) 
     return pre ? ld_h4(*io.in1[sig], x, y, 0) : ld_h4(*io.in[sig], x, y, io.inOff[sig] + 8);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Tap texels (REBLUR radiance flavours: no SH, no OCCLUSION). What a Blur / PostBlur tap needs - depth, normal, roughness, material
+// and the signal - sits in ONE 16-byte texel per signal, so a tap is one gather instead of two (guide + radiance): the spatial passes
+// are bound by what moves through the texture path, not by arithmetic (profiles/r03_ab_setup_planes.txt).
+//   w0 = viewZ rounded to 22 bits | roughness as the 10-bit code of IN_NORMAL_ROUGHNESS   (read back AS A FLOAT it is the depth, the
+//        roughness code perturbing it by < 2^-13 relative - every consumer reads it that way, centre and taps alike)
+//   w1 = normal x | y << 10 | z << 20, 10 bits per component (n = code * 2/1023 - 1, not re-normalised) | materialID << 30
+//   w2, w3 = the signal {Y, Co | Cg, hitT} as 4 x fp16
+// HistoryFix packs the guide part from the 16-byte guide texel; Blur copies it through; both passes take their CENTRE pixel's guide
+// from the texel as well (they do not touch the guide plane). Precision: the normal arrives in IN_NORMAL_ROUGHNESS as a 10 + 10 bit
+// octahedron, the roughness as 10 bits - the texel is as fine as the input; only the depth loses its 10 low mantissa bits.
+// --------------------------------------------------------------------------------------------------
+struct TapTexel {
+    uint32_t w0, w1, w2, w3;
+};
+static inline uint32_t qn10(float v) { return (uint32_t)floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
+static inline void pack_tap_guide(const Guide& g, uint32_t& w0, uint32_t& w1) {
+    uint32_t rc = (uint32_t)floorf(fma_(sat(g.roughness), 1023.0f, 0.5f));
+    w0 = ((f2u(g.z) + 0x200u) & 0xFFFFFC00u) | rc;
+    w1 = qn10(g.n.x) | (qn10(g.n.y) << 10) | (qn10(g.n.z) << 20) | (g.mat << 30);
+}
+static inline Guide unpack_tap_guide(uint32_t w0, uint32_t w1, float range) {
+    Guide g;
+    g.z = u2f(w0);
+    g.roughness = (float)(w0 & 1023u) * (1.0f / 1023.0f);
+    const float s = 2.0f / 1023.0f;
+    g.n = {fma_((float)(w1 & 1023u), s, -1.0f), fma_((float)((w1 >> 10) & 1023u), s, -1.0f), fma_((float)((w1 >> 20) & 1023u), s, -1.0f)};
+    g.mat = w1 >> 30;
+    g.sky = !(absf(g.z) <= range);
+    return g;
+}
+static inline TapTexel ld_tap(const Plane& P, int x, int y) {
+    TapTexel t;
+    std::memcpy(&t, texel(P, x, y), 16);
+    return t;
+}
+static inline void st_tap(const Plane& P, int x, int y, uint32_t w0, uint32_t w1, f4 v) {
+    uint16_t h[4] = {f32_to_f16(clampf(v.x, -FP16_MAX, FP16_MAX)), f32_to_f16(clampf(v.y, -FP16_MAX, FP16_MAX)),
+                     f32_to_f16(clampf(v.z, -FP16_MAX, FP16_MAX)), f32_to_f16(clampf(v.w, -FP16_MAX, FP16_MAX))};
+    uint8_t* t = texel(P, x, y);
+    std::memcpy(t, &w0, 4);
+    std::memcpy(t + 4, &w1, 4);
+    std::memcpy(t + 8, h, 8);
+}
+static inline f4 tap_signal(const TapTexel& t) {
+    return {f16_to_f32((uint16_t)(t.w2 & 0xffffu)), f16_to_f32((uint16_t)(t.w2 >> 16)), f16_to_f32((uint16_t)(t.w3 & 0xffffu)), f16_to_f32((uint16_t)(t.w3 >> 16))};
+}
+static inline bool tap_texels(const DenoiserState& d) { return d.kind == Kind::REBLUR && !d.sh; } // (OCCLUSION signals travel as {h, 0, 0, h} internally: same planes)
+
 void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1) {
     const Consts& c = k.c;
     const nrd::ReblurSettings& s = k.d.reblur;
@@ -361,11 +413,20 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const bool relaxIn = k.d.kind == Kind::RELAX && variant == PRE; // RELAX inputs: linear RGB + world-space hit distance
     const bool occIn = k.d.occlusion && variant == PRE && !prepare_mode(k.d).any; // PrepareInputs already expanded them to {h, 0, 0, h}
     const bool sh = k.d.sh;
+    const bool tap = variant != PRE && tap_texels(k.d); // Blur / PostBlur on tap texels: io.in[sig] (and Blur's io.out[sig]) are tap planes
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
-            Guide g = load_guide(G, x, y, c.denoisingRange);
+            TapTexel ctap[2] = {};
+            if (tap)
+                for (int sig = 0; sig < k.d.nsig; sig++)
+                    ctap[sig] = ld_tap(*io.in[sig], x, y);
+            Guide g = tap ? unpack_tap_guide(ctap[0].w0, ctap[0].w1, c.denoisingRange) : load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
                 for (int sig = 0; sig < k.d.nsig; sig++) {
+                    if (tap && variant == BLUR) { // the guide part travels on (PostBlur takes its sky test from it)
+                        st_tap(*io.out[sig], x, y, ctap[sig].w0, ctap[sig].w1, {0, 0, 0, 0});
+                        continue;
+                    }
                     st_h4(*io.out[sig], x, y, {0, 0, 0, 0}, io.outOff[sig]);
                     if (sh)
                         st_h4(*io.out[sig], x, y, {0, 0, 0, 0}, io.outOff[sig] + 8);
@@ -400,7 +461,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 bool isSpec = (sig == k.sigSpec()) && k.d.hasSpec;
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
-                f4 center = load_signal(*io.in[sig], x, y, io.inOff[sig], occIn);
+                f4 center = tap ? tap_signal(ctap[sig]) : load_signal(*io.in[sig], x, y, io.inOff[sig], occIn);
                 if (relaxIn)
                     center = rgb_to_ycocg4(center);
                 f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
@@ -479,20 +540,34 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         if (variant == PRE && !valid)
                             continue;
                         int px = (int)clampf(fpx, (float)loX, (float)hiX), py = (int)clampf(fpy, (float)loY, (float)hiY) - c.yOff;
-                        Guide gs = load_guide(G, px, py, c.denoisingRange);
+                        TapTexel tt = {};
+                        if (tap)
+                            tt = ld_tap(*io.in[sig], px, py);
+                        Guide gs = tap ? unpack_tap_guide(tt.w0, tt.w1, c.denoisingRange) : load_guide(G, px, py, c.denoisingRange);
                         valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
                         if (variant == PRE && !valid)
                             continue;
-                        f4 sv = load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
+                        f4 sv = tap ? tap_signal(tt) : load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
                         if (relaxIn)
                             sv = rgb_to_ycocg4(sv);
                         float w = 0.0f;
                         if (valid) {
                             w = g_poisson8[t][2];
                             w *= geo_weight(pg, fpx, fpy, gs.z);
-                            w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                            if (isSpec)
-                                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                            if (tap) {
+                                // the tap's normal and roughness stay 10-bit codes: scale and offset of their decode are folded into
+                                // per-pixel constants (N . Ns = sum (2/1023 N_i) code_i - sum N_i; roughness likewise)
+                                const float ns = 2.0f / 1023.0f;
+                                const float nb = -((g.n.x + g.n.y) + g.n.z);
+                                float cosn = fma_(g.n.x * ns, (float)(tt.w1 & 1023u), fma_(g.n.y * ns, (float)((tt.w1 >> 10) & 1023u), fma_(g.n.z * ns, (float)((tt.w1 >> 20) & 1023u), nb)));
+                                w *= normal_weight(cosn, normalW2);
+                                if (isSpec)
+                                    w *= smoothstep01(1.0f - absf(fma_((float)(tt.w0 & 1023u), roughA * (1.0f / 1023.0f), roughB)));
+                            } else {
+                                w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                                if (isSpec)
+                                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                            }
                             w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                         }
                         sum = fma4(sv, w, sum);
@@ -510,7 +585,10 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     res = center;
                     res1 = center1;
                 }
-                st_h4(*io.out[sig], x, y, res, io.outOff[sig]);
+                if (tap && variant == BLUR)
+                    st_tap(*io.out[sig], x, y, ctap[sig].w0, ctap[sig].w1, res);
+                else
+                    st_h4(*io.out[sig], x, y, res, io.outOff[sig]);
                 if (sh)
                     st_h4(*io.out[sig], x, y, res1, io.outOff[sig] + 8);
                 if (variant == PRE && isSpec)
@@ -859,6 +937,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
     const Plane& IN = k.trans(T_TMP2);
     const bool relax = d.kind == Kind::RELAX;
     const Plane& OUT = relax ? k.perm(P_HIST) : k.trans(T_TMP1); // RELAX: the fixed + clamped signal IS the next frame's history
+    const bool tap = tap_texels(d); // REBLUR radiance flavours: the result goes out as tap texels (guide + signal) for the Blur
     const Plane& FAST = k.perm(P_FAST_A + k.cur);
     const Plane& D1T = k.trans(T_DATA1);
     const Plane& D1C = k.perm(P_DATA1_A + k.cur);
@@ -870,8 +949,15 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
+            uint32_t tw0 = 0, tw1 = 0;
+            if (tap)
+                pack_tap_guide(g, tw0, tw1);
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
+                    if (tap) {
+                        st_tap(k.trans(T_TAP_D_A + ((sig == k.sigSpec() && d.hasSpec) ? 1 : 0)), x, y, tw0, tw1, {0, 0, 0, 0});
+                        continue;
+                    }
                     st_h4(OUT, x, y, {0, 0, 0, 0}, sig * sb);
                     if (d.sh)
                         st_h4(OUT, x, y, {0, 0, 0, 0}, sig * sb + 8);
@@ -1014,7 +1100,10 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     val1.y *= scale;
                     val1.z *= scale;
                 }
-                st_h4(OUT, x, y, val, sig * sb);
+                if (tap)
+                    st_tap(k.trans(T_TAP_D_A + (isSpec ? 1 : 0)), x, y, tw0, tw1, val);
+                else
+                    st_h4(OUT, x, y, val, sig * sb);
                 if (d.sh)
                     st_h4(OUT, x, y, val1, sig * sb + 8);
             }
@@ -1425,6 +1514,20 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
     trans.push_back({"REBLUR::Prepared_Spec", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, 1});
     trans.push_back({"REBLUR::Prepared_DiffSh1", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
     trans.push_back({"REBLUR::Prepared_SpecSh1", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.sh ? 1 : 16)});
+    // tap texels of Blur / PostBlur (TapTexel; radiance flavours only): _A HistoryFix -> Blur, _B Blur -> PostBlur
+    const bool tap = tap_texels(d);
+    trans.push_back({"REBLUR::Tap_Diff_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
+    trans.push_back({"REBLUR::Tap_Spec_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
+    trans.push_back({"REBLUR::Tap_Diff_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
+    trans.push_back({"REBLUR::Tap_Spec_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
+}
+
+// the tap planes of the signals present, diffuse first (base = T_TAP_D_A or T_TAP_D_B)
+static void push_tap_planes(const DenoiserState& d, uint32_t tb, int base, std::vector<uint32_t>& list) {
+    if (d.hasDiff)
+        list.push_back(enc_trans(tb + base));
+    if (d.hasSpec)
+        list.push_back(enc_trans(tb + base + 1));
 }
 
 void reblur_build(Instance& I, DenoiserState& d) {
@@ -1438,6 +1541,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
     const nrd::ReblurSettings& s = d.reblur;
     ReblurReach rr = reblur_reach(s);
     const float GB = 16.0f; // guide texel bytes
+    const bool tap = tap_texels(d);
     {
         Pass p;
         p.name = "REBLUR::ClassifyTiles";
@@ -1525,9 +1629,13 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::HistoryFix";
         p.kernel = "nrd_reblur_history_fix";
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
-        p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + 8 * nr + 2;
+        p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + (tap ? 16 * n : 8 * nr) + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
-        p.written = {T(T_TMP1), P(P_DATA1_A + cur)};
+        if (tap) {
+            push_tap_planes(d, tb, T_TAP_D_A, p.written);
+            p.written.push_back(P(P_DATA1_A + cur));
+        } else
+            p.written = {T(T_TMP1), P(P_DATA1_A + cur)};
         p.run = history_fix;
         d.passes.push_back(p);
     }
@@ -1536,9 +1644,16 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::Blur";
         p.kernel = "nrd_reblur_blur";
         p.haloRows = (uint16_t)rr.blur;
-        p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
-        p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
-        p.written = {T(T_TMP2)};
+        if (tap) { // the tap texels carry the guide: no guide plane access
+            p.bytesPerPixel = 2 + 16 * n + 16 * n;
+            p.read = {P(P_DATA1_A + cur)};
+            push_tap_planes(d, tb, T_TAP_D_A, p.read);
+            push_tap_planes(d, tb, T_TAP_D_B, p.written);
+        } else {
+            p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
+            p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
+            p.written = {T(T_TMP2)};
+        }
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
             const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
@@ -1546,8 +1661,9 @@ void reblur_build(Instance& I, DenoiserState& d) {
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).blur;
             for (int sig = 0; sig < d.nsig; sig++) {
-                io.in[sig] = &k.trans(T_TMP1);
-                io.out[sig] = &k.trans(T_TMP2);
+                const int spec = (sig == k.sigSpec() && d.hasSpec) ? 1 : 0;
+                io.in[sig] = tap_texels(d) ? &k.trans(T_TAP_D_A + spec) : &k.trans(T_TMP1);
+                io.out[sig] = tap_texels(d) ? &k.trans(T_TAP_D_B + spec) : &k.trans(T_TMP2);
                 io.inOff[sig] = io.outOff[sig] = sig * sb;
             }
             spatial_filter(k, BLUR, io, y0, y1);
@@ -1559,8 +1675,14 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PostBlur";
         p.kernel = "nrd_reblur_post_blur";
         p.haloRows = (uint16_t)rr.post;
-        p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
-        p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
+        if (tap) {
+            p.bytesPerPixel = 2 + 16 * n + 8 * nr;
+            p.read = {P(P_DATA1_A + cur)};
+            push_tap_planes(d, tb, T_TAP_D_B, p.read);
+        } else {
+            p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
+            p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
+        }
         p.written = {P(P_HIST)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
@@ -1569,7 +1691,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
             SpatialIO io = {};
             io.reach = reblur_reach(d.reblur).post;
             for (int sig = 0; sig < d.nsig; sig++) {
-                io.in[sig] = &k.trans(T_TMP2);
+                const int spec = (sig == k.sigSpec() && d.hasSpec) ? 1 : 0;
+                io.in[sig] = tap_texels(d) ? &k.trans(T_TAP_D_B + spec) : &k.trans(T_TMP2);
                 io.out[sig] = &k.perm(P_HIST);
                 io.inOff[sig] = io.outOff[sig] = sig * sb;
             }
