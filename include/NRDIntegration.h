@@ -71,8 +71,10 @@ public:
     Integration& operator=(const Integration&) = delete;
 
     // `device`: HIP device ordinal (the sample passes its nri::Device*): the pools are allocated there, and every later call makes it
-    // current for its duration (and restores the caller's device), so a multi-GPU host can drive several Integrations from one thread
-    inline Result Recreate(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device = 0) {
+    // current for its duration (and restores the caller's device), so a multi-GPU host can drive several Integrations from one thread.
+    // Default -1 = no device of its own: every call runs on whatever device is current (a caller that never mentions a device keeps
+    // its pools, its bound planes and its stream on one GPU without thinking about it)
+    inline Result Recreate(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device = -1) {
         return RecreateBand(integrationDesc, instanceDesc, device, nullptr);
     }
 
@@ -172,10 +174,60 @@ class TiledIntegration : public Integration {
 public:
     inline ~TiledIntegration() { DestroyTiler(); }
 
-    // band rows of `rank`: whole tiles, the last rank takes the remainder; `haloRows` from nrdhip_required_halo (multiple of 16)
-    static inline void BandOf(uint16_t frameHeight, int world, int rank, uint32_t haloRows, int32_t band[4], uint16_t& localHeight) {
-        int base = world > 1 ? (frameHeight / world) / 16 * 16 : frameHeight;
-        int own0 = rank * base, own1 = rank == world - 1 ? frameHeight : own0 + base;
+    // First owned row of every rank plus frameHeight (world + 1 entries). Bands are whole TILE ROWS (16 pixel rows) and every rank gets
+    // its share of them, not a remainder: 270 tile rows over 8 ranks are 34, 34, 34, 34, 34, 34, 33, 33. `tileRowCost` (optional, one
+    // value per tile row, e.g. tiles with geometry + 0.15 x tiles without): the boundaries then balance the COST of the bands instead of
+    // their height; every band keeps at least `minRows` rows (pass the halo: a neighbour's halo must come from one band). Boundaries are
+    // fixed for the life of the instance (plane sizes depend on them): re-balancing = Recreate = an accumulation restart.
+    static inline bool BandBounds(uint16_t frameHeight, int world, int32_t* bounds, const float* tileRowCost = nullptr, uint32_t minRows = 16) {
+        const int n = (frameHeight + 15) / 16, minT = (int)((minRows + 15) / 16) > 1 ? (int)((minRows + 15) / 16) : 1;
+        if (world <= 1) {
+            bounds[0] = 0;
+            bounds[1] = frameHeight;
+            return true;
+        }
+        if (n < world * minT)
+            return false;
+        double total = 0.0;
+        if (tileRowCost)
+            for (int i = 0; i < n; i++)
+                total += tileRowCost[i] > 0.0f ? (double)tileRowCost[i] : 0.0;
+        int cut = 0;
+        bounds[0] = 0;
+        if (!tileRowCost || total <= 0.0) {
+            for (int r = 0; r < world; r++) {
+                cut += n / world + (r < n % world ? 1 : 0);
+                bounds[r + 1] = cut * 16 > frameHeight ? frameHeight : cut * 16;
+            }
+            return true;
+        }
+        double cum = 0.0; // cost of tile rows [0, i)
+        int i = 0;
+        for (int k = 1; k < world; k++) {
+            const int lo = cut + minT, hi = n - (world - k) * minT;
+            const double target = total * k / world;
+            while (i < lo)
+                cum += tileRowCost[i] > 0.0f ? (double)tileRowCost[i] : 0.0, i++;
+            double prev = cum;
+            while (i < hi && cum < target)
+                prev = cum, cum += tileRowCost[i] > 0.0f ? (double)tileRowCost[i] : 0.0, i++;
+            if (i > lo && cum >= target && (target - prev) < (cum - target)) // the nearer of the two candidate cuts
+                i--, cum = prev;
+            cut = i;
+            bounds[k] = cut * 16;
+        }
+        bounds[world] = frameHeight;
+        return true;
+    }
+    // band of `rank` inside the bounds above: band = {frame height, first stored row, first owned row (local), owned rows}
+    static inline void BandOf(uint16_t frameHeight, int world, int rank, uint32_t haloRows, int32_t band[4], uint16_t& localHeight,
+                              const int32_t* bounds = nullptr) {
+        int32_t even[66];
+        if (!bounds) {
+            BandBounds(frameHeight, world > 64 ? 64 : world, even);
+            bounds = even;
+        }
+        int own0 = bounds[rank], own1 = bounds[rank + 1];
         int row0 = own0 - (int)haloRows < 0 ? 0 : own0 - (int)haloRows;
         int row1 = own1 + (int)haloRows > frameHeight ? frameHeight : own1 + (int)haloRows;
         band[0] = frameHeight;
@@ -186,9 +238,11 @@ public:
     }
 
     inline Result Recreate(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device, int rank, int world,
-                           uint32_t haloRows, const nrdhip_transport* transport = nullptr) {
+                           uint32_t haloRows, const nrdhip_transport* transport = nullptr, const int32_t* bounds = nullptr) {
         DestroyTiler();
-        BandOf(integrationDesc.resourceHeight, world, rank, haloRows, m_Band, m_LocalHeight);
+        if (world > 64 || rank < 0 || rank >= world)
+            return Result::INVALID_ARGUMENT;
+        BandOf(integrationDesc.resourceHeight, world, rank, haloRows, m_Band, m_LocalHeight, bounds);
         IntegrationCreationDesc local = integrationDesc;
         local.resourceHeight = m_LocalHeight;
         Result r = RecreateBand(local, instanceDesc, device, m_Band);

@@ -91,7 +91,9 @@ NRDHIP_API int nrdhip_set_common(nrdhip_instance* inst, const void* settings, si
  * `settings` = nrd::ReblurSettings | RelaxSettings | SigmaSettings | ReferenceSettings by denoiser kind */
 NRDHIP_API int nrdhip_set_denoiser(nrdhip_instance* inst, uint32_t identifier, const void* settings, size_t size);
 /* nrd::ResourceSnapshot::SetResource (Source/NRDSample.cpp:447-501): bind a caller-owned plane to a slot.
- * `slot` = nrd::ResourceType, `format` = nrd::Format, device pointer + row pitch instead of nri::Texture*. */
+ * `slot` = nrd::ResourceType, `format` = nrd::Format, device pointer + row pitch instead of nri::Texture*.
+ * `width` / `height` (texels) are mandatory: nrdhip_denoise checks every plane a pass touches against the rect (full rect width;
+ * half of it for the noisy signal inputs of a checkerboarded denoiser; confidence planes any size) and refuses a smaller one. */
 NRDHIP_API int nrdhip_bind(nrdhip_instance* inst, uint32_t slot, void* dev_ptr, uint32_t pitch_bytes,
                            uint32_t format, uint16_t width, uint16_t height);
 /* forget every slot binding (a ResourceSnapshot is complete: slots absent from it must not keep last frame's pointers) */
@@ -129,6 +131,8 @@ NRDHIP_API int nrdhip_bind_pool(nrdhip_instance* inst, uint32_t pool, uint32_t i
  * nrdhip_slot_info - the plane currently bound to a resource slot (ptr NULL = unbound). */
 NRDHIP_API int nrdhip_denoiser_kind(nrdhip_instance* inst, uint32_t identifier, uint32_t* kind);
 NRDHIP_API int nrdhip_get_band(nrdhip_instance* inst, int32_t out[5]);
+/* HIP device ordinal the instance was created for (nrdhip_create_desc::device_plus1 - 1), -1 = "whatever is current at each call" */
+NRDHIP_API int nrdhip_get_device(nrdhip_instance* inst);
 NRDHIP_API int nrdhip_slot_info(nrdhip_instance* inst, uint32_t slot, nrdhip_plane_info* out);
 
 /* nrd::Integration::Get{Total,Persistent,Aliasable}MemoryUsageInMb (Source/NRDSample.cpp:1038): out[0..2] */

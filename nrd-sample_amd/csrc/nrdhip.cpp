@@ -1240,6 +1240,8 @@ NRDHIP_API int nrdhip_denoiser_kind(nrdhip_instance* inst, uint32_t identifier, 
     return 0;
 }
 
+NRDHIP_API int nrdhip_get_device(nrdhip_instance* inst) { return inst ? inst->device : -1; }
+
 NRDHIP_API int nrdhip_get_band(nrdhip_instance* inst, int32_t out[5]) {
     if (!inst || !out)
         return (int)nrd::Result::INVALID_ARGUMENT;
@@ -1409,7 +1411,15 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                     const uint32_t slot = s & 0xffff;
                     const Plane& P = I.slots[slot];
                     const bool conf = slot == (uint32_t)nrd::ResourceType::IN_DIFF_CONFIDENCE || slot == (uint32_t)nrd::ResourceType::IN_SPEC_CONFIDENCE;
-                    const uint32_t needW = conf ? 1u : (uint32_t)(I.common.rectSize[0] + 1) / 2u; // >= half the rect width in any mode
+                    // only the noisy signal inputs of a checkerboarded denoiser are half width; every other slot spans the rect
+                    bool halfWidth = false;
+                    if (d.kind == Kind::REBLUR || d.kind == Kind::RELAX) {
+                        const bool checker = (d.kind == Kind::REBLUR ? d.reblur.checkerboardMode : d.relax.checkerboardMode) != nrd::CheckerboardMode::OFF;
+                        using RT = nrd::ResourceType;
+                        const RT t = (RT)slot;
+                        halfWidth = checker && (t == in_slot(d, false) || t == in_slot(d, true) || t == RT::IN_DIFF_SH1 || t == RT::IN_SPEC_SH1);
+                    }
+                    const uint32_t needW = conf ? 1u : (halfWidth ? (uint32_t)(I.common.rectSize[0] + 1) / 2u : (uint32_t)I.common.rectSize[0]);
                     const uint32_t needH = conf ? 1u : (uint32_t)std::min<int>(I.resH, std::max<int>((int)I.common.rectSize[1] - I.yOff, 1));
                     if (P.pitch < (uint32_t)P.w * P.bpt || P.w < needW || P.h < needH) {
                         I.error = std::string("resource slot plane smaller than the rect (or pitch < width x texel size) for pass ") + x.name;

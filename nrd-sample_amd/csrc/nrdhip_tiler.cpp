@@ -121,9 +121,25 @@ int fail(nrdhip_tiler& T, int code, const std::string& what) {
 bool plane_of(nrdhip_tiler& T, uint32_t code, nrdhip_plane_info& P, uint32_t& div) {
     if ((code >> 16) > 1 || nrdhip_pool_info(T.inst, code >> 16, code & 0xffff, &P) != 0 || !P.ptr || !P.height)
         return false;
-    div = std::max<uint32_t>((uint32_t)((T.localH + P.height / 2) / P.height), 1u);
-    return true;
+    div = (int32_t)P.height == T.localH ? 1u : 16u; // pool planes are full resolution or one texel per 16x16 tile (rounding localH / height
+    return true;                                    // went wrong for short bands: 449 rows over 29 tile rows is 15)
 }
+
+// the instance's HIP device made current for a call (streams, events and the RCCL communicator of the tiler must live on the GPU
+// the pools live on), the caller's restored afterwards
+struct TilerDeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit TilerDeviceScope(nrdhip_tiler& T) {
+        const int device = nrdhip_get_device(T.inst);
+        if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device)
+            switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~TilerDeviceScope() {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+};
 
 struct Op {
     bool send;
@@ -347,9 +363,10 @@ NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* T, const void* unique_id128)
         return INVALID;
     if (!g_rccl.load(T->error))
         return FAILURE;
+    TilerDeviceScope scope(*T);
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof(id));
-    ncclResult_t r = g_rccl.CommInitRank(&T->comm, T->world, id, T->rank); // on the current HIP device (one rank per GPU)
+    ncclResult_t r = g_rccl.CommInitRank(&T->comm, T->world, id, T->rank); // on the instance's HIP device (one rank per GPU)
     if (r != ncclSuccess)
         return fail(*T, FAILURE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
     if (hipStreamCreateWithFlags(&T->commStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T->evCompute, hipEventDisableTiming) != hipSuccess ||
@@ -367,6 +384,7 @@ NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     if (!T)
         return;
 #ifndef NRD_HOST_EMULATION
+    TilerDeviceScope scope(*T);
     if (T->comm)
         g_rccl.CommDestroy(T->comm);
     if (T->commStream)
@@ -391,6 +409,7 @@ NRDHIP_API int nrdhip_tiler_exchange_inputs(nrdhip_tiler* T, const uint32_t* slo
         return INVALID;
     if (T->world == 1)
         return 0;
+    TilerDeviceScope scope(*T);
     std::vector<Op> ops;
     for (uint32_t i = 0; i < n; i++) {
         nrdhip_plane_info P;
@@ -416,6 +435,7 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
     hipStream_t st = (hipStream_t)stream;
     if (T->world == 1)
         return nrdhip_denoise(T->inst, ids, n, stream);
+    TilerDeviceScope scope(*T);
     int r = build_plan(*T, ids, n);
     if (r)
         return r;
@@ -483,7 +503,12 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
 }
 
 // rows only the next frame reads may still be travelling: make `stream` wait for them (end of a run, before reading pool planes)
-NRDHIP_API int nrdhip_tiler_finish(nrdhip_tiler* T, void* stream) { return T ? wait_deferred(*T, (hipStream_t)stream) : INVALID; }
+NRDHIP_API int nrdhip_tiler_finish(nrdhip_tiler* T, void* stream) {
+    if (!T)
+        return INVALID;
+    TilerDeviceScope scope(*T);
+    return wait_deferred(*T, (hipStream_t)stream);
+}
 
 NRDHIP_API int nrdhip_tiler_stats(nrdhip_tiler* T, uint64_t out[4]) {
     if (!T || !out)

@@ -121,7 +121,7 @@ class Scene:
 
     def __init__(self, width, height, seed=0x9E3779B9, hfov=90.0, dolly=0.01, denoiser="REBLUR", rough_bands=True,
                  translucent_sphere=True, device="cpu", frame_height=None, row0=0, ortho=False, roll_deg=0.0, forward=None,
-                 sun_deg=(-147.0, 45.0, 0.533), hit_dist_scale=3.0):
+                 sun_deg=(-147.0, 45.0, 0.533), hit_dist_scale=3.0, wall_height=5.0):
         self.w, self.h, self.seed = width, height, seed
         self.ortho = ortho
         self.roll = math.radians(roll_deg)
@@ -140,6 +140,7 @@ class Scene:
         # spheres: centre, radius, roughness, materialID
         self.spheres = [((-1.6, 0.7, 4.0), 0.7, 0.05, 1), ((0.3, 1.0, 5.5), 1.0, 0.3, 0), ((2.2, 0.6, 3.5), 0.6, 0.7, 1)]
         self.wall_z = 9.0
+        self.wall_height = float(wall_height)  # sky shows above the back wall; float("inf") closes the view (no sky pixel: bench.py's full-coverage leg)
         az, el = math.radians(sun_deg[0]), math.radians(sun_deg[1])
         # the sample's sun direction is z-up (Source/NRDSample.cpp:587-594); this scene is y-up: swap
         sun = np.array([math.cos(az) * math.cos(el), math.sin(el), math.sin(az) * math.cos(el)])
@@ -180,7 +181,7 @@ class Scene:
         t = torch.where(ok, tg, t)
         obj = torch.where(ok, torch.zeros_like(obj), obj)
         tw = (self.wall_z - o[..., 2]) / d[..., 2]
-        ok = (tw > 1e-4) & torch.isfinite(tw) & (tw < t) & ((o[..., 1] + tw * d[..., 1]) < 5.0)
+        ok = (tw > 1e-4) & torch.isfinite(tw) & (tw < t) & ((o[..., 1] + tw * d[..., 1]) < self.wall_height)
         t = torch.where(ok, tw, t)
         obj = torch.where(ok, torch.ones_like(obj), obj)
         for i, (c, r, _, _) in enumerate(self.spheres):

@@ -23,14 +23,71 @@ class HaloError(ValueError):
     """a pass reads farther than the rows the band stores: the tiled result would differ from the single-GPU frame"""
 
 
-def band_layout(frame_h, world, rank, halo):
-    """rows owned by `rank` and the local window [row0, row0 + local_h) it stores"""
-    base = (frame_h // world) // 16 * 16 if world > 1 else frame_h
-    own0 = rank * base
-    own1 = frame_h if rank == world - 1 else own0 + base
+SKY_TILE_COST = 0.15  # cost of a 16x16 tile without geometry relative to a filtered one (4K bench scene: 28 % sky costs the frame ~19 %)
+
+
+def band_bounds(frame_h, world, tile_row_cost=None, min_rows=16):
+    """First owned row of every rank, plus frame_h (world + 1 entries). Bands are whole TILE ROWS (16 pixel rows; the band tile grids
+    then coincide with the single-GPU tile grid) and every rank gets its share of them, not a remainder: 270 tile rows over 8 ranks
+    are 34, 34, 34, 34, 34, 34, 33, 33 (== nrd::TiledIntegration::BandBounds).
+    ``tile_row_cost``: one non-negative number per tile row (e.g. tiles with geometry + SKY_TILE_COST x tiles without, from last
+    frame's Tiles mask or the depth buffer): the boundaries then balance the COST of the bands instead of their height - a frame
+    whose upper third is sky would otherwise hand the upper ranks almost nothing to do. Every band keeps at least ``min_rows`` rows
+    (a neighbour's halo must come from ONE band: pass the halo). Boundaries are fixed for the life of the band instances (plane
+    sizes depend on them): re-balancing means re-creating the bands, i.e. an accumulation restart - nothing moves them mid-stream."""
+    n = (frame_h + 15) // 16
+    if world <= 1:
+        return [0, frame_h]
+    min_t = max((min_rows + 15) // 16, 1)
+    if n < world * min_t:
+        raise ValueError("%d rows cannot be split into %d bands of at least %d rows" % (frame_h, world, min_rows))
+    if tile_row_cost is None:
+        q, rem = divmod(n, world)
+        counts = [q + (1 if r < rem else 0) for r in range(world)]
+        cuts = [0]
+        for k in counts:
+            cuts.append(cuts[-1] + k)
+    else:
+        cost = [max(float(c), 0.0) for c in tile_row_cost]
+        if len(cost) != n:
+            raise ValueError("tile_row_cost needs one entry per tile row (%d), got %d" % (n, len(cost)))
+        total = sum(cost)
+        if total <= 0.0:
+            return band_bounds(frame_h, world, None, min_rows)
+        cum = [0.0]
+        for c in cost:
+            cum.append(cum[-1] + c)
+        cuts = [0]
+        for k in range(1, world):
+            lo, hi = cuts[-1] + min_t, n - (world - k) * min_t  # leave room for the bands above and below
+            target = total * k / world
+            i = lo
+            while i < hi and cum[i] < target:
+                i += 1
+            if i > lo and (target - cum[i - 1]) < (cum[i] - target):  # the nearer of the two candidate cuts
+                i -= 1
+            cuts.append(i)
+        cuts.append(n)
+    return [min(c * 16, frame_h) for c in cuts]
+
+
+def band_layout(frame_h, world, rank, halo, bounds=None):
+    """rows owned by `rank` and the local window [row0, row0 + local_h) it stores; ``bounds`` from band_bounds() (default: even)"""
+    bounds = bounds if bounds is not None else band_bounds(frame_h, world)
+    own0, own1 = bounds[rank], bounds[rank + 1]
     row0 = max(own0 - halo, 0)
     row1 = min(own1 + halo, frame_h)
     return dict(own0=own0, own1=own1, row0=row0, local_h=row1 - row0, own_first=own0 - row0, own_rows=own1 - own0)
+
+
+def tile_row_cost_from_depth(viewz, denoising_range, sky_cost=SKY_TILE_COST):
+    """band_bounds() cost profile from a depth buffer (any resolution that is a whole fraction of the frame's: one texel row of a
+    1/16-resolution buffer = one tile row): geometry tiles count 1, sky tiles ``sky_cost``"""
+    import numpy as np
+
+    z = np.abs(np.asarray(viewz, dtype=np.float64))
+    geo = (z <= denoising_range)
+    return [float(row.sum() + sky_cost * (row.size - row.sum())) for row in geo]
 
 
 def required_halo(dispatches, motion_rows=DEFAULT_MOTION_ROWS):
@@ -68,8 +125,9 @@ def probe_halo(backend, denoisers, settings=None, motion_rows=DEFAULT_MOTION_ROW
 class BandHarness(Harness):
     """Harness for one row band: planes are local_h rows tall, CommonSettings describe the whole frame."""
 
-    def __init__(self, backend, denoisers, width, frame_h, rank, world, halo=DEFAULT_HALO):
-        self.layout = band_layout(frame_h, world, rank, halo)
+    def __init__(self, backend, denoisers, width, frame_h, rank, world, halo=DEFAULT_HALO, bounds=None):
+        self.layout = band_layout(frame_h, world, rank, halo, bounds)
+        self.bounds = bounds if bounds is not None else band_bounds(frame_h, world)
         self.frame_h, self.rank, self.world, self.halo = frame_h, rank, world, halo
         L = self.layout
         super().__init__(backend, denoisers, width, L["local_h"], frame_height=frame_h, band_row0=L["row0"],
@@ -231,7 +289,7 @@ class Tiler:
         items = []
         for code, rows, *skip in todo:
             p = self._plane_of(code)
-            div = max(int(round(local_h / p["height"])), 1)
+            div = 1 if p["height"] == local_h else 16  # pool planes: full resolution, or one texel per 16x16 tile
             items.append((self._as_tensor(p["buf"]), div, rows, *skip))
         return items
 
@@ -444,7 +502,7 @@ class TiledRunner:
     """bench.py's N > 1 path: every rank renders its band of the synthetic scene on its GPU, then steps the tiler."""
 
     def __init__(self, pkg, backend, device, dens, width, frame_h, rank, world, unique, dolly, settings_of, tiler="python",
-                 motion_rows=DEFAULT_MOTION_ROWS):
+                 motion_rows=DEFAULT_MOTION_ROWS, balance=True):
         import torch
         import torch.distributed as dist
 
@@ -455,7 +513,19 @@ class TiledRunner:
         # the rows a band stores beyond its own come from the settings actually used (reach of every pass + motion), not a constant
         probe_scene = pkg.synth.Scene(64, 64, dolly=dolly, device=device)
         self.halo = probe_halo(backend, dens, settings_of(pkg.api, probe_scene, dens), motion_rows)
-        self.band = BandHarness(backend, dens, width, frame_h, rank, world, halo=self.halo)
+        # Band boundaries balance the COST of the bands, not their height: a tile without geometry costs a fraction of a filtered one,
+        # and the sky of this scene sits in the upper rows. The profile comes from the depth of the first frame at one texel per tile
+        # (every rank renders the same 1/16-resolution proxy: no communication); a renderer would use last frame's Tiles mask and
+        # re-create its bands on an accumulation restart.
+        self.bounds = None
+        if balance and world > 1:
+            proxy = pkg.synth.Scene((width + 15) // 16, (frame_h + 15) // 16, dolly=dolly, device="cpu")
+            pz = proxy.frame(0, noise=False)
+            rng = float(proxy.common_settings(pkg.api, pz, 0).denoisingRange)
+            vz = pz["viewz"]
+            vz = vz.cpu().numpy() if hasattr(vz, "cpu") else vz
+            self.bounds = band_bounds(frame_h, world, tile_row_cost_from_depth(vz, rng), min_rows=self.halo)
+        self.band = BandHarness(backend, dens, width, frame_h, rank, world, halo=self.halo, bounds=self.bounds)
         if tiler == "native":
             self.tiler = NativeTiler(self.band, dist, transport="rccl" if dist.get_backend() == "nccl" else "dist")
         else:
@@ -533,3 +603,65 @@ class TiledRunner:
     def dispatch_table(self):
         """[(pass name, algorithmic bytes per pixel)] of one frame (for the roofline object when no per-dispatch events exist)"""
         return [(x["name"], x["bytes_per_pixel"]) for x in self.band.nrd.dispatches(self.ids)]
+
+
+def verify_tiled_against_single(pkg, backend, device, dens, width, frame_h, rank, world, settings_of, dolly, halo, bounds, tiler="python",
+                                frames=3):
+    """Bit-identity of the row-tiled frame against ONE instance over the whole frame, on the workload's own frame size: every rank
+    renders the same full frames (same seeds, same code: identical planes on every GPU), cuts out its band, and steps `frames` frames
+    from a restart through the tiler; rank 0 also runs the single instance and compares every output row the bands own.
+    Returns (identical, detail) on rank 0, (None, "") elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    api = pkg.api
+    scene = pkg.synth.Scene(width, frame_h, dolly=dolly, device=device)
+    settings = settings_of(api, scene, dens)
+    band = BandHarness(backend, dens, width, frame_h, rank, world, halo=halo, bounds=bounds)
+    t = NativeTiler(band, dist, transport="rccl" if dist.get_backend() == "nccl" else "dist") if tiler == "native" else Tiler(band, dist)
+    single = Harness(backend, dens, width, frame_h) if rank == 0 else None
+    L = band.layout
+    ids = [int(d) for d in dens]
+    for f in range(frames):
+        fr = scene.frame(f)
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        local = {k: (v[L["row0"]:L["row0"] + L["local_h"]] if hasattr(v, "shape") and v.shape[0] == frame_h else v) for k, v in fr.items()}
+        planes = band.upload(local)
+        band.nrd.new_frame()
+        band.nrd.set_common_settings(cs)
+        band.bind(planes)
+        for d in dens:
+            band.nrd.set_denoiser_settings(int(d), settings[d])
+        t.denoise(ids)
+        if single is not None:
+            single.frame(cs, single.upload(fr), settings)
+        del fr, local, planes
+    t.finish()
+    torch.cuda.synchronize()
+    keys = [k for k in ("out_diff", "out_spec") if k in band.outputs]
+    bad = []
+    for key in keys:
+        own = band.own_rows(band.outputs[key]).contiguous()
+        if rank == 0:
+            ref = single.outputs[key]
+            rows = [own] + [None] * (world - 1)
+            for r in range(1, world):
+                b0, b1 = band.bounds[r], band.bounds[r + 1]
+                buf = torch.empty((b1 - b0, own.shape[1]), dtype=own.dtype, device=own.device)
+                dist.recv(buf, src=r)
+                rows[r] = buf
+            for r in range(world):
+                b0, b1 = band.bounds[r], band.bounds[r + 1]
+                if not torch.equal(rows[r], ref[b0:b1]):
+                    bad.append("%s rows %d-%d (rank %d): %d bytes differ" % (key, b0, b1, r, int((rows[r] != ref[b0:b1]).sum().item())))
+        else:
+            dist.send(own, dst=0)
+    if hasattr(t, "destroy"):
+        t.destroy()
+    band.nrd.destroy()
+    if single is not None:
+        single.nrd.destroy()
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None, ""
+    return (not bad), ("; ".join(bad) if bad else "%d frames, %s, every owned row of %d bands" % (frames, " + ".join(keys), world))

@@ -38,7 +38,7 @@ def test_multi_gpu_default_is_baseline_config_5(monkeypatch, pkg):
     assert bench.WORKLOADS[a.workload] == (7680, 4320, ["REBLUR_DIFFUSE_SPECULAR"])
     from nrd_sample_amd import tiler
     bands = [tiler.band_layout(4320, 8, r, 80) for r in range(8)]
-    assert sum(b["own_rows"] for b in bands) == 4320 and all(b["own_rows"] >= 528 and b["own0"] % 16 == 0 for b in bands)
+    assert sum(b["own_rows"] for b in bands) == 4320 and all(528 <= b["own_rows"] <= 544 and b["own0"] % 16 == 0 for b in bands)
     assert all(a["own1"] == b["own0"] for a, b in zip(bands, bands[1:]))
 
 
