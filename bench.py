@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--motion-rows", type=int, default=8, help="row tiling: vertical motion (rows) the stored halo must cover beyond the passes' reach")
     ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-upstream-leg", action="store_true", help="skip the timed leg on the NRD_UPSTREAM_FORMULAS build flavour, 1-GPU runs")
     ap.add_argument("--no-full-coverage", action="store_true", help="skip the second timed leg (the same scene without sky), 1-GPU runs")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
@@ -377,6 +378,26 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # a reported extra: never lose the headline line to it
                 out["config"]["full_coverage"] = {"error": str(e)}
+        if world == 1 and not args.force_tiled and not args.no_upstream_leg and not args.preset and os.path.exists(pkg.HIP_LIB_UPSTREAM):
+            # the price of the frozen simplifications: the same workload through libnrdhip_upstream.so - the build flavour with the
+            # recalled upstream forms of ledger rows 1, 2, 7 (exp(-3|x|) hit-distance weight, arccosine normal weight, per-pixel Blur
+            # rotation; csrc/nrd_device.h NRD_UPSTREAM_FORMULAS)
+            try:
+                hip_up = pkg.hip_backend(dev, flavour="upstream")
+                scene_up = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
+                                       roll_deg=args.roll)
+                hz_up = Harness(hip_up, dens, w, band_h)
+                runner_up = SingleRunner(api, hz_up, scene_up, dens, args.unique_frames, settings_of(api, scene_up, dens))
+                dt_up = timed_run(runner_up)
+                pp = runner_up.pass_times_ms()
+                out["config"]["upstream_formulas"] = {
+                    "value": round(w * frame_h * args.steps / dt_up / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_up / args.steps * 1e3, 4),
+                    "passes_ms": {k: round(v[0], 4) for k, v in pp.items()},
+                    "what": "same workload, libnrdhip_upstream.so: hit-distance weight exp(-3|x|), normal weight on the angle (arccosine), Blur rotation per pixel"}
+                del runner_up, hz_up
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["config"]["upstream_formulas"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:  # reported on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of, dev, w, wl_h)

@@ -224,16 +224,47 @@ NRD_DEV float atan_pos(float x) {
     return inv ? 1.57079633f - p : p;
 }
 
-// compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped
+// NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of four frozen simplifications (oracle/README.md
+// ledger rows 1, 2, 7): hit-distance weight exp(-3 |x|), normal weight on the ANGLE (through an arccosine), Blur rotation per pixel.
+// It exists to put a price on those deviations (bench.py config.upstream_formulas) and as the switch to flip the day External/NRD is
+// vendored; libnrdhip_upstream.so / liboracle_upstream.so are built from the same sources with -DNRD_UPSTREAM_FORMULAS=1.
+#ifndef NRD_UPSTREAM_FORMULAS
+#define NRD_UPSTREAM_FORMULAS 0
+#endif
+constexpr bool UPSTREAM_FORMULAS = NRD_UPSTREAM_FORMULAS != 0;
+constexpr int BLUR_ROTATION_SHIFT = UPSTREAM_FORMULAS ? 0 : 1; // Blur's Poisson rotation: per pixel (upstream) / per 2x2 quad (frozen)
+
+// arccosine on [0, 1] (Abramowitz & Stegun 4.4.45, |error| <= 5e-5): sqrt(1 - x) (a0 + a1 x + a2 x^2 + a3 x^3)
+NRD_DEV float acos01_poly(float x) {
+    x = sat(x);
+    float p = -0.0187293f;
+    p = fma_(p, x, 0.0742610f);
+    p = fma_(p, x, -0.2121144f);
+    p = fma_(p, x, 1.5707288f);
+    return sqrt_(1.0f - x) * p;
+}
+// hit-distance weight: compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped; upstream flavour: exp(-3 |x|)
 NRD_DEV float exp_weight(float ax) {
+    if (UPSTREAM_FORMULAS)
+        return exp2_poly(-4.32808512f * ax); // 3 log2(e)
     float t = sat(1.0f - ax);
     return t * t;
 }
-// normal weight on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; w2 = 1 / angleMax^2
-NRD_DEV float normal_weight(float cosa, float w2) { return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), w2, 1.0f)); }
-// same value with the factor -2 folded into the per-pixel constant (m2w2 = -2 * w2): scaling by 2 is exact, so
-// fma(-2 t, w2, 1) and fma(t, -2 w2, 1) round the same exact product - one multiply less per tap
-NRD_DEV float normal_weight_m2(float cosa, float m2w2) { return smoothstep01(fma_(sat(1.0f - cosa), m2w2, 1.0f)); }
+// Normal weight. Frozen form: on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; its per-pixel parameter is w2 = 1 / angleMax^2
+// (normal_weight) or -2 w2 (normal_weight_m2: scaling by 2 is exact, so fma(-2 t, w2, 1) and fma(t, -2 w2, 1) round the same exact
+// product - one multiply less per tap). Upstream flavour: smoothstep(1 - acos(cos) / angleMax), parameter = 1 / angleMax for both.
+NRD_DEV float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : normalW * normalW; }
+NRD_DEV float nw_param_m2(float normalW) { return UPSTREAM_FORMULAS ? normalW : -2.0f * (normalW * normalW); }
+NRD_DEV float normal_weight(float cosa, float prm) {
+    if (UPSTREAM_FORMULAS)
+        return smoothstep01(fma_(-acos01_poly(cosa), prm, 1.0f));
+    return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), prm, 1.0f));
+}
+NRD_DEV float normal_weight_m2(float cosa, float prm) {
+    if (UPSTREAM_FORMULAS)
+        return smoothstep01(fma_(-acos01_poly(cosa), prm, 1.0f));
+    return smoothstep01(fma_(sat(1.0f - cosa), prm, 1.0f));
+}
 
 // ---- input decode (once per pixel, in the ClassifyTiles passes) ---------------------------------------------------
 NRD_DEV f3 oct_decode(float px, float py) {

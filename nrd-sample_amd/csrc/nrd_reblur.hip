@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
             float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
             float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
             normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-            float normalW2 = normalW * normalW;
+            float normalW2 = nw_param(normalW);
             float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             float roughB = -rough * roughA;
             float sum = 0.0f, wsum = 0.0f;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
     // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
     // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
     constexpr bool PER_PIXEL = VARIANT == 1;
-    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x >> 1 : 0u, PER_PIXEL ? (uint32_t)gy0 >> 1 : 0u, c.frameIndex, (uint32_t)VARIANT + 1u); // one rotation per 2x2 quad
+    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x >> BLUR_ROTATION_SHIFT : 0u, PER_PIXEL ? (uint32_t)gy0 >> BLUR_ROTATION_SHIFT : 0u, c.frameIndex, (uint32_t)VARIANT + 1u); // one rotation per 2x2 quad
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-        float normalW2 = normalW * normalW;
-        m2w2[sig] = -2.0f * normalW2;
+        float normalW2 = nw_param(normalW);
+        m2w2[sig] = nw_param_m2(normalW);
         float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
         hitA[sig] = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
         hitB[sig] = -center.w * hitA[sig];
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                 float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, rcp_(1.0f + Acur));
                 float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                 normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-                float normalW2 = normalW * normalW;
+                float normalW2 = nw_param(normalW);
                 float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
                 float roughB = -rough * roughA;
                 f4 sum = mul4(val, 1.0f + Acur);
@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
             normalW *= lerpf(1.0f, conf, p.normRelax);
             roughRelax = lerpf(1.0f, conf, p.roughRelax);
         }
-        normalW2[sig] = -2.0f * (normalW * normalW); // holds -2 w^2 (normal_weight_m2)
+        normalW2[sig] = nw_param_m2(normalW); // holds -2 w^2 (normal_weight_m2)
         if (isSpec) {
             roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             roughB = -rough * roughA;

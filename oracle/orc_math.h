@@ -204,13 +204,39 @@ static inline float atan_pos(float x) {
 // acos(x) ~ sqrt(2) * sqrt(1 - x), x in [0, 1] (small-angle exact, monotonic)
 static inline float acos_approx(float x) { return 1.41421356f * sqrtf(sat(1.0f - x)); }
 
-// compact-support stand-in for exp(-3 |x|) used by the hit-distance weights: (1 - |x|)^2 clamped (division-free)
+// NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of ledger rows 1, 2 and 7 (oracle/README.md):
+// hit-distance weight exp(-3 |x|), normal weight on the angle, Blur rotation per pixel - liboracle_upstream.so, the checker of
+// libnrdhip_upstream.so (same switch, same formulas: nrd-sample_amd/csrc/nrd_device.h)
+#ifndef NRD_UPSTREAM_FORMULAS
+#define NRD_UPSTREAM_FORMULAS 0
+#endif
+static const bool UPSTREAM_FORMULAS = NRD_UPSTREAM_FORMULAS != 0;
+static const int BLUR_ROTATION_SHIFT = NRD_UPSTREAM_FORMULAS ? 0 : 1; // Blur's Poisson rotation: per pixel (upstream) / per 2x2 quad (frozen)
+
+// arccosine on [0, 1] (Abramowitz & Stegun 4.4.45, |error| <= 5e-5)
+static inline float acos01_poly(float x) {
+    x = sat(x);
+    float p = -0.0187293f;
+    p = fma_(p, x, 0.0742610f);
+    p = fma_(p, x, -0.2121144f);
+    p = fma_(p, x, 1.5707288f);
+    return sqrt_(1.0f - x) * p;
+}
+// hit-distance weight: compact-support stand-in for exp(-3 |x|): (1 - |x|)^2 clamped (division-free); upstream flavour: exp(-3 |x|)
 static inline float exp_weight(float ax) {
+    if (UPSTREAM_FORMULAS)
+        return exp2_poly(-4.32808512f * ax); // 3 log2(e)
     float t = sat(1.0f - ax);
     return t * t;
 }
-// normal weight on the SQUARED angle: angle^2 ~ 2 (1 - cos) (sqrt-free); w2 = 1 / angleMax^2
-static inline float normal_weight(float cosa, float w2) { return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), w2, 1.0f)); }
+// normal weight: on the SQUARED angle, angle^2 ~ 2 (1 - cos) (sqrt-free), parameter w2 = 1 / angleMax^2; upstream flavour: on the
+// angle through the arccosine, parameter 1 / angleMax
+static inline float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : normalW * normalW; }
+static inline float normal_weight(float cosa, float prm) {
+    if (UPSTREAM_FORMULAS)
+        return smoothstep01(fma_(-acos01_poly(cosa), prm, 1.0f));
+    return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), prm, 1.0f));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Packing

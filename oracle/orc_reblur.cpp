@@ -298,7 +298,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                     float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
                     float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                     normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-                    float normalW2 = normalW * normalW;
+                    float normalW2 = nw_param(normalW);
                     float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
                     float sum = 0.0f, wsum = 0.0f;
@@ -451,7 +451,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
             float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
             // Poisson rotation: per frame for PrePass / PostBlur (neighbouring pixels then gather neighbouring texels), per 2x2 quad for Blur
             bool perPixel = variant == BLUR;
-            uint32_t h = hash_px(perPixel ? (uint32_t)x >> 1 : 0u, perPixel ? (uint32_t)gy0 >> 1 : 0u, c.frameIndex, (uint32_t)variant + 1u); // one rotation per 2x2 quad
+            uint32_t h = hash_px(perPixel ? (uint32_t)x >> BLUR_ROTATION_SHIFT : 0u, perPixel ? (uint32_t)gy0 >> BLUR_ROTATION_SHIFT : 0u, c.frameIndex, (uint32_t)variant + 1u); // one rotation per 2x2 quad
             float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
             float diffA = 0.0f, specA = 0.0f;
             if (variant != PRE)
@@ -511,7 +511,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
                     float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                     normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-                    float normalW2 = normalW * normalW;
+                    float normalW2 = nw_param(normalW);
                     float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
                     float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
                     float hitB = -center.w * hitA;
@@ -991,7 +991,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                         float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, rcp_(1.0f + Acur));
                         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-                        float normalW2 = normalW * normalW;
+                        float normalW2 = nw_param(normalW);
                         float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                         float roughB = -rough * roughA;
                         f4 sum = mul4(val, 1.0f + Acur);
@@ -1391,7 +1391,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                     normalW *= lerpf(1.0f, conf, sat(s.normalEdgeStoppingRelaxation));
                     roughRelax = lerpf(1.0f, conf, sat(s.roughnessEdgeStoppingRelaxation));
                 }
-                float normalW2 = normalW * normalW;
+                float normalW2 = nw_param(normalW);
                 float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                 float roughB = -rough * roughA;
                 f3 sum = {c0.x, c0.y, c0.z};

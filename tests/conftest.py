@@ -45,3 +45,24 @@ def emulated(pkg):
 def hip(pkg):
     """The product: libnrdhip.so on cuda:0. Fails (does not skip) when the library or the device is missing."""
     return pkg.hip_backend("cuda:0")
+
+
+# ---- the NRD_UPSTREAM_FORMULAS build flavour (recalled upstream forms of ledger rows 1, 2, 7; oracle/README.md) ----
+@pytest.fixture(scope="session")
+def oracle_upstream(pkg):
+    if not os.path.exists(graft.ORACLE_LIB_UPSTREAM):
+        graft.build_oracle()
+    return graft.oracle_backend("upstream")
+
+
+@pytest.fixture(scope="session")
+def emulated_upstream(pkg):
+    path = graft.build_emulated(flavour="upstream")
+    b = pkg.api.Backend(path, "nrdhip_", "cpu")
+    b.check_abi()
+    return b
+
+
+@pytest.fixture(scope="session")
+def hip_upstream(pkg):
+    return pkg.hip_backend("cuda:0", flavour="upstream")

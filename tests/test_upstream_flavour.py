@@ -1,0 +1,57 @@
+"""The NRD_UPSTREAM_FORMULAS build flavour (csrc/nrd_device.h, oracle/orc_math.h): the recalled upstream forms of three frozen
+simplifications - hit-distance weight exp(-3 |x|) instead of (1 - |x|)^2, normal weight on the angle (arccosine) instead of the
+squared angle, Blur rotation per pixel instead of per 2x2 quad (oracle/README.md ledger rows 1, 2, 7). Same sources, own libraries
+(libnrdhip_upstream.so, liboracle_upstream.so); it exists to put a price on those deviations (bench.py config.upstream_formulas)
+and must be as exact against ITS oracle as the default flavour is against its own."""
+import numpy as np
+import pytest
+
+import util
+
+CASES = [["REBLUR_DIFFUSE_SPECULAR"], ["RELAX_DIFFUSE_SPECULAR"], ["REBLUR_DIFFUSE_SPECULAR_SH"]]
+
+
+def run(pkg, api, backend, dens, w, h, frames):
+    scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
+    dd = [api.Denoiser[x] for x in dens]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    return util.run_frames(api, pkg.harness, backend, scene, dd, frames, settings=st)
+
+
+@pytest.mark.parametrize("dens", CASES)
+def test_upstream_flavour_emulated_bit_exact(pkg, api, oracle_upstream, emulated_upstream, dens):
+    ho = run(pkg, api, oracle_upstream, dens, 72, 40, 2)
+    he = run(pkg, api, emulated_upstream, dens, 72, 40, 2)
+    assert util.compare_all(ho, he, exact=True) == []
+
+
+def test_upstream_flavour_differs_from_the_frozen_one(pkg, api, oracle, oracle_upstream):
+    """the switch does something: same inputs, different (but close) outputs - and the size of the difference is on record"""
+    dens = ["REBLUR_DIFFUSE_SPECULAR"]
+    a = run(pkg, api, oracle, dens, 96, 64, 4)
+    b = run(pkg, api, oracle_upstream, dens, 96, 64, 4)
+    for key in ("out_diff", "out_spec"):
+        x, y = a.output(key).astype(np.float32), b.output(key).astype(np.float32)
+        assert not np.array_equal(x, y)
+        p = util.psnr(x, y)
+        print("%s: frozen vs upstream-formulas flavour PSNR %.1f dB, %.1f %% of the values differ by more than 1 fp16 ULP" % (
+            key, p, 100.0 * float((np.abs(util.f16_ordered(a.output(key)) - util.f16_ordered(b.output(key))) > 1).mean())))
+        assert 25.0 < p < 80.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dens", CASES)
+def test_upstream_flavour_hip_matches_its_oracle(pkg, api, oracle_upstream, hip_upstream, dens):
+    w, h = 480, 270
+    scene = pkg.synth.Scene(w, h, dolly=0.02, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
+    dd = [api.Denoiser[x] for x in dens]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    ho = pkg.harness.Harness(oracle_upstream, dd, w, h)
+    oracle_upstream.lib.orc_set_threads(ho.nrd.handle, 16)
+    hg = pkg.harness.Harness(hip_upstream, dd, w, h)
+    for f in range(4):
+        fr = scene.frame(f)
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        ho.frame(cs, ho.upload(fr), st)
+        hg.frame(cs, hg.upload(fr), st)
+        assert util.compare_all(ho, hg, exact=True) == [], "frame %d" % f
