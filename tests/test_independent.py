@@ -122,3 +122,103 @@ def test_deviation_ledger_measurements(pkg, api, oracle, capsys):
     assert rows["f32_guide"]["psnr"] > 55.0           # storing the guide normal as fp16 is a rounding-level change
     assert rows["no_reach"]["frac_changed"] < 0.05    # the hard reach only bites on the longest taps at grazing angles
     assert rows["exp_hit_weight"]["psnr"] > 25.0 and rows["angle_normal_weight"]["psnr"] > 25.0  # weight-shape changes: visible, bounded
+
+
+# ---- the temporal half: TemporalAccumulation, HistoryFix, TemporalStabilization, restated in numpy / float64 with
+# no code shared with oracle/orc_math.h (tests/indep/reblur_temporal_numpy.py). Every pass gets the planes the oracle's own pass got
+# (pool snapshots between dispatches), so a disagreement is that pass's and nobody else's; frames 1-3 of the golden inputs, each with
+# the history the frames before it built.
+import reblur_temporal_numpy as tmp  # noqa: E402
+
+
+def temporal_settings(st):
+    return dict(maxAccumulatedFrameNum=st.maxAccumulatedFrameNum, maxFastAccumulatedFrameNum=st.maxFastAccumulatedFrameNum,
+                maxStabilizedFrameNum=st.maxStabilizedFrameNum, minMaterialForDiffuse=st.minMaterialForDiffuse,
+                minMaterialForSpecular=st.minMaterialForSpecular, roughnessFraction=st.roughnessFraction, lobeAngleFraction=st.lobeAngleFraction,
+                planeDistanceSensitivity=st.planeDistanceSensitivity, historyFixFrameNum=st.historyFixFrameNum,
+                historyFixBasePixelStride=st.historyFixBasePixelStride, fastHistoryClampingSigmaScale=st.fastHistoryClampingSigmaScale,
+                responsiveRoughnessThreshold=st.responsiveAccumulationSettings.roughnessThreshold,
+                responsiveMinAccum=float(st.responsiveAccumulationSettings.minAccumulatedFrameNum),
+                antilagSigmaScale=st.antilagSettings.luminanceSigmaScale, antilagSensitivity=st.antilagSettings.luminanceSensitivity)
+
+
+def agree(name, got, want, min_frac, mask=None):
+    d = ulp16(got, want)
+    if mask is not None:
+        d = d[mask]
+    frac = float((d <= 1).mean())
+    assert frac >= min_frac, "%s: only %.2f %% of the values within 1 fp16 ULP (max %d)" % (name, 100 * frac, int(d.max()))
+    return frac
+
+
+@pytest.mark.parametrize("f", [1, 2, 3])
+def test_temporal_passes_independent(pkg, api, oracle, f):
+    D = api.Denoiser
+    den = int(D.REBLUR_DIFFUSE_SPECULAR)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H)
+    st = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    s = temporal_settings(st)
+    for g in range(f):  # the history this frame inherits
+        fr = frame(g)
+        hz.frame(scene.common_settings(api, fr, g, reset=(g == 0)), hz.upload(fr), {D.REBLUR_DIFFUSE_SPECULAR: st})
+    fr, prev = frame(f), frame(f - 1)
+    cs = scene.common_settings(api, fr, f)
+    hz.nrd.new_frame()
+    hz.nrd.set_common_settings(cs)
+    hz.bind(hz.upload(fr))
+    hz.nrd.set_denoiser_settings(den, st)
+    names = [d["name"].split("::")[1] for d in hz.nrd.dispatches([den])]
+    assert names == ["ClassifyTiles", "PrePass", "TemporalAccumulation", "HistoryFix", "Blur", "PostBlur", "TemporalStabilization"]
+    cur, old = ("_A", "_B") if f % 2 == 0 else ("_B", "_A")
+    rad = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2, 4)
+    lum = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2)
+    c = tmp.Consts(fr, W, H, cs.denoisingRange, cs.disocclusionThreshold)
+    gcur = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
+    gprev = ind.decode_guide(prev["viewz"], prev["normal_roughness"])
+    geo = np.abs(gcur[0]) <= cs.denoisingRange
+
+    # ---- TemporalAccumulation
+    hz.nrd.denoise_range([den], 0, 2)
+    tmp1, hist, fast_prev = rad("REBLUR::Tmp1"), rad("REBLUR::History"), lum("REBLUR::FastHistory" + old)
+    speeds_prev = hz.pool("REBLUR::Data1" + old).copy().view(np.uint16).reshape(H, W)
+    track = hz.pool("REBLUR::SpecHitDistForTracking").copy().view(np.float16).reshape(H, W)
+    hz.nrd.denoise_range([den], 2, 1)
+    tmp2, fast, speeds_tmp = rad("REBLUR::Tmp2"), lum("REBLUR::FastHistory" + cur), hz.pool("REBLUR::Data1_Tmp").copy().view(np.uint16).reshape(H, W)
+    data2 = hz.pool("REBLUR::Data2").copy().view(np.uint32).reshape(H, W)
+    w_tmp2, w_fast, w_speeds, w_data2, info = tmp.temporal_accumulation(c, s, gcur, gprev, fr["mv"], tmp1, hist, fast_prev, speeds_prev, track, fr["confidence"], True)
+    assert info["smb_ok"][geo].mean() > 0.8 and info["vmb_ok"][geo].mean() > 0.5  # the test exercises both footprints, not the fallbacks
+    agree("TA radiance", tmp2, w_tmp2, 0.99)
+    agree("TA fast history", fast, w_fast, 0.99)
+    # validity bits of the 2 x 4 footprint texels: the surface-motion ones must agree; the virtual-motion footprint tests texels against
+    # the SURFACE's plane, which puts whole rows of them next to the threshold (the ground / wall seam of this scene) where float32 and
+    # float64 decide differently for a percent of the pixels
+    assert float(((data2 & 15) == (w_data2 & 15)).mean()) > 0.995
+    assert float((((data2 >> 4) & 15) == ((w_data2 >> 4) & 15)).mean()) > 0.97
+    assert float((np.abs(((data2 >> 8) & 255).astype(np.int32) - ((w_data2 >> 8) & 255).astype(np.int32)) <= 1).mean()) > 0.99  # virtual-motion amount
+    for shift in (0, 8):  # accumulation speeds, quarter frames
+        a, b = (speeds_tmp >> shift) & 255, (w_speeds >> shift) & 255
+        assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99 and float((a == b).mean()) > 0.95
+
+    # ---- HistoryFix (fed with the ORACLE's TemporalAccumulation outputs)
+    hz.nrd.denoise_range([den], 3, 1)
+    taps = [hz.pool("REBLUR::Tap_%s_A" % k).copy().view(np.uint32).reshape(H, W, 4) for k in ("Diff", "Spec")]
+    speeds_cur = hz.pool("REBLUR::Data1" + cur).copy().view(np.uint16).reshape(H, W)
+    w_sig, w_speeds_cur, (w0, w1) = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast)
+    for k in range(2):
+        got = np.ascontiguousarray(taps[k][..., 2:4]).view(np.float16).reshape(H, W, 4)
+        agree("HistoryFix signal %d" % k, got, w_sig[:, :, k], 0.99)
+        assert np.array_equal(taps[k][..., 0], w0) and np.array_equal(taps[k][..., 1], w1), "guide part of the tap texels"
+    for shift in (0, 8):
+        a, b = (speeds_cur >> shift) & 255, (w_speeds_cur >> shift) & 255
+        assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99
+
+    # ---- TemporalStabilization (fed with the ORACLE's PostBlur output)
+    hz.nrd.denoise_range([den], 4, 2)
+    post, stab_prev = rad("REBLUR::History"), lum("REBLUR::StabilizedLuma" + old)
+    hz.nrd.denoise_range([den], 6, 1)
+    stab = lum("REBLUR::StabilizedLuma" + cur)
+    out = np.stack([hz.output("out_diff"), hz.output("out_spec")], 2)
+    w_out, w_stab = tmp.temporal_stabilization(c, s, gcur, fr["mv"], post, speeds_cur, data2, stab_prev, track, True)
+    agree("TS output", out, w_out, 0.99)
+    agree("TS stabilized luma", stab, w_stab, 0.99)
