@@ -386,3 +386,229 @@ def temporal_stabilization(c, s, gcur, mv, hist, speeds, data2, stab_prev, hit_t
         stab[..., sig] = y_out
     out[sky], stab[sky] = 0.0, 0.0
     return f16(out), f16(stab)
+
+
+# =====================================================================================================================
+# RELAX: one variance-guided A-trous iteration (3x3 taps at stride 2^it), iteration 0 and the middle iterations
+# =====================================================================================================================
+def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=None):
+    """plane_in [H, W, 2, 4] fp16: iteration 0 = History {Y, Co, Cg, hitT}, later = {Y, Co, Cg, variance}; moments [H, W, 2] fp16
+    (second luma moment, iteration 0 only); data2 uint32 (reprojection confidence of the specular history in bits 16..23).
+    Returns the ping-pong texel {Y, Co, Cg, variance} as fp16"""
+    H, W = c.H, c.W
+    z, n, rough_g, mat = gcur
+    sky = ~(np.abs(z) <= c.range)
+    yy, xx = np.mgrid[0:H, 0:W]
+    stride = 1 << it
+    relax_edges = stride <= 4
+    pg = pixel_geo(c, z, n, max(s["depthThreshold"], 0.001) * 4.0)
+    pin = plane_in.astype(np.float64)
+    Ad, As = unpack_speeds(speeds) if speeds is not None else (None, None)
+    out = np.zeros((H, W, 2, 4))
+
+    def variance0(sig):
+        Y = pin[:, :, sig, 0]
+        var = np.maximum(moments.astype(np.float64)[..., sig] - Y * Y, 0.0)
+        A = As if sig == 1 else Ad
+        sy, sy2, cnt = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W))
+        for j in (-1, 0, 1):
+            for i in (-1, 0, 1):
+                px, py = xx + i, yy + j
+                ok = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+                cx, cy = np.clip(px, 0, W - 1), np.clip(py, 0, H - 1)
+                ok &= np.abs(z[cy, cx]) <= c.range
+                Yt = np.where(ok, Y[cy, cx], 0.0)
+                sy, sy2, cnt = sy + Yt, sy2 + Yt * Yt, cnt + ok
+        cnt = np.maximum(cnt, 1.0)
+        spatial = np.maximum(sy2 / cnt - (sy / cnt) ** 2, 0.0)
+        var = np.where(A < s["spatialVarianceEstimationHistoryThreshold"], np.maximum(var, spatial), var)
+        return var * (1.0 + s["specularVarianceBoost"]) if sig == 1 else var
+
+    for sig, is_spec in ((0, False), (1, True)):
+        rough = rough_g if is_spec else np.ones_like(rough_g)
+        min_mat = s["minMaterialForSpecular"] if is_spec else s["minMaterialForDiffuse"]
+        c0 = pin[:, :, sig]
+        var = variance0(sig) if it == 0 else c0[..., 3]
+        # what a TAP contributes as its variance: its texel's variance channel; in iteration 0 the tap's temporal variance alone (the
+        # spatial estimate and the specular boost belong to the centre pixel)
+        var_all = np.maximum(moments.astype(np.float64)[..., sig] - c0[..., 0] ** 2, 0.0) if it == 0 else var
+        sigma = np.sqrt(var)
+        phi = s["specularPhiLuminance"] if is_spec else s["diffusePhiLuminance"]
+        min_lw = s["specularMinLuminanceWeight"] if is_spec else s["diffuseMinLuminanceWeight"]
+        inv_l = 0.3333 / (phi * sigma + 1e-4)
+        angle = np.arctan(3.0 * np.clip(rough, 0, 1) ** 2) * s["lobeAngleFraction"]
+        if is_spec:
+            angle = angle + s["specularLobeAngleSlack"] * 0.017453292
+        normal_w = 1.0 / np.maximum(angle, NORMAL_ANGLE_MIN)
+        rough_relax = 1.0
+        if is_spec and relax_edges:
+            conf = ((data2.astype(np.int64) >> 16) & 255) / 255.0
+            inv_l = inv_l * (1.0 + (conf - 1.0) * np.clip(s["luminanceEdgeStoppingRelaxation"], 0, 1))
+            normal_w = normal_w * (1.0 + (conf - 1.0) * np.clip(s["normalEdgeStoppingRelaxation"], 0, 1))
+            rough_relax = 1.0 + (conf - 1.0) * np.clip(s["roughnessEdgeStoppingRelaxation"], 0, 1)
+        roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
+        acc, acc_var, wsum = c0[..., :3].copy(), var.copy(), np.ones((H, W))
+        for j in (-1, 0, 1):
+            for i in (-1, 0, 1):
+                if i == 0 and j == 0:
+                    continue
+                px, py = xx + i * stride, yy + j * stride
+                inside = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+                cx, cy = np.clip(px, 0, W - 1), np.clip(py, 0, H - 1)
+                zs, ms = z[cy, cx], mat[cy, cx]
+                ok = inside & (np.abs(zs) <= c.range) & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
+                sv = pin[cy, cx, sig]
+                w = 0.5 if (i == 0 or j == 0) else 0.25
+                w = w * sp.smoothstep01(1.0 - np.abs(zs * (pg["gax"] * px + pg["gay"] * py + pg["ga0"]) + pg["geoB"]))
+                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - (n * n[cy, cx]).sum(-1), 0, 1) * normal_w * normal_w)
+                if is_spec and s["enableRoughnessEdgeStopping"]:
+                    rw = sp.smoothstep01(1.0 - np.abs(rough_g[cy, cx] * roughA - rough * roughA))
+                    w = w * ((1.0 + (rw - 1.0) * rough_relax) if relax_edges else rw)
+                w = w * np.maximum(np.clip(1.0 - np.abs(sv[..., 0] - c0[..., 0]) * inv_l, 0, 1) ** 2, min_lw)
+                w = np.where(ok, w, 0.0)
+                acc = acc + sv[..., :3] * w[..., None]
+                acc_var = acc_var + var_all[cy, cx] * w * w
+                wsum = wsum + w
+        out[:, :, sig, :3] = acc / wsum[..., None]
+        out[:, :, sig, 3] = acc_var / (wsum * wsum)
+    out[sky] = 0.0
+    return f16(out)
+
+
+# =====================================================================================================================
+# SIGMA_SHADOW_TRANSLUCENCY: Blur / PostBlur and TemporalStabilization
+# =====================================================================================================================
+SIGMA_MAX_PIXEL_RADIUS, SIGMA_BLUR_REACH, SIGMA_STAB_SIGMA_SCALE = 48.0, 56, 2.0
+
+
+def sigma_input_visibility(pen, transl):
+    """raw input texel -> visibility: lit -> 1, shadowed -> (0, translucency.yzw)"""
+    lit = pen >= 65504.0
+    t = transl.astype(np.float64) / 255.0
+    v = np.stack([np.zeros_like(pen), t[..., 1], t[..., 2], t[..., 3]], -1)
+    return np.where(lit[..., None], 1.0, v)
+
+
+def sigma_blur(c, s, z, n, tiles_smooth, pen_in, vis_in, frame_index, pass_index):
+    """pass 0 (Blur): pen_in = IN_PENUMBRA, vis_in = input visibility; pass 1 (PostBlur): pen_in = Penumbra1, vis_in = Shadow1.
+    Returns (shadow [H, W, 4] fp16, penumbra [H, W] fp16 - meaningful for pass 0)"""
+    H, W = c.H, c.W
+    yy, xx = np.mgrid[0:H, 0:W]
+    sky = ~(np.abs(z) <= c.range)
+    absz = np.abs(z)
+    pen = pen_in.astype(np.float64)
+    lit = (pen >= 65504.0) if pass_index == 0 else ~(pen > 0.0)
+    centre = vis_in.astype(np.float64)
+    tile = tiles_smooth.astype(np.int64)[yy // 16, xx // 16]
+    mixed = (tile & 1) != 0
+    pixel_world = c.unproject * absz
+    radius = np.minimum(np.where(lit, (tile >> 8).astype(np.float64), pen / pixel_world), SIGMA_MAX_PIXEL_RADIUS)
+    world_radius = radius * pixel_world
+    Xv = c.reconstruct_px(xx, yy, z)
+    Nv = n @ c.w2v.T
+    geoA = 1.0 / (s["planeDistanceSensitivity"] * c.min_dim_unproject * absz)
+    gax, gay = Nv[..., 0] * c.pv[2] * geoA, Nv[..., 1] * c.pv[3] * geoA
+    ga0 = (Nv[..., 0] * c.pv[0] + Nv[..., 1] * c.pv[1] + Nv[..., 2]) * geoA
+    geoB = -(Nv * Xv).sum(-1) * geoA
+    T, B = sp.basis(Nv)
+    T, B = T * world_radius[..., None], B * world_radius[..., None]
+    inv = 1.0 / (c.pj[4] * z)
+    nu = (c.pj[0] * Xv[..., 0] + c.pj[2] * z) * inv
+    nv_ = (c.pj[1] * Xv[..., 1] + c.pj[3] * z) * inv
+    kuz, kvz = c.pj[2] - nu * c.pj[4], c.pj[3] - nv_ * c.pj[4]
+    ju, jv = 0.5 * W * inv, -0.5 * H * inv
+    jtx, jty = ju * (c.pj[0] * T[..., 0] + kuz * T[..., 2]), jv * (c.pj[1] * T[..., 1] + kvz * T[..., 2])
+    jbx, jby = ju * (c.pj[0] * B[..., 0] + kuz * B[..., 2]), jv * (c.pj[1] * B[..., 1] + kvz * B[..., 2])
+    if pass_index == 0:
+        k = sp.hash_px(xx.astype(np.int64), yy.astype(np.int64), frame_index, 17) & 63
+    else:
+        k = np.full((H, W), sp.hash_px(0, 0, frame_index, 18) & 63, np.int64)
+    ang = 2.0 * np.pi * k / 64.0
+    rc, rs = np.cos(ang).astype(np.float32).astype(np.float64), np.sin(ang).astype(np.float32).astype(np.float64)
+    jtx, jbx = rc * jtx + rs * jbx, rc * jbx - rs * jtx
+    jty, jby = rc * jty + rs * jby, rc * jby - rs * jty
+    acc, wsum = centre.copy(), np.ones((H, W))
+    pen_sum, pen_w = np.where(lit, 0.0, pen), np.where(lit, 0.0, 1.0)
+    for t in range(8):
+        ox, oy, pw = sp.POISSON8[t]
+        fpx, fpy = np.floor(ox * jtx + oy * jbx + xx + 0.5), np.floor(ox * jty + oy * jby + yy + 0.5)
+        ok = (radius > 0) & (fpx >= 0) & (fpx < W) & (fpy >= 0) & (fpy < H) & (np.abs(fpx - xx) <= SIGMA_BLUR_REACH) & (np.abs(fpy - yy) <= SIGMA_BLUR_REACH)
+        px, py = np.clip(fpx, 0, W - 1).astype(np.int64), np.clip(fpy, 0, H - 1).astype(np.int64)
+        zs = z[py, px]
+        ok &= np.abs(zs) <= c.range
+        w = pw * sp.smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
+        w = np.where(ok, w, 0.0)
+        ps = pen[py, px]
+        lits = (ps >= 65504.0) if pass_index == 0 else ~(ps > 0.0)
+        acc = acc + centre[py, px] * w[..., None]
+        wsum = wsum + w
+        pen_sum = pen_sum + np.where(lits, 0.0, ps * w)
+        pen_w = pen_w + np.where(lits, 0.0, w)
+    shadow = np.where(mixed[..., None], acc / wsum[..., None], centre)
+    pen_out = np.where(mixed, np.where(pen_w > 0, pen_sum / np.where(pen_w > 0, pen_w, 1.0), 0.0), np.where(lit, 0.0, pen))
+    shadow[sky], pen_out = 0.0, np.where(sky, 0.0, pen_out)
+    return f16(shadow), f16(pen_out)
+
+
+def sigma_encode(v):
+    q = np.floor(np.sqrt(np.clip(v, 0, 1)) * 255.0 + 0.5).astype(np.uint32)
+    return q[..., 0] | (q[..., 1] << 8) | (q[..., 2] << 16) | (q[..., 3] << 24)
+
+
+def sigma_decode(p):
+    b = np.stack([(p >> (8 * i)) & 255 for i in range(4)], -1).astype(np.float64) / 255.0
+    return b * b
+
+
+def sigma_temporal_stabilization(c, s, gcur, gprev, mv, shadow2, tiles_smooth, hist_prev, history_ok):
+    """returns the packed RGBA8 (sqrt-encoded) history / output [H, W] uint32"""
+    H, W = c.H, c.W
+    z, n, _, _ = gcur
+    zp, np_, _, _ = gprev
+    yy, xx = np.mgrid[0:H, 0:W]
+    u, v = (xx + 0.5) / W, (yy + 0.5) / H
+    sky = ~(np.abs(z) <= c.range)
+    cur = shadow2.astype(np.float64)
+    mixed = (tiles_smooth.astype(np.int64)[yy // 16, xx // 16] & 1) != 0
+    m1, m2 = np.zeros((H, W, 4)), np.zeros((H, W, 4))
+    for j in range(-2, 3):
+        for i in range(-2, 3):
+            px, py = xx + i, yy + j
+            inside = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+            cx, cy = np.clip(px, 0, W - 1), np.clip(py, 0, H - 1)
+            f = np.where((inside & (np.abs(z[cy, cx]) <= c.range))[..., None], cur[cy, cx], cur)
+            m1, m2 = m1 + f, m2 + f * f
+    m1, m2 = m1 / 25.0, m2 / 25.0
+    Xv = c.reconstruct_px(xx, yy, z)
+    m = mv.astype(np.float64)[..., :3] * c.mv_scale
+    su, sv = u + m[..., 0], v + m[..., 1]
+    Xv_prev = c.reconstruct_uv(su, sv, z + m[..., 2])
+    Nv_prev = n @ c.w2v_prev.T
+    threshold = c.disocclusion * c.min_dim_unproject * np.abs(Xv_prev[..., 2])
+    px, py = su * W - 0.5, sv * H - 0.5
+    fx0, fy0 = np.floor(px), np.floor(py)
+    fx, fy = px - fx0, py - fy0
+    sane = (fx0 >= -2.0) & (fx0 <= W + 1.0) & (fy0 >= -2.0) & (fy0 <= H + 1.0)
+    ix, iy = np.where(sane, fx0, 0).astype(np.int64), np.where(sane, fy0, 0).astype(np.int64)
+    bw = [(1 - fx) * (1 - fy), fx * (1 - fy), (1 - fx) * fy, fx * fy]
+    plane_ref = (Nv_prev * Xv_prev).sum(-1)
+    g0 = Nv_prev[..., 0] * c.pv[0] + Nv_prev[..., 1] * c.pv[1] + Nv_prev[..., 2]
+    gx, gy = Nv_prev[..., 0] * c.pv[2], Nv_prev[..., 1] * c.pv[3]
+    hp = sigma_decode(hist_prev.astype(np.uint32))
+    acc, wsum = np.zeros((H, W, 4)), np.zeros((H, W))
+    for i in range(4):
+        tx, ty = ix + (i & 1), iy + (i >> 1)
+        ok = sane & (tx >= 0) & (tx < W) & (ty >= 0) & (ty < H)
+        cx, cy = np.clip(tx, 0, W - 1), np.clip(ty, 0, H - 1)
+        zt = zp[cy, cx]
+        ok &= (np.abs(zt) <= c.range) & (np.abs(zt * (gx * tx + gy * ty + g0) - plane_ref) <= threshold) & ((n * np_[cy, cx]).sum(-1) > PREV_NORMAL_COS)
+        acc = acc + np.where(ok[..., None], hp[cy, cx] * bw[i][..., None], 0.0)
+        wsum = wsum + np.where(ok, bw[i], 0.0)
+    have = history_ok & (wsum > 0)
+    hist = np.where(have[..., None], acc / np.where(wsum > 0, wsum, 1.0)[..., None], cur)
+    max_stab = float(min(s["maxStabilizedFrameNum"], 7))
+    w = np.where(have, max_stab / (1.0 + max_stab), 0.0)
+    sigma = np.sqrt(np.maximum(m2 - m1 * m1, 0.0)) * SIGMA_STAB_SIGMA_SCALE
+    o = cur + (np.clip(hist, m1 - sigma, m1 + sigma) - cur) * w[..., None]
+    packed = np.where(mixed, sigma_encode(o), sigma_encode(cur))
+    return np.where(sky, 0, packed).astype(np.uint32)

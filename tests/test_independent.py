@@ -222,3 +222,91 @@ def test_temporal_passes_independent(pkg, api, oracle, f):
     w_out, w_stab = tmp.temporal_stabilization(c, s, gcur, fr["mv"], post, speeds_cur, data2, stab_prev, track, True)
     agree("TS output", out, w_out, 0.99)
     agree("TS stabilized luma", stab, w_stab, 0.99)
+
+
+@pytest.mark.parametrize("f", [1, 3])
+def test_relax_atrous_iterations_independent(pkg, api, oracle, f):
+    """one variance-guided A-trous iteration of RELAX_DIFFUSE_SPECULAR, twice: iteration 0 (variance from the accumulated moments +
+    the 3x3 spatial estimate of short histories, stride 1) and iteration 1 (stride 2, variance carried in the texel)"""
+    D = api.Denoiser
+    den = int(D.RELAX_DIFFUSE_SPECULAR)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    hz = pkg.harness.Harness(oracle, [D.RELAX_DIFFUSE_SPECULAR], W, H)
+    st = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    s = {k: getattr(st, k) for k in ("depthThreshold", "spatialVarianceEstimationHistoryThreshold", "specularVarianceBoost", "diffusePhiLuminance",
+                                     "specularPhiLuminance", "diffuseMinLuminanceWeight", "specularMinLuminanceWeight", "lobeAngleFraction",
+                                     "specularLobeAngleSlack", "luminanceEdgeStoppingRelaxation", "normalEdgeStoppingRelaxation",
+                                     "roughnessEdgeStoppingRelaxation", "roughnessFraction", "enableRoughnessEdgeStopping", "minMaterialForDiffuse",
+                                     "minMaterialForSpecular")}
+    for g in range(f):
+        fr = frame(g)
+        hz.frame(scene.common_settings(api, fr, g, reset=(g == 0)), hz.upload(fr), {D.RELAX_DIFFUSE_SPECULAR: st})
+    fr = frame(f)
+    cs = scene.common_settings(api, fr, f)
+    hz.nrd.new_frame()
+    hz.nrd.set_common_settings(cs)
+    hz.bind(hz.upload(fr))
+    hz.nrd.set_denoiser_settings(den, st)
+    names = [d["name"].split("::")[1] for d in hz.nrd.dispatches([den])]
+    assert names[:6] == ["ClassifyTiles", "PrePass", "TemporalAccumulation", "HistoryFix", "Atrous0", "Atrous1"]
+    cur = "_A" if f % 2 == 0 else "_B"
+    c = tmp.Consts(fr, W, H, cs.denoisingRange, cs.disocclusionThreshold)
+    gcur = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
+    rad = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2, 4)
+    hz.nrd.denoise_range([den], 0, 4)
+    hist, moments = rad("RELAX::History"), hz.pool("RELAX::Moments" + cur).copy().view(np.float16).reshape(H, W, 2)
+    speeds = hz.pool("RELAX::HistoryLength" + cur).copy().view(np.uint16).reshape(H, W)
+    data2 = hz.pool("RELAX::Data2").copy().view(np.uint32).reshape(H, W)
+    hz.nrd.denoise_range([den], 4, 1)
+    a0 = rad("RELAX::Atrous_A")
+    agree("A-trous iteration 0", a0, tmp.atrous_iteration(c, s, gcur, hist, 0, speeds, moments, data2), 0.99)
+    hz.nrd.denoise_range([den], 5, 1)
+    agree("A-trous iteration 1", rad("RELAX::Atrous_B"), tmp.atrous_iteration(c, s, gcur, a0, 1, data2=data2), 0.99)
+
+
+@pytest.mark.parametrize("f", [1, 2, 3])
+def test_sigma_passes_independent(pkg, api, oracle, f):
+    """SIGMA_SHADOW_TRANSLUCENCY: Blur, PostBlur (penumbra-sized tangent-plane blur of the visibility) and TemporalStabilization
+    (reprojection with occlusion test, per-channel 5x5 moment clamp, sqrt-encoded RGBA8 history)"""
+    D = api.Denoiser
+    den = int(D.SIGMA_SHADOW_TRANSLUCENCY)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    hz = pkg.harness.Harness(oracle, [D.SIGMA_SHADOW_TRANSLUCENCY], W, H)
+    st = api.SigmaSettings(lightDirection=list(scene.sun))
+    s = dict(planeDistanceSensitivity=st.planeDistanceSensitivity, maxStabilizedFrameNum=st.maxStabilizedFrameNum)
+    for g in range(f):
+        fr = frame(g)
+        hz.frame(scene.common_settings(api, fr, g, reset=(g == 0)), hz.upload(fr), {D.SIGMA_SHADOW_TRANSLUCENCY: st})
+    fr, prev = frame(f), frame(f - 1)
+    cs = scene.common_settings(api, fr, f)
+    hz.nrd.new_frame()
+    hz.nrd.set_common_settings(cs)
+    hz.bind(hz.upload(fr))
+    hz.nrd.set_denoiser_settings(den, st)
+    names = [d["name"].split("::")[1] for d in hz.nrd.dispatches([den])]
+    assert names == ["ClassifyTiles", "SmoothTiles", "Blur", "PostBlur", "TemporalStabilization"]
+    cur, old = ("_A", "_B") if f % 2 == 0 else ("_B", "_A")
+    c = tmp.Consts(fr, W, H, cs.denoisingRange, cs.disocclusionThreshold)
+    gcur = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
+    gprev = ind.decode_guide(prev["viewz"], prev["normal_roughness"])
+    z, n = gcur[0], gcur[1]
+    hz.nrd.denoise_range([den], 0, 2)
+    tiles = hz.pool("SIGMA::SmoothTiles").copy().view(np.uint16).reshape((H + 15) // 16, (W + 15) // 16)
+    assert (tiles & 1).any(), "the scene must have penumbra tiles for this test to mean anything"
+    vis = tmp.sigma_input_visibility(fr["penumbra"].astype(np.float64), fr["translucency"])
+    w_sh1, w_pen1 = tmp.sigma_blur(c, s, z, n, tiles, fr["penumbra"], vis, cs.frameIndex, 0)
+    hz.nrd.denoise_range([den], 2, 1)
+    sh1 = hz.pool("SIGMA::Shadow1").copy().view(np.float16).reshape(H, W, 4)
+    pen1 = hz.pool("SIGMA::Penumbra1").copy().view(np.float16).reshape(H, W)
+    agree("SIGMA Blur shadow", sh1, w_sh1, 0.99)
+    agree("SIGMA Blur penumbra", pen1, w_pen1, 0.99)
+    w_sh2, _ = tmp.sigma_blur(c, s, z, n, tiles, pen1, sh1, cs.frameIndex, 1)
+    hz.nrd.denoise_range([den], 3, 1)
+    sh2 = hz.pool("SIGMA::Shadow2").copy().view(np.float16).reshape(H, W, 4)
+    agree("SIGMA PostBlur shadow", sh2, w_sh2, 0.99)
+    hist_prev = hz.pool("SIGMA::History" + old).copy().view(np.uint32).reshape(H, W)
+    hz.nrd.denoise_range([den], 4, 1)
+    hist = hz.pool("SIGMA::History" + cur).copy().view(np.uint8).reshape(H, W, 4).astype(np.int32)
+    want = tmp.sigma_temporal_stabilization(c, s, gcur, gprev, fr["mv"], sh2, tiles, hist_prev, True)
+    want = np.stack([(want >> (8 * i)) & 255 for i in range(4)], -1).astype(np.int32)
+    assert float((np.abs(hist - want) <= 1).mean()) > 0.99 and float((hist == want).mean()) > 0.97
