@@ -34,6 +34,9 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_TAP_DEPTH
 #define NRD_TAP_DEPTH NRD_PIPE_DEPTH
 #endif
+#ifndef NRD_PRE_WAVES // PrePass: waves per SIMD
+#define NRD_PRE_WAVES 4
+#endif
 #ifndef NRD_TAP_WAVES // 104 VGPRs at 4 waves; capped at 102 for a fifth wave: Blur 0.202 -> 0.198 ms, PostBlur 0.179 -> 0.1705
 #define NRD_TAP_WAVES 5  // (depth 6 / 8 at 5 waves: equal; depth 12 / 16 at 4 waves: slower - profiles/r03_ab_tap_texels.txt)
 #endif
@@ -107,7 +110,21 @@ NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) 
 
 // REBLUR / RELAX::Tiles (written by ClassifyTiles): 1 = no pixel of the 16x16 tile has geometry. One byte per tile, same address for
 // the whole workgroup: a scalar value
-NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty) { return __builtin_amdgcn_readfirstlane((int)ld<uint8_t>(tiles, tx, ty, 1)) != 0; }
+#ifndef NRD_SCALAR_TILE_FLAG
+#define NRD_SCALAR_TILE_FLAG 1
+#endif
+NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty) {
+#if defined(NRD_HOST_EMULATION) || !NRD_SCALAR_TILE_FLAG
+    return __builtin_amdgcn_readfirstlane((int)ld<uint8_t>(tiles, tx, ty, 1)) != 0;
+#else
+    // through the SCALAR data path (constant address space: s_load_dword of the aligned word that holds the byte): the flag then does not
+    // queue behind - or in front of - the vector loads of the workgroup in the in-order vector memory counter
+    const uintptr_t a = (uintptr_t)tiles.p + texel_offset(tiles, tx, ty, 1, 0);
+    typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+    const uint32_t w = *(const_u32_ptr)(a & ~(uintptr_t)3);
+    return ((w >> ((uint32_t)(a & 3) * 8u)) & 0xffu) != 0u;
+#endif
+}
 NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty) { return tile_is_sky(p.tiles, tx, ty); }
 
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
 template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
 // 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
 // carry 16 more registers of tap data and stay at 3
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 0 && MODE == 0) ? NRD_TAP_WAVES : 4)) void k_spatial(const ReblurParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 0 && MODE == 0) ? NRD_TAP_WAVES : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr bool SH = MODE == 3 || MODE == 4;
     constexpr int sb = SH ? 16 : 8;   // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
