@@ -38,6 +38,7 @@ WORKLOADS = {
     "relax_ds_sh_4k": (3840, 2160, ["RELAX_DIFFUSE_SPECULAR_SH"]),  # BASELINE.json configs[3]
     "reblur_ds_sh_4k": (3840, 2160, ["REBLUR_DIFFUSE_SPECULAR_SH"]),
     "reblur_ds_8k": (7680, 4320, ["REBLUR_DIFFUSE_SPECULAR"]),  # BASELINE.json configs[4] on ONE GPU (the 8-GPU run row-tiles 4K bands)
+    "sample_passes_4k": (3840, 2160, []),  # the sample's own passes around the denoiser, timed kernel by kernel
 }
 
 
@@ -203,6 +204,11 @@ def main():
     w, wl_h, den_names = WORKLOADS[args.workload]
     dens = [api.Denoiser[n] for n in den_names]
     hip = pkg.hip_backend(dev)
+    if args.workload == "sample_passes_4k":
+        if world > 1:
+            raise SystemExit("sample_passes_4k is a single-GPU workload")
+        print(json.dumps(run_sample_passes(args, pkg, hip, dev, w, wl_h)))
+        return
     strong = args.scaling == "strong"
     band_h = wl_h  # rows a rank owns in weak mode / at N = 1; strong mode: band_layout() splits wl_h
 
@@ -406,6 +412,78 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_sample_passes(args, pkg, hip, dev, w, h):
+    """--workload sample_passes_4k: the sample-side passes either side of the denoiser, each timed on its own with HIP
+    events and priced against its algorithmic bytes: ConfidenceBlur x 5 at 1/5 resolution (Source/NRDSample.cpp:3999-4026), the
+    front-end pack (TraceOpaque.cs.hlsl:421-801), the back-end unpack + composition (Composition.cs.hlsl:57-188) and TAA
+    (Taa.cs.hlsl:11-159). Not the headline metric: one JSON line of the same shape, `value` = pixels / time of the whole chain."""
+    import numpy as np
+    import torch
+
+    from nrd_sample_amd import sample_passes as sp
+
+    g = torch.Generator(device=dev).manual_seed(7)
+    rnd = lambda *shape: torch.rand(*shape, device=dev, generator=g, dtype=torch.float32)
+    as_bytes = lambda t: t.contiguous().view(torch.uint8).reshape(t.shape[0], -1)
+    n = torch.nn.functional.normalize(rnd(h, w, 3) - 0.5, dim=-1)
+    normal = as_bytes(torch.cat([n, rnd(h, w, 1)], -1))
+    mat = as_bytes(torch.floor(rnd(h, w) * 3.99))
+    viewz = as_bytes(1.0 + 30.0 * rnd(h, w))
+    rad = lambda: as_bytes(torch.cat([rnd(h, w, 3), 5.0 * rnd(h, w, 1)], -1))
+    diff32, spec32, shadow32 = rad(), rad(), as_bytes(torch.cat([70000.0 * (rnd(h, w, 1) > 0.5) + rnd(h, w, 1), rnd(h, w, 3)], -1))
+    z8 = lambda bpt: torch.zeros((h, w * bpt), dtype=torch.uint8, device=dev)
+    nr, pdiff, pspec, pen, transl = z8(4), z8(8), z8(8), z8(2), z8(4)
+    udiff, uspec, ushadow, cdiff, cspec = z8(8), z8(8), z8(8), z8(8), z8(8)
+    base = as_bytes((rnd(h, w, 4) * 255).to(torch.uint8))
+    mv = as_bytes(torch.cat([rnd(h, w, 2) - 0.5, torch.zeros(h, w, 1, device=dev), 0.125 * (1.0 + 30.0 * rnd(h, w, 1))], -1).to(torch.float16))
+    hist_a, hist_b = as_bytes(rnd(h, w, 4).to(torch.float16)), z8(8)
+    sw, sh_ = sp.sharc_dims(w, h)
+    ping = torch.from_numpy(sp.synth_gradient(sw, sh_).view(np.uint8).reshape(sh_, sw * 8)).to(dev)
+    pong = torch.zeros_like(ping)
+    frustum = (-1.0, 0.5625, 2.0, -1.125)
+    hdp = (3.0, 0.1, 20.0, -25.0)
+    stages = [
+        ("Sample::ConfidenceBlur x5 (1/25 of the pixels)", 5 * 16.0 * sw * sh_ / (w * h),
+         lambda: sp.confidence_blur(hip, ping, pong, sw, sh_, frustum, float(w), 1.0 / (0.5 * h), 0, 30)),
+        ("Sample::FrontEndPack", 72.0 + 26.0,
+         lambda: sp.frontend_pack(hip, w, h, hit_distance_parameters=hdp, tan_of_light_angular_radius=0.005, normal=normal, material_id=mat, viewz=viewz,
+                                  diff=diff32, spec=spec32, shadow=shadow32, out_normal_roughness=nr, out_diff=pdiff, out_spec=pspec,
+                                  out_penumbra=pen, out_translucency=transl)),
+        ("Sample::BackEndUnpack", 20.0 + 24.0,
+         lambda: sp.backend_unpack(hip, w, h, diff=pdiff, spec=pspec, shadow=transl, out_diff=udiff, out_spec=uspec, out_shadow=ushadow)),
+        ("Sample::Compose", 28.0 + 16.0,
+         lambda: sp.compose(hip, w, h, diff=udiff, spec=uspec, normal_roughness=nr, viewz=viewz, base_color_metalness=base, out_diff=cdiff, out_spec=cspec)),
+        ("Sample::Taa", 24.0 + 8.0, lambda: sp.taa(hip, mv, cdiff, hist_a, hist_b, w, h)),
+    ]
+    for _, _, fn in stages:
+        for _ in range(max(args.warmup // 8, 2)):
+            fn()
+    torch.cuda.synchronize()
+    times = {}
+    t0 = time.perf_counter()
+    for name, bpp, fn in stages:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(args.steps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        times[name] = (a.elapsed_time(b) / args.steps, bpp)
+    dt = time.perf_counter() - t0
+    total_ms = sum(v[0] for v in times.values())
+    dom = max(times.items(), key=lambda kv: kv[1][0])
+    gbs = {k: round(bpp * w * h / (ms * 1e-3) / 1e9, 1) for k, (ms, bpp) in times.items()}
+    return {"metric": "Mpixels/s sample-side passes (pack, unpack, compose, TAA, ConfidenceBlur)", "value": round(w * h / (total_ms * 1e-3) / 1e6, 2),
+            "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "sample_passes_4k: the sample's passes around the denoiser at %dx%d (ConfidenceBlur at %dx%d); NOT the headline metric"
+                                   % (w, h, sw, sh_), "wall_s": round(dt, 3)},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": gbs[dom[0]], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs[dom[0]] / HBM_PEAK_GBS, 4), "traffic": None},
+            "passes_ms": {k: round(v[0], 4) for k, v in times.items()}, "passes_gbs": gbs,
+            "passes_algorithmic_bytes_per_pixel": {k: round(v[1], 2) for k, v in times.items()}}
 
 
 def pingpong(n, f):

@@ -162,7 +162,13 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     const FrameConsts& c = p.c;
     // a streaming pass without neighbour reads: plain 2-D grid of tiles (the XCD traversal of the other passes costs a wave ~700
     // cycles of scalar index arithmetic and buys this pass nothing: 0.0485 -> 0.0462 ms, profiles/r03_ab_setup_planes.txt)
-    const int tx = (int)blockIdx.x, ty = (int)blockIdx.y + c.tileY0;
+    // Consecutive workgroups go to the 8 XCDs round robin and two horizontally adjacent tiles share the 128-byte lines of the 4-byte
+    // input planes: within every group of 16 tiles the pairs (2j, 2j + 1) are handed to ONE XCD (workgroups j and j + 8), or each
+    // line is fetched by two L2s (measured: 16 instead of 8 B/px of fetch, profiles/r03v1_hbm_traffic_reblur_ds_4k.json)
+    const int bx = (int)blockIdx.x;
+    const int tx = (bx & ~15) | ((bx & 7) << 1) | ((bx >> 3) & 1), ty = (int)blockIdx.y + c.tileY0;
+    if (tx >= c.tilesX) // (the grid is padded to whole groups of 16; block-uniform exit before the barrier below)
+        return;
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     bool valid = x < c.W && y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
     int notSky = 0;
@@ -1843,7 +1849,7 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(u
 }
 #endif
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)p.c.tilesX, (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
+    hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)((p.c.tilesX + 15) / 16 * 16), (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
 }
 #if defined(NRD_HOST_EMULATION) && !NRD_ORTHO
 // test hook, host-emulated build only (tests/test_tile_traversal.py): the tile that workgroup `block` of a launch over tilesX x

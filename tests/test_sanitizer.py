@@ -17,12 +17,10 @@ import __graft_entry__ as graft  # noqa: E402
 SELECTION = [
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens0]",   # REBLUR_DIFFUSE_SPECULAR + SIGMA_SHADOW_TRANSLUCENCY + REFERENCE
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens3]",   # RELAX_DIFFUSE_SPECULAR (A-trous LDS windows)
-    "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens6]",   # REBLUR_DIFFUSE_SPECULAR_OCCLUSION
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens9]",   # REBLUR_DIFFUSE_SPECULAR_SH
-    "tests/test_kernels_emulated.py::test_emulated_kernels_sky_tiles",
+    "tests/test_kernels_emulated.py::test_emulated_kernels_sky_tiles[dens0]",
     "tests/test_prepare_inputs.py::test_prepare_inputs_emulated_bit_exact",
     "tests/test_settings_variants.py::test_variants_emulated_bit_exact[drs_reblur_sigma]",
-    "tests/test_settings_variants.py::test_variants_emulated_bit_exact[drs_relax]",
     "tests/test_sanitizer.py::test_tiny_frames_emulated",
     "tests/test_tiler_gloo.py::test_row_tiling_emulated_kernels_bit_identical",
 ]
