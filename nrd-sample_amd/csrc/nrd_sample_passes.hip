@@ -279,23 +279,23 @@ NRD_DEV f3 clamp_aabb(f3 center, f3 ext, f3 prev) { // Color::ClampAabb: clip to
 }
 
 __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
-    __shared__ float sColor[3][400];
-    __shared__ float sMv[3][400];
+    // one 16-byte LDS texel per window position: {tonemapped colour, signed viewZ} - what each of the 25 (or 9) moment taps reads, in
+    // ONE ds_read_b128 (the transliterated form kept six float arrays: four scalar reads per tap; 0.244 ms at 4K,
+    // profiles/r03v2_bench_sample_passes.json); the motion xy is only read at the chosen offset and keeps its own array
+    __shared__ float4 sTile[400];
+    __shared__ float2 sMvXY[400];
     const int tidx = (int)threadIdx.x, tidy = (int)threadIdx.y;
     const int x = (int)blockIdx.x * 16 + tidx, y = (int)blockIdx.y * 16 + tidy;
     {   // PRELOAD_INTO_SMEM (:17-28, :33-39)
         int bx = (int)blockIdx.x * 16 - 2, by = (int)blockIdx.y * 16 - 2;
         for (int i = tidy * 16 + tidx; i < 400; i += 256) {
-            int gx = imin(imax(bx + i % 20, 0), p.W - 1), gy = imin(imax(by + i / 20, 0), p.H - 1);
+            const int ly = (i * 3277) >> 16, lx = i - ly * 20; // i / 20 for i < 400 without a division
+            int gx = imin(imax(bx + lx, 0), p.W - 1), gy = imin(imax(by + ly, 0), p.H - 1);
             f4 c = unpack_h4(ld<uint2>(p.composed, gx, gy, 8));
             f3 t = taa_tonemap(p, {c.x, c.y, c.z});
             f4 m = unpack_h4(ld<uint2>(p.mv, gx, gy, 8));
-            sColor[0][i] = t.x;
-            sColor[1][i] = t.y;
-            sColor[2][i] = t.z;
-            sMv[0][i] = m.x;
-            sMv[1][i] = m.y;
-            sMv[2][i] = m.w; // dZ is not needed
+            sTile[i] = float4{t.x, t.y, t.z, m.w}; // dZ is not needed
+            sMvXY[i] = float2{m.x, m.y};
         }
     }
     __syncthreads();
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
     float sum = 0.0f;
     f3 m1 = {0, 0, 0}, m2 = {0, 0, 0}, input = {0, 0, 0};
     const int ci = (tidy + 2) * 20 + tidx + 2;
-    float centerZ = sMv[2][ci];
+    float centerZ = sTile[ci].w;
     float minViewZ = absf(centerZ);
     int offx = 2, offy = 2;
     const bool want5x5 = centerZ < 0.0f;
@@ -317,8 +317,9 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
             if (border && !want5x5)
                 continue;
             int si = (tidy + dy) * 20 + tidx + dx;
-            f3 c = {sColor[0][si], sColor[1][si], sColor[2][si]};
-            float viewZ = absf(sMv[2][si]);
+            const float4 tt = sTile[si];
+            f3 c = {tt.x, tt.y, tt.z};
+            float viewZ = absf(tt.w);
             if (dx == 2 && dy == 2)
                 input = c;
             else if (viewZ < minViewZ) {
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
     f3 sigma = {sqrt_(absf(m2.x - m1.x * m1.x)) * 2.0f, sqrt_(absf(m2.y - m1.y * m1.y)) * 2.0f, sqrt_(absf(m2.z - m1.z * m1.z)) * 2.0f}; // TAA_SIGMA_SCALE
     // previous pixel position (:118-119): motion of the closest-depth neighbour
     const int mi = (tidy + offy) * 20 + tidx + offx;
-    float pu = fma_(sMv[0][mi], p.invW, u), pv = fma_(sMv[1][mi], p.invH, v);
+    const float2 mxy = sMvXY[mi];
+    float pu = fma_(mxy.x, p.invW, u), pv = fma_(mxy.y, p.invH, v);
     f4 history = bicubic_no_corners(p, sat(pu) * p.Wp, sat(pv) * p.Hp);
     f3 hist = {fmax2(history.x, 0.0f), fmax2(history.y, 0.0f), fmax2(history.z, 0.0f)};
     float mixRate = sat(history.w);

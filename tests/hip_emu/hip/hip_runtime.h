@@ -38,6 +38,9 @@ struct uint4 {
 struct float4 {
     float x, y, z, w;
 };
+struct float2 {
+    float x, y;
+};
 
 #define NRD_HOST_EMULATION 1 // host-side sources that talk to RCCL / dlopen compile that part out (nrdhip_tiler.cpp)
 typedef int hipError_t;
