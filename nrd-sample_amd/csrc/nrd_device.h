@@ -285,11 +285,20 @@ NRD_DEV float unorm10_(uint32_t v) {
     return fma_(fma_(-q, 1023.0f, x), r, q);
 }
 
-// guide texel (16 bytes): {viewZ f32 | nx f16, ny f16 | nz f16, roughness f16 | materialID u32}
-NRD_DEV uint4 encode_guide(float z, uint32_t packedNR) {
+// guide texel (8 bytes, round 3; == the guide part of the Blur / PostBlur tap texels):
+//   .x = viewZ rounded to 22 bits | roughness as the 10-bit code of IN_NORMAL_ROUGHNESS. Read back AS ONE FLOAT it is the depth (the
+//        roughness code perturbs it by < 2^-13 relative) - every consumer reads it that way
+//   .y = normal x | y << 10 | z << 20, 10 bits per component (n = code * 2/1023 - 1, not re-normalised) | materialID << 30
+// Written once per pixel by the ClassifyTiles passes. Round 3 measured what the passes pay for - bytes and memory instructions, not
+// arithmetic (profiles/r03_ab_setup_planes.txt) - so the guide is as small as the input allows: the normal arrives in
+// IN_NORMAL_ROUGHNESS as a 10 + 10 bit octahedron and the roughness as 10 bits, 3 x 10 bits and the original roughness code are as fine
+// as that; only the depth loses its 10 low mantissa bits. A decode is a handful of bfe / cvt / fma instead of 3 fp16 converts.
+constexpr int GUIDE_BYTES = 8;
+NRD_DEV uint32_t qn10(float v) { return (uint32_t)__builtin_floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
+NRD_DEV uint2 encode_guide(float z, uint32_t packedNR) {
     f3 n = oct_decode(unorm10_(packedNR & 1023u), unorm10_((packedNR >> 10) & 1023u));
-    float roughness = unorm10_((packedNR >> 20) & 1023u);
-    return uint4{f2u(z), (uint32_t)f2h(n.x) | ((uint32_t)f2h(n.y) << 16), (uint32_t)f2h(n.z) | ((uint32_t)f2h(roughness) << 16), packedNR >> 30};
+    return uint2{((f2u(z) + 0x200u) & 0xFFFFFC00u) | ((packedNR >> 20) & 1023u),
+                 qn10(n.x) | (qn10(n.y) << 10) | (qn10(n.z) << 20) | ((packedNR >> 30) << 30)};
 }
 
 struct Guide {
@@ -298,44 +307,40 @@ struct Guide {
     float roughness;
     uint32_t mat;
     bool sky;
+    uint32_t nw; // the texel's normal | material word (normal_cos works on the codes)
 };
 
-NRD_DEV Guide decode_guide(uint4 g, float range) {
+// Cosine of the angle between two guide normals, from their 10-bit CODES: cos = 1 - |n_a - n_b|^2 / 2 (exact for unit vectors). The
+// dot product of two quantised, not re-normalised vectors is useless for what the normal weights need - 1 - cos at the 1e-4 level for
+// the narrow specular lobes: |n|^2 is off by up to 2e-3, so identical normals would score like a 3 degree bend - while the squared
+// difference of the codes is exact (integers below 2^24 in fp32), zero for equal normals and as fine as the quantisation step.
+NRD_DEV f3 normal_codes(uint32_t nw) { return {(float)(nw & 1023u), (float)((nw >> 10) & 1023u), (float)((nw >> 20) & 1023u)}; }
+NRD_DEV float normal_cos(f3 centreCodes, uint32_t nw) {
+    const f3 c = normal_codes(nw);
+    const float dx = c.x - centreCodes.x, dy = c.y - centreCodes.y, dz = c.z - centreCodes.z;
+    const float d2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    return fma_(d2, -0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f), 1.0f);
+}
+
+NRD_DEV Guide decode_guide(uint2 g, float range) {
     Guide r;
+    r.nw = g.y;
     r.z = u2f(g.x);
-    r.n = {h2f((uint16_t)(g.y & 0xffffu)), h2f((uint16_t)(g.y >> 16)), h2f((uint16_t)(g.z & 0xffffu))};
-    r.roughness = h2f((uint16_t)(g.z >> 16));
-    r.mat = g.w;
+    r.roughness = (float)(g.x & 1023u) * (1.0f / 1023.0f);
+    const float s = 2.0f / 1023.0f;
+    r.n = {fma_((float)(g.y & 1023u), s, -1.0f), fma_((float)((g.y >> 10) & 1023u), s, -1.0f), fma_((float)((g.y >> 20) & 1023u), s, -1.0f)};
+    r.mat = g.y >> 30;
     r.sky = !(absf(r.z) <= range);
     return r;
 }
+NRD_DEV uint2 ld_guide(const PlaneRef& P, int x, int y);
 
-// ---- tap texels of REBLUR's Blur / PostBlur (radiance flavours) -------------------------------------------------------------
+// ---- tap texels of REBLUR's Blur / PostBlur (flavours without SH) --------------------------------------------------------------
 // What a tap needs - depth, normal, roughness, material and the signal - in ONE 16-byte texel per signal, so a tap is one gather
-// instead of two (guide + radiance): the spatial passes are bound by what moves through the texture path, not by arithmetic
-// (profiles/r03_ab_setup_planes.txt).
-//   .x = viewZ rounded to 22 bits | roughness as the 10-bit code of IN_NORMAL_ROUGHNESS   (read back AS A FLOAT it is the depth, the
-//        roughness code perturbing it by < 2^-13 relative - every consumer reads it that way, centre and taps alike)
-//   .y = normal x | y << 10 | z << 20, 10 bits per component (n = code * 2/1023 - 1, not re-normalised) | materialID << 30
-//   .z .w = the signal {Y, Co | Cg, hitT} as 4 x fp16
-// HistoryFix packs the guide part from the 16-byte guide texel, Blur copies it through, and both passes take their CENTRE pixel's
-// guide from the texel too (no guide plane access). The normal arrives in IN_NORMAL_ROUGHNESS as a 10 + 10 bit octahedron and the
-// roughness as 10 bits: the texel is as fine as the input; only the depth loses its 10 low mantissa bits.
-NRD_DEV uint32_t qn10(float v) { return (uint32_t)__builtin_floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
-NRD_DEV uint2 pack_tap_guide(const Guide& g) {
-    const uint32_t rc = (uint32_t)__builtin_floorf(fma_(sat(g.roughness), 1023.0f, 0.5f));
-    return uint2{((f2u(g.z) + 0x200u) & 0xFFFFFC00u) | rc, qn10(g.n.x) | (qn10(g.n.y) << 10) | (qn10(g.n.z) << 20) | (g.mat << 30)};
-}
-NRD_DEV Guide unpack_tap_guide(uint32_t w0, uint32_t w1, float range) {
-    Guide g;
-    g.z = u2f(w0);
-    g.roughness = (float)(w0 & 1023u) * (1.0f / 1023.0f);
-    const float s = 2.0f / 1023.0f;
-    g.n = {fma_((float)(w1 & 1023u), s, -1.0f), fma_((float)((w1 >> 10) & 1023u), s, -1.0f), fma_((float)((w1 >> 20) & 1023u), s, -1.0f)};
-    g.mat = w1 >> 30;
-    g.sky = !(absf(g.z) <= range);
-    return g;
-}
+// instead of two (guide + radiance): {guide texel (.x .y) | signal {Y, Co | Cg, hitT} as 4 x fp16 (.z .w)}. HistoryFix copies the
+// pixel's guide texel in, Blur copies it through, and both passes take their CENTRE pixel's guide from the texel too (no guide plane
+// access).
+NRD_DEV Guide unpack_tap_guide(uint32_t w0, uint32_t w1, float range) { return decode_guide(uint2{w0, w1}, range); }
 
 NRD_DEV f3 linear_to_ycocg(f3 c) {
     float Y = c.x * 0.25f + c.y * 0.5f + c.z * 0.25f;
@@ -473,6 +478,7 @@ template <typename T>
 NRD_DEV void st(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
     *reinterpret_cast<T*>(P.p + texel_offset(P, x, y, bpt, off)) = v;
 }
+NRD_DEV uint2 ld_guide(const PlaneRef& P, int x, int y) { return ld<uint2>(P, x, y, GUIDE_BYTES); }
 // Streaming accesses (the "nt" bit of the memory instruction): lines without reuse inside the kernel - an output nobody reads before
 // the launch is over, a plane read at the thread's own pixel only - should not evict the lines the tap gathers live on. Measured per
 // kernel (profiles/r03_ab_setup_planes.txt): a win where the data is not wanted again soon, a loss where the NEXT kernel reads it at

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     int notSky = 0;
     if (valid) {
         float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
-        st<uint4>(p.guide, x, y, 16, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
+        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
         notSky = absf(z) <= c.denoisingRange ? 1 : 0;
     }
     int any = __syncthreads_or(notSky);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
     if (!my_pixel(c, x, y, tx, ty))
         return;
     const bool occ = p.occlusion != 0, checker = p.checker != 0, sh1 = p.prepSh1 != 0, dirOcc = p.dirOcc != 0;
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     const int gy0 = y + c.yOff;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                 int px = x + (n ? 1 : -1);
                 ok[n] = px >= 0 && px < c.W;
                 int cpx = imin(imax(px, 0), c.W - 1);
-                Guide gn = decode_guide(ld<uint4>(p.guide, cpx, y, 16), c.denoisingRange);
+                Guide gn = decode_guide(ld_guide(p.guide, cpx, y), c.denoisingRange);
                 load_pair(cpx >> 1, y, vn[n], v1n[n]);
                 ok[n] = ok[n] && !gn.sky;
                 float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                         continue;
                     if (!has_data(phase, px, gy, c.frameIndex))
                         continue;
-                    Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
+                    Guide gs = decode_guide(ld_guide(p.guide, px, py), c.denoisingRange);
                     if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                         continue;
                     f4 hv, hv1;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                     if (!(h > 0.0f))
                         continue;
                     float w = geo_weight(pg, (float)px, (float)gy, gs.z);
-                    w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                    w *= normal_weight(normal_cos(normal_codes(g.nw), gs.nw), normalW2);
                     if (isSpec)
                         w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                     sum = fma_(h, w, sum);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         for (int sig = 0; sig < NSIG; sig++)
             ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
     }
-    Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             if (TAP && VARIANT == 1) { // the guide part travels on (PostBlur takes its sky test from it)
@@ -361,10 +361,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
     }
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
-    // tap texels: the tap's normal and roughness stay 10-bit codes; scale and offset of their decode are folded into per-pixel
-    // constants (N . Ns = sum (2/1023 N_i) code_i - sum N_i; roughness likewise)
-    const f3 nsc = mul3(g.n, 2.0f / 1023.0f);
-    const float nb = -((g.n.x + g.n.y) + g.n.z);
+    const f3 ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
     f3 V = to_viewer(pg.Xv);
     // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic: no
     // perspective divide and no z terms
@@ -532,7 +529,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
                 graw[T] = ldb<uint4>(srcB[sig], px, gpy, 16);
                 return;
             }
-            graw[T] = ldb<uint4>(guideB, px, gpy, 16);
+            {
+                const uint2 gt = ldb<uint2>(guideB, px, gpy, GUIDE_BYTES);
+                graw[T] = uint4{gt.x, gt.y, 0u, 0u};
+            }
             if constexpr (SH && VARIANT != 0) { // SH0 | SH1 of a signal sit side by side in the internal planes: ONE 16-byte gather
                 const uint4 both = ldb<uint4>(srcB[sig], px, gpy, srcBpt, srcOffs[sig]);
                 sraw[T] = uint2{both.x, both.y};
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
                 gs.sky = !(absf(gs.z) <= c.denoisingRange);
                 sv = unpack_h4(uint2{graw[T].z, graw[T].w});
             } else {
-                gs = decode_guide(graw[T], c.denoisingRange);
+                gs = decode_guide(uint2{graw[T].x, graw[T].y}, c.denoisingRange);
                 sv = decode_signal(p, sraw[T], occIn);
             }
             const bool valid = inWin[T] & active[sig] & !gs.sky & !material_mismatch(g.mat, gs.mat, minMats[sig]); // bitwise: one basic block
@@ -571,13 +571,11 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
             float w = g_poisson8[t][2];
             w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
             if constexpr (TAP) {
-                const uint32_t nw = graw[T].y;
-                const float cosn = fma_(nsc.x, (float)(nw & 1023u), fma_(nsc.y, (float)((nw >> 10) & 1023u), fma_(nsc.z, (float)((nw >> 20) & 1023u), nb)));
-                w *= normal_weight_m2(cosn, m2w2[sig]);
+                w *= normal_weight_m2(normal_cos(ncodes, graw[T].y), m2w2[sig]);
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_((float)(graw[T].x & 1023u), roughA[sig], roughB[sig])));
             } else {
-                w *= normal_weight_m2(dot3(g.n, gs.n), m2w2[sig]);
+                w *= normal_weight_m2(normal_cos(ncodes, gs.nw), m2w2[sig]);
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
             }
@@ -746,7 +744,7 @@ NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
 // virtual-motion footprints together are one memory round trip instead of a chain of dependent ones.
 template <int RBPT, int LBPT, bool RELAX>
 struct FootRaw {
-    uint4 g[4];
+    uint2 g[4];
     uint16_t a[4];
     uint2 t[4][RBPT / 8];
     uint32_t f[4]; // fast luma history texel: LBPT bytes = one fp16 per signal
@@ -776,7 +774,7 @@ NRD_DEV void load_foot(const ReblurParams& p, const FootPos& fp, FootRaw<RBPT, L
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tx = imin(imax(fp.ix + (i & 1), 0), c.Wprev - 1), ty = imin(imax(fp.iy + (i >> 1) - c.yOff, 0), c.resH - 1);
-        r.g[i] = ld<uint4>(p.guidePrev, tx, ty, 16);
+        r.g[i] = ld_guide(p.guidePrev, tx, ty);
         r.a[i] = ld<uint16_t>(p.data1Prev, tx, ty, 2);
         load_texel<RBPT>(p.hist, tx, ty, r.t[i]);
         r.f[i] = load_luma(p.fastPrev, tx, ty, LBPT);
@@ -784,7 +782,7 @@ NRD_DEV void load_foot(const ReblurParams& p, const FootPos& fp, FootRaw<RBPT, L
     }
 }
 // validation of the four texels of a footprint
-NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const uint4 (&graw)[4], f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
+NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const uint2 (&graw)[4], f3 NvPrev, f3 XvPrev, f3 N, uint32_t mat, uint32_t minMat, float threshold) {
     Footprint f;
     f.ix = fp.ix;
     f.iy = fp.iy;
@@ -853,7 +851,7 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     int x, y, tx, ty;
     if (!my_pixel_w(c, x, y, tx, ty))
         return;
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb);
@@ -952,8 +950,12 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         uint32_t vmbBits = vmb.bits;
         bool vmbOk = vmb.wsum > 0.0f;
         // roughness of the virtual footprint: guide texel bytes 10..11 = upper half of .z
-        uint32_t rr[4] = {vraw.g[0].z, vraw.g[1].z, vraw.g[2].z, vraw.g[3].z};
-        float prevRough = blend1(vmb, rr, 1);
+        // roughness of the virtual footprint: the 10-bit code in the low bits of the guide texel's depth word
+        float prevRough = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            prevRough = fma_((float)(vraw.g[i].x & 1023u) * (1.0f / 1023.0f), vmb.w[i], prevRough);
+        prevRough *= rcp_(vmb.wsum);
         float roughA = rcp_(lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction)));
         float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
         float amount = vmbOk ? spec_dominant_factor(g.roughness) * vmb.wsum * rconf : 0.0f;
@@ -1092,11 +1094,11 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     // a tile without geometry (ClassifyTiles: Tiles = 1; block-uniform): every pixel takes the sky path - no staging, no barrier
     if (tile_is_sky(p, tx, ty)) {
         if (live)
-            sky_out(tapTex ? pack_tap_guide(decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange)) : uint2{0u, 0u});
+            sky_out(tapTex ? ld_guide(p.guide, x, y) : uint2{0u, 0u});
         return;
     }
     const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
-    const uint4 graw = ld<uint4>(p.guide, cxp, cyp, 16);
+    const uint2 graw = ld_guide(p.guide, cxp, cyp);
     const uint16_t data1Raw = ld<uint16_t>(p.data1Tmp, cxp, cyp, 2);
     uint2 ctex[RBPT / 8];
     load_texel<RBPT>(p.tmp2, cxp, cyp, ctex);
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
             bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
             int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
-            float zt = ld<float>(p.guide, cx, cy, 16, 0);
+            float zt = ld<float>(p.guide, cx, cy, GUIDE_BYTES, 0);
             uint32_t l = load_luma(p.fast, cx, cy, LBPT);
             bool ok = inside && absf(zt) <= c.denoisingRange;
             bad |= ok ? 0 : 1;
@@ -1133,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     if (!live)
         return;
     Guide g = decode_guide(graw, c.denoisingRange);
-    const uint2 tapGuide = tapTex ? pack_tap_guide(g) : uint2{0u, 0u};
+    const uint2 tapGuide = graw; // the tap texels carry the pixel's guide texel as it is
     if (g.sky) {
         sky_out(tapGuide);
         return;
@@ -1177,12 +1179,12 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                         int px = x + i * stride, py = y + j * stride, gy = py + c.yOff;
                         if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
                             continue;
-                        Guide gs = decode_guide(ld<uint4>(p.guide, px, py, 16), c.denoisingRange);
+                        Guide gs = decode_guide(ld_guide(p.guide, px, py), c.denoisingRange);
                         if (gs.sky || material_mismatch(g.mat, gs.mat, minMat))
                             continue;
                         float w = rcp_(1.0f + (float)(i * i + j * j));
                         w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                        w *= p.relax ? pow01(dot3(g.n, gs.n), p.hfNormalPower) : normal_weight(dot3(g.n, gs.n), normalW2);
+                        w *= p.relax ? pow01(normal_cos(normal_codes(g.nw), gs.nw), p.hfNormalPower) : normal_weight(normal_cos(normal_codes(g.nw), gs.nw), normalW2);
                         if (isSpec)
                             w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         float tA[2];
@@ -1331,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         return;
     }
     const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside still take part in the staging
-    const uint4 graw = ld<uint4>(p.guide, cxp, cyp, 16);
+    const uint2 graw = ld_guide(p.guide, cxp, cyp);
     uint2 ctex[RBPT / 8];
     load_texel<RBPT>(p.hist, cxp, cyp, ctex);
     const uint2 mvTexel = ld<uint2>(p.inMV, cxp, cyp, 8);
@@ -1355,7 +1357,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
         stIn[sweep] = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
         int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
-        stZ[sweep] = ld<float>(p.guide, cx, cy, 16, 0);
+        stZ[sweep] = ld<float>(p.guide, cx, cy, GUIDE_BYTES, 0);
         load_texel<RBPT>(p.hist, cx, cy, stT[sweep]);
     }
     const int gy0 = y + c.yOff;
@@ -1458,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_validation(const ReblurParams p) {
     int x, y, tx, ty;
     if (!my_pixel(c, x, y, tx, ty))
         return;
-    Guide g = decode_guide(ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     uint32_t packed = 0;
     if (!g.sky) {
         float dA, sA;
@@ -1494,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     constexpr int T = 16 + 2 * LS; // staged window edge
-    __shared__ uint4 sG[LS ? T * T : 1];
+    __shared__ uint2 sG[LS ? T * T : 1];
     __shared__ uint2 sT[LS ? T * T * TW : 1];
     __shared__ uint32_t sM[(LS && FIRST) ? T * T : 1];
     const FrameConsts& c = p.c;
@@ -1543,7 +1545,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         if (HAS_SPEC)
             d2raw = ld<uint32_t>(p.data2, sx, sy, 4);
         constexpr int TRIPS = (T * T + 255) / 256;
-        uint4 gq[TRIPS];
+        uint2 gq[TRIPS];
         uint2 tq[TRIPS][TW];
         uint32_t mq[TRIPS];
         bool ins[TRIPS];
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
             const int px = tx * 16 + lx - LS, py = ty * 16 + ly - LS;
             ins[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
             const int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
-            gq[k] = ld<uint4>(p.guide, cpx, cpy, 16);
+            gq[k] = ld_guide(p.guide, cpx, cpy);
             load_texel<RBPT>(p.in, cpx, cpy, tq[k]);
             mq[k] = FIRST ? load_luma(p.mom, cpx, cpy, LBPT) : 0u;
         }
@@ -1583,7 +1585,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW;
     bool split = last && u < c.splitScreen;
-    Guide g = decode_guide(LS ? sG[ci] : ld<uint4>(p.guide, x, y, 16), c.denoisingRange);
+    Guide g = decode_guide(LS ? sG[ci] : ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         sky_out();
         return;
@@ -1631,7 +1633,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                             int px = x + i, py = y + j, gy = py + c.yOff;
                             if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
                                 continue;
-                            if (!(absf(ld<float>(p.guide, px, py, 16, 0)) <= c.denoisingRange))
+                            if (!(absf(ld<float>(p.guide, px, py, GUIDE_BYTES, 0)) <= c.denoisingRange))
                                 continue;
                             Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb));
                         }
@@ -1683,7 +1685,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
 #define NRD_ATROUS_DEPTH 4
 #endif
     constexpr int DEPTH = LS ? (SH ? 4 : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
-    uint4 graw[8];
+    uint2 graw[8];
     uint2 stex[8][RBPT / 8];
     uint16_t mraw[8][NSIG];
     bool inside[8];
@@ -1704,7 +1706,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         int px = x + i * stride, py = y + j * stride;
         inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
         int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
-        graw[k] = ld<uint4>(p.guide, cpx, cpy, 16);
+        graw[k] = ld_guide(p.guide, cpx, cpy);
         load_texel<RBPT>(p.in, cpx, cpy, stex[k]);
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++)
@@ -1715,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         int px = x + i * stride, gy = y + j * stride + c.yOff;
         Guide gs = decode_guide(graw[k], c.denoisingRange);
         float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
-        float nDot = dot3(g.n, gs.n);
+        float nDot = normal_cos(normal_codes(g.nw), gs.nw);
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;

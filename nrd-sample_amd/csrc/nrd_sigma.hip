@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams 
     float r = 0.0f;
     if (valid) {
         float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
-        st<uint4>(p.guide, x, y, 16, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
+        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
         if (absf(z) <= c.denoisingRange) {
             float pen = h2f(ld<uint16_t>(p.inPen, x, y, 2));
             if (pen >= NRD_FP16_MAX)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
         return;
     const PlaneRef& inPen = PASS == 0 ? p.inPen : p.pen1;
     const PlaneRef& outSh = PASS == 0 ? p.shadow1 : p.shadow2;
-    uint4 graw = ld<uint4>(p.guide, x, y, 16);
+    uint2 graw = ld_guide(p.guide, x, y);
     float z = u2f(graw.x);
     if (!(absf(z) <= c.denoisingRange)) {
         st<uint2>(outSh, x, y, 8, uint2{0u, 0u});
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
             int ddx = px - x, ddy = gy - gy0;
             valid = valid && !(ddx > BLUR_REACH || -ddx > BLUR_REACH || ddy > BLUR_REACH || -ddy > BLUR_REACH) && py >= 0 && py < c.resH;
             py = py < 0 ? 0 : (py >= c.resH ? c.resH - 1 : py);
-            float zs = ld<float>(p.guide, px, py, 16, 0);
+            float zs = ld<float>(p.guide, px, py, GUIDE_BYTES, 0);
             uint16_t praw = ld<uint16_t>(inPen, px, py, 2);
             uint2 sraw = PASS == 0 ? uint2{0u, 0u} : ld<uint2>(p.shadow1, px, py, 8);
             if (!valid || !(absf(zs) <= c.denoisingRange))
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
             return;
         float u = ((float)x + 0.5f) * c.invW;
         bool split = u < c.splitScreen;
-        float z = ld<float>(p.guide, x, y, 16, 0);
+        float z = ld<float>(p.guide, x, y, GUIDE_BYTES, 0);
         bool sky = !(absf(z) <= c.denoisingRange);
         uint32_t packed = sky ? 0u : encode_shadow(unpack_h4(ld<uint2>(p.shadow2, x, y, 8)));
         st<uint32_t>(p.hist, x, y, 4, packed);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
         int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
         uint2 val = uint2{0xffffffffu, 0xffffffffu};
         if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
-            float zt = ld<float>(p.guide, px, py, 16, 0);
+            float zt = ld<float>(p.guide, px, py, GUIDE_BYTES, 0);
             if (absf(zt) <= c.denoisingRange)
                 val = ld<uint2>(p.shadow2, px, py, 8);
         }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     bool split = u < c.splitScreen;
-    uint4 graw = ld<uint4>(p.guide, x, y, 16);
+    uint2 graw = ld_guide(p.guide, x, y);
     float z = u2f(graw.x);
     if (!(absf(z) <= c.denoisingRange)) {
         st<uint32_t>(p.hist, x, y, 4, 0u);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
                 int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
                 if (ttx < 0 || ttx >= c.Wprev || gy < 0 || gy >= c.Hprev || tty < 0 || tty >= c.resH)
                     continue;
-                Guide gp = decode_guide(ld<uint4>(p.guidePrev, ttx, tty, 16), c.denoisingRange);
+                Guide gp = decode_guide(ld_guide(p.guidePrev, ttx, tty), c.denoisingRange);
                 if (gp.sky)
                     continue;
                 float lin = fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));

@@ -17,9 +17,7 @@
 #include <string>
 #include <vector>
 
-#ifndef NRD_HOST_EMULATION
 #include <dlfcn.h>
-#endif
 
 using namespace nrdhip;
 
@@ -195,8 +193,8 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
         uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig; // SH mode: SH0 + SH1 texels per signal
-        perm.push_back({"REBLUR::Guide_A", F::RGBA32_UINT, 16, 1});
-        perm.push_back({"REBLUR::Guide_B", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"REBLUR::Guide_A", F::RG32_UINT, GUIDE_BYTES, 1});
+        perm.push_back({"REBLUR::Guide_B", F::RG32_UINT, GUIDE_BYTES, 1});
         perm.push_back({"REBLUR::Data1_A", F::R16_UINT, 2, 1});
         perm.push_back({"REBLUR::Data1_B", F::R16_UINT, 2, 1});
         perm.push_back({"REBLUR::History", fmtRad, bRad, 1});
@@ -226,8 +224,8 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
         uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig; // SH mode: SH0 + SH1 texels per signal
-        perm.push_back({"RELAX::Guide_A", F::RGBA32_UINT, 16, 1});
-        perm.push_back({"RELAX::Guide_B", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"RELAX::Guide_A", F::RG32_UINT, GUIDE_BYTES, 1});
+        perm.push_back({"RELAX::Guide_B", F::RG32_UINT, GUIDE_BYTES, 1});
         perm.push_back({"RELAX::HistoryLength_A", F::R16_UINT, 2, 1});
         perm.push_back({"RELAX::HistoryLength_B", F::R16_UINT, 2, 1});
         perm.push_back({"RELAX::History", fmtRad, bRad, 1});
@@ -250,8 +248,8 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"RELAX::Atrous_A", fmtRad, bRad, 1});
         trans.push_back({"RELAX::Atrous_B", fmtRad, bRad, 1});
     } else if (d.kind == Kind::SIGMA) {
-        perm.push_back({"SIGMA::Guide_A", F::RGBA32_UINT, 16, 1});
-        perm.push_back({"SIGMA::Guide_B", F::RGBA32_UINT, 16, 1});
+        perm.push_back({"SIGMA::Guide_A", F::RG32_UINT, GUIDE_BYTES, 1});
+        perm.push_back({"SIGMA::Guide_B", F::RG32_UINT, GUIDE_BYTES, 1});
         perm.push_back({"SIGMA::History_A", F::RGBA8_UNORM, 4, 1});
         perm.push_back({"SIGMA::History_B", F::RGBA8_UNORM, 4, 1});
         trans.push_back({"SIGMA::Tiles", F::R16_UINT, 2, 16});
@@ -470,7 +468,7 @@ void push_prepare_dispatch(DenoiserState& d, const PrepareMode& pm, const Reblur
     using RT = nrd::ResourceType;
     float n = (float)d.nsig;
     float inB = (d.occlusion ? 2.0f : 8.0f) * (pm.checker ? 0.5f : 1.0f);
-    Dispatch x{name, "nrd_reblur_prepare_inputs", (uint16_t)pm.radius, 16.0f + n * (inB + 8.0f) + (pm.sh1 ? n * ((d.dirOcc ? 0.0f : 4.0f) + 8.0f) : 0.0f), {}, {}, nullptr};
+    Dispatch x{name, "nrd_reblur_prepare_inputs", (uint16_t)pm.radius, (float)GUIDE_BYTES + n * (inB + 8.0f) + (pm.sh1 ? n * ((d.dirOcc ? 0.0f : 4.0f) + 8.0f) : 0.0f), {}, {}, nullptr};
     x.read = {guide};
     for (int spec = 0; spec < 2; spec++) {
         if (spec ? !d.hasSpec : !d.hasDiff)
@@ -491,7 +489,7 @@ void push_prepare_dispatch(DenoiserState& d, const PrepareMode& pm, const Reblur
 void push_validation_dispatch(nrdhip_instance& I, DenoiserState& d, const ReblurParams& p, const char* name, uint32_t guide, uint32_t data1, uint32_t data2) {
     if (!I.common.enableValidation || !I.slots[(size_t)nrd::ResourceType::OUT_VALIDATION].p)
         return;
-    Dispatch x{name, "nrd_reblur_validation", 0, 16.0f + 2.0f + 4.0f + 4.0f, {}, {}, nullptr};
+    Dispatch x{name, "nrd_reblur_validation", 0, (float)GUIDE_BYTES + 2.0f + 4.0f + 4.0f, {}, {}, nullptr};
     x.read = {guide, data1, data2};
     x.written = {enc_slot(nrd::ResourceType::OUT_VALIDATION)};
     x.launch = [p](hipStream_t st) { launch_reblur_validation(p, st); };
@@ -650,7 +648,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     float sp = d.hasSpec ? 2.0f : 0.0f;
     uint16_t blurHalo = (uint16_t)p.reachBlur, postHalo = (uint16_t)p.reachPost, preHalo = (uint16_t)p.reachPre;
-    const float GB = 16.0f; // guide texel bytes
+    const float GB = (float)GUIDE_BYTES; // guide texel bytes
     const bool tap = tap_texels(d);
     {
         Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
@@ -775,7 +773,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     float n = (float)d.nsig;
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     float sp = d.hasSpec ? 2.0f : 0.0f;
-    const float GB = 16.0f;
+    const float GB = (float)GUIDE_BYTES;
     {
         Dispatch x{"RELAX::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
@@ -920,7 +918,7 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     p.pen1 = TP(sg::PEN1);
     p.shadow2 = TP(sg::SHADOW2);
     float tr = d.translucency ? 4.0f : 0.0f;
-    const float GB = 16.0f;
+    const float GB = (float)GUIDE_BYTES;
     {
         Dispatch x{"SIGMA::ClassifyTiles", "nrd_sigma_classify_tiles", 0, 4 + 4 + 2 + GB + 2.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS), enc_slot(RT::IN_PENUMBRA)};
@@ -1008,7 +1006,6 @@ struct Markers {
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
     Markers() {
-#ifndef NRD_HOST_EMULATION
         const char* env = std::getenv("NRDHIP_MARKERS");
         if (env && env[0] == '0')
             return;
@@ -1021,7 +1018,6 @@ struct Markers {
         pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
         if (!push || !pop)
             push = nullptr, pop = nullptr;
-#endif
     }
 };
 struct MarkerScope {

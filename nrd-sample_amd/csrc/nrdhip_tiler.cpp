@@ -27,10 +27,8 @@
 #include <string>
 #include <vector>
 
-#ifndef NRD_HOST_EMULATION
 #include <dlfcn.h>
-#include <rccl/rccl.h>
-#endif
+#include <rccl/rccl.h> // declarations only: librccl is resolved with dlopen at nrdhip_tiler_rccl_init, never linked
 
 namespace {
 
@@ -41,7 +39,6 @@ struct PlanEntry {
     std::vector<Xfer> now, later;
 };
 
-#ifndef NRD_HOST_EMULATION
 struct RcclApi {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -84,7 +81,6 @@ struct RcclApi {
     }
 };
 RcclApi g_rccl;
-#endif
 
 } // namespace
 
@@ -95,9 +91,7 @@ struct nrdhip_tiler {
     int32_t frameH = 0, row0 = 0, ownFirst = 0, ownRows = 0, localH = 0;
     nrdhip_transport tr{};
     bool custom = false;
-#ifndef NRD_HOST_EMULATION
     ncclComm_t comm = nullptr;
-#endif
     hipStream_t commStream = nullptr;
     hipEvent_t evCompute = nullptr, evComm = nullptr, evDeferred = nullptr;
     bool deferredPending = false;
@@ -187,7 +181,6 @@ int run_ops(nrdhip_tiler& T, const std::vector<Op>& ops, hipStream_t stream) {
             return fail(T, FAILURE, "transport group_end failed");
         return 0;
     }
-#ifndef NRD_HOST_EMULATION
     if (!T.comm)
         return fail(T, INVALID, "no transport: call nrdhip_tiler_rccl_init or pass callbacks to nrdhip_tiler_create");
     ncclResult_t r = g_rccl.GroupStart();
@@ -202,9 +195,6 @@ int run_ops(nrdhip_tiler& T, const std::vector<Op>& ops, hipStream_t stream) {
     if (r != ncclSuccess)
         return fail(T, FAILURE, std::string("RCCL: ") + g_rccl.GetErrorString(r));
     return 0;
-#else
-    return fail(T, INVALID, "no transport callbacks");
-#endif
 }
 
 int collect(nrdhip_tiler& T, const std::vector<Xfer>& list, std::vector<Op>& ops) {
@@ -345,20 +335,14 @@ NRDHIP_API int nrdhip_tiler_create(nrdhip_instance* inst, int rank, int world, c
 }
 
 NRDHIP_API int nrdhip_tiler_rccl_unique_id(void* out128) {
-#ifndef NRD_HOST_EMULATION
     std::string err;
     if (!out128 || !g_rccl.load(err))
         return FAILURE;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
     return g_rccl.GetUniqueId((ncclUniqueId*)out128) == ncclSuccess ? 0 : FAILURE;
-#else
-    (void)out128;
-    return UNSUPPORTED;
-#endif
 }
 
 NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* T, const void* unique_id128) {
-#ifndef NRD_HOST_EMULATION
     if (!T || !unique_id128 || T->custom)
         return INVALID;
     if (!g_rccl.load(T->error))
@@ -373,17 +357,11 @@ NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* T, const void* unique_id128)
         hipEventCreateWithFlags(&T->evComm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&T->evDeferred, hipEventDisableTiming) != hipSuccess)
         return fail(*T, FAILURE, "side stream / events");
     return 0;
-#else
-    (void)T;
-    (void)unique_id128;
-    return UNSUPPORTED;
-#endif
 }
 
 NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     if (!T)
         return;
-#ifndef NRD_HOST_EMULATION
     TilerDeviceScope scope(*T);
     if (T->comm)
         g_rccl.CommDestroy(T->comm);
@@ -392,7 +370,6 @@ NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     for (hipEvent_t e : {T->evCompute, T->evComm, T->evDeferred})
         if (e)
             (void)hipEventDestroy(e);
-#endif
     delete T;
 }
 

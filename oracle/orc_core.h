@@ -135,35 +135,53 @@ static inline bool project(const float* pj, f3 X, float& u, float& v) {
     return true;
 }
 
-// ---- guide texel (16 bytes): {viewZ f32 | nx f16, ny f16 | nz f16, roughness f16 | materialID u32} ----------------
-// written once per pixel by the ClassifyTiles passes from IN_VIEWZ + IN_NORMAL_ROUGHNESS, so that every bilateral tap
-// decodes its guides with four f16 -> f32 converts instead of an octahedral decode + normalisation.
+// ---- guide texel (8 bytes, round 3; == the guide part of the Blur / PostBlur tap texels) -----------------------------------------------
+//   w0 = viewZ rounded to 22 bits | roughness as the 10-bit code of IN_NORMAL_ROUGHNESS. Read back AS ONE FLOAT it is the depth (the
+//        roughness code perturbs it by < 2^-13 relative) - every consumer reads it that way
+//   w1 = normal x | y << 10 | z << 20, 10 bits per component (n = code * 2/1023 - 1, not re-normalised) | materialID << 30
+// written once per pixel by the ClassifyTiles passes from IN_VIEWZ + IN_NORMAL_ROUGHNESS: every bilateral tap decodes its guide with a
+// few integer / convert operations instead of an octahedral decode + normalisation, and every pass moves 8 instead of 16 bytes per guide
+// access (round 3 measured what these passes pay for: bytes and memory instructions, not arithmetic). The normal arrives as a 10 + 10 bit
+// octahedron and the roughness as 10 bits: the texel is as fine as the input; only the depth loses its 10 low mantissa bits.
 struct Guide {
-    float z; // signed view z (already multiplied by viewZScale)
+    float z; // signed view z (already multiplied by viewZScale), roughness code in its 10 low mantissa bits
     f3 n;
     float roughness;
     uint32_t mat;
     bool sky;
+    uint32_t nw; // the texel's normal | material word (normal_cos works on the codes)
 };
+static const int GUIDE_BYTES = 8;
+// Cosine of the angle between two guide normals from their 10-bit CODES: cos = 1 - |n_a - n_b|^2 / 2 (exact for unit vectors). The dot
+// product of two quantised, not re-normalised vectors cannot resolve 1 - cos at the 1e-4 level the narrow specular lobes ask for (|n|^2
+// is off by up to 2e-3); the squared difference of the codes is exact, zero for equal normals, as fine as the quantisation step.
+static inline float normal_cos(uint32_t nwCentre, uint32_t nw) {
+    const float dx = (float)(nw & 1023u) - (float)(nwCentre & 1023u), dy = (float)((nw >> 10) & 1023u) - (float)((nwCentre >> 10) & 1023u),
+                dz = (float)((nw >> 20) & 1023u) - (float)((nwCentre >> 20) & 1023u);
+    const float d2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    return fma_(d2, -0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f), 1.0f);
+}
+static inline uint32_t guide_qn10(float v) { return (uint32_t)floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
 static inline void store_guide(const Plane& G, int x, int y, float z, uint32_t packedNR) {
     NormalRoughness nr = unpack_normal_roughness(packedNR);
-    st_f32(G, x, y, z, 0);
-    st_u16(G, x, y, f32_to_f16(nr.n.x), 4);
-    st_u16(G, x, y, f32_to_f16(nr.n.y), 6);
-    st_u16(G, x, y, f32_to_f16(nr.n.z), 8);
-    st_u16(G, x, y, f32_to_f16(nr.roughness), 10);
-    st_u32(G, x, y, nr.materialID, 12);
+    uint32_t w0 = ((f2u(z) + 0x200u) & 0xFFFFFC00u) | ((packedNR >> 20) & 1023u);
+    uint32_t w1 = guide_qn10(nr.n.x) | (guide_qn10(nr.n.y) << 10) | (guide_qn10(nr.n.z) << 20) | (nr.materialID << 30);
+    st_u32(G, x, y, w0, 0);
+    st_u32(G, x, y, w1, 4);
 }
-static inline Guide load_guide(const Plane& G, int x, int y, float range) {
+static inline Guide decode_guide_words(uint32_t w0, uint32_t w1, float range) {
     Guide g;
-    g.z = ld_f32(G, x, y, 0);
-    g.n = {ld_h(G, x, y, 4), ld_h(G, x, y, 6), ld_h(G, x, y, 8)};
-    g.roughness = ld_h(G, x, y, 10);
-    g.mat = ld_u32(G, x, y, 12);
+    g.nw = w1;
+    g.z = u2f(w0);
+    g.roughness = (float)(w0 & 1023u) * (1.0f / 1023.0f);
+    const float s = 2.0f / 1023.0f;
+    g.n = {fma_((float)(w1 & 1023u), s, -1.0f), fma_((float)((w1 >> 10) & 1023u), s, -1.0f), fma_((float)((w1 >> 20) & 1023u), s, -1.0f)};
+    g.mat = w1 >> 30;
     g.sky = !(absf(g.z) <= range);
     return g;
 }
-static inline float guide_roughness(const Plane& G, int x, int y) { return ld_h(G, x, y, 10); }
+static inline Guide load_guide(const Plane& G, int x, int y, float range) { return decode_guide_words(ld_u32(G, x, y, 0), ld_u32(G, x, y, 4), range); }
+static inline float guide_roughness(const Plane& G, int x, int y) { return (float)(ld_u32(G, x, y, 0) & 1023u) * (1.0f / 1023.0f); }
 // material comparison: ids differ and the larger one takes part in material-aware filtering
 static inline bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
 

@@ -320,7 +320,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                             if (!(h > 0.0f))
                                 continue;
                             float w = geo_weight(pg, (float)px, (float)gy, gs.z);
-                            w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                            w *= normal_weight(normal_cos(g.nw, gs.nw), normalW2);
                             if (isSpec)
                                 w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                             sum = fma_(h, w, sum);
@@ -362,29 +362,14 @@ static inline f4 load_sh1(const SpatialIO& io, int sig, int x, int y, bool pre) 
 //        roughness code perturbing it by < 2^-13 relative - every consumer reads it that way, centre and taps alike)
 //   w1 = normal x | y << 10 | z << 20, 10 bits per component (n = code * 2/1023 - 1, not re-normalised) | materialID << 30
 //   w2, w3 = the signal {Y, Co | Cg, hitT} as 4 x fp16
-// HistoryFix packs the guide part from the 16-byte guide texel; Blur copies it through; both passes take their CENTRE pixel's guide
-// from the texel as well (they do not touch the guide plane). Precision: the normal arrives in IN_NORMAL_ROUGHNESS as a 10 + 10 bit
+// The guide part IS the pixel's 8-byte guide texel (orc_core.h): HistoryFix copies it in, Blur copies it through, and both passes take
+// their CENTRE pixel's guide from the texel as well (they do not touch the guide plane). Precision: the normal arrives in IN_NORMAL_ROUGHNESS as a 10 + 10 bit
 // octahedron, the roughness as 10 bits - the texel is as fine as the input; only the depth loses its 10 low mantissa bits.
 // --------------------------------------------------------------------------------------------------
 struct TapTexel {
     uint32_t w0, w1, w2, w3;
 };
-static inline uint32_t qn10(float v) { return (uint32_t)floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
-static inline void pack_tap_guide(const Guide& g, uint32_t& w0, uint32_t& w1) {
-    uint32_t rc = (uint32_t)floorf(fma_(sat(g.roughness), 1023.0f, 0.5f));
-    w0 = ((f2u(g.z) + 0x200u) & 0xFFFFFC00u) | rc;
-    w1 = qn10(g.n.x) | (qn10(g.n.y) << 10) | (qn10(g.n.z) << 20) | (g.mat << 30);
-}
-static inline Guide unpack_tap_guide(uint32_t w0, uint32_t w1, float range) {
-    Guide g;
-    g.z = u2f(w0);
-    g.roughness = (float)(w0 & 1023u) * (1.0f / 1023.0f);
-    const float s = 2.0f / 1023.0f;
-    g.n = {fma_((float)(w1 & 1023u), s, -1.0f), fma_((float)((w1 >> 10) & 1023u), s, -1.0f), fma_((float)((w1 >> 20) & 1023u), s, -1.0f)};
-    g.mat = w1 >> 30;
-    g.sky = !(absf(g.z) <= range);
-    return g;
-}
+static inline Guide unpack_tap_guide(uint32_t w0, uint32_t w1, float range) { return decode_guide_words(w0, w1, range); }
 static inline TapTexel ld_tap(const Plane& P, int x, int y) {
     TapTexel t;
     std::memcpy(&t, texel(P, x, y), 16);
@@ -554,20 +539,12 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         if (valid) {
                             w = g_poisson8[t][2];
                             w *= geo_weight(pg, fpx, fpy, gs.z);
-                            if (tap) {
-                                // the tap's normal and roughness stay 10-bit codes: scale and offset of their decode are folded into
-                                // per-pixel constants (N . Ns = sum (2/1023 N_i) code_i - sum N_i; roughness likewise)
-                                const float ns = 2.0f / 1023.0f;
-                                const float nb = -((g.n.x + g.n.y) + g.n.z);
-                                float cosn = fma_(g.n.x * ns, (float)(tt.w1 & 1023u), fma_(g.n.y * ns, (float)((tt.w1 >> 10) & 1023u), fma_(g.n.z * ns, (float)((tt.w1 >> 20) & 1023u), nb)));
-                                w *= normal_weight(cosn, normalW2);
+                            w *= normal_weight(normal_cos(g.nw, gs.nw), normalW2);
+                            if (tap) { // the tap's roughness stays a 10-bit code: the scale of its decode is folded into the per-pixel constant
                                 if (isSpec)
                                     w *= smoothstep01(1.0f - absf(fma_((float)(tt.w0 & 1023u), roughA * (1.0f / 1023.0f), roughB)));
-                            } else {
-                                w *= normal_weight(dot3(g.n, gs.n), normalW2);
-                                if (isSpec)
-                                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                            }
+                            } else if (isSpec)
+                                w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                             w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
                         }
                         sum = fma4(sv, w, sum);
@@ -949,9 +926,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             Guide g = load_guide(G, x, y, c.denoisingRange);
-            uint32_t tw0 = 0, tw1 = 0;
-            if (tap)
-                pack_tap_guide(g, tw0, tw1);
+            const uint32_t tw0 = ld_u32(G, x, y, 0), tw1 = ld_u32(G, x, y, 4); // the tap texels carry the guide texel as it is
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
                     if (tap) {
@@ -1010,7 +985,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                 float w = rcp_(1.0f + (float)(i * i + j * j));
                                 w *= geo_weight(pg, (float)px, (float)gy, gs.z);
                                 // RELAX: pow(N.Ns, historyFixEdgeStoppingNormalPower) (sample UI Source/NRDSample.cpp:1626) instead of the lobe weight
-                                w *= relax ? pow01(dot3(g.n, gs.n), d.relax.historyFixEdgeStoppingNormalPower) : normal_weight(dot3(g.n, gs.n), normalW2);
+                                w *= relax ? pow01(normal_cos(g.nw, gs.nw), d.relax.historyFixEdgeStoppingNormalPower) : normal_weight(normal_cos(g.nw, gs.nw), normalW2);
                                 if (isSpec)
                                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 float tA[2];
@@ -1416,7 +1391,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         if (valid) {
                             w = (i == 0 || j == 0) ? 0.5f : 0.25f;
                             w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                            w *= normal_weight(dot3(g.n, gs.n), normalW2);
+                            w *= normal_weight(normal_cos(g.nw, gs.nw), normalW2);
                             if (isSpec && s.enableRoughnessEdgeStopping) {
                                 float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 w *= relaxEdges ? lerpf(1.0f, rw, roughRelax) : rw;
@@ -1482,7 +1457,7 @@ static void push_validation_pass(Instance& I, DenoiserState& d, const char* name
     p.name = name;
     p.kernel = "nrd_reblur_validation";
     p.haloRows = 0;
-    p.bytesPerPixel = 16.0f + 2.0f + 4.0f + 4.0f;
+    p.bytesPerPixel = (float)GUIDE_BYTES + 2.0f + 4.0f + 4.0f;
     p.read = {guide, data1, data2};
     p.written = {enc_slot(nrd::ResourceType::OUT_VALIDATION)};
     p.run = validation;
@@ -1493,8 +1468,8 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
     uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
     uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
     uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig; // SH mode: SH0 + SH1 texels per signal
-    perm.push_back({"REBLUR::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
-    perm.push_back({"REBLUR::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"REBLUR::Guide_A", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"REBLUR::Guide_B", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
     perm.push_back({"REBLUR::Data1_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     perm.push_back({"REBLUR::Data1_B", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     perm.push_back({"REBLUR::History", fmtRad, bRad, 1});
@@ -1540,7 +1515,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     const nrd::ReblurSettings& s = d.reblur;
     ReblurReach rr = reblur_reach(s);
-    const float GB = 16.0f; // guide texel bytes
+    const float GB = (float)GUIDE_BYTES; // guide texel bytes
     const bool tap = tap_texels(d);
     {
         Pass p;
@@ -1757,8 +1732,8 @@ void relax_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<
     uint32_t fmtRad = (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT);
     uint32_t fmtLum = (uint32_t)(d.nsig == 2 ? nrd::Format::RG16_SFLOAT : nrd::Format::R16_SFLOAT);
     uint32_t bRad = 8u * d.nsig * (d.sh ? 2u : 1u), bLum = 2u * d.nsig;
-    perm.push_back({"RELAX::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
-    perm.push_back({"RELAX::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"RELAX::Guide_A", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"RELAX::Guide_B", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
     perm.push_back({"RELAX::HistoryLength_A", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     perm.push_back({"RELAX::HistoryLength_B", (uint32_t)nrd::Format::R16_UINT, 2, 1});
     perm.push_back({"RELAX::History", fmtRad, bRad, 1});
@@ -1793,7 +1768,7 @@ void relax_build(Instance& I, DenoiserState& d) {
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     const nrd::ReblurSettings& s = d.reblur;
     ReblurReach rr = reblur_reach(s);
-    const float GB = 16.0f;
+    const float GB = (float)GUIDE_BYTES;
     float sp = d.hasSpec ? 2.0f : 0.0f;
     {
         Pass p;

@@ -361,8 +361,8 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
 } // namespace
 
 void sigma_describe(DenoiserState&, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
-    perm.push_back({"SIGMA::Guide_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
-    perm.push_back({"SIGMA::Guide_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, 1});
+    perm.push_back({"SIGMA::Guide_A", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
+    perm.push_back({"SIGMA::Guide_B", (uint32_t)nrd::Format::RG32_UINT, 8, 1});
     perm.push_back({"SIGMA::History_A", (uint32_t)nrd::Format::RGBA8_UNORM, 4, 1});
     perm.push_back({"SIGMA::History_B", (uint32_t)nrd::Format::RGBA8_UNORM, 4, 1});
     trans.push_back({"SIGMA::Tiles", (uint32_t)nrd::Format::R16_UINT, 2, 16});
@@ -379,7 +379,7 @@ void sigma_build(Instance& I, DenoiserState& d) {
     auto P = [&](int i) { return enc_perm(pb + i); };
     auto T = [&](int i) { return enc_trans(tb + i); };
     float tr = d.translucency ? 4.0f : 0.0f;
-    const float GB = 16.0f;
+    const float GB = (float)GUIDE_BYTES;
     {
         Pass p;
         p.name = "SIGMA::ClassifyTiles";

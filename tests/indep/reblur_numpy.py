@@ -7,7 +7,8 @@ Switches (all False = the frozen algorithm):
   exp_hit_weight ...... hit-distance weight exp(-3 |x|) instead of the compact-support stand-in (1 - |x|)^2
   angle_normal_weight . normal weight on the angle itself, smoothstep(1 - acos(cos) / angleMax), instead of the squared-angle form
   no_reach ............ no hard tap reach (the reach exists for row tiling: it bounds what a pass may read beyond a band)
-  f32_guide ........... normals / roughness of the guide kept at decode precision instead of being stored as fp16
+  f32_guide ........... guide kept at decode precision (fp32 depth, normalised fp64 normal) instead of the 8-byte guide texel's 22-bit depth
+                        and 3 x 10-bit normal codes
 """
 import numpy as np
 
@@ -35,8 +36,8 @@ def smoothstep01(x):
 
 
 def decode_guide(viewz, packed, viewz_scale=1.0, f32_guide=False):
-    """ClassifyTiles: viewZ * scale; octahedral normal (10 + 10 bits), linear roughness (10 bits), materialID (2 bits); the
-    guide plane stores the decoded normal and roughness as fp16"""
+    """ClassifyTiles: viewZ * scale; octahedral normal (10 + 10 bits), linear roughness (10 bits), materialID (2 bits); the guide
+    plane stores {depth 22 bit | roughness code, normal 3 x 10 bit | material} and every consumer reads THAT"""
     ox, oy = (packed & 1023) / 1023.0, ((packed >> 10) & 1023) / 1023.0
     fx, fy = ox * 2.0 - 1.0, oy * 2.0 - 1.0
     nz = 1.0 - np.abs(fx) - np.abs(fy)
@@ -44,10 +45,34 @@ def decode_guide(viewz, packed, viewz_scale=1.0, f32_guide=False):
     n = np.stack([fx + np.where(fx >= 0, -t, t), fy + np.where(fy >= 0, -t, t), nz], -1)
     n /= np.sqrt((n * n).sum(-1, keepdims=True))
     rough = ((packed >> 20) & 1023) / 1023.0
+    z = viewz.astype(np.float64) * viewz_scale
     if not f32_guide:
-        n = f16(n).astype(np.float64)
-        rough = f16(rough).astype(np.float64)
-    return viewz.astype(np.float64) * viewz_scale, n, rough, (packed >> 30).astype(np.int64)
+        # the 8-byte guide texel: normal as 3 x 10-bit codes (code * 2/1023 - 1, not re-normalised), roughness = the input's own 10-bit
+        # code, depth rounded to 22 bits with the roughness code in the 10 low mantissa bits - and read back as one float
+        codes = np.floor(np.clip(n * 511.5 + 512.0, 0.0, 1023.0))
+        n = codes * (2.0 / 1023.0) - 1.0
+        zb = z.astype(np.float32).view(np.uint32).astype(np.uint64)
+        zb = (((zb + 0x200) & 0xFFFFFC00) | ((packed.astype(np.uint64) >> 20) & 1023)).astype(np.uint32)
+        z = zb.view(np.float32).astype(np.float64)
+    return z, n, rough, (packed >> 30).astype(np.int64)
+
+
+def guide_words(viewz, packed, viewz_scale=1.0):
+    """the two 32-bit words of the guide texel as ClassifyTiles stores them (for a bit-exact comparison with the guide plane)"""
+    z, n, rough, mat = decode_guide(viewz, packed, viewz_scale)
+    w0 = z.astype(np.float32).view(np.uint32)
+    c = np.round((n + 1.0) * (1023.0 / 2.0)).astype(np.uint32)
+    return w0, c[..., 0] | (c[..., 1] << 10) | (c[..., 2] << 20) | (mat.astype(np.uint32) << 30)
+
+
+def normal_cos(n, ns, unit_vectors=False):
+    """cosine between two guide normals: 1 - |n - ns|^2 / 2 (the guide's normals are 10-bit codes that are not re-normalised: their dot
+    product cannot resolve 1 - cos at the 1e-4 level the narrow specular lobes need, the squared difference can); for true unit vectors
+    (the f32_guide switch) the plain dot product"""
+    if unit_vectors:
+        return (n * ns).sum(-1)
+    d = n - ns
+    return 1.0 - 0.5 * (d * d).sum(-1)
 
 
 def reference_accumulate(history, signal, frames_since_reset, max_accum, restart):
@@ -168,7 +193,7 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
             sv = plane[py, px].astype(np.float64)
             valid = in_win & active & ~sky[py, px] & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
             w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
-            cosa = (n * ns).sum(-1)
+            cosa = normal_cos(n, ns, f32_guide)
             if angle_normal_weight:
                 w = w * smoothstep01(1.0 - np.arccos(np.clip(cosa, -1, 1)) * normal_w)
             else:

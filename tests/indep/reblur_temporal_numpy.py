@@ -258,16 +258,12 @@ def moments5x5(c, plane, centre, z, skip_centre=False):
     return m1 / k, m2 / k
 
 
-def pack_tap_guide(z, n, rough, mat):
-    """guide part of a tap texel: viewZ rounded to 22 bits | 10-bit roughness code ; 3 x 10-bit normal | material"""
-    zb = z.astype(np.float32).view(np.uint32).astype(np.uint64)
-    w0 = (((zb + 0x200) & 0xFFFFFC00) | np.floor(np.clip(rough, 0, 1) * 1023.0 + 0.5).astype(np.uint64)).astype(np.uint32)
-    q = lambda v: np.floor(np.clip(v * 511.5 + 512.0, 0.0, 1023.0)).astype(np.uint32)
-    w1 = q(n[..., 0]) | (q(n[..., 1]) << 10) | (q(n[..., 2]) << 20) | (mat.astype(np.uint32) << 30)
-    return w0, w1
+def pack_tap_guide(viewz, packed_nr):
+    """guide part of a tap texel = the pixel's guide texel: viewZ rounded to 22 bits | 10-bit roughness code ; 3 x 10-bit normal | material"""
+    return sp.guide_words(viewz, packed_nr)
 
 
-def history_fix(c, s, gcur, tmp2, speeds_tmp, fast):
+def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr):
     """returns signal [H, W, 2, 4] fp16 (what goes into the tap texels), speeds uint16, tap guide words (w0, w1)"""
     H, W = c.H, c.W
     z, n, rough_g, mat = gcur
@@ -303,7 +299,7 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast):
                 ok = fix & inside & (np.abs(zs) <= c.range) & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
                 w = 1.0 / (1.0 + i * i + j * j)
                 w = w * sp.smoothstep01(1.0 - np.abs(zs * (pg["gax"] * px + pg["gay"] * py + pg["ga0"]) + pg["geoB"]))
-                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - (n * n[cy, cx]).sum(-1), 0, 1) * normal_w * normal_w)
+                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - sp.normal_cos(n, n[cy, cx]), 0, 1) * normal_w * normal_w)
                 if is_spec:
                     w = w * sp.smoothstep01(1.0 - np.abs(rough_g[cy, cx] * roughA - rough * roughA))
                 tA = (As if is_spec else Ad)[cy, cx]
@@ -324,7 +320,7 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast):
         out[:, :, sig] = val
     out[sky] = 0.0
     speeds = np.where(sky, 0, pack_speeds(outA[0], outA[1])).astype(np.uint16)
-    return f16(out), speeds, pack_tap_guide(z, n, rough_g, mat)
+    return f16(out), speeds, pack_tap_guide(viewz, packed_nr)
 
 
 def temporal_stabilization(c, s, gcur, mv, hist, speeds, data2, stab_prev, hit_track, history_ok):
@@ -460,7 +456,7 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
                 sv = pin[cy, cx, sig]
                 w = 0.5 if (i == 0 or j == 0) else 0.25
                 w = w * sp.smoothstep01(1.0 - np.abs(zs * (pg["gax"] * px + pg["gay"] * py + pg["ga0"]) + pg["geoB"]))
-                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - (n * n[cy, cx]).sum(-1), 0, 1) * normal_w * normal_w)
+                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - sp.normal_cos(n, n[cy, cx]), 0, 1) * normal_w * normal_w)
                 if is_spec and s["enableRoughnessEdgeStopping"]:
                     rw = sp.smoothstep01(1.0 - np.abs(rough_g[cy, cx] * roughA - rough * roughA))
                     w = w * ((1.0 + (rw - 1.0) * rough_relax) if relax_edges else rw)

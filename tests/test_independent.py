@@ -75,12 +75,14 @@ def test_reference_accumulation_independent(pkg, api, oracle):
 @pytest.mark.parametrize("f", [0, 2])
 def test_guide_and_prepass_independent(pkg, api, oracle, f):
     fr, cs, st, tmp1, track, guide = oracle_prepass(pkg, api, oracle, f)
-    # guide texel {viewZ f32 | nx ny f16 | nz roughness f16 | materialID}
-    z, n, rough, mat = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
-    g = guide.view(np.uint32).reshape(H, W, 4)
-    assert np.array_equal(g[..., 0].view(np.float32), fr["viewz"]) and np.array_equal(g[..., 3], mat.astype(np.uint32))
-    gn = np.stack([(g[..., 1] & 0xFFFF).astype(np.uint16).view(np.float16), (g[..., 1] >> 16).astype(np.uint16).view(np.float16), (g[..., 2] & 0xFFFF).astype(np.uint16).view(np.float16)], -1)
-    assert ulp16(gn, n.astype(np.float16)).max() <= 1 and ulp16((g[..., 2] >> 16).astype(np.uint16).view(np.float16), rough.astype(np.float16)).max() <= 1
+    # guide texel {viewZ 22 bit | roughness code, normal 3 x 10 bit | materialID}: depth word and material exact; a normal code may sit
+    # one step off where the float32 octahedral decode and the float64 one round to different sides (a handful of texels)
+    w0, w1 = ind.guide_words(fr["viewz"], fr["normal_roughness"])
+    g = guide.view(np.uint32).reshape(H, W, 2)
+    assert np.array_equal(g[..., 0], w0) and np.array_equal(g[..., 1] >> 30, w1 >> 30)
+    for sh in (0, 10, 20):
+        d = np.abs(((g[..., 1] >> sh) & 1023).astype(np.int32) - ((w1 >> sh) & 1023).astype(np.int32))
+        assert d.max() <= 1 and float((d == 0).mean()) > 0.98
     want, want_track = ind.prepass(fr["viewz"], fr["normal_roughness"], fr["diff"], fr["spec"], fr["view_to_clip"], fr["world_to_view"], cs.frameIndex, cs.denoisingRange,
                                    settings_dict(st))
     d = ulp16(tmp1, want)
@@ -119,7 +121,9 @@ def test_deviation_ledger_measurements(pkg, api, oracle, capsys):
     with capsys.disabled():
         for k, v in rows.items():
             print("deviation %-20s max %5d ULP fp16, %.1f %% of values move > 1 ULP, max relative %.3f, PSNR %.1f dB" % (k, v["max_ulp"], 100 * v["frac_changed"], v["max_rel"], v["psnr"]))
-    assert rows["f32_guide"]["psnr"] > 55.0           # storing the guide normal as fp16 is a rounding-level change
+    # the 8-byte guide (22-bit depth, 3 x 10-bit normal): the 1e-3 normal step tilts the tap basis enough to move ~3 % of the taps (30-pixel
+    # radius) onto the neighbouring texel - a different, equally valid sample of a noisy input, not a weight error (the depth alone: 65 dB)
+    assert rows["f32_guide"]["psnr"] > 45.0 and rows["f32_guide"]["frac_changed"] < 0.06
     assert rows["no_reach"]["frac_changed"] < 0.05    # the hard reach only bites on the longest taps at grazing angles
     assert rows["exp_hit_weight"]["psnr"] > 25.0 and rows["angle_normal_weight"]["psnr"] > 25.0  # weight-shape changes: visible, bounded
 
@@ -204,11 +208,12 @@ def test_temporal_passes_independent(pkg, api, oracle, f):
     hz.nrd.denoise_range([den], 3, 1)
     taps = [hz.pool("REBLUR::Tap_%s_A" % k).copy().view(np.uint32).reshape(H, W, 4) for k in ("Diff", "Spec")]
     speeds_cur = hz.pool("REBLUR::Data1" + cur).copy().view(np.uint16).reshape(H, W)
-    w_sig, w_speeds_cur, (w0, w1) = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast)
+    w_sig, w_speeds_cur, (w0, w1) = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast, fr["viewz"], fr["normal_roughness"])
     for k in range(2):
         got = np.ascontiguousarray(taps[k][..., 2:4]).view(np.float16).reshape(H, W, 4)
         agree("HistoryFix signal %d" % k, got, w_sig[:, :, k], 0.99)
-        assert np.array_equal(taps[k][..., 0], w0) and np.array_equal(taps[k][..., 1], w1), "guide part of the tap texels"
+        assert np.array_equal(taps[k][..., 0], w0), "guide part of the tap texels: depth | roughness word"
+        assert float((taps[k][..., 1] == w1).mean()) > 0.98 and np.array_equal(taps[k][..., 1] >> 30, w1 >> 30), "guide part of the tap texels: normal | material word"
     for shift in (0, 8):
         a, b = (speeds_cur >> shift) & 255, (w_speeds_cur >> shift) & 255
         assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99
