@@ -19,7 +19,8 @@ SELECTION = [
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens3]",   # RELAX_DIFFUSE_SPECULAR (A-trous LDS windows)
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens9]",   # REBLUR_DIFFUSE_SPECULAR_SH
     "tests/test_kernels_emulated.py::test_emulated_kernels_sky_tiles[dens0]",
-    "tests/test_prepare_inputs.py::test_prepare_inputs_emulated_bit_exact",
+    "tests/test_prepare_inputs.py::test_prepare_inputs_emulated_bit_exact[dens0-WHITE-AREA_5X5]",  # checkerboard + 5x5 hit-distance reconstruction
+    "tests/test_prepare_inputs.py::test_prepare_inputs_emulated_bit_exact[dens1-BLACK-None]",
     "tests/test_settings_variants.py::test_variants_emulated_bit_exact[drs_reblur_sigma]",
     "tests/test_sanitizer.py::test_tiny_frames_emulated",
     "tests/test_tiler_gloo.py::test_row_tiling_emulated_kernels_bit_identical",
