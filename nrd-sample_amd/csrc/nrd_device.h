@@ -72,6 +72,7 @@ struct FrameConsts {
     int ortho; // orthographic projection: view position of pixel (px, gy) = (pv0 + pv2 px, pv1 + pv3 gy, z); pj = {m0, m5, m12, m13, 1}
     int tilesX, tilesY; // tile grid covering the owned rows: tile row 0 starts at local row tileY0 * 16
     int tileY0;
+    int reverse; // 1: every XCD walks its tile sequence backwards (consecutive passes alternate: the reader starts where the writer ended)
     float rot[64][2];
 };
 
@@ -591,9 +592,13 @@ NRD_HD int xcd_grid_blocks(int tilesX, int tilesY) { // launch size: 8 x (larges
     const int rows = xcd_rows(tilesY);
     return xcd_cols(tilesX) * rows * ((tilesY + rows - 1) / rows) * 8;
 }
-NRD_DEV bool xcd_tile_kj(const FrameConsts& c, const int k, const int j, int& tx, int& ty) { // j-th tile of XCD k
+NRD_DEV bool xcd_tile_kj(const FrameConsts& c, const int k, const int jIn, int& tx, int& ty) { // j-th tile of XCD k
     const int cols = xcd_cols(c.tilesX), rows = xcd_rows(c.tilesY);
     const int perBlock = cols * rows;
+    // c.reverse: the launch walks the XCD's tile sequence back to front. A pass that reads what the previous one wrote then starts in
+    // what the 256 MiB Infinity Cache still holds of a 133-266 MB plane instead of chasing the eviction front (which pass runs reversed:
+    // nrdhip.cpp directed(), measured per pass)
+    const int j = c.reverse ? perBlock * ((c.tilesY + rows - 1) / rows) - 1 - jIn : jIn;
     const int by = j / perBlock, jb = j - by * perBlock;
     const int band = (k + 5 * by) & 7; // 5 = -3 mod 8: block (band, by) belongs to XCD (band + 3 by) mod 8
     const int x0 = band * cols, y0 = by * rows;

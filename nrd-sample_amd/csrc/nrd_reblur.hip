@@ -1856,8 +1856,9 @@ void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
 #if defined(NRD_HOST_EMULATION) && !NRD_ORTHO
 // test hook, host-emulated build only (tests/test_tile_traversal.py): the tile that workgroup `block` of a launch over tilesX x
 // tilesY tiles works on (returns 0 when the workgroup is a spare one), and the launch size
-extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of(int tilesX, int tilesY, int tileY0, unsigned block, int* tx, int* ty) {
+extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of(int tilesX, int tilesY, int tileY0, unsigned block, int reverse, int* tx, int* ty) {
     FrameConsts c = {};
+    c.reverse = reverse;
     c.tilesX = tilesX;
     c.tilesY = tilesY;
     c.tileY0 = tileY0;

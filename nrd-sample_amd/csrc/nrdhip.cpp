@@ -398,6 +398,20 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
 }
 
 // ---- dispatch lists ------------------------------------------------------------------------------------------------
+// Direction in which a dispatch walks the tiles (FrameConsts::reverse, nrd_device.h xcd_tile_kj). A reader that walks the frame AGAINST
+// its writer starts in what the 256 MiB Infinity Cache still holds of a 133-266 MB plane; one that follows the writer chases the
+// eviction front. Measured per pass at 4K (profiles/r03_ab_traversal_direction.txt): reversing HistoryFix alone (it reads what
+// TemporalAccumulation wrote, and Blur then reads HistoryFix's tap texels against ITS direction) takes HistoryFix -8 % and Blur -6 %;
+// reversing any other REBLUR pass costs that pass 2-3 % or buys nothing, so the direction is a per-pass property, not an alternation.
+#ifndef NRD_REVERSE_HISTORY_FIX
+#define NRD_REVERSE_HISTORY_FIX 1
+#endif
+template <typename Params>
+Params directed(Params q, bool reverse) {
+    q.c.reverse = reverse ? 1 : 0;
+    return q;
+}
+
 void build_reference(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     using RT = nrd::ResourceType;
     ReferenceParams p;
@@ -654,7 +668,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
-        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
+        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); }; // (plain grid, no direction: does not take part in the alternation)
         d.dispatches.push_back(x);
     }
     const PrepareMode pm = prepare_mode(d, s);
@@ -690,7 +704,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             x.written.push_back(P(rb::DATA1_A + cur));
         } else
             x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
-        x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
+        { auto q = directed(p, NRD_REVERSE_HISTORY_FIX != 0); x.launch = [q](hipStream_t st) { launch_reblur_history_fix(q, st); }; }
         d.dispatches.push_back(x);
     }
     {
@@ -778,7 +792,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"RELAX::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
-        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); };
+        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); }; // (plain grid, no direction: does not take part in the alternation)
         d.dispatches.push_back(x);
     }
     const PrepareMode pm = prepare_mode(d, s);
@@ -808,7 +822,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
                    GB + 2 + 8 * nr + 2 * n + 2 * n + 8 * nr + 2, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur), P(rb::STAB_A + cur)}; // moments: antilag
         x.written = {P(rb::HIST), P(rb::DATA1_A + cur)};
-        x.launch = [p](hipStream_t st) { launch_reblur_history_fix(p, st); };
+        { auto q = directed(p, NRD_REVERSE_HISTORY_FIX != 0); x.launch = [q](hipStream_t st) { launch_reblur_history_fix(q, st); }; }
         d.dispatches.push_back(x);
     }
     AtrousParams a;

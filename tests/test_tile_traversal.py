@@ -10,27 +10,28 @@ import pytest
 @pytest.fixture(scope="module")
 def emu_lib(emulated):
     lib = emulated.lib
-    lib.nrdhip_debug_tile_of.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.nrdhip_debug_tile_of.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     lib.nrdhip_debug_tile_of.restype = ctypes.c_int
     lib.nrdhip_debug_grid_blocks.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.nrdhip_debug_grid_blocks.restype = ctypes.c_uint
     return lib
 
 
-def walk(lib, tiles_x, tiles_y, tile_y0=0):
+def walk(lib, tiles_x, tiles_y, tile_y0=0, reverse=0):
     n = lib.nrdhip_debug_grid_blocks(tiles_x, tiles_y)
     tx, ty = ctypes.c_int(), ctypes.c_int()
     out = []
     for b in range(n):
-        if lib.nrdhip_debug_tile_of(tiles_x, tiles_y, tile_y0, b, ctypes.byref(tx), ctypes.byref(ty)):
+        if lib.nrdhip_debug_tile_of(tiles_x, tiles_y, tile_y0, b, reverse, ctypes.byref(tx), ctypes.byref(ty)):
             out.append((b, tx.value, ty.value))
     return n, out
 
 
 @pytest.mark.parametrize("tiles", [(1, 1), (3, 2), (4, 3), (7, 9), (8, 8), (9, 17), (15, 8), (16, 1), (30, 34), (61, 5), (120, 68), (240, 135)])
-def test_every_tile_exactly_once(emu_lib, tiles):
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_every_tile_exactly_once(emu_lib, tiles, reverse):
     tiles_x, tiles_y = tiles
-    n, seen = walk(emu_lib, tiles_x, tiles_y, tile_y0=3)
+    n, seen = walk(emu_lib, tiles_x, tiles_y, tile_y0=3, reverse=reverse)
     assert n % 8 == 0 and n >= tiles_x * tiles_y
     assert sorted((x, y) for _, x, y in seen) == [(x, y) for x in range(tiles_x) for y in range(3, 3 + tiles_y)]
     assert n <= 8 * ((tiles_x + 7) // 8) * (tiles_y + 8)  # spare workgroups: band rounding + at most one block row of slack per block row
@@ -67,3 +68,16 @@ def test_8k_strips(emu_lib):
     first = [(x, y) for b, x, y in seen if b % 8 == 0][:30 * 34]
     xs = {x for x, _ in first}
     assert max(xs) - min(xs) == 29  # the first strip of XCD 0's first block: 30 tiles wide, all 34 rows of the block before the next strip
+
+
+def test_reverse_walks_each_xcd_back_to_front(emu_lib):
+    """FrameConsts::reverse (HistoryFix): XCD k visits the same tiles as in a forward launch, in the opposite order - the first
+    workgroups of the launch work on the LAST tile rows, which is what the writer before it left in the Infinity Cache"""
+    tiles_x, tiles_y = 240, 135
+    _, fwd = walk(emu_lib, tiles_x, tiles_y)
+    _, rev = walk(emu_lib, tiles_x, tiles_y, reverse=1)
+    for k in range(8):
+        f = [(x, y) for b, x, y in fwd if b % 8 == k]
+        r = [(x, y) for b, x, y in rev if b % 8 == k]
+        assert r == f[::-1]
+    assert min(y for b, x, y in rev if b < 8 * 240) >= tiles_y - 17 - 8  # the first 240 workgroups of every XCD: the bottom block row
