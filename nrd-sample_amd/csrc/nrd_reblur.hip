@@ -108,6 +108,27 @@ NRD_DEV void load_texel(const PlaneRef& P, int x, int y, uint2 (&t)[BYTES / 8]) 
     }
 }
 
+// ... and out in as few stores: the signals of a pixel share one texel, so their results leave together (a memory instruction costs the
+// texture addresser the same 16 cycles per wave whether it carries 8 or 16 bytes per lane)
+template <int BYTES, bool STREAM = false>
+NRD_DEV void store_texel(const PlaneRef& P, int x, int y, const uint2 (&t)[BYTES / 8]) {
+    if constexpr (BYTES == 8) {
+        if (STREAM)
+            st_stream<uint2>(P, x, y, 8, t[0]);
+        else
+            st<uint2>(P, x, y, 8, t[0]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; k++) {
+            const uint4 v = {t[2 * k].x, t[2 * k].y, t[2 * k + 1].x, t[2 * k + 1].y};
+            if (STREAM)
+                st_stream<uint4>(P, x, y, BYTES, v, k * 16);
+            else
+                st<uint4>(P, x, y, BYTES, v, k * 16);
+        }
+    }
+}
+
 // REBLUR / RELAX::Tiles (written by ClassifyTiles): 1 = no pixel of the 16x16 tile has geometry. One byte per tile, same address for
 // the whole workgroup: a scalar value
 #ifndef NRD_SCALAR_TILE_FLAG
@@ -615,6 +636,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    uint2 outw[RBPT / 8];
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
@@ -629,21 +651,22 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         // Blur / PostBlur results are not read again before the gathers of this launch are done (PostBlur's only by the next frame):
         // streamed past the caches, they stop evicting the tap texels (PostBlur -8 %, Blur -4 %). The PrePass result is read by the
         // next kernel at once and travels through the Infinity Cache: a plain store (profiles/r03_ab_setup_planes.txt)
-        if (VARIANT == 0) {
-            st<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
-            if (SH)
-                st<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
-        } else if (TAP && VARIANT == 1) {
+        if (TAP && VARIANT == 1) {
             const uint2 rv = pack_h4(res);
             st_stream<uint4>(p.tapB[isSpec ? 1 : 0], x, y, 16, uint4{ctap[sig].x, ctap[sig].y, rv.x, rv.y});
         } else {
-            st_stream<uint2>(outP, x, y, RBPT, pack_h4(res), sig * sb);
+            outw[sig * (sb / 8)] = pack_h4(res);
             if (SH)
-                st_stream<uint2>(outP, x, y, RBPT, pack_h4(res1), sig * sb + 8);
+                outw[sig * (sb / 8) + 1] = pack_h4(res1);
         }
         if (VARIANT == 0 && isSpec)
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig]));
     }
+    // the signals of the pixel share one texel of the output plane: one store
+    if (VARIANT == 0)
+        store_texel<RBPT, false>(outP, x, y, outw);
+    else if (!(TAP && VARIANT == 1))
+        store_texel<RBPT, true>(outP, x, y, outw);
 }
 
 // =====================================================================================================================
@@ -751,6 +774,12 @@ struct FootRaw {
     uint32_t m[4]; // RELAX: second luma moment history
 };
 NRD_DEV uint32_t load_luma(const PlaneRef& P, int x, int y, int lbpt) { return lbpt == 4 ? ld<uint32_t>(P, x, y, 4) : (uint32_t)ld<uint16_t>(P, x, y, 2); }
+NRD_DEV void store_luma(const PlaneRef& P, int x, int y, int lbpt, uint32_t v) {
+    if (lbpt == 4)
+        st<uint32_t>(P, x, y, 4, v);
+    else
+        st<uint16_t>(P, x, y, 2, (uint16_t)v);
+}
 
 struct FootPos {
     int ix, iy;
@@ -770,6 +799,9 @@ NRD_DEV FootPos foot_pos(const FrameConsts& c, float pu, float pv) {
 }
 template <int RBPT, int LBPT, bool RELAX>
 NRD_DEV void load_foot(const ReblurParams& p, const FootPos& fp, FootRaw<RBPT, LBPT, RELAX>& r) {
+    // one load per texel and plane. Fetching the two texels of a footprint row with ONE texel-aligned wide load (16 bytes at an 8-byte
+    // boundary, a dword at a 2-byte one: 20 memory instructions instead of 32) works and is bit-identical, but the addresser splits
+    // such accesses: TemporalAccumulation +10 %, TemporalStabilization +12 % (profiles/r03_ab_staging_and_pair_loads.txt)
     const FrameConsts& c = p.c;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -839,8 +871,11 @@ NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, flo
     sA *= inv;
 }
 
+#ifndef NRD_TA_WAVES // waves per SIMD the compiler budgets TemporalAccumulation's registers for (REBLUR radiance flavours use 107 VGPRs: 4)
+#define NRD_TA_WAVES 4
+#endif
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
-__global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WAVES) void k_temporal_accumulation(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
@@ -911,6 +946,8 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
     float quality = smbOk ? smb.wsum : 0.0f;
     float outDiffA = 0.0f, outSpecA = 0.0f;
     uint32_t data2 = smbOk ? smb.bits : 0u;
+    uint2 outw[RBPT / 8]; // the signals of the pixel share one texel of Tmp2 / of the fast history: they leave in one store each
+    uint32_t fastw = 0u, m2w = 0u;
 
     if (HAS_DIFF) {
         f4 in = unpack_h4(ctex[0]);
@@ -920,17 +957,17 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         float nonLin = rcp_(1.0f + A);
         f4 hist = smbOk ? blend4(smb, sraw.t, 0) : in;
         float fastHist = smbOk ? blend1(smb, sraw.f, 0) : in.x;
-        st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), 0);
+        outw[0] = pack_h4(lerp4(hist, in, nonLin));
         if (SH) { // SH1 follows SH0: same footprint, same blend factor
             f4 in1 = unpack_h4(ctex[S1]);
             f4 hist1 = smbOk ? blend4(smb, sraw.t, S1) : in1;
-            st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist1, in1, nonLin)), 8);
+            outw[S1] = pack_h4(lerp4(hist1, in1, nonLin));
         }
-        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastA)))), 0);
+        fastw = (uint32_t)f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastA))));
         if (RELAX) { // second luma moment history (lives in the stabilized-luma slots)
             float m2 = in.x * in.x;
             float m2prev = smbOk ? blend1(smb, sraw.m, 0) : m2;
-            st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(m2prev, m2, nonLin)), 0);
+            m2w = (uint32_t)f2h(lerpf(m2prev, m2, nonLin));
         }
         outDiffA = A;
     }
@@ -979,24 +1016,28 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
         float nonLin = rcp_(1.0f + A);
         f4 hist = lerp4(smbHist, vmbHist, amount);
         float fastHist = lerpf(smbFast, vmbFast, amount);
-        st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(hist, in, nonLin)), so);
+        outw[sw] = pack_h4(lerp4(hist, in, nonLin));
         if (SH) {
             f4 in1 = unpack_h4(ctex[sw + S1]);
             f4 smb1 = smbOk ? blend4(smb, sraw.t, sw + S1) : in1;
             f4 vmb1 = vmbOk ? blend4(vmb, vraw.t, sw + S1) : in1;
-            st<uint2>(p.tmp2, x, y, RBPT, pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin)), so + 8);
+            outw[sw + S1] = pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin));
         }
-        st<uint16_t>(p.fast, x, y, LBPT, f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastASpec)))), lo);
+        fastw |= (uint32_t)f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastASpec)))) << (8 * lo);
         if (RELAX) {
             float m2 = in.x * in.x;
             float m2smb = smbOk ? blend1(smb, sraw.m, SIG_SPEC) : m2;
             float m2vmb = vmbOk ? blend1(vmb, vraw.m, SIG_SPEC) : m2;
-            st<uint16_t>(p.stab, x, y, LBPT, f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)), lo);
+            m2w |= (uint32_t)f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)) << (8 * lo);
         }
         outSpecA = A;
         // bits 16..23: reprojection confidence of the specular history (RELAX A-trous edge-stopping relaxation)
         data2 |= (vmbBits << 4) | ((uint32_t)__builtin_floorf(fma_(sat(amount), 255.0f, 0.5f)) << 8) | (RELAX ? (uint32_t)__builtin_floorf(fma_(sat(q), 255.0f, 0.5f)) << 16 : 0u);
     }
+    store_texel<RBPT>(p.tmp2, x, y, outw);
+    store_luma(p.fast, x, y, LBPT, fastw);
+    if (RELAX)
+        store_luma(p.stab, x, y, LBPT, m2w);
     st<uint16_t>(p.data1Tmp, x, y, 2, pack_data1(outDiffA, outSpecA));
     st<uint32_t>(p.data2, x, y, 4, data2);
 }
@@ -1004,25 +1045,21 @@ __global__ __launch_bounds__(256) void k_temporal_accumulation(const ReblurParam
 // =====================================================================================================================
 // 5x5 luma tile in LDS: 20x20 floats, NaN marks "sky / outside" (the consumer substitutes its own centre value)
 // =====================================================================================================================
-// The 400 texels of a 20x20 tile are staged by the 256 threads of the workgroup in two sweeps without a divide: sweep 0 = the
-// thread's own pixel moved to tile position (tx + 0..15, ty + 0..15) of the 20x20 window [-2, 18)^2 ... i.e. window column
-// threadIdx.x, row threadIdx.y; sweep 1 (threads 0..143) = the 4 remaining columns of rows 0..15 and the 4 remaining rows
-NRD_DEV bool tile_pos(int sweep, int tid, int& lx, int& ly) {
-    if (sweep == 0) {
-        lx = tid & 15;
-        ly = tid >> 4;
-        return true;
-    }
+// The 400 texels of a 20x20 tile (window [-2, 18)^2 around the workgroup's 16x16 pixels): the 256 interior positions ARE the threads'
+// own pixels - every thread writes what its centre loads returned to window position (threadIdx + 2), no second load of the same
+// texel (round 3: that sweep was 12-24 bytes per pixel through L1 for values the workgroup already held) - and threads 0..143 each
+// fetch one position of the 2-texel ring: rows 0, 1, 18, 19 (80 positions), then columns 0, 1, 18, 19 of rows 2..17 (64)
+NRD_DEV bool ring_pos(int tid, int& lx, int& ly) {
     if (tid >= 144)
         return false;
-    if (tid < 64) { // columns 16..19 of rows 0..15
-        lx = 16 + (tid & 3);
-        ly = tid >> 2;
-    } else { // rows 16..19, all 20 columns
-        const int k = tid - 64;
-        ly = (k >= 20 ? 1 : 0) + (k >= 40 ? 1 : 0) + (k >= 60 ? 1 : 0);
-        lx = k - ly * 20;
-        ly += 16;
+    if (tid < 80) { // rows 0, 1, 18, 19: all 20 columns
+        const int r = (tid >= 20 ? 1 : 0) + (tid >= 40 ? 1 : 0) + (tid >= 60 ? 1 : 0);
+        lx = tid - r * 20;
+        ly = r + (r >= 2 ? 16 : 0);
+    } else { // columns 0, 1, 18, 19 of rows 2..17
+        const int k = tid - 80, q = k & 3;
+        lx = q + (q >= 2 ? 16 : 0);
+        ly = 2 + (k >> 2);
     }
     return true;
 }
@@ -1105,14 +1142,27 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     const uint32_t fastRaw = p.clampEnabled ? load_luma(p.fast, cxp, cyp, LBPT) : 0u;
     bool holes = false; // some texel of the staged tiles is sky / outside (block-uniform)
     if (p.clampEnabled || p.antiFirefly) {
-        // 20x20 luma tiles of all signals (depth + one luma texel per position, clamped unconditional loads)
+        // 20x20 luma tiles of all signals: the interior from the centre loads, the ring as depth + one luma texel per position
+        // (clamped unconditional loads)
         int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
         int bad = 0;
+        {
+            const int i = ((int)threadIdx.y + 2) * 20 + (int)threadIdx.x + 2;
+            const int gy = y + c.yOff;
+            bool ok = x < c.W && gy >= 0 && gy < c.H && y >= 0 && y < c.resH && absf(u2f(graw.x)) <= c.denoisingRange;
+            bad |= ok ? 0 : 1;
+            const uint32_t l = p.clampEnabled ? fastRaw : load_luma(p.fast, cxp, cyp, LBPT);
 #pragma unroll
-        for (int sweep = 0; sweep < 2; sweep++) {
-            int lx, ly;
-            if (!tile_pos(sweep, tid, lx, ly))
-                continue;
+            for (int sig = 0; sig < NSIG; sig++)
+                tile[sig][i] = ok ? h2f((uint16_t)(l >> (16 * sig))) : u2f(0x7fc00000u);
+            if (p.antiFirefly) {
+#pragma unroll
+                for (int sig = 0; sig < NSIG; sig++)
+                    tileCur[sig][i] = ok ? h2f((uint16_t)ctex[sig * (sb / 8)].x) : u2f(0x7fc00000u);
+            }
+        }
+        int lx, ly;
+        if (ring_pos(tid, lx, ly)) {
             const int i = ly * 20 + lx;
             int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
             bool inside = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
@@ -1340,25 +1390,24 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     const uint32_t data2 = ld<uint32_t>(p.data2, cxp, cyp, 4);
     const uint16_t data1Raw = ld<uint16_t>(p.data1, cxp, cyp, 2);
     const uint16_t hitRaw = HAS_SPEC ? ld<uint16_t>(p.hitTrack, cxp, cyp, 2) : (uint16_t)0;
-    // 20x20 luma tiles of all signals: guide depth + whole radiance texel per position, fetched unconditionally at clamped
-    // coordinates (NaN marks "sky / outside"). The loads go to registers first: the history footprints below only need the
-    // centre loads (issued earlier, so they return earlier) and are issued BEFORE the staged texels are waited for and written to
-    // LDS - centre, staging and footprint traffic overlap instead of forming three dependent round trips.
+    // 20x20 luma tiles of all signals: the interior positions are the threads' own pixels (centre loads above), threads 0..143 fetch
+    // one position of the 2-texel ring each (guide depth + radiance texel, unconditionally at clamped coordinates; NaN marks "sky /
+    // outside"). The ring loads go to registers first: the history footprints below only need the centre loads (issued earlier, so
+    // they return earlier) and are issued BEFORE the ring texels are waited for and written to LDS - centre, ring and footprint
+    // traffic overlap instead of forming three dependent round trips.
     const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-    float stZ[2];
-    uint2 stT[2][RBPT / 8];
-    bool stIn[2], stOn[2];
-    int stI[2];
-#pragma unroll
-    for (int sweep = 0; sweep < 2; sweep++) {
-        int lx = 0, ly = 0;
-        stOn[sweep] = tile_pos(sweep, tid, lx, ly);
-        stI[sweep] = ly * 20 + lx;
-        int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
-        stIn[sweep] = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
+    int rlx = 0, rly = 0;
+    const bool ringOn = ring_pos(tid, rlx, rly);
+    const int ringI = rly * 20 + rlx;
+    float ringZ;
+    uint2 ringT[RBPT / 8];
+    bool ringIn;
+    {
+        int px = tx * 16 + rlx - 2, py = ty * 16 + rly - 2, gy = py + c.yOff;
+        ringIn = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
         int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
-        stZ[sweep] = ld<float>(p.guide, cx, cy, GUIDE_BYTES, 0);
-        load_texel<RBPT>(p.hist, cx, cy, stT[sweep]);
+        ringZ = ld<float>(p.guide, cx, cy, GUIDE_BYTES, 0);
+        load_texel<RBPT>(p.hist, cx, cy, ringT);
     }
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
@@ -1385,15 +1434,20 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     }
     __builtin_amdgcn_sched_barrier(0);
     int bad = 0;
+    {
+        const bool ok = x < c.W && gy0 >= 0 && gy0 < c.H && y >= 0 && y < c.resH && absf(u2f(graw.x)) <= c.denoisingRange;
+        bad |= ok ? 0 : 1;
+        const int i = ((int)threadIdx.y + 2) * 20 + (int)threadIdx.x + 2;
 #pragma unroll
-    for (int sweep = 0; sweep < 2; sweep++) {
-        if (!stOn[sweep])
-            continue;
-        bool ok = stIn[sweep] && absf(stZ[sweep]) <= c.denoisingRange;
+        for (int sig = 0; sig < NSIG; sig++)
+            tile[sig][i] = ok ? h2f((uint16_t)ctex[sig * SW].x) : u2f(0x7fc00000u);
+    }
+    if (ringOn) {
+        const bool ok = ringIn && absf(ringZ) <= c.denoisingRange;
         bad |= ok ? 0 : 1;
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++)
-            tile[sig][stI[sweep]] = ok ? h2f((uint16_t)stT[sweep][sig * SW].x) : u2f(0x7fc00000u);
+            tile[sig][ringI] = ok ? h2f((uint16_t)ringT[sig * SW].x) : u2f(0x7fc00000u);
     }
     const bool holes = __syncthreads_or(bad) != 0; // some texel of the staged tiles is sky / outside (block-uniform)
     if (!live)
@@ -1408,6 +1462,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     for (int sig = 0; sig < NSIG; sig++)
         moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, h2f((uint16_t)ctex[sig * SW].x), holes, m1s[sig], m2s[sig]);
     __builtin_amdgcn_sched_barrier(0);
+    uint32_t stabw = 0u; // stabilized luma of the pixel's signals: one texel, one store
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
@@ -1434,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         f4 o = {Yout, cur.y * scale, cur.z * scale, cur.w};
         if (p.returnHistLen) // OCCLUSION variants: the single output channel reports the normalised history length instead
             o.x = sat(Acur * p.invMaxA);
-        st<uint16_t>(p.stab, x, y, LBPT, f2h(Yout), sig * 2);
+        stabw |= (uint32_t)f2h(Yout) << (16 * sig);
         const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
         const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;
         if (SH && p.dirOcc) {
@@ -1449,6 +1504,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
             st<uint2>(isSpec ? p.outSpec1 : p.outDiff1, x, y, 8, split ? pack_h4(unpack_h4(ld<uint2>(isSpec ? p.inSpec1 : p.inDiff1, x, y, 8))) : pack_h4(o1));
         }
     }
+    store_luma(p.stab, x, y, LBPT, stabw);
 }
 
 // =====================================================================================================================

@@ -406,6 +406,7 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
 #ifndef NRD_REVERSE_HISTORY_FIX
 #define NRD_REVERSE_HISTORY_FIX 1
 #endif
+
 template <typename Params>
 Params directed(Params q, bool reverse) {
     q.c.reverse = reverse ? 1 : 0;
