@@ -179,28 +179,46 @@ NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) 
 // =====================================================================================================================
 // K0 ClassifyTiles + guide packing
 // =====================================================================================================================
+#ifndef NRD_CT_TILES // tiles per ClassifyTiles workgroup (a horizontal run)
+#define NRD_CT_TILES 4
+#endif
 __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     const FrameConsts& c = p.c;
-    // a streaming pass without neighbour reads: plain 2-D grid of tiles (the XCD traversal of the other passes costs a wave ~700
-    // cycles of scalar index arithmetic and buys this pass nothing: 0.0485 -> 0.0462 ms, profiles/r03_ab_setup_planes.txt)
-    // Consecutive workgroups go to the 8 XCDs round robin and two horizontally adjacent tiles share the 128-byte lines of the 4-byte
-    // input planes: within every group of 16 tiles the pairs (2j, 2j + 1) are handed to ONE XCD (workgroups j and j + 8), or each
-    // line is fetched by two L2s (measured: 16 instead of 8 B/px of fetch, profiles/r03v1_hbm_traffic_reblur_ds_4k.json)
-    const int bx = (int)blockIdx.x;
-    const int tx = (bx & ~15) | ((bx & 7) << 1) | ((bx >> 3) & 1), ty = (int)blockIdx.y + c.tileY0;
-    if (tx >= c.tilesX) // (the grid is padded to whole groups of 16; block-uniform exit before the barrier below)
-        return;
-    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
-    bool valid = x < c.W && y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
-    int notSky = 0;
-    if (valid) {
-        float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
-        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
-        notSky = absf(z) <= c.denoisingRange ? 1 : 0;
+    // a streaming pass without neighbour reads: plain 2-D grid (the XCD traversal of the other passes costs a wave ~700 cycles of
+    // scalar index arithmetic and buys this pass nothing: 0.0485 -> 0.0462 ms, profiles/r03_ab_setup_planes.txt). What it waits for is
+    // the one round trip of its two loads, so a workgroup takes a run of NRD_CT_TILES horizontally adjacent tiles - every thread has the
+    // loads of 4 pixels in flight before the first returns - and a run of 4 tiles is two whole 128-byte lines of the 4-byte input
+    // planes per row: no line is fetched by the L2s of two XCDs (what the tile pairing of the one-tile version was for)
+    __shared__ int sGeo[NRD_CT_TILES];
+    const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    if (tid < NRD_CT_TILES)
+        sGeo[tid] = 0;
+    __syncthreads();
+    const int tx0 = (int)blockIdx.x * NRD_CT_TILES, ty = (int)blockIdx.y + c.tileY0;
+    const int y = ty * 16 + (int)threadIdx.y;
+    const bool rowValid = y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
+    float z[NRD_CT_TILES];
+    uint32_t nr[NRD_CT_TILES];
+#pragma unroll
+    for (int k = 0; k < NRD_CT_TILES; k++) {
+        const int x = (tx0 + k) * 16 + (int)threadIdx.x;
+        const bool valid = rowValid && x < c.W;
+        z[k] = valid ? ld<float>(p.inZ, x, y, 4) : 0.0f;
+        nr[k] = valid ? ld<uint32_t>(p.inNR, x, y, 4) : 0u;
     }
-    int any = __syncthreads_or(notSky);
-    if (threadIdx.x == 0 && threadIdx.y == 0)
-        st<uint8_t>(p.tiles, tx, ty, 1, any ? 0 : 1);
+#pragma unroll
+    for (int k = 0; k < NRD_CT_TILES; k++) {
+        const int x = (tx0 + k) * 16 + (int)threadIdx.x;
+        if (rowValid && x < c.W) {
+            const float zs = z[k] * c.viewZScale;
+            st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(zs, nr[k]));
+            if (absf(zs) <= c.denoisingRange)
+                sGeo[k] = 1; // same value from every writer
+        }
+    }
+    __syncthreads();
+    if (tid < NRD_CT_TILES && tx0 + tid < c.tilesX)
+        st<uint8_t>(p.tiles, tx0 + tid, ty, 1, sGeo[tid] ? 0 : 1);
 }
 
 // =====================================================================================================================
@@ -1907,7 +1925,7 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(u
 }
 #endif
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)((p.c.tilesX + 15) / 16 * 16), (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
+    hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)((p.c.tilesX + NRD_CT_TILES - 1) / NRD_CT_TILES), (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
 }
 #if defined(NRD_HOST_EMULATION) && !NRD_ORTHO
 // test hook, host-emulated build only (tests/test_tile_traversal.py): the tile that workgroup `block` of a launch over tilesX x
