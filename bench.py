@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--motion-rows", type=int, default=8, help="row tiling: vertical motion (rows) the stored halo must cover beyond the passes' reach")
     ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip the HIP-graph replay leg (NRDHIP_FLAG_GRAPH), 1-GPU runs")
     ap.add_argument("--no-upstream-leg", action="store_true", help="skip the timed leg on the NRD_UPSTREAM_FORMULAS build flavour, 1-GPU runs")
     ap.add_argument("--no-full-coverage", action="store_true", help="skip the second timed leg (the same scene without sky), 1-GPU runs")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
@@ -386,7 +387,7 @@ def main():
                 out["config"]["full_coverage"] = {"error": str(e)}
         if world == 1 and not args.force_tiled and not args.no_upstream_leg and not args.preset and os.path.exists(pkg.HIP_LIB_UPSTREAM):
             # the price of the frozen simplifications: the same workload through libnrdhip_upstream.so - the build flavour with the
-            # recalled upstream forms of ledger rows 1, 2, 7 (exp(-3|x|) hit-distance weight, arccosine normal weight, per-pixel Blur
+            # recalled upstream forms of ledger rows 1, 2, 7, 13 (exp(-3|x|) hit-distance weight, arccosine normal weight, per-pixel Blur
             # rotation; csrc/nrd_device.h NRD_UPSTREAM_FORMULAS)
             try:
                 hip_up = pkg.hip_backend(dev, flavour="upstream")
@@ -399,11 +400,39 @@ def main():
                 out["config"]["upstream_formulas"] = {
                     "value": round(w * frame_h * args.steps / dt_up / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_up / args.steps * 1e3, 4),
                     "passes_ms": {k: round(v[0], 4) for k, v in pp.items()},
-                    "what": "same workload, libnrdhip_upstream.so: hit-distance weight exp(-3|x|), normal weight on the angle (arccosine), Blur rotation per pixel"}
+                    "what": "same workload, libnrdhip_upstream.so: hit-distance weight exp(-3|x|), normal weight on the angle (arccosine), Blur rotation per pixel, RELAX in linear RGB throughout"}
                 del runner_up, hz_up
                 torch.cuda.empty_cache()
             except Exception as e:
                 out["config"]["upstream_formulas"] = {"error": str(e)}
+        if world == 1 and not args.force_tiled and not args.no_graph_leg and not args.preset:
+            # NRDHIP_FLAG_GRAPH: the frame as ONE HIP graph launch (captured every frame, the executable graph patched with the new kernel
+            # arguments) against pass-by-pass launches, both on the same non-default stream and without per-pass events: on the
+            # workload itself and on the band one rank of 8 holds of the 8K frame (BASELINE config 5), where a frame is ~0.5 ms of
+            # GPU work and the launch thread matters most
+            try:
+                leg = {}
+                side = torch.cuda.Stream(device=dev)
+                for tag, (gw, gh) in (("workload", (w, band_h)), ("band_7680x544", (7680, 544))):
+                    row = {}
+                    for mode in ("direct", "graph"):
+                        scene_g = synth.Scene(gw, gh, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
+                                              roll_deg=args.roll)
+                        hz_g = Harness(hip, dens, gw, gh, graph=(mode == "graph"))
+                        runner_g = SingleRunner(api, hz_g, scene_g, dens, args.unique_frames, settings_of(api, scene_g, dens))
+                        runner_g.never_events = True
+                        torch.cuda.synchronize()
+                        with torch.cuda.stream(side):
+                            dt_g = timed_run(runner_g)
+                        row[mode + "_ms_per_step"] = round(dt_g / args.steps * 1e3, 4)
+                        if mode == "graph":
+                            row["graph_stats"] = hz_g.nrd.graph_stats()
+                        del runner_g, hz_g, scene_g
+                        torch.cuda.empty_cache()
+                    leg[tag] = row
+                out["config"]["graph_replay"] = leg
+            except Exception as e:
+                out["config"]["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:  # reported on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(pkg, den_names, settings_of, dev, w, wl_h)
@@ -523,7 +552,7 @@ class SingleRunner:
         self.names = None
 
     def enable_events(self, on):
-        self.events_on = on
+        self.events_on = on and not getattr(self, "never_events", False)
 
     def sky_fraction(self):
         """share of the frame's pixels beyond the denoising range (first input frame; the dolly moves it by a fraction of a percent)"""

@@ -61,6 +61,7 @@ struct IntegrationCreationDesc {
     bool promoteFloat16to32 = false;                   // not supported
     bool demoteFloat32to16 = false;                    // not supported
     bool autoWaitForIdle = true;                       // ignored
+    bool submitAsGraph = false; // (extension) Denoise replays one HIP graph per frame instead of launching the passes one by one (NRDHIP_FLAG_GRAPH)
 };
 
 class Integration {
@@ -147,7 +148,7 @@ protected:
             return Result::UNSUPPORTED;
         m_Desc = integrationDesc;
         m_Device = device;
-        Result r = CreateInstance(instanceDesc, integrationDesc.resourceWidth, integrationDesc.resourceHeight, m_Instance, 0, device, band);
+        Result r = CreateInstance(instanceDesc, integrationDesc.resourceWidth, integrationDesc.resourceHeight, m_Instance, integrationDesc.submitAsGraph ? NRDHIP_FLAG_GRAPH : 0u, device, band);
         if (r != Result::SUCCESS)
             m_Instance = nullptr;
         return r;

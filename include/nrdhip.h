@@ -36,7 +36,13 @@ typedef struct nrdhip_denoiser_desc {
 } nrdhip_denoiser_desc;
 
 enum {
-    NRDHIP_FLAG_EXTERNAL_POOLS = 1u /* caller allocates pool planes (nrdhip_pool_info + nrdhip_bind_pool) */
+    NRDHIP_FLAG_EXTERNAL_POOLS = 1u, /* caller allocates pool planes (nrdhip_pool_info + nrdhip_bind_pool) */
+    /* nrdhip_denoise submits the frame as ONE HIP graph launch: the dispatch list is stream-captured every frame (no GPU work, a few
+     * microseconds per node), the instance's executable graph takes the new kernel arguments through hipGraphExecUpdate (it is only
+     * re-instantiated when the list changes shape: another denoiser set, a CLEAR_AND_RESTART frame with its clears) and is launched
+     * on the caller's stream. Needs a capturable stream: on the legacy default stream (NULL) the passes are launched one by one as
+     * without the flag. Results are bit-identical either way; nrdhip_graph_stats reports what happened. */
+    NRDHIP_FLAG_GRAPH = 2u
 };
 
 /* == nrd::InstanceCreationDesc + nrd::IntegrationCreationDesc (Source/NRDSample.cpp:924-936).
@@ -100,6 +106,10 @@ NRDHIP_API int nrdhip_bind(nrdhip_instance* inst, uint32_t slot, void* dev_ptr, 
 NRDHIP_API int nrdhip_unbind_all(nrdhip_instance* inst);
 /* nrd::Integration::Denoise (Source/NRDSample.cpp:521): enqueue every pass of the given denoisers on `stream`. */
 NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, void* hip_stream);
+
+/* NRDHIP_FLAG_GRAPH bookkeeping: {frames replayed through the graph, executable graphs instantiated, frames that fell back to direct
+ * launches (default stream, capture unsupported)} */
+NRDHIP_API int nrdhip_graph_stats(nrdhip_instance* inst, uint32_t out[3]);
 
 /* nrd::GetComputeDispatches equivalent (the core API beneath the Integration layer):
  * number of dispatches the given denoisers record this frame, their description, and ranged submission

@@ -364,6 +364,7 @@ class ComposeDesc(C.Structure):
 
 UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH, PACK_DIRECTIONAL_OCCLUSION = 0, 1, 2, 3
 FLAG_EXTERNAL_POOLS = 1
+FLAG_GRAPH = 2  # nrdhip_denoise replays one HIP graph per frame (include/nrdhip.h NRDHIP_FLAG_GRAPH)
 
 
 class NrdError(RuntimeError):
@@ -400,6 +401,8 @@ class Backend:
         self._sig("set_denoiser", C.c_int, [C.c_void_p, _u32, C.c_void_p, C.c_size_t])
         self._sig("bind", C.c_int, [C.c_void_p, _u32, C.c_void_p, _u32, _u32, _u16, _u16])
         self._sig("denoise", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
+        if hasattr(self.lib, self.prefix + "graph_stats"):  # product library (the CPU oracle of the tests has no graphs)
+            self._sig("graph_stats", C.c_int, [C.c_void_p, C.POINTER(_u32)])
         self._sig("dispatch_count", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.POINTER(_u32)])
         self._sig("dispatch_info_get", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, _u32, C.POINTER(DispatchInfo)])
         self._sig("denoise_range", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, _u32, _u32, C.c_void_p])
@@ -479,7 +482,7 @@ class Integration:
         self._bound = {}
 
     # nrd::Integration::Recreate(IntegrationCreationDesc, InstanceCreationDesc, device) -> Result
-    def recreate(self, denoisers, resource_width, resource_height, frame_height=0, band_row0=0, band_own_first=0, band_own_rows=0):
+    def recreate(self, denoisers, resource_width, resource_height, frame_height=0, band_row0=0, band_own_first=0, band_own_rows=0, graph=False):
         """``denoisers``: list of (identifier, Denoiser). Returns Result (SUCCESS or the failure code), never raises for
         library-side failures - the sample tests ``!= SUCCESS`` (Source/NRDSample.cpp:982-983)."""
         self.destroy()
@@ -487,7 +490,7 @@ class Integration:
         dev = self.backend.device
         device_plus1 = int(dev.split(":")[1]) + 1 if isinstance(dev, str) and dev.startswith("cuda:") else 0  # kernels + checks on the device torch allocates on
         desc = CreateDesc(arr, len(denoisers), resource_width, resource_height, frame_height, band_own_first, band_own_rows, device_plus1,
-                          band_row0, FLAG_EXTERNAL_POOLS)
+                          band_row0, FLAG_EXTERNAL_POOLS | (FLAG_GRAPH if graph else 0))
         h = C.c_void_p()
         r = self.backend.create(C.byref(desc), C.byref(h))
         if r != 0:
@@ -564,6 +567,12 @@ class Integration:
     def denoise(self, identifiers):
         ids, n = self._ids(identifiers)
         self._check(self.backend.denoise(self.handle, ids, n, self._stream()), "Denoise")
+
+    def graph_stats(self):
+        """NRDHIP_FLAG_GRAPH bookkeeping: dict(replayed, instantiated, direct)"""
+        out = (_u32 * 3)()
+        self._check(self.backend.graph_stats(self.handle, out), "graph_stats")
+        return dict(replayed=out[0], instantiated=out[1], direct=out[2])
 
     def dispatches(self, identifiers):
         ids, n = self._ids(identifiers)

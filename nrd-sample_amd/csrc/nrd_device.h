@@ -226,7 +226,8 @@ NRD_DEV float atan_pos(float x) {
 }
 
 // NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of four frozen simplifications (oracle/README.md
-// ledger rows 1, 2, 7): hit-distance weight exp(-3 |x|), normal weight on the ANGLE (through an arccosine), Blur rotation per pixel.
+// ledger rows 1, 2, 7, 13): hit-distance weight exp(-3 |x|), normal weight on the ANGLE (through an arccosine), Blur rotation per pixel,
+// RELAX in linear RGB throughout (RELAX_LINEAR_RGB below).
 // It exists to put a price on those deviations (bench.py config.upstream_formulas) and as the switch to flip the day External/NRD is
 // vendored; libnrdhip_upstream.so / liboracle_upstream.so are built from the same sources with -DNRD_UPSTREAM_FORMULAS=1.
 #ifndef NRD_UPSTREAM_FORMULAS
@@ -356,6 +357,21 @@ NRD_DEV f3 ycocg_to_linear(f3 c) {
 NRD_DEV f4 rgb_to_ycocg4(f4 v) {
     f3 c = linear_to_ycocg({v.x, v.y, v.z});
     return {c.x, c.y, c.z, v.w};
+}
+
+// Ledger row 13 (NRD_UPSTREAM_FORMULAS flavour): RELAX keeps its radiance in linear RGB from input to output, as upstream does; the
+// frozen build converts to YCoCg in the PrePass and back in the last A-trous iteration (one code path with REBLUR). Wherever the
+// RELAX passes want the luminance of a texel it is then Rec.709 of the rgb instead of channel 0, and a luminance clamp scales all
+// three channels.
+constexpr bool RELAX_LINEAR_RGB = UPSTREAM_FORMULAS;
+NRD_DEV float luma709(f4 v) { return fma_(v.x, 0.2126f, fma_(v.y, 0.7152f, v.z * 0.0722f)); }
+NRD_DEV float signal_luma(f4 v, bool relax) { return (RELAX_LINEAR_RGB && relax) ? luma709(v) : v.x; }
+NRD_DEV float texel_luma(uint2 texel, bool relax) { return (RELAX_LINEAR_RGB && relax) ? luma709(unpack_h4(texel)) : h2f((uint16_t)texel.x); }
+// luminance Y of `v` replaced by Yc (scale = Yc / Y), chroma (or the rgb ratios) kept
+NRD_DEV void clamp_luma(f4& v, float Yc, float scale, bool relax) {
+    v.x = (RELAX_LINEAR_RGB && relax) ? v.x * scale : Yc;
+    v.y *= scale;
+    v.z *= scale;
 }
 
 NRD_DEV float spec_magic_curve(float roughness) {

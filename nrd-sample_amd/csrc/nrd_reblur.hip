@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         srcPs[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec : &p.inDiff) : &inP;
         srcOffs[sig] = VARIANT == 0 ? 0 : sig * sb;
         f4 center = TAP ? unpack_h4(uint2{ctap[sig].z, ctap[sig].w}) : load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
-        if (relaxIn)
+        if (relaxIn && !RELAX_LINEAR_RGB)
             center = rgb_to_ycocg4(center);
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
         src1Ps[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec1 : &p.inDiff1) : &inP;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
             }
-            if (relaxIn)
+            if (relaxIn && !RELAX_LINEAR_RGB)
                 sv = rgb_to_ycocg4(sv);
             w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA[sig], hitB[sig]))));
             if (VARIANT == 0) {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         f4 res = mul4(sum[sig], invw), res1 = mul4(sum1[sig], invw);
         if (VARIANT == 0 && isSpec && p.prepassTrackOnly) { // pass-through: the centre is fetched again instead of being kept live across the tap loop
             res = load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
-            if (relaxIn)
+            if (relaxIn && !RELAX_LINEAR_RGB)
                 res = rgb_to_ycocg4(res);
             res1 = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
         }
@@ -974,16 +974,17 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
         A *= lerpf(quality, 1.0f, rcp_(1.0f + A));
         float nonLin = rcp_(1.0f + A);
         f4 hist = smbOk ? blend4(smb, sraw.t, 0) : in;
-        float fastHist = smbOk ? blend1(smb, sraw.f, 0) : in.x;
+        const float inY = signal_luma(in, RELAX);
+        float fastHist = smbOk ? blend1(smb, sraw.f, 0) : inY;
         outw[0] = pack_h4(lerp4(hist, in, nonLin));
         if (SH) { // SH1 follows SH0: same footprint, same blend factor
             f4 in1 = unpack_h4(ctex[S1]);
             f4 hist1 = smbOk ? blend4(smb, sraw.t, S1) : in1;
             outw[S1] = pack_h4(lerp4(hist1, in1, nonLin));
         }
-        fastw = (uint32_t)f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastA))));
+        fastw = (uint32_t)f2h(lerpf(fastHist, inY, rcp_(1.0f + fmin2(A, p.maxFastA))));
         if (RELAX) { // second luma moment history (lives in the stabilized-luma slots)
-            float m2 = in.x * in.x;
+            float m2 = inY * inY;
             float m2prev = smbOk ? blend1(smb, sraw.m, 0) : m2;
             m2w = (uint32_t)f2h(lerpf(m2prev, m2, nonLin));
         }
@@ -1018,9 +1019,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
         blendA(vmb, vraw.a, dA, sA);
         float Avmb = vmbOk ? fmin2(sA + 1.0f, p.maxASpec) : 0.0f;
         f4 vmbHist = vmbOk ? blend4(vmb, vraw.t, sw) : in;
-        float vmbFast = vmbOk ? blend1(vmb, vraw.f, SIG_SPEC) : in.x;
+        const float inY = signal_luma(in, RELAX);
+        float vmbFast = vmbOk ? blend1(vmb, vraw.f, SIG_SPEC) : inY;
         f4 smbHist = smbOk ? blend4(smb, sraw.t, sw) : in;
-        float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : in.x;
+        float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : inY;
         if (!smbOk)
             Asmb = 0.0f;
         float A = lerpf(Asmb, Avmb, amount);
@@ -1041,9 +1043,9 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
             f4 vmb1 = vmbOk ? blend4(vmb, vraw.t, sw + S1) : in1;
             outw[sw + S1] = pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin));
         }
-        fastw |= (uint32_t)f2h(lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, p.maxFastASpec)))) << (8 * lo);
+        fastw |= (uint32_t)f2h(lerpf(fastHist, inY, rcp_(1.0f + fmin2(A, p.maxFastASpec)))) << (8 * lo);
         if (RELAX) {
-            float m2 = in.x * in.x;
+            float m2 = inY * inY;
             float m2smb = smbOk ? blend1(smb, sraw.m, SIG_SPEC) : m2;
             float m2vmb = vmbOk ? blend1(vmb, vraw.m, SIG_SPEC) : m2;
             m2w |= (uint32_t)f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)) << (8 * lo);
@@ -1176,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             if (p.antiFirefly) {
 #pragma unroll
                 for (int sig = 0; sig < NSIG; sig++)
-                    tileCur[sig][i] = ok ? h2f((uint16_t)ctex[sig * (sb / 8)].x) : u2f(0x7fc00000u);
+                    tileCur[sig][i] = ok ? texel_luma(ctex[sig * (sb / 8)], p.relax != 0) : u2f(0x7fc00000u);
             }
         }
         int lx, ly;
@@ -1195,7 +1197,8 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             if (p.antiFirefly) {
 #pragma unroll
                 for (int sig = 0; sig < NSIG; sig++)
-                    tileCur[sig][i] = ok ? h2f(ld<uint16_t>(p.tmp2, cx, cy, RBPT, sig * sb)) : u2f(0x7fc00000u);
+                    tileCur[sig][i] = ok ? ((RELAX_LINEAR_RGB && p.relax) ? texel_luma(ld<uint2>(p.tmp2, cx, cy, RBPT, sig * sb), true) : h2f(ld<uint16_t>(p.tmp2, cx, cy, RBPT, sig * sb)))
+                                         : u2f(0x7fc00000u);
             }
         }
         holes = __syncthreads_or(bad) != 0;
@@ -1272,12 +1275,10 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             float m1, m2;
             moments5x5(tile[sig], (int)threadIdx.x, (int)threadIdx.y, fc, holes, m1, m2);
             float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fastHistoryClampingSigmaScale;
-            float Y = val.x;
+            float Y = signal_luma(val, p.relax != 0);
             float Yc = clampf(Y, m1 - sigma, m1 + sigma);
             float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
-            val.x = Yc;
-            val.y *= scale;
-            val.z *= scale;
+            clamp_luma(val, Yc, scale, p.relax != 0);
             val1.x *= scale;
             val1.y *= scale;
             val1.z *= scale;
@@ -1310,12 +1311,10 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
             m1 *= 1.0f / 24.0f;
             m2 *= 1.0f / 24.0f;
             float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * p.fireflyScale;
-            float Y = val.x;
+            float Y = signal_luma(val, p.relax != 0);
             float Yc = clampf(Y, m1 - sigma, m1 + sigma);
             float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
-            val.x = Yc;
-            val.y *= scale;
-            val.z *= scale;
+            clamp_luma(val, Yc, scale, p.relax != 0);
             val1.x *= scale;
             val1.y *= scale;
             val1.z *= scale;
@@ -1676,6 +1675,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     } else
         load_texel<RBPT>(p.in, x, y, ctex);
     f4 c0[NSIG], sum1[NSIG];
+    float c0Y[NSIG]; // luminance of the centre texel
     f3 sum[NSIG];
     float sumVar[NSIG], wsum[NSIG], invL[NSIG], normalW2[NSIG], minLw[NSIG];
     uint32_t minMat[NSIG];
@@ -1688,11 +1688,12 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         minMat[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
         minLw[sig] = p.minLw[si];
         c0[sig] = unpack_h4(ctex[sig * SW]);
+        c0Y[sig] = signal_luma(c0[sig], true);
         sum1[sig] = SH ? unpack_h4(ctex[sig * SW + (SH ? 1 : 0)]) : f4{0, 0, 0, 0};
         float var;
         if (FIRST) {
             float m2 = h2f(LS ? (uint16_t)(sM[ci] >> (16 * sig)) : ld<uint16_t>(p.mom, x, y, LBPT, sig * 2));
-            var = fmax2(fma_(-c0[sig].x, c0[sig].x, m2), 0.0f);
+            var = fmax2(fma_(-c0Y[sig], c0Y[sig], m2), 0.0f);
             if (A[si] < p.histThreshold) { // short history: 3x3 spatial estimate
                 float sy = 0.0f, sy2 = 0.0f, n = 0.0f;
                 for (int j = -1; j <= 1; j++)
@@ -1702,14 +1703,14 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
                             int q = ci + j * T + i;
                             if (!(absf(u2f(sG[q].x)) <= c.denoisingRange))
                                 continue;
-                            Y = h2f((uint16_t)sT[q * TW + sig * SW].x);
+                            Y = texel_luma(sT[q * TW + sig * SW], true);
                         } else {
                             int px = x + i, py = y + j, gy = py + c.yOff;
                             if (px < 0 || px >= c.W || gy < 0 || gy >= c.H || py < 0 || py >= c.resH)
                                 continue;
                             if (!(absf(ld<float>(p.guide, px, py, GUIDE_BYTES, 0)) <= c.denoisingRange))
                                 continue;
-                            Y = h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb));
+                            Y = RELAX_LINEAR_RGB ? texel_luma(ld<uint2>(p.hist, px, py, RBPT, sig * sb), true) : h2f(ld<uint16_t>(p.hist, px, py, RBPT, sig * sb));
                         }
                         sy += Y;
                         sy2 = fma_(Y, Y, sy2);
@@ -1808,8 +1809,8 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
             f4 sv = unpack_h4(stex[k][sig * SW]);
             float vs = sv.w;
             if (FIRST)
-                vs = fmax2(fma_(-sv.x, sv.x, h2f(mraw[k][sig])), 0.0f);
-            w *= fmax2(exp_weight(absf(sv.x - c0[sig].x) * invL[sig]), minLw[sig]);
+                vs = fmax2(fma_(-signal_luma(sv, true), signal_luma(sv, true), h2f(mraw[k][sig])), 0.0f);
+            w *= fmax2(exp_weight(absf(signal_luma(sv, true) - c0Y[sig]) * invL[sig]), minLw[sig]);
             // a rejected tap enters with weight 0 (its texel is a finite value of an internal plane, fetched at the clamped
             // position): one select on the weight instead of one per accumulated component
             w = valid ? w : 0.0f;
@@ -1853,7 +1854,7 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         f3 o = mul3(sum[sig], inv);
         float ov = sumVar[sig] * inv * inv;
         if (last) {
-            f3 rgb = ycocg_to_linear(o);
+            f3 rgb = RELAX_LINEAR_RGB ? f3{fmax2(o.x, 0.0f), fmax2(o.y, 0.0f), fmax2(o.z, 0.0f)} : ycocg_to_linear(o);
             float hitDist = h2f(ld<uint16_t>(p.hist, x, y, RBPT, sig * sb + 6));
             const PlaneRef& op = isSpec ? p.outSpec : p.outDiff;
             const PlaneRef& in = isSpec ? p.inSpec : p.inDiff;

@@ -130,6 +130,8 @@ struct nrdhip_instance {
     size_t transArenaBytes = 0;
     Plane slots[(size_t)nrd::ResourceType::MAX_NUM];
     std::string error;
+    hipGraphExec_t graphExec = nullptr; // NRDHIP_FLAG_GRAPH: the executable graph of the last frame's dispatch list
+    uint32_t graphStats[3] = {0, 0, 0}; // replayed frames, instantiations, direct-launch fallbacks
 };
 
 namespace {
@@ -1189,6 +1191,8 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
                 (void)hipFree(P.p);
     if (inst->transArena)
         (void)hipFree(inst->transArena);
+    if (inst->graphExec)
+        (void)hipGraphExecDestroy(inst->graphExec);
     delete inst;
 }
 
@@ -1473,7 +1477,65 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
     int r = nrdhip_dispatch_count(inst, ids, n, &count);
     if (r)
         return r;
-    return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    if (!(inst->flags & NRDHIP_FLAG_GRAPH))
+        return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    // One graph launch per frame. The kernels take their per-frame constants by value, so the list is captured again every frame -
+    // capture records nodes, it launches nothing - and the executable graph of the previous frame is patched with the new arguments
+    nrdhip_instance& I = *inst;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceScope scope(I.device);
+    if (!st || hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        I.graphStats[2]++;
+        return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    }
+    r = nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (r || e != hipSuccess || !graph) {
+        if (graph)
+            (void)hipGraphDestroy(graph);
+        if (!r) {
+            I.error = std::string("HIP stream capture failed: ") + hipGetErrorString(e);
+            r = (int)nrd::Result::FAILURE;
+        }
+        return r;
+    }
+    if (I.graphExec) {
+        hipGraphNode_t bad = nullptr;
+        hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+        if (hipGraphExecUpdate(I.graphExec, graph, &bad, &res) != hipSuccess || res != hipGraphExecUpdateSuccess) {
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(I.graphExec);
+            I.graphExec = nullptr;
+        }
+    }
+    if (!I.graphExec) {
+        e = hipGraphInstantiate(&I.graphExec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            I.graphExec = nullptr;
+            (void)hipGraphDestroy(graph);
+            I.error = std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e);
+            return (int)nrd::Result::FAILURE;
+        }
+        I.graphStats[1]++;
+    }
+    e = hipGraphLaunch(I.graphExec, st);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        I.error = std::string("hipGraphLaunch failed: ") + hipGetErrorString(e);
+        return (int)nrd::Result::FAILURE;
+    }
+    I.graphStats[0]++;
+    return 0;
+}
+
+NRDHIP_API int nrdhip_graph_stats(nrdhip_instance* inst, uint32_t out[3]) {
+    if (!inst || !out)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    for (int i = 0; i < 3; i++)
+        out[i] = inst->graphStats[i];
+    return 0;
 }
 
 NRDHIP_API int nrdhip_get_memory_mb(nrdhip_instance* inst, float out[3]) {

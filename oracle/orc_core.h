@@ -54,6 +54,8 @@ static inline f4 ld_h4(const Plane& P, int x, int y, int off = 0) {
     std::memcpy(v, texel(P, x, y) + off, 8);
     return {f16_to_f32(v[0]), f16_to_f32(v[1]), f16_to_f32(v[2]), f16_to_f32(v[3])};
 }
+// luminance of the radiance texel at byte offset `off`: its first fp16 (Y of YCoCg), or Rec.709 of the rgb for the linear-RGB RELAX flavour
+static inline float ld_luma(const Plane& P, int x, int y, int off, bool relax) { return (RELAX_LINEAR_RGB && relax) ? luma709(ld_h4(P, x, y, off)) : ld_h(P, x, y, off); }
 static inline void st_f32(const Plane& P, int x, int y, float v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 4); }
 static inline void st_u32(const Plane& P, int x, int y, uint32_t v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 4); }
 static inline void st_u16(const Plane& P, int x, int y, uint16_t v, int off = 0) { std::memcpy(texel(P, x, y) + off, &v, 2); }

@@ -204,8 +204,8 @@ static inline float atan_pos(float x) {
 // acos(x) ~ sqrt(2) * sqrt(1 - x), x in [0, 1] (small-angle exact, monotonic)
 static inline float acos_approx(float x) { return 1.41421356f * sqrtf(sat(1.0f - x)); }
 
-// NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of ledger rows 1, 2 and 7 (oracle/README.md):
-// hit-distance weight exp(-3 |x|), normal weight on the angle, Blur rotation per pixel - liboracle_upstream.so, the checker of
+// NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of ledger rows 1, 2, 7 and 13 (oracle/README.md):
+// hit-distance weight exp(-3 |x|), normal weight on the angle, Blur rotation per pixel, RELAX in linear RGB - liboracle_upstream.so, the checker of
 // libnrdhip_upstream.so (same switch, same formulas: nrd-sample_amd/csrc/nrd_device.h)
 #ifndef NRD_UPSTREAM_FORMULAS
 #define NRD_UPSTREAM_FORMULAS 0
@@ -300,6 +300,17 @@ static inline f3 ycocg_to_linear(f3 c) {
     float t = c.x - c.z;
     f3 r = {t + c.y, c.x + c.z, t - c.y};
     return {fmax2(r.x, 0.0f), fmax2(r.y, 0.0f), fmax2(r.z, 0.0f)};
+}
+
+// ledger row 13 (NRD_UPSTREAM_FORMULAS flavour): RELAX keeps linear RGB internally; the luminance of a RELAX texel is then Rec.709 of
+// its rgb instead of channel 0 (Y of YCoCg), and a luminance clamp scales all three channels
+static const bool RELAX_LINEAR_RGB = UPSTREAM_FORMULAS;
+static inline float luma709(f4 v) { return fma_(v.x, 0.2126f, fma_(v.y, 0.7152f, v.z * 0.0722f)); }
+static inline float signal_luma(f4 v, bool relax) { return (RELAX_LINEAR_RGB && relax) ? luma709(v) : v.x; }
+static inline void clamp_luma(f4& v, float Yc, float scale, bool relax) {
+    v.x = (RELAX_LINEAR_RGB && relax) ? v.x * scale : Yc;
+    v.y *= scale;
+    v.z *= scale;
 }
 
 // (1 - 2^(-200 r^2)) * sqrt(r)   [Shaders/Shared.hlsli:305-311]

@@ -447,7 +447,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
                 f4 center = tap ? tap_signal(ctap[sig]) : load_signal(*io.in[sig], x, y, io.inOff[sig], occIn);
-                if (relaxIn)
+                if (relaxIn && !RELAX_LINEAR_RGB)
                     center = rgb_to_ycocg4(center);
                 f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
                 const f4 center1 = sum1;
@@ -533,7 +533,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         if (variant == PRE && !valid)
                             continue;
                         f4 sv = tap ? tap_signal(tt) : load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
-                        if (relaxIn)
+                        if (relaxIn && !RELAX_LINEAR_RGB)
                             sv = rgb_to_ycocg4(sv);
                         float w = 0.0f;
                         if (valid) {
@@ -807,16 +807,16 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 A *= lerpf(quality, 1.0f, rcp_(1.0f + A));
                 float nonLin = rcp_(1.0f + A);
                 f4 hist = smbOk ? fetch4(k, HIST, sig * sb, smb) : in;
-                float fastHist = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
+                float fastHist = smbOk ? fetch1(k, FASTP, sig * 2, smb) : signal_luma(in, relax);
                 st_h4(OUT, x, y, lerp4(hist, in, nonLin), sig * sb);
                 if (d.sh) { // SH1 follows SH0: same footprint, same blend factor
                     f4 in1 = ld_h4(IN, x, y, sig * sb + 8);
                     f4 hist1 = smbOk ? fetch4(k, HIST, sig * sb + 8, smb) : in1;
                     st_h4(OUT, x, y, lerp4(hist1, in1, nonLin), sig * sb + 8);
                 }
-                st_h(FASTC, x, y, lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, maxFastA))), sig * 2);
+                st_h(FASTC, x, y, lerpf(fastHist, signal_luma(in, relax), rcp_(1.0f + fmin2(A, maxFastA))), sig * 2);
                 if (relax) {
-                    float m2 = in.x * in.x;
+                    float m2 = signal_luma(in, relax) * signal_luma(in, relax);
                     float m2prev = smbOk ? fetch1(k, MOMP, sig * 2, smb) : m2;
                     st_h(MOMC, x, y, lerpf(m2prev, m2, nonLin), sig * 2);
                 }
@@ -839,7 +839,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                 float vu, vv;
                 float amount = 0.0f, Avmb = 0.0f;
                 f4 vmbHist = in;
-                float vmbFast = in.x;
+                float vmbFast = signal_luma(in, relax);
                 Footprint vmb;
                 vmb.bits = 0;
                 vmb.wsum = 0.0f;
@@ -863,7 +863,7 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                     }
                 }
                 f4 smbHist = smbOk ? fetch4(k, HIST, sig * sb, smb) : in;
-                float smbFast = smbOk ? fetch1(k, FASTP, sig * 2, smb) : in.x;
+                float smbFast = smbOk ? fetch1(k, FASTP, sig * 2, smb) : signal_luma(in, relax);
                 if (!smbOk)
                     Asmb = 0.0f;
                 float A = lerpf(Asmb, Avmb, amount);
@@ -886,9 +886,9 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
                     f4 vmb1 = vmb.wsum > 0.0f ? fetch4(k, HIST, sig * sb + 8, vmb) : in1;
                     st_h4(OUT, x, y, lerp4(lerp4(smb1, vmb1, amount), in1, nonLin), sig * sb + 8);
                 }
-                st_h(FASTC, x, y, lerpf(fastHist, in.x, rcp_(1.0f + fmin2(A, maxFastAs))), sig * 2);
+                st_h(FASTC, x, y, lerpf(fastHist, signal_luma(in, relax), rcp_(1.0f + fmin2(A, maxFastAs))), sig * 2);
                 if (relax) {
-                    float m2 = in.x * in.x;
+                    float m2 = signal_luma(in, relax) * signal_luma(in, relax);
                     float m2smb = smbOk ? fetch1(k, MOMP, sig * 2, smb) : m2;
                     float m2vmb = vmb.wsum > 0.0f ? fetch1(k, MOMP, sig * 2, vmb) : m2;
                     st_h(MOMC, x, y, lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin), sig * 2);
@@ -1019,12 +1019,10 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     m1 *= 1.0f / 25.0f;
                     m2 *= 1.0f / 25.0f;
                     float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * s.fastHistoryClampingSigmaScale;
-                    float Y = val.x;
+                    float Y = signal_luma(val, relax);
                     float Yc = clampf(Y, m1 - sigma, m1 + sigma);
                     float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
-                    val.x = Yc;
-                    val.y *= scale;
-                    val.z *= scale;
+                    clamp_luma(val, Yc, scale, relax);
                     val1.x *= scale;
                     val1.y *= scale;
                     val1.z *= scale;
@@ -1046,7 +1044,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                 // ---- anti-firefly (enableAntiFirefly, sample UI Source/NRDSample.cpp:1515-1582): luma clamped to the moments of the
                 // 5x5 neighbourhood of the incoming signal WITHOUT its centre, chroma (and SH1) re-scaled with it
                 if (s.enableAntiFirefly) {
-                    float cc = ld_h(IN, x, y, sig * sb);
+                    float cc = ld_luma(IN, x, y, sig * sb, relax);
                     float m1 = 0.0f, m2 = 0.0f;
                     for (int j = -2; j <= 2; j++)
                         for (int i = -2; i <= 2; i++) {
@@ -1057,7 +1055,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                             if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
                                 float zt = ld_f32(G, px, py, 0);
                                 if (absf(zt) <= c.denoisingRange)
-                                    f = ld_h(IN, px, py, sig * sb);
+                                    f = ld_luma(IN, px, py, sig * sb, relax);
                             }
                             m1 += f;
                             m2 = fma_(f, f, m2);
@@ -1065,12 +1063,10 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                     m1 *= 1.0f / 24.0f;
                     m2 *= 1.0f / 24.0f;
                     float sigma = sqrt_(fmax2(fma_(-m1, m1, m2), 0.0f)) * s.fireflySuppressorMinRelativeScale;
-                    float Y = val.x;
+                    float Y = signal_luma(val, relax);
                     float Yc = clampf(Y, m1 - sigma, m1 + sigma);
                     float scale = (Yc + 1e-6f) * rcps_(Y + 1e-6f);
-                    val.x = Yc;
-                    val.y *= scale;
-                    val.z *= scale;
+                    clamp_luma(val, Yc, scale, relax);
                     val1.x *= scale;
                     val1.y *= scale;
                     val1.z *= scale;
@@ -1314,11 +1310,12 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 float rough = isSpec ? g.roughness : 1.0f;
                 uint32_t minMat = isSpec ? s.minMaterialForSpecular : s.minMaterialForDiffuse;
                 f4 c0 = ld_h4(IN, x, y, sig * sb);
+                const float c0Y = signal_luma(c0, true); // luminance of the centre texel
                 f4 sum1 = d.sh ? ld_h4(IN, x, y, sig * sb + 8) : f4{0, 0, 0, 0};
                 float var;
                 if (it == 0) {
                     float m2 = ld_h(MOM, x, y, sig * 2);
-                    var = fmax2(fma_(-c0.x, c0.x, m2), 0.0f);
+                    var = fmax2(fma_(-c0Y, c0Y, m2), 0.0f);
                     if (A[isSpec ? 1 : 0] < histThreshold) { // short history: 3x3 spatial estimate
                         float sy = 0.0f, sy2 = 0.0f, n = 0.0f;
                         for (int j = -1; j <= 1; j++)
@@ -1328,7 +1325,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                                     continue;
                                 if (!(absf(ld_f32(G, px, py, 0)) <= c.denoisingRange))
                                     continue;
-                                float Y = ld_h(HIST, px, py, sig * sb);
+                                float Y = ld_luma(HIST, px, py, sig * sb, true);
                                 sy += Y;
                                 sy2 = fma_(Y, Y, sy2);
                                 n += 1.0f;
@@ -1386,7 +1383,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         f4 sv = ld_h4(IN, cpx, cpy, sig * sb);
                         float vs = sv.w;
                         if (it == 0)
-                            vs = fmax2(fma_(-sv.x, sv.x, ld_h(MOM, cpx, cpy, sig * 2)), 0.0f);
+                            vs = fmax2(fma_(-signal_luma(sv, true), signal_luma(sv, true), ld_h(MOM, cpx, cpy, sig * 2)), 0.0f);
                         float w = 0.0f;
                         if (valid) {
                             w = (i == 0 || j == 0) ? 0.5f : 0.25f;
@@ -1396,7 +1393,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                                 float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 w *= relaxEdges ? lerpf(1.0f, rw, roughRelax) : rw;
                             }
-                            w *= fmax2(exp_weight(absf(sv.x - c0.x) * invL), minLw);
+                            w *= fmax2(exp_weight(absf(signal_luma(sv, true) - c0Y) * invL), minLw);
                         }
                         sum = {fma_(sv.x, w, sum.x), fma_(sv.y, w, sum.y), fma_(sv.z, w, sum.z)};
                         if (d.sh)
@@ -1408,7 +1405,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                 f3 o = mul3(sum, inv);
                 float ov = sumVar * inv * inv;
                 if (last) {
-                    f3 rgb = ycocg_to_linear(o);
+                    f3 rgb = RELAX_LINEAR_RGB ? f3{fmax2(o.x, 0.0f), fmax2(o.y, 0.0f), fmax2(o.z, 0.0f)} : ycocg_to_linear(o);
                     float hitDist = ld_h(HIST, x, y, sig * sb + 6);
                     st_h4(*outSlot[sig], x, y, split ? ld_h4(*inSlot[sig], x, y) : f4{rgb.x, rgb.y, rgb.z, hitDist});
                     if (d.sh)

@@ -58,6 +58,19 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullpt
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+// graphs: not emulated - capture reports "unsupported" and the host code takes its direct-launch path
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeThreadLocal = 1 };
+enum hipGraphExecUpdateResult { hipGraphExecUpdateSuccess = 0 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return 1; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 1; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphExecUpdate(hipGraphExec_t, hipGraph_t, hipGraphNode_t*, hipGraphExecUpdateResult*) { return 1; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return 1; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
 
 namespace hipemu {
 struct Idx {

@@ -1,6 +1,7 @@
-"""The NRD_UPSTREAM_FORMULAS build flavour (csrc/nrd_device.h, oracle/orc_math.h): the recalled upstream forms of three frozen
+"""The NRD_UPSTREAM_FORMULAS build flavour (csrc/nrd_device.h, oracle/orc_math.h): the recalled upstream forms of four frozen
 simplifications - hit-distance weight exp(-3 |x|) instead of (1 - |x|)^2, normal weight on the angle (arccosine) instead of the
-squared angle, Blur rotation per pixel instead of per 2x2 quad (oracle/README.md ledger rows 1, 2, 7). Same sources, own libraries
+squared angle, Blur rotation per pixel instead of per 2x2 quad, RELAX in linear RGB from input to output instead of YCoCg inside
+(oracle/README.md ledger rows 1, 2, 7, 13). Same sources, own libraries
 (libnrdhip_upstream.so, liboracle_upstream.so); it exists to put a price on those deviations (bench.py config.upstream_formulas)
 and must be as exact against ITS oracle as the default flavour is against its own."""
 import numpy as np
@@ -37,6 +38,37 @@ def test_upstream_flavour_differs_from_the_frozen_one(pkg, api, oracle, oracle_u
         print("%s: frozen vs upstream-formulas flavour PSNR %.1f dB, %.1f %% of the values differ by more than 1 fp16 ULP" % (
             key, p, 100.0 * float((np.abs(util.f16_ordered(a.output(key)) - util.f16_ordered(b.output(key))) > 1).mean())))
         assert 25.0 < p < 80.0
+
+
+def test_upstream_relax_stays_in_linear_rgb(pkg, api, oracle, oracle_upstream, emulated_upstream):
+    """ledger row 13: with anti-firefly and fast-history clamping on (the luminance clamps that must scale r, g and b alike) the emulated
+    kernels of the flavour match its oracle bit for bit; against the frozen YCoCg-inside build the outputs differ, by how much is
+    printed; and a GREY input stays grey to the last bit - in linear RGB no chroma channel exists that rounding could tint"""
+    dens = ["RELAX_DIFFUSE_SPECULAR"]
+    scene = pkg.synth.Scene(72, 40, dolly=0.04, denoiser="RELAX")
+    dd = [api.Denoiser[x] for x in dens]
+    st = {dd[0]: api.RelaxSettings(enableAntiFirefly=True, minMaterialForDiffuse=0, minMaterialForSpecular=1)}
+    ho = util.run_frames(api, pkg.harness, oracle_upstream, scene, dd, 3, settings=st)
+    he = util.run_frames(api, pkg.harness, emulated_upstream, scene, dd, 3, settings=st)
+    assert util.compare_all(ho, he, exact=True) == []
+    hf = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st)
+    for key in ("out_diff", "out_spec"):
+        x, y = hf.output(key).astype(np.float32), ho.output(key).astype(np.float32)
+        assert not np.array_equal(x, y)
+        print("%s: RELAX YCoCg-inside vs linear-RGB flavour PSNR %.1f dB" % (key, util.psnr(x, y)))
+        assert util.psnr(x, y) > 25.0
+
+    def grey(f, fr):
+        for key in ("diff", "spec"):
+            v = fr[key].copy()
+            v[..., 1] = v[..., 0]
+            v[..., 2] = v[..., 0]
+            fr[key] = v
+
+    hg = util.run_frames(api, pkg.harness, oracle_upstream, scene, dd, 3, settings=st, frame_hook=grey)
+    for key in ("out_diff", "out_spec"):
+        o = hg.output(key)
+        assert np.array_equal(o[..., 0], o[..., 1]) and np.array_equal(o[..., 0], o[..., 2]), key
 
 
 @pytest.mark.gpu
