@@ -12,8 +12,9 @@ its <= 2 row neighbours between passes (SURVEY.md 8e scheme A) through torch.dis
 round-1 mode: every rank owns a full band of the workload's height (a W x (H N) frame).
 
 One JSON line on stdout (rank 0). `roofline` is computed for the slowest kernel from HIP events recorded on the launch
-stream around every dispatch of every 4th step of the timed region (--event-stride; the event records themselves idle the
-GPU for ~40 us per frame, so the remaining steps enqueue the frame exactly as the sample would, with one Denoise call); `cpu_baseline` times the CPU oracle (a scalar C++ port, oracle/) on a
+stream around every dispatch of every 8th step of the timed region (--event-stride; the 14 event records idle the GPU for
+~90 us of such a frame - measured r3: 0.998 ms per frame without any, 1.021 at stride 4 - so the remaining steps enqueue the
+frame exactly as the sample would, with one Denoise call); `cpu_baseline` times the CPU oracle (a scalar C++ port, oracle/) on a
 bounded sample of the same workload on this box's host cores - a reported baseline, not the target.
 """
 import argparse
@@ -74,10 +75,10 @@ def parse():
     ap.add_argument("--checkerboard", action="store_true",
                     help="the sample's default operating point (tracingMode RESOLUTION_HALF): half-width checkerboarded inputs, "
                          "CheckerboardMode::WHITE -> the PrepareInputs pass runs (single-GPU runner)")
-    ap.add_argument("--event-stride", type=int, default=4,
+    ap.add_argument("--event-stride", type=int, default=8,
                     help="record the per-dispatch HIP events on every S-th timed step (1 = every step); the other steps enqueue the frame "
-                         "with one Denoise call. 14 event records per frame cost ~40 us of GPU idle time between the seven kernels "
-                         "(measured: 5200 -> 5340 Mpix/s at stride 4), which is instrumentation, not pipeline")
+                         "with one Denoise call. 14 event records per frame cost ~90 us of GPU idle time between the seven kernels "
+                         "(measured r3 at 4K: 0.998 ms per frame with no events, 1.021 ms at stride 4), which is instrumentation, not pipeline")
     ap.add_argument("--atrous", type=int, default=0, help="RELAX: atrousIterationNum override (2..8; BASELINE config 4 also asks for an 8-iteration stress run)")
     a = ap.parse_args()
     if a.workload is None:

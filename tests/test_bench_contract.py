@@ -23,7 +23,7 @@ def test_pingpong_camera_path_is_continuous():
 
 def test_traffic_lookup_reads_the_newest_committed_counter_table():
     px = 3840 * 2160
-    for name, algorithmic_bpp in (("REBLUR::Blur", 50), ("REBLUR::ClassifyTiles", 24)):
+    for name, algorithmic_bpp in (("REBLUR::Blur", 50), ("REBLUR::ClassifyTiles", 16)):
         t = bench.measured_traffic("reblur_ds_4k", name)
         assert isinstance(t, int) and 0.8 * algorithmic_bpp * px < t < 2.0 * algorithmic_bpp * px, (name, t)
     assert bench.measured_traffic("reblur_ds_4k", "REBLUR::NoSuchPass") is None

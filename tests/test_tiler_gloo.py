@@ -92,7 +92,7 @@ def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
 def test_row_tiling_emulated_kernels_bit_identical(tmp_path, pkg, api, oracle, emulated):
     """the kernel sources themselves (compiled for the host) on two bands: rows stored at a band offset, nrdhip_denoise_rows strips,
     halo rows owned by the neighbour - against the single-instance oracle run"""
-    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 448, "default", "emu", w=48)
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 448, "default", "emu", w=32, nframes=2)
 
 
 @pytest.mark.gpu
