@@ -179,9 +179,6 @@ NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) 
 // =====================================================================================================================
 // K0 ClassifyTiles + guide packing
 // =====================================================================================================================
-#ifndef NRD_EARLY_CENTRE // 1: PrePass / TemporalAccumulation issue their centre loads together with the guide load (before the sky test)
-#define NRD_EARLY_CENTRE 1
-#endif
 #ifndef NRD_CT_TILES // tiles per ClassifyTiles workgroup (a horizontal run)
 #define NRD_CT_TILES 4
 #endif
@@ -386,33 +383,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         for (int sig = 0; sig < NSIG; sig++)
             ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
     }
-    const uint2 graw0 = TAP ? uint2{ctap[0].x, ctap[0].y} : ld_guide(p.guide, x, y);
-    // PrePass, radiance inputs: the centre texels of the noisy inputs travel WITH the guide texel instead of after the sky test that
-    // needs it (one dependent round trip less at the start of every wave); the compiler barrier keeps the loads above the branch
-    // without making anybody wait for them
-    constexpr bool EARLY = NRD_EARLY_CENTRE != 0 && VARIANT == 0 && MODE == 0;
-    uint2 craw[NSIG];
-    if (EARLY) {
-#pragma unroll
-        for (int sig = 0; sig < NSIG; sig++)
-            craw[sig] = ld<uint2>((HAS_SPEC && sig == SIG_SPEC) ? p.inSpec : p.inDiff, x, y, 8);
-    }
-    // Blur / PostBlur: the accumulation speeds and Blur's per-quad rotation (a per-lane read of the 64-entry table in the kernel
-    // arguments) need nothing but the pixel position either. Without the barrier the compiler splits the 16-byte tap-texel loads,
-    // fetches the guide halves, branches on the sky test and only then fetches the signal halves, the speeds and the rotation: one more
-    // dependent round trip before the first tap can be issued
-    const int gy0 = y + c.yOff;
-    // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
-    // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
-    constexpr bool PER_PIXEL = VARIANT == 1;
-    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x >> BLUR_ROTATION_SHIFT : 0u, PER_PIXEL ? (uint32_t)gy0 >> BLUR_ROTATION_SHIFT : 0u, c.frameIndex, (uint32_t)VARIANT + 1u); // one rotation per 2x2 quad
-    float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
-    uint16_t data1Raw = 0;
-    if (VARIANT != 0)
-        data1Raw = ld_stream<uint16_t>(p.data1, x, y, 2);
-    if (NRD_EARLY_CENTRE != 0)
-        asm volatile("" ::: "memory");
-    Guide g = decode_guide(graw0, c.denoisingRange);
+    Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             if (TAP && VARIANT == 1) { // the guide part travels on (PostBlur takes its sky test from it)
@@ -427,6 +398,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
             st<uint16_t>(p.hitTrack, x, y, 2, (uint16_t)0);
         return;
     }
+    const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
     const f3 ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
     f3 V = to_viewer(pg.Xv);
@@ -441,9 +413,14 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         kvz = c.pj[3] - nv * c.pj[4];
     }
     float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
+    // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
+    // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
+    constexpr bool PER_PIXEL = VARIANT == 1;
+    uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x >> BLUR_ROTATION_SHIFT : 0u, PER_PIXEL ? (uint32_t)gy0 >> BLUR_ROTATION_SHIFT : 0u, c.frameIndex, (uint32_t)VARIANT + 1u); // one rotation per 2x2 quad
+    float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
     float diffA = 0.0f, specA = 0.0f;
     if (VARIANT != 0)
-        unpack_data1(data1Raw, diffA, specA);
+        unpack_data1(ld_stream<uint16_t>(p.data1, x, y, 2), diffA, specA);
     // tap window (global pixel coordinates): within `reach` of the centre, inside the frame and inside the held rows
     const int loX = imax(x - reach, 0), hiX = imin(x + reach, c.W - 1);
     const int loY = imax(gy0 - reach, imax(c.yOff, 0)), hiY = imin(gy0 + reach, imin(c.yOff + c.resH, c.H) - 1);
@@ -468,7 +445,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         minMats[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
         srcPs[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec : &p.inDiff) : &inP;
         srcOffs[sig] = VARIANT == 0 ? 0 : sig * sb;
-        f4 center = TAP ? unpack_h4(uint2{ctap[sig].z, ctap[sig].w}) : (EARLY ? unpack_h4(craw[sig]) : load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn));
+        f4 center = TAP ? unpack_h4(uint2{ctap[sig].z, ctap[sig].w}) : load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
         if (relaxIn && !RELAX_LINEAR_RGB)
             center = rgb_to_ycocg4(center);
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
@@ -927,19 +904,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
     int x, y, tx, ty;
     if (!my_pixel_w(c, x, y, tx, ty))
         return;
-    const uint2 graw0 = ld_guide(p.guide, x, y);
-    // the centre texels travel with the guide texel, not after the sky test that needs it (see k_spatial)
-    constexpr bool EARLY = NRD_EARLY_CENTRE != 0;
-    uint2 ctex[RBPT / 8];
-    uint2 mvTexel = {0u, 0u};
-    uint16_t hitRaw = 0;
-    if (EARLY) {
-        load_texel<RBPT>(p.tmp1, x, y, ctex);
-        mvTexel = ld<uint2>(p.inMV, x, y, 8);
-        hitRaw = HAS_SPEC ? ld<uint16_t>(p.hitTrack, x, y, 2) : (uint16_t)0;
-        asm volatile("" ::: "memory");
-    }
-    Guide g = decode_guide(graw0, c.denoisingRange);
+    Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb);
@@ -954,13 +919,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
         return;
     }
     // ---- centre loads
-    if (!EARLY) {
-        load_texel<RBPT>(p.tmp1, x, y, ctex);
-        mvTexel = ld<uint2>(p.inMV, x, y, 8);
-        hitRaw = HAS_SPEC ? ld<uint16_t>(p.hitTrack, x, y, 2) : (uint16_t)0;
-    }
-    f4 mvRaw = unpack_h4(mvTexel);
-    float hitDist = HAS_SPEC ? h2f(hitRaw) : 0.0f;
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.tmp1, x, y, ctex);
+    f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
+    float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     float confD = (HAS_DIFF && c.confAvail) ? sample_confidence(p.confD, u, v) : 1.0f;
