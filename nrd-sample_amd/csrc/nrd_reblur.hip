@@ -179,6 +179,9 @@ NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) 
 // =====================================================================================================================
 // K0 ClassifyTiles + guide packing
 // =====================================================================================================================
+#ifndef NRD_SKIP_SKY_TILES // 1: PrePass, TemporalAccumulation and PostBlur write nothing in tiles without geometry
+#define NRD_SKIP_SKY_TILES 1
+#endif
 #ifndef NRD_CT_TILES // tiles per ClassifyTiles workgroup (a horizontal run)
 #define NRD_CT_TILES 4
 #endif
@@ -377,6 +380,20 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
     // (Blur: tapA -> tapB, PostBlur: tapB -> History) - one gather per tap, and the centre's guide comes from its own texel
     constexpr bool TAP = VARIANT != 0 && MODE == 0;
     const PlaneRef* tapIn = VARIANT == 1 ? p.tapA : p.tapB;
+    // A tile without geometry (ClassifyTiles: Tiles = 1, one scalar load per workgroup). Nobody reads what PrePass or PostBlur would
+    // write there: Tmp1 / the hit tracker are read at the thread's own pixel only, by passes that skip the tile as well, and the
+    // history is read through footprints and 5x5 windows that test the guide first and select (or weigh with an exact 0 a plane
+    // that only ever holds finite values). So they write nothing - a pixel beyond the denoising range used to cost these two passes
+    // 34 + 48 bytes of traffic, a third of what a pixel with geometry costs. Blur must keep the tap texels of the tile current (PostBlur's
+    // taps take their sky test from the guide inside the texel): it copies the guide texel in, without reading HistoryFix's texels.
+    if (NRD_SKIP_SKY_TILES && (VARIANT != 1 || TAP) && tile_is_sky(p, tx, ty)) {
+        if (VARIANT == 1) {
+            const uint2 gsky = ld_guide(p.guide, x, y);
+            for (int sig = 0; sig < NSIG; sig++)
+                st_stream<uint4>(p.tapB[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16, uint4{gsky.x, gsky.y, 0u, 0u});
+        }
+        return;
+    }
     uint4 ctap[NSIG];
     if (TAP) {
 #pragma unroll
@@ -903,6 +920,11 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
     const FrameConsts& c = p.c;
     int x, y, tx, ty;
     if (!my_pixel_w(c, x, y, tx, ty))
+        return;
+    // a tile without geometry: Tmp2, the fast history, Data1Tmp and Data2 of its pixels are read by nobody who has not tested the guide
+    // first (HistoryFix skips the tile, its reconstruction taps and 5x5 windows test the tap's depth; next frame's footprints weigh a
+    // texel beyond the range with an exact 0) - nothing to write (k_spatial has the full argument)
+    if (NRD_SKIP_SKY_TILES && tile_is_sky(p, tx, ty))
         return;
     Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {

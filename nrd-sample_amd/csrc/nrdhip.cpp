@@ -1451,7 +1451,9 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                     return (int)nrd::Result::UNSUPPORTED;
                 }
             }
-        if ((part & NRDHIP_PART_FIRST) && fl[i].index == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART)
+        // (also before the very first frame of a denoiser, whatever the mode: passes leave the tiles without geometry unwritten, and a history
+        // texel nobody has ever written must still hold a finite value - caller-allocated pools arrive with whatever the allocator left)
+        if ((part & NRDHIP_PART_FIRST) && fl[i].index == 0 && (I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART || !d.historyValid))
             for (uint32_t k = d.permBase; k < d.permEnd; k++)
                 (void)hipMemset2DAsync(I.perm[k].p, I.perm[k].pitch, 0, (size_t)I.perm[k].w * I.perm[k].bpt, I.perm[k].h, st);
         if (!(part & 4u)) {

@@ -498,7 +498,7 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                 I.error = std::string("output slot not bound for pass ") + p.name;
                 return (int)nrd::Result::INVALID_ARGUMENT;
             }
-        if ((part & NRDHIP_PART_FIRST) && fl[i].passIndex == 0 && I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART) {
+        if ((part & NRDHIP_PART_FIRST) && fl[i].passIndex == 0 && (I.common.accumulationMode == nrd::AccumulationMode::CLEAR_AND_RESTART || !d.historyValid)) {
             // clear this denoiser's permanent planes (history content is discarded)
             uint32_t end = (uint32_t)I.perm.size();
             for (auto& o : I.denoisers)

@@ -399,8 +399,13 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const bool occIn = k.d.occlusion && variant == PRE && !prepare_mode(k.d).any; // PrepareInputs already expanded them to {h, 0, 0, h}
     const bool sh = k.d.sh;
     const bool tap = variant != PRE && tap_texels(k.d); // Blur / PostBlur on tap texels: io.in[sig] (and Blur's io.out[sig]) are tap planes
+    const Plane& TILES = k.trans(T_TILES);
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
+            // a tile without geometry (ClassifyTiles): PrePass and PostBlur write nothing there - what they would write is read by nobody
+            // who has not tested the guide first (csrc/nrd_reblur.hip k_spatial). Blur keeps the tap texels of the tile current (below).
+            if ((variant == PRE || variant == POST) && *texel(TILES, x >> 4, y >> 4))
+                continue;
             TapTexel ctap[2] = {};
             if (tap)
                 for (int sig = 0; sig < k.d.nsig; sig++)
@@ -759,6 +764,8 @@ void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y
     const Plane& MOMC = k.perm(P_STAB_A + k.cur);
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
+            if (*texel(k.trans(T_TILES), x >> 4, y >> 4)) // a tile without geometry: nothing to write (csrc/nrd_reblur.hip k_temporal_accumulation)
+                continue;
             Guide g = load_guide(G, x, y, c.denoisingRange);
             if (g.sky) {
                 for (int sig = 0; sig < d.nsig; sig++) {
