@@ -61,3 +61,53 @@ def test_emulated_kernels_sky_tiles(pkg, api, oracle, emulated, dens):
         assert util.compare_all(ho, he, exact=True) == []
         tiles = np.asarray(he.pool(("RELAX" if dens[0].startswith("RELAX") else "REBLUR") + "::Tiles"))
         assert tiles.max() == 1 and tiles.min() == 0  # the run had sky tiles and geometry tiles
+
+
+@pytest.mark.parametrize("dens,kw", [(["REBLUR_DIFFUSE_SPECULAR"], dict(enableAntiFirefly=True)), (["RELAX_DIFFUSE_SPECULAR"], {}),
+                                     (["REBLUR_DIFFUSE_SPECULAR_SH"], {}), (["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], {})])
+def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, kw):
+    """PrePass, TemporalAccumulation and PostBlur write nothing in tiles without geometry (csrc/nrd_reblur.hip k_spatial): whatever
+    their planes - and every other internal plane - hold at pixels beyond the denoising range must not matter. Two instances of the
+    emulated kernels run the same frames; in one of them every internal plane except the guides is overwritten, before every frame,
+    with random FINITE fp16 bit patterns at the pixels that are beyond the range in the previous AND the current frame (a texel that
+    had geometry a frame ago holds history the reprojection is entitled to). Every output of every frame must be bit-identical: no
+    pass consumes such a texel other than through a test of the guide that selects it out, or with a weight of exactly 0."""
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    for roll, (w, h) in ((0.0, (40, 104)), (90.0, (104, 40))):
+        scene = pkg.synth.Scene(w, h, dolly=0.06, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR", roll_deg=roll)
+        dd = [api.Denoiser[x] for x in dens]
+        st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1, **kw)
+        if dens[0].startswith("RELAX"):
+            st = {dd[0]: api.RelaxSettings(enableAntiFirefly=True, minMaterialForDiffuse=0, minMaterialForSpecular=1)}
+        ha = pkg.harness.Harness(emulated, dd, w, h)
+        hb = pkg.harness.Harness(emulated, dd, w, h)
+        prev_sky = None
+        poisoned = 0
+        for f in range(5):
+            fr = scene.frame(f)
+            cs = scene.common_settings(api, fr, f, reset=(f == 0))
+            sky = np.abs(fr["viewz"].astype(np.float32) * float(cs.viewZScale)) > float(cs.denoisingRange)
+            if prev_sky is not None:
+                both = sky & prev_sky
+                for pool in (0, 1):
+                    for p in hb.nrd.pools[pool]:
+                        if "Guide" in p["name"] or p["height"] != h or p["width"] != w:
+                            continue
+                        words = p["bpt"] // 2
+                        if words == 0:
+                            continue
+                        arr = p["buf"].view(np.uint16).reshape(h, -1)[:, : w * words].reshape(h, w, words)
+                        junk = rng.integers(0, 1 << 16, size=arr.shape, dtype=np.uint16)
+                        junk = np.where((junk & 0x7c00) == 0x7c00, junk & np.uint16(0xbbff), junk)  # no Inf / NaN: finite fp16 only
+                        arr[both] = junk[both]
+                        poisoned += int(both.sum())
+            prev_sky = sky
+            ha.frame(cs, ha.upload(fr), st)
+            hb.frame(cs, hb.upload(fr), st)
+            for key in ha.outputs:
+                assert np.array_equal(ha.fetch(ha.outputs[key]), hb.fetch(hb.outputs[key])), (roll, f, key)
+        assert poisoned > 0
+        tiles = np.asarray(hb.pool(("RELAX" if dens[0].startswith("RELAX") else "REBLUR") + "::Tiles"))
+        assert tiles.max() == 1 and tiles.min() == 0
