@@ -633,6 +633,38 @@ NRD_DEV bool xcd_tile_kj(const FrameConsts& c, const int k, const int jIn, int& 
     ty = y0 + tyl + c.tileY0;
     return true;
 }
+// The 400 texels of a 20x20 tile (window [-2, 18)^2 around the workgroup's 16x16 pixels): the 256 interior positions ARE the threads'
+// own pixels - every thread writes what its centre loads returned to window position (threadIdx + 2), no second load of the same
+// texel (round 3: that sweep was 12-24 bytes per pixel through L1 for values the workgroup already held) - and threads 0..143 each
+// fetch one position of the 2-texel ring: rows 0, 1, 18, 19 (80 positions), then columns 0, 1, 18, 19 of rows 2..17 (64)
+NRD_DEV bool ring_pos(int tid, int& lx, int& ly) {
+    if (tid >= 144)
+        return false;
+    if (tid < 80) { // rows 0, 1, 18, 19: all 20 columns
+        const int r = (tid >= 20 ? 1 : 0) + (tid >= 40 ? 1 : 0) + (tid >= 60 ? 1 : 0);
+        lx = tid - r * 20;
+        ly = r + (r >= 2 ? 16 : 0);
+    } else { // columns 0, 1, 18, 19 of rows 2..17
+        const int k = tid - 80, q = k & 3;
+        lx = q + (q >= 2 ? 16 : 0);
+        ly = 2 + (k >> 2);
+    }
+    return true;
+}
+
+// One 16-bit word of a per-tile plane through the SCALAR data path (same address for the whole workgroup; constant address space:
+// s_load_dword of the aligned word that holds it): the flag does not queue in the in-order vector memory counter with the workgroup's loads
+NRD_DEV uint32_t ld_tile_u16(const PlaneRef& P, int tx, int ty) {
+#ifdef NRD_HOST_EMULATION
+    return (uint32_t)ld<uint16_t>(P, tx, ty, 2);
+#else
+    const uintptr_t a = (uintptr_t)P.p + texel_offset(P, tx, ty, 2, 0);
+    typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+    const uint32_t w = *(const_u32_ptr)(a & ~(uintptr_t)3);
+    return (w >> ((uint32_t)(a & 2) * 8u)) & 0xffffu;
+#endif
+}
+
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) { // one 16 x 16 workgroup per tile
     const int b = (int)blockIdx.x;
     return xcd_tile_kj(c, b & 7, b >> 3, tx, ty);

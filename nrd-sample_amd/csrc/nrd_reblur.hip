@@ -1087,24 +1087,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
 // =====================================================================================================================
 // 5x5 luma tile in LDS: 20x20 floats, NaN marks "sky / outside" (the consumer substitutes its own centre value)
 // =====================================================================================================================
-// The 400 texels of a 20x20 tile (window [-2, 18)^2 around the workgroup's 16x16 pixels): the 256 interior positions ARE the threads'
-// own pixels - every thread writes what its centre loads returned to window position (threadIdx + 2), no second load of the same
-// texel (round 3: that sweep was 12-24 bytes per pixel through L1 for values the workgroup already held) - and threads 0..143 each
-// fetch one position of the 2-texel ring: rows 0, 1, 18, 19 (80 positions), then columns 0, 1, 18, 19 of rows 2..17 (64)
-NRD_DEV bool ring_pos(int tid, int& lx, int& ly) {
-    if (tid >= 144)
-        return false;
-    if (tid < 80) { // rows 0, 1, 18, 19: all 20 columns
-        const int r = (tid >= 20 ? 1 : 0) + (tid >= 40 ? 1 : 0) + (tid >= 60 ? 1 : 0);
-        lx = tid - r * 20;
-        ly = r + (r >= 2 ? 16 : 0);
-    } else { // columns 0, 1, 18, 19 of rows 2..17
-        const int k = tid - 80, q = k & 3;
-        lx = q + (q >= 2 ? 16 : 0);
-        ly = 2 + (k >> 2);
-    }
-    return true;
-}
+// (ring_pos - which thread fetches which position of the 2-texel ring of a 20x20 window - lives in nrd_device.h: SIGMA uses it too)
 
 // `holes` is block-uniform: false when every texel of the staged 20x20 tile is valid (the common case), and the per-tap NaN test
 // of the substitution is dropped - the sums are the same either way

@@ -17,13 +17,18 @@ constexpr int BLUR_REACH = 56; // (int)(48 * 1.1) + 3
 constexpr float PREV_NORMAL_COS = 0.7f;
 constexpr float STAB_SIGMA_SCALE = 2.0f;
 
-NRD_DEV f4 input_visibility(const SigmaParams& p, int x, int y, float pen) {
+// visibility of an input texel from its penumbra and (SIGMA_SHADOW_TRANSLUCENCY) its IN_TRANSLUCENCY texel `t`
+NRD_DEV f4 visibility_of(const SigmaParams& p, float pen, uint32_t t) {
     if (pen >= NRD_FP16_MAX)
         return {1, 1, 1, 1};
     if (!p.translucency)
         return {0, 0, 0, 0};
-    uint32_t t = ld<uint32_t>(p.inTransl, x, y, 4);
     return {0.0f, (float)((t >> 8) & 255u) * (1.0f / 255.0f), (float)((t >> 16) & 255u) * (1.0f / 255.0f), (float)(t >> 24) * (1.0f / 255.0f)};
+}
+NRD_DEV f4 input_visibility(const SigmaParams& p, int x, int y, float pen) {
+    if (pen >= NRD_FP16_MAX || !p.translucency)
+        return visibility_of(p, pen, 0u);
+    return visibility_of(p, pen, ld<uint32_t>(p.inTransl, x, y, 4));
 }
 
 NRD_DEV uint32_t encode_shadow(f4 v) {
@@ -42,18 +47,21 @@ NRD_DEV f4 decode_shadow(uint32_t p) {
 __global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams p) {
     __shared__ float smax[4];
     const FrameConsts& c = p.c;
-    int tx, ty;
-    if (!xcd_tile(c, tx, ty))
-        return;
+    // a streaming pass without neighbour reads: plain 2-D grid of tiles (like REBLUR's ClassifyTiles: the XCD traversal's ~700 cycles of
+    // scalar index arithmetic buy it nothing), and the penumbra texel travels with depth and normal instead of after the range test
+    const int tx = (int)blockIdx.x, ty = (int)blockIdx.y + c.tileY0;
     int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
     bool valid = x < c.W && y < c.resH && (y + c.yOff) < c.H && (y + c.yOff) >= 0;
     int shadowed = 0, lit = 0;
     float r = 0.0f;
     if (valid) {
-        float z = ld<float>(p.inZ, x, y, 4) * c.viewZScale;
-        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, ld<uint32_t>(p.inNR, x, y, 4)));
+        const float zRaw = ld<float>(p.inZ, x, y, 4);
+        const uint32_t nr = ld<uint32_t>(p.inNR, x, y, 4);
+        const uint16_t penRaw = ld<uint16_t>(p.inPen, x, y, 2);
+        float z = zRaw * c.viewZScale;
+        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, nr));
         if (absf(z) <= c.denoisingRange) {
-            float pen = h2f(ld<uint16_t>(p.inPen, x, y, 2));
+            float pen = h2f(penRaw);
             if (pen >= NRD_FP16_MAX)
                 lit = 1;
             else {
@@ -122,10 +130,12 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
         return;
     }
     float absZ = absf(z);
+    // (round 3: fetching guide, penumbra and signal texels in one batch, ahead of the range test, measured +3 % - like every other
+    // attempt to trade dependent round trips for bytes in these kernels; only the tile word moved, to the scalar data path)
     float pen = h2f(ld<uint16_t>(inPen, x, y, 2));
     bool lit = PASS == 0 ? pen >= NRD_FP16_MAX : !(pen > 0.0f);
     f4 center = PASS == 0 ? input_visibility(p, x, y, pen) : unpack_h4(ld<uint2>(p.shadow1, x, y, 8));
-    uint32_t tile = ld<uint16_t>(p.tilesSmooth, tx, ty, 2);
+    const uint32_t tile = ld_tile_u16(p.tilesSmooth, tx, ty);
     if (!(tile & 1u)) {
         st<uint2>(outSh, x, y, 8, pack_h4(center));
         if (PASS == 0)
@@ -218,73 +228,68 @@ NRD_DEV void store_out(const SigmaParams& p, int x, int y, uint32_t packed) {
         st<uint32_t>(p.out, x, y, 4, packed);
 }
 
-__global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const SigmaParams p) {
-    __shared__ uint2 tile[400]; // RGBA16F texels, 0xffffffff marks "sky / outside"
+// Two kernels over the same grid, each taking the tiles of its kind and leaving at once on the others: COPY = tiles without penumbra
+// in reach (most of a frame), a streaming copy that wants many waves in flight (17 VGPRs: 8 waves per SIMD); !COPY = the stabilization
+// proper, which keeps 25 window texels + two footprints in registers and runs at 3 waves per SIMD. As ONE kernel the copy tiles ran at
+// the register budget of the heavy path: 1.6 TB/s for a 24 B/px copy.
+template <bool COPY>
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(COPY ? 8 : 2) void k_sigma_temporal_stabilization(const SigmaParams p) {
+    __shared__ uint2 tile[COPY ? 1 : 400]; // RGBA16F texels, 0xffffffff marks "sky / outside"
     const FrameConsts& c = p.c;
     int tx, ty;
     if (!xcd_tile(c, tx, ty))
         return;
-    // tile check (block-uniform): no penumbra in this tile or its 8 neighbours (SmoothTiles) -> every texel of the 5x5 windows
-    // is an unfiltered lit / umbra value: nothing to stabilize, the history simply follows the signal - a streaming copy
-    if (!(ld<uint16_t>(p.tilesSmooth, tx, ty, 2) & 1u)) {
-        int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
-        if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
+    const int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
+    const bool live = x < c.W && y >= c.ownY0 && y < c.ownY1;
+    // tile check (block-uniform, scalar load): no penumbra in this tile or its 8 neighbours (SmoothTiles) -> every texel of the 5x5
+    // windows is an unfiltered lit / umbra value: nothing to stabilize, the history simply follows the signal - a streaming copy
+    const bool copyTile = !(ld_tile_u16(p.tilesSmooth, tx, ty) & 1u);
+    if (copyTile != COPY)
+        return;
+    if constexpr (COPY) {
+        if (!live)
             return;
         float u = ((float)x + 0.5f) * c.invW;
         bool split = u < c.splitScreen;
         float z = ld<float>(p.guide, x, y, GUIDE_BYTES, 0);
+        const uint2 sh = ld<uint2>(p.shadow2, x, y, 8);
         bool sky = !(absf(z) <= c.denoisingRange);
-        uint32_t packed = sky ? 0u : encode_shadow(unpack_h4(ld<uint2>(p.shadow2, x, y, 8)));
+        uint32_t packed = sky ? 0u : encode_shadow(unpack_h4(sh));
         st<uint32_t>(p.hist, x, y, 4, packed);
         store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : packed);
         return;
+    } else {
+    // Round 3: what this kernel waits for is memory round trips (it used to make about ten dependent ones: staging guide -> staging
+    // texel, twice, barrier, centre guide -> centre texel -> motion vector -> four footprint guides -> four history texels). Now three:
+    // (1) the centre loads of the pixel and the ring of the 20x20 window - the 256 interior positions ARE the threads' own pixels, staged
+    // from the centre loads -, all unconditional at clamped coordinates; (2) the footprint: four guide and four history texels at
+    // clamped positions, validated with selects afterwards; (3) nothing - the 5x5 moments are read from LDS while (2) travels.
+    const int cxp = imin(x, c.W - 1), cyp = imin(imax(y, 0), c.resH - 1); // clamped: threads outside the frame still stage
+    const uint2 graw = ld_guide(p.guide, cxp, cyp);
+    const uint2 craw = ld<uint2>(p.shadow2, cxp, cyp, 8);
+    const uint2 mvTexel = ld<uint2>(p.inMV, cxp, cyp, 8);
+    const uint32_t mixRaw = c.mixAvail ? (uint32_t)ld<uint8_t>(p.inMix, cxp, cyp, 1) : 0u;
+    const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    int rlx = 0, rly = 0;
+    const bool ringOn = ring_pos(tid, rlx, rly);
+    float ringZ;
+    uint2 ringT;
+    bool ringIn;
+    {
+        const int px = tx * 16 + rlx - 2, py = ty * 16 + rly - 2, gy = py + c.yOff;
+        ringIn = px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH;
+        const int cx = imin(imax(px, 0), c.W - 1), cy = imin(imax(py, 0), c.resH - 1);
+        ringZ = ld<float>(p.guide, cx, cy, GUIDE_BYTES, 0);
+        ringT = ld<uint2>(p.shadow2, cx, cy, 8);
     }
-    int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
-    for (int i = tid; i < 400; i += 256) {
-        int lx = i % 20, ly = i / 20;
-        int px = tx * 16 + lx - 2, py = ty * 16 + ly - 2, gy = py + c.yOff;
-        uint2 val = uint2{0xffffffffu, 0xffffffffu};
-        if (px >= 0 && px < c.W && gy >= 0 && gy < c.H && py >= 0 && py < c.resH) {
-            float zt = ld<float>(p.guide, px, py, GUIDE_BYTES, 0);
-            if (absf(zt) <= c.denoisingRange)
-                val = ld<uint2>(p.shadow2, px, py, 8);
-        }
-        tile[i] = val;
-    }
-    __syncthreads();
-    int x = tx * 16 + (int)threadIdx.x, y = ty * 16 + (int)threadIdx.y;
-    if (!(x < c.W && y >= c.ownY0 && y < c.ownY1))
-        return;
+    // ---- reprojection of the centre, footprint loads
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     bool split = u < c.splitScreen;
-    uint2 graw = ld_guide(p.guide, x, y);
     float z = u2f(graw.x);
-    if (!(absf(z) <= c.denoisingRange)) {
-        st<uint32_t>(p.hist, x, y, 4, 0u);
-        store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : 0u);
-        return;
-    }
-    f4 cur = unpack_h4(ld<uint2>(p.shadow2, x, y, 8));
-    float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 5; j++)
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            uint2 raw = tile[((int)threadIdx.y + j) * 20 + (int)threadIdx.x + i];
-            f4 f = raw.x == 0xffffffffu && raw.y == 0xffffffffu ? cur : unpack_h4(raw);
-            m1[0] += f.x;
-            m2[0] = fma_(f.x, f.x, m2[0]);
-            m1[1] += f.y;
-            m2[1] = fma_(f.y, f.y, m2[1]);
-            m1[2] += f.z;
-            m2[2] = fma_(f.z, f.z, m2[2]);
-            m1[3] += f.w;
-            m2[3] = fma_(f.w, f.w, m2[3]);
-        }
     Guide g = decode_guide(graw, c.denoisingRange);
     f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
-    f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
+    f4 mvRaw = unpack_h4(mvTexel);
     f3 Xw = rot3(c.v2w, Xv);
     f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
     float su, sv;
@@ -302,45 +307,87 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
         else
             XvPrev = rot3(c.w2vPrev, sub3(Xw, cd));
     }
+    float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
+    float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
+    float fx = px - fx0, fy = py - fy0;
+    // (a sky / outside pixel or an unusable position computes harmless clamped addresses; NaN compares false: not sane)
+    const bool sane = c.historyOk && uvOk && fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
+    const int ix = sane ? (int)fx0 : -4, iy = sane ? (int)fy0 : -4;
+    uint2 fg[4];
+    uint32_t fh[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ttx = imin(imax(ix + (i & 1), 0), c.Wprev - 1), tty = imin(imax(iy + (i >> 1) - c.yOff, 0), c.resH - 1);
+        fg[i] = ld_guide(p.guidePrev, ttx, tty);
+        fh[i] = ld<uint32_t>(p.histPrev, ttx, tty, 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the 20x20 window: interior from the centre loads, ring from the ring loads
+    {
+        const bool ok = x < c.W && gy0 >= 0 && gy0 < c.H && y >= 0 && y < c.resH && absf(z) <= c.denoisingRange;
+        tile[((int)threadIdx.y + 2) * 20 + (int)threadIdx.x + 2] = ok ? craw : uint2{0xffffffffu, 0xffffffffu};
+    }
+    if (ringOn)
+        tile[rly * 20 + rlx] = (ringIn && absf(ringZ) <= c.denoisingRange) ? ringT : uint2{0xffffffffu, 0xffffffffu};
+    __syncthreads();
+    if (!live)
+        return;
+    if (!(absf(z) <= c.denoisingRange)) {
+        st<uint32_t>(p.hist, x, y, 4, 0u);
+        store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : 0u);
+        return;
+    }
+    f4 cur = unpack_h4(craw);
+    float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            uint2 raw = tile[((int)threadIdx.y + j) * 20 + (int)threadIdx.x + i];
+            f4 f = raw.x == 0xffffffffu && raw.y == 0xffffffffu ? cur : unpack_h4(raw);
+            m1[0] += f.x;
+            m2[0] = fma_(f.x, f.x, m2[0]);
+            m1[1] += f.y;
+            m2[1] = fma_(f.y, f.y, m2[1]);
+            m1[2] += f.z;
+            m2[2] = fma_(f.z, f.z, m2[2]);
+            m1[3] += f.w;
+            m2[3] = fma_(f.w, f.w, m2[3]);
+        }
     f4 hist = cur;
     bool have = false;
-    if (c.historyOk && uvOk) {
+    if (sane) {
         f3 NvPrev = rot3(c.w2vPrev, g.n);
         float thrBase = c.disocclusionThreshold;
         if (c.mixAvail) // per-pixel blend toward disocclusionThresholdAlternate
-            thrBase = lerpf(thrBase, c.disoccAlt, (float)ld<uint8_t>(p.inMix, x, y, 1) * (1.0f / 255.0f));
+            thrBase = lerpf(thrBase, c.disoccAlt, (float)mixRaw * (1.0f / 255.0f));
         float threshold = thrBase * c.minRectDimMulUnproject * zpersp(absf(XvPrev.z));
-        float px = fma_(su, (float)c.Wprev, -0.5f), py = fma_(sv, (float)c.Hprev, -0.5f);
-        float fx0 = __builtin_floorf(px), fy0 = __builtin_floorf(py);
-        float fx = px - fx0, fy = py - fy0;
-        bool sane = fx0 >= -2.0f && fx0 <= (float)c.Wprev + 1.0f && fy0 >= -2.0f && fy0 <= (float)c.Hprev + 1.0f;
-        if (sane) {
-            int ix = (int)fx0, iy = (int)fy0;
-            float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
-            float planeRef = dot3(NvPrev, XvPrev);
-            float g0 = ORTHO ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
-            float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
-            f4 sum = {0, 0, 0, 0};
-            float wsum = 0.0f;
+        float bw[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+        float planeRef = dot3(NvPrev, XvPrev);
+        float g0 = ORTHO ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
+        float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
+        f4 sum = {0, 0, 0, 0};
+        float wsum = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
-                if (ttx < 0 || ttx >= c.Wprev || gy < 0 || gy >= c.Hprev || tty < 0 || tty >= c.resH)
-                    continue;
-                Guide gp = decode_guide(ld_guide(p.guidePrev, ttx, tty), c.denoisingRange);
-                if (gp.sky)
-                    continue;
-                float lin = fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
-                float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin;
-                if (!(absf(plane - planeRef) <= threshold) || !(dot3(g.n, gp.n) > PREV_NORMAL_COS))
-                    continue;
-                sum = fma4(decode_shadow(ld<uint32_t>(p.histPrev, ttx, tty, 4)), bw[i], sum);
-                wsum += bw[i];
-            }
-            if (wsum > 0.0f) {
-                hist = mul4(sum, 1.0f / wsum);
-                have = true;
-            }
+        for (int i = 0; i < 4; i++) {
+            int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
+            bool ok = !(ttx < 0 || ttx >= c.Wprev || gy < 0 || gy >= c.Hprev || tty < 0 || tty >= c.resH);
+            Guide gp = decode_guide(fg[i], c.denoisingRange);
+            float lin = fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
+            float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin;
+            ok = ok && !gp.sky && absf(plane - planeRef) <= threshold && dot3(g.n, gp.n) > PREV_NORMAL_COS;
+            // a rejected texel is selected out (the history plane holds RGBA8: any bit pattern decodes to finite values, but the sums
+            // must see exactly the texels the oracle adds)
+            const f4 acc = fma4(decode_shadow(fh[i]), bw[i], sum);
+            sum.x = ok ? acc.x : sum.x; // (component by component: a select of the whole struct goes through scratch memory)
+            sum.y = ok ? acc.y : sum.y;
+            sum.z = ok ? acc.z : sum.z;
+            sum.w = ok ? acc.w : sum.w;
+            wsum = ok ? wsum + bw[i] : wsum;
+        }
+        if (wsum > 0.0f) {
+            hist = mul4(sum, 1.0f / wsum);
+            have = true;
         }
     }
     float w = have ? p.maxStab / (1.0f + p.maxStab) : 0.0f;
@@ -355,6 +402,7 @@ __global__ __launch_bounds__(256) void k_sigma_temporal_stabilization(const Sigm
     uint32_t packed = encode_shadow({o[0], o[1], o[2], o[3]});
     st<uint32_t>(p.hist, x, y, 4, packed);
     store_out(p, x, y, split ? encode_shadow(input_visibility(p, x, y, h2f(ld<uint16_t>(p.inPen, x, y, 2)))) : packed);
+    }
 }
 
 // REFERENCE: running mean in an RGBA32F history (Source/NRDSample.cpp:4213-4224; in place, :484-485)
@@ -384,7 +432,7 @@ NRD_KERNELS_END
 namespace NRD_PROJ_NS {
 
 void launch_sigma_classify_tiles(const SigmaParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_sigma_classify_tiles, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+    hipLaunchKernelGGL(k_sigma_classify_tiles, dim3((unsigned)p.c.tilesX, (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
 }
 void launch_sigma_smooth_tiles(const SigmaParams& p, hipStream_t s) {
     int total = p.c.tilesX * p.c.tilesY;
@@ -397,7 +445,8 @@ void launch_sigma_blur(const SigmaParams& p, int pass, hipStream_t s) {
         hipLaunchKernelGGL(k_sigma_blur<1>, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
 }
 void launch_sigma_temporal_stabilization(const SigmaParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_sigma_temporal_stabilization, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
+    hipLaunchKernelGGL(k_sigma_temporal_stabilization<true>, grid_for(p.c), dim3(16, 16, 1), 0, s, p);  // tiles without penumbra in reach: copy
+    hipLaunchKernelGGL(k_sigma_temporal_stabilization<false>, grid_for(p.c), dim3(16, 16, 1), 0, s, p); // the others (disjoint tiles: any order)
 }
 void launch_reference_accumulate(const ReferenceParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_reference_accumulate, grid_for(p.c), dim3(16, 16, 1), 0, s, p);
