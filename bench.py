@@ -25,6 +25,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / tensor sharing across ranks fails with the legacy mode)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
