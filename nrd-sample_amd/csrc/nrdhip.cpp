@@ -408,6 +408,9 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
 #ifndef NRD_REVERSE_HISTORY_FIX
 #define NRD_REVERSE_HISTORY_FIX 1
 #endif
+#ifndef NRD_ATROUS_ALTERNATE // 1: odd RELAX A-trous iterations walk the tiles back to front when the planes outgrow the Infinity Cache
+#define NRD_ATROUS_ALTERNATE 1
+#endif
 
 template <typename Params>
 Params directed(Params q, bool reverse) {
@@ -895,7 +898,12 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             push_signal_slots(d, x.read, false);
         } else
             x.written = {T(rb::AT_A + (it & 1))};
-        AtrousParams ap = a;
+        // An iteration reads the whole plane the previous one wrote. When that plane is larger than what the 256 MiB Infinity Cache keeps of
+        // it (SH texels at 4K: 266 MB), odd iterations walk the tiles back to front and start in what is still cached: iterations 1-4
+        // -3 ... -6 % (RELAX_DIFFUSE_SPECULAR_SH 4K +1.9 %). A 133 MB plane is still there whichever end the reader starts at: no gain,
+        // no reversal (profiles/r03_ab_traversal_direction.txt). Iteration 0 reads what the reversed HistoryFix wrote: forward.
+        const bool alternate = (uint64_t)I.resW * (uint64_t)I.resH * (uint64_t)(8u * d.nsig * (d.sh ? 2u : 1u)) > (192ull << 20);
+        AtrousParams ap = directed(a, NRD_ATROUS_ALTERNATE != 0 && alternate && (it & 1) != 0);
         x.launch = [ap](hipStream_t st) { launch_relax_atrous(ap, st); };
         d.dispatches.push_back(x);
     }
