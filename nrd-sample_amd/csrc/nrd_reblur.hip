@@ -520,7 +520,6 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
         float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
-        float normalW2 = nw_param(normalW);
         m2w2[sig] = nw_param_m2(normalW);
         float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
         hitA[sig] = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
@@ -1013,7 +1012,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
         outDiffA = A;
     }
     if (HAS_SPEC) {
-        constexpr int so = SIG_SPEC * sb, sw = SIG_SPEC * SW;
+        constexpr int sw = SIG_SPEC * SW;
         constexpr int lo = SIG_SPEC * 2;
         f4 in = unpack_h4(ctex[sw]);
         f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
