@@ -34,6 +34,12 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_TAP_DEPTH
 #define NRD_TAP_DEPTH NRD_PIPE_DEPTH
 #endif
+#ifndef NRD_PRE_DEPTH // taps in flight: REBLUR radiance PrePass
+#define NRD_PRE_DEPTH 2
+#endif
+#ifndef NRD_POST_DEPTH // taps in flight: PostBlur on tap texels
+#define NRD_POST_DEPTH 4
+#endif
 #ifndef NRD_PRE_WAVES // PrePass: waves per SIMD
 #define NRD_PRE_WAVES 4
 #endif
@@ -548,7 +554,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
     if (anyRadius) { // uniform (kernel argument)
         constexpr int NT = 8 * NSIG;
         // PrePass (hit-distance tracking state) and the SH flavours (a second radiance texel per tap) carry more registers per tap
-        constexpr int DEPTH_WANTED = (VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? NRD_TAP_DEPTH : NRD_PIPE_DEPTH);
+        // Re-tuned at the end of round 3 (profiles/r03_ab_pipeline_depth.txt): with the 8-byte guide and the tap texels the radiance PrePass
+        // is fastest with 2 taps in flight (78 VGPRs, 6 waves per SIMD: -6 % against 5 taps / 4 waves) and PostBlur with 4 (-2.3 %); Blur
+        // stays at 8; RELAX's radiance PrePass: 3 (-3 %). The SH and OCCLUSION flavours keep round 2's depths (SH Blur at 3 or 2: +6 %).
+        constexpr int DEPTH_WANTED = (VARIANT == 0 && MODE == 0) ? NRD_PRE_DEPTH : (VARIANT == 0 && MODE == 1) ? 3 : ((VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? (VARIANT == 2 ? NRD_POST_DEPTH : NRD_TAP_DEPTH) : NRD_PIPE_DEPTH));
         constexpr int DEPTH = DEPTH_WANTED < NT ? DEPTH_WANTED : NT;
         const PlaneBuf guideB = plane_buf(p.guide, c.yOff);
         PlaneBuf srcB[NSIG], src1B[NSIG];
