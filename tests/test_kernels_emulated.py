@@ -75,7 +75,7 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
     import numpy as np
 
     rng = np.random.default_rng(7)
-    for roll, (w, h) in ((0.0, (40, 104)), (90.0, (104, 40))):
+    for roll, (w, h) in (((0.0, (40, 104)), (90.0, (104, 40))) if dens[0] == "REBLUR_DIFFUSE_SPECULAR" else ((0.0, (40, 72)),)):  # (the emulated kernels are slow)
         scene = pkg.synth.Scene(w, h, dolly=0.06, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR", roll_deg=roll)
         dd = [api.Denoiser[x] for x in dens]
         st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1, **kw)
@@ -85,7 +85,7 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
         hb = pkg.harness.Harness(emulated, dd, w, h)
         prev_sky = None
         poisoned = 0
-        for f in range(4):
+        for f in range(3):
             fr = scene.frame(f)
             cs = scene.common_settings(api, fr, f, reset=(f == 0))
             sky = np.abs(fr["viewz"].astype(np.float32) * float(cs.viewZScale)) > float(cs.denoisingRange)
