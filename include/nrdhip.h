@@ -38,8 +38,8 @@ typedef struct nrdhip_denoiser_desc {
 enum {
     NRDHIP_FLAG_EXTERNAL_POOLS = 1u, /* caller allocates pool planes (nrdhip_pool_info + nrdhip_bind_pool) */
     /* nrdhip_denoise submits the frame as ONE HIP graph launch: the dispatch list is stream-captured every frame (no GPU work, a few
-     * microseconds per node), the instance's executable graph takes the new kernel arguments through hipGraphExecUpdate (it is only
-     * re-instantiated when the list changes shape: another denoiser set, a CLEAR_AND_RESTART frame with its clears) and is launched
+     * microseconds per node), the executable graph the instance keeps for that identifier list takes the new kernel arguments through
+     * hipGraphExecUpdate (it is only re-instantiated when the list changes shape: a CLEAR_AND_RESTART frame with its clears) and is launched
      * on the caller's stream. Needs a capturable stream: on the legacy default stream (NULL) the passes are launched one by one as
      * without the flag. Results are bit-identical either way; nrdhip_graph_stats reports what happened. */
     NRDHIP_FLAG_GRAPH = 2u

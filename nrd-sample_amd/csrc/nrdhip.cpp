@@ -130,7 +130,9 @@ struct nrdhip_instance {
     size_t transArenaBytes = 0;
     Plane slots[(size_t)nrd::ResourceType::MAX_NUM];
     std::string error;
-    hipGraphExec_t graphExec = nullptr; // NRDHIP_FLAG_GRAPH: the executable graph of the last frame's dispatch list
+    // NRDHIP_FLAG_GRAPH: one executable graph per identifier list a frame is submitted with (the sample calls Denoise three times a
+    // frame - shadow, opaque, reference - each with its own list: Source/NRDSample.cpp:4082, :4126, :4224)
+    std::vector<std::pair<std::vector<uint32_t>, hipGraphExec_t>> graphExecs;
     uint32_t graphStats[3] = {0, 0, 0}; // replayed frames, instantiations, direct-launch fallbacks
 };
 
@@ -1199,8 +1201,9 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
                 (void)hipFree(P.p);
     if (inst->transArena)
         (void)hipFree(inst->transArena);
-    if (inst->graphExec)
-        (void)hipGraphExecDestroy(inst->graphExec);
+    for (auto& g : inst->graphExecs)
+        if (g.second)
+            (void)hipGraphExecDestroy(g.second);
     delete inst;
 }
 
@@ -1511,26 +1514,41 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
         }
         return r;
     }
-    if (I.graphExec) {
+    const std::vector<uint32_t> key(ids, ids + n);
+    size_t slot = 0;
+    while (slot < I.graphExecs.size() && I.graphExecs[slot].first != key)
+        slot++;
+    if (slot == I.graphExecs.size()) {
+        if (I.graphExecs.size() >= 16) { // (a caller cycling through many identifier lists: start over)
+            for (auto& g : I.graphExecs)
+                if (g.second)
+                    (void)hipGraphExecDestroy(g.second);
+            I.graphExecs.clear();
+            slot = 0;
+        }
+        I.graphExecs.push_back({key, nullptr});
+    }
+    hipGraphExec_t& exec = I.graphExecs[slot].second;
+    if (exec) {
         hipGraphNode_t bad = nullptr;
         hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
-        if (hipGraphExecUpdate(I.graphExec, graph, &bad, &res) != hipSuccess || res != hipGraphExecUpdateSuccess) {
+        if (hipGraphExecUpdate(exec, graph, &bad, &res) != hipSuccess || res != hipGraphExecUpdateSuccess) {
             (void)hipGetLastError();
-            (void)hipGraphExecDestroy(I.graphExec);
-            I.graphExec = nullptr;
+            (void)hipGraphExecDestroy(exec);
+            exec = nullptr;
         }
     }
-    if (!I.graphExec) {
-        e = hipGraphInstantiate(&I.graphExec, graph, nullptr, nullptr, 0);
+    if (!exec) {
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (e != hipSuccess) {
-            I.graphExec = nullptr;
+            exec = nullptr;
             (void)hipGraphDestroy(graph);
             I.error = std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e);
             return (int)nrd::Result::FAILURE;
         }
         I.graphStats[1]++;
     }
-    e = hipGraphLaunch(I.graphExec, st);
+    e = hipGraphLaunch(exec, st);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) {
         I.error = std::string("hipGraphLaunch failed: ") + hipGetErrorString(e);

@@ -8,7 +8,7 @@ import pytest
 import util
 
 
-def run_pair(pkg, api, backend, dens, frames, w=320, h=192, stream=None, rects=None):
+def run_pair(pkg, api, backend, dens, frames, w=320, h=192, stream=None, rects=None, split_calls=False):
     import contextlib
 
     scene = pkg.synth.Scene(w, h, dolly=0.02, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
@@ -32,8 +32,9 @@ def run_pair(pkg, api, backend, dens, frames, w=320, h=192, stream=None, rects=N
             elif rects and (f - 1) in rects:
                 cs.rectSizePrev[0], cs.rectSizePrev[1] = rects[f - 1]
             pa, pb = ha.upload(fr), hb.upload(fr)
-            ha.frame(cs, pa, st, order=[[d for d in dd]])
-            hb.frame(cs, pb, st, order=[[d for d in dd]])
+            order = [[d] for d in dd] if split_calls else [[d for d in dd]]  # the sample: one Denoise call per denoiser (NRDSample.cpp:4082, :4126, :4224)
+            ha.frame(cs, pa, st, order=order)
+            hb.frame(cs, pb, st, order=order)
             if stream is not None:
                 stream.synchronize()
             for key in ha.outputs:
@@ -55,6 +56,18 @@ def test_graph_replay_bit_identical(pkg, api, hip, dens):
     # (clears again) and frame 5 - every other frame only patches kernel arguments
     assert stats["replayed"] == 8 and stats["direct"] == 0, stats
     assert stats["instantiated"] <= 4, stats
+
+
+@pytest.mark.gpu
+def test_graph_replay_one_graph_per_identifier_list(pkg, api, hip):
+    """the sample's call pattern - one Denoise per denoiser, three a frame: every identifier list keeps its own executable graph, so a
+    steady frame patches arguments only (an instance with ONE graph would re-instantiate it at every call)"""
+    import torch
+
+    side = torch.cuda.Stream()
+    stats = run_pair(pkg, api, hip, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW", "REFERENCE"], frames=8, stream=side, split_calls=True)
+    assert stats["replayed"] == 8 * 3 and stats["direct"] == 0, stats
+    assert stats["instantiated"] <= 3 * 4, stats  # per list: first frame (restart clears), second frame, the restart at frame 4, the frame after
 
 
 @pytest.mark.gpu
