@@ -104,7 +104,9 @@ NRDHIP_API int nrdhip_bind(nrdhip_instance* inst, uint32_t slot, void* dev_ptr, 
                            uint32_t format, uint16_t width, uint16_t height);
 /* forget every slot binding (a ResourceSnapshot is complete: slots absent from it must not keep last frame's pointers) */
 NRDHIP_API int nrdhip_unbind_all(nrdhip_instance* inst);
-/* nrd::Integration::Denoise (Source/NRDSample.cpp:521): enqueue every pass of the given denoisers on `stream`. */
+/* nrd::Integration::Denoise (Source/NRDSample.cpp:521): enqueue every pass of the given denoisers on `stream`.
+ * A denoiser's permanent planes are cleared (on `stream`) in front of its first pass on a CLEAR_AND_RESTART frame and on its very first
+ * frame whatever the mode: the passes leave tiles without geometry unwritten, so caller-allocated pools need no initialisation. */
 NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, void* hip_stream);
 
 /* NRDHIP_FLAG_GRAPH bookkeeping: {frames replayed through the graph, executable graphs instantiated, frames that fell back to direct
