@@ -109,6 +109,19 @@ NRDHIP_API int nrdhip_unbind_all(nrdhip_instance* inst);
  * frame whatever the mode: the passes leave tiles without geometry unwritten, so caller-allocated pools need no initialisation. */
 NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, void* hip_stream);
 
+/* Checkpoint / resume of a denoiser's history ("dump / load of the permanent pool"; the reference keeps its history in GPU
+ * textures only and can but reset it, Source/NRDSample.cpp:3864). Everything a denoiser carries from one frame to the next is its
+ * permanent planes (nrdhip_pool_info gives pointer, pitch and size of each: copy them out / in) and these counters; read them between
+ * frames, write them - with the planes restored - before the next frame's SetCommonSettings. A restored instance continues bit-identically. */
+typedef struct nrdhip_history_state {
+    uint32_t frame_counter;      /* frames denoised so far (its parity selects the ping-pong planes) */
+    uint32_t frames_since_reset; /* REFERENCE: accumulated frame count */
+    uint32_t history_valid;      /* 0 before the first frame */
+    uint32_t reserved;
+} nrdhip_history_state;
+NRDHIP_API int nrdhip_get_history_state(nrdhip_instance* inst, uint32_t identifier, nrdhip_history_state* out);
+NRDHIP_API int nrdhip_set_history_state(nrdhip_instance* inst, uint32_t identifier, const nrdhip_history_state* in);
+
 /* NRDHIP_FLAG_GRAPH bookkeeping: {frames replayed through the graph, executable graphs instantiated, frames that fell back to direct
  * launches (default stream, capture unsupported)} */
 NRDHIP_API int nrdhip_graph_stats(nrdhip_instance* inst, uint32_t out[3]);

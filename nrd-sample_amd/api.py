@@ -362,6 +362,10 @@ class ComposeDesc(C.Structure):
         ("view_to_world", _f * 9), ("camera_frustum", _f * 4), ("inv_rect_size", _f * 2)]
 
 
+class HistoryState(C.Structure):  # nrdhip_history_state
+    _fields_ = [("frame_counter", _u32), ("frames_since_reset", _u32), ("history_valid", _u32), ("reserved", _u32)]
+
+
 UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH, PACK_DIRECTIONAL_OCCLUSION = 0, 1, 2, 3
 FLAG_EXTERNAL_POOLS = 1
 FLAG_GRAPH = 2  # nrdhip_denoise replays one HIP graph per frame (include/nrdhip.h NRDHIP_FLAG_GRAPH)
@@ -401,6 +405,8 @@ class Backend:
         self._sig("set_denoiser", C.c_int, [C.c_void_p, _u32, C.c_void_p, C.c_size_t])
         self._sig("bind", C.c_int, [C.c_void_p, _u32, C.c_void_p, _u32, _u32, _u16, _u16])
         self._sig("denoise", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
+        self._sig("get_history_state", C.c_int, [C.c_void_p, _u32, C.POINTER(HistoryState)])
+        self._sig("set_history_state", C.c_int, [C.c_void_p, _u32, C.POINTER(HistoryState)])
         if hasattr(self.lib, self.prefix + "graph_stats"):  # product library (the CPU oracle of the tests has no graphs)
             self._sig("graph_stats", C.c_int, [C.c_void_p, C.POINTER(_u32)])
         self._sig("dispatch_count", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.POINTER(_u32)])
@@ -567,6 +573,42 @@ class Integration:
     def denoise(self, identifiers):
         ids, n = self._ids(identifiers)
         self._check(self.backend.denoise(self.handle, ids, n, self._stream()), "Denoise")
+
+    # checkpoint / resume (include/nrdhip.h nrdhip_history_state): permanent planes + per-denoiser counters
+    def save_history(self, path):
+        """write every permanent plane and the history counters of every denoiser to an .npz - between frames"""
+        import numpy as np
+
+        out = {}
+        for i, p in enumerate(self.pools[0]):
+            buf = p["buf"]
+            out["plane%d" % i] = buf.cpu().numpy() if hasattr(buf, "cpu") else np.asarray(buf)
+            out["name%d" % i] = np.array(p["name"])
+        for ident, _ in self.denoisers:
+            st = HistoryState()
+            self._check(self.backend.get_history_state(self.handle, int(ident), C.byref(st)), "get_history_state")
+            out["state%d" % int(ident)] = np.array([st.frame_counter, st.frames_since_reset, st.history_valid], dtype=np.uint32)
+        np.savez(path, **out)
+
+    def load_history(self, path):
+        """restore what save_history wrote into an instance created with the same denoisers and size - before the next frame"""
+        import numpy as np
+
+        z = np.load(path)
+        for i, p in enumerate(self.pools[0]):
+            if str(z["name%d" % i]) != p["name"] or z["plane%d" % i].shape != tuple(p["buf"].shape):
+                raise ValueError("history file does not match this instance: plane %d (%s)" % (i, p["name"]))
+            src = z["plane%d" % i]
+            if hasattr(p["buf"], "copy_"):
+                import torch
+
+                p["buf"].copy_(torch.from_numpy(src))
+            else:
+                p["buf"][...] = src
+        for ident, _ in self.denoisers:
+            a = z["state%d" % int(ident)]
+            st = HistoryState(int(a[0]), int(a[1]), int(a[2]), 0)
+            self._check(self.backend.set_history_state(self.handle, int(ident), C.byref(st)), "set_history_state")
 
     def graph_stats(self):
         """NRDHIP_FLAG_GRAPH bookkeeping: dict(replayed, instantiated, direct)"""

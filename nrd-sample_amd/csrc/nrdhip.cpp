@@ -1558,6 +1558,24 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
     return 0;
 }
 
+NRDHIP_API int nrdhip_get_history_state(nrdhip_instance* inst, uint32_t identifier, nrdhip_history_state* out) {
+    DenoiserState* d = inst ? find(*inst, identifier) : nullptr;
+    if (!d || !out)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    *out = {d->frameCounter, d->framesSinceReset, d->historyValid ? 1u : 0u, 0u};
+    return 0;
+}
+
+NRDHIP_API int nrdhip_set_history_state(nrdhip_instance* inst, uint32_t identifier, const nrdhip_history_state* in) {
+    DenoiserState* d = inst ? find(*inst, identifier) : nullptr;
+    if (!d || !in)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    d->frameCounter = in->frame_counter;
+    d->framesSinceReset = in->frames_since_reset;
+    d->historyValid = in->history_valid != 0;
+    return 0;
+}
+
 NRDHIP_API int nrdhip_graph_stats(nrdhip_instance* inst, uint32_t out[3]) {
     if (!inst || !out)
         return (int)nrd::Result::INVALID_ARGUMENT;

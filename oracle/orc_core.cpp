@@ -539,6 +539,24 @@ NRDHIP_API int orc_get_memory_mb(nrdhip_instance* inst, float out[3]) {
     return 0;
 }
 
+// checkpoint / resume counters (include/nrdhip.h nrdhip_history_state): what a denoiser carries between frames besides its permanent planes
+NRDHIP_API int orc_get_history_state(nrdhip_instance* inst, uint32_t identifier, nrdhip_history_state* out) {
+    DenoiserState* d = inst ? find(inst->I, identifier) : nullptr;
+    if (!d || !out)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    *out = {d->frameCounter, d->framesSinceReset, d->historyValid ? 1u : 0u, 0u};
+    return 0;
+}
+NRDHIP_API int orc_set_history_state(nrdhip_instance* inst, uint32_t identifier, const nrdhip_history_state* in) {
+    DenoiserState* d = inst ? find(inst->I, identifier) : nullptr;
+    if (!d || !in)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    d->frameCounter = in->frame_counter;
+    d->framesSinceReset = in->frames_since_reset;
+    d->historyValid = in->history_valid != 0;
+    return 0;
+}
+
 NRDHIP_API uint32_t orc_sizeof(uint32_t which) {
     switch (which) {
         case 0: return sizeof(nrd::CommonSettings);
