@@ -4,8 +4,10 @@
 // always built by hipcc against the real HIP runtime, and this emulated library is only ever loaded by tests.
 //
 // Model: blocks run one after another; threads of a block run sequentially until one of them reaches a block-level
-// primitive (__syncthreads*, __shfl_xor), at which point the block is re-run with one OS thread per HIP thread and real
-// barriers (all kernels here are idempotent per block, so the re-run is safe).
+// primitive (__syncthreads*, __shfl_xor), at which point the block is re-run with one FIBER per HIP thread (ucontext, all on
+// the calling OS thread: a barrier is "yield until every fiber has arrived", ~100 ns per switch instead of a mutex / condition
+// variable hand-off between 256 OS threads; all kernels here are idempotent per block, so the re-run is safe). The sanitizer
+// build (-DHIPEMU_USE_THREADS: ASan does not follow swapcontext) keeps one OS thread per HIP thread and real barriers.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -16,6 +18,9 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#ifndef HIPEMU_USE_THREADS
+#include <ucontext.h>
+#endif
 
 #define __global__
 #define __device__
@@ -99,9 +104,96 @@ inline std::atomic<int> g_or{0};
 inline float g_shfl[1024];
 inline int g_blockThreads = 0;
 
+#ifdef HIPEMU_USE_THREADS
+template <typename F>
+void run_block_lockstep(dim3 block, unsigned bx, unsigned by, unsigned bz, F& body) {
+    int nthreads = (int)(block.x * block.y * block.z);
+    g_barrier.count = nthreads;
+    g_barrier.waiting = 0;
+    g_blockThreads = nthreads;
+    std::vector<std::thread> th;
+    for (unsigned tz = 0; tz < block.z; tz++)
+        for (unsigned ty = 0; ty < block.y; ty++)
+            for (unsigned tx = 0; tx < block.x; tx++)
+                th.emplace_back([=, &body] {
+                    t_threaded = true;
+                    t_blockIdx = {bx, by, bz};
+                    t_threadIdx = {tx, ty, tz};
+                    body();
+                });
+    for (auto& t : th)
+        t.join();
+}
+inline void sync() {
+    if (!t_threaded)
+        throw NeedThreads();
+    g_barrier.wait();
+}
+#else
+// ---- fibers: every HIP thread of the block is a ucontext on the calling OS thread; sync() yields to the scheduler, which resumes the
+// fibers round robin - one pass over all of them takes every fiber from barrier k to barrier k + 1 (or to its end)
+struct Fibers {
+    static constexpr size_t STACK = 256 * 1024;
+    std::vector<ucontext_t> ctx;
+    std::vector<char> stacks;
+    std::vector<char> done;
+    ucontext_t sched;
+    std::function<void()> body;
+    int current = -1;
+};
+inline thread_local Fibers* t_fibers = nullptr;
+inline void fiber_entry() {
+    Fibers& f = *t_fibers;
+    f.body();
+    f.done[f.current] = 1;
+    swapcontext(&f.ctx[f.current], &f.sched); // never resumed
+}
+template <typename F>
+void run_block_lockstep(dim3 block, unsigned bx, unsigned by, unsigned bz, F& body) {
+    static thread_local Fibers fibers;
+    Fibers& f = fibers;
+    t_fibers = &f;
+    const int n = (int)(block.x * block.y * block.z);
+    g_blockThreads = n;
+    if ((int)f.ctx.size() < n) {
+        f.ctx.resize(n);
+        f.stacks.resize((size_t)n * Fibers::STACK);
+    }
+    f.done.assign(n, 0);
+    f.body = [&body] { body(); };
+    for (int i = 0; i < n; i++) {
+        getcontext(&f.ctx[i]);
+        f.ctx[i].uc_stack.ss_sp = f.stacks.data() + (size_t)i * Fibers::STACK;
+        f.ctx[i].uc_stack.ss_size = Fibers::STACK;
+        f.ctx[i].uc_link = &f.sched;
+        makecontext(&f.ctx[i], fiber_entry, 0);
+    }
+    int live = n;
+    while (live > 0) {
+        for (int i = 0; i < n; i++) {
+            if (f.done[i])
+                continue;
+            f.current = i;
+            t_threaded = true;
+            t_blockIdx = {bx, by, bz};
+            t_threadIdx = {(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
+            swapcontext(&f.sched, &f.ctx[i]);
+            if (f.done[i])
+                live--;
+        }
+    }
+    t_threaded = false;
+}
+inline void sync() {
+    if (!t_threaded)
+        throw NeedThreads();
+    Fibers& f = *t_fibers;
+    swapcontext(&f.ctx[f.current], &f.sched);
+}
+#endif
+
 template <typename F>
 void launch(dim3 grid, dim3 block, F body) {
-    int nthreads = (int)(block.x * block.y * block.z);
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++) {
@@ -118,30 +210,9 @@ void launch(dim3 grid, dim3 block, F body) {
                 } catch (NeedThreads&) {
                     needThreads = true;
                 }
-                if (!needThreads)
-                    continue;
-                g_barrier.count = nthreads;
-                g_barrier.waiting = 0;
-                g_blockThreads = nthreads;
-                std::vector<std::thread> th;
-                for (unsigned tz = 0; tz < block.z; tz++)
-                    for (unsigned ty = 0; ty < block.y; ty++)
-                        for (unsigned tx = 0; tx < block.x; tx++)
-                            th.emplace_back([=] {
-                                t_threaded = true;
-                                t_blockIdx = {bx, by, bz};
-                                t_threadIdx = {tx, ty, tz};
-                                body();
-                                // threads that left early keep servicing barriers until everybody is done
-                            });
-                for (auto& t : th)
-                    t.join();
+                if (needThreads)
+                    run_block_lockstep(block, bx, by, bz, body);
             }
-}
-inline void sync() {
-    if (!t_threaded)
-        throw NeedThreads();
-    g_barrier.wait();
 }
 } // namespace hipemu
 
