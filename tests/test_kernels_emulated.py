@@ -64,7 +64,8 @@ def test_emulated_kernels_sky_tiles(pkg, api, oracle, emulated, dens):
 
 
 @pytest.mark.parametrize("dens,kw", [(["REBLUR_DIFFUSE_SPECULAR"], dict(enableAntiFirefly=True)), (["RELAX_DIFFUSE_SPECULAR"], {}),
-                                     (["REBLUR_DIFFUSE_SPECULAR_SH"], {})])
+                                     (["REBLUR_DIFFUSE_SPECULAR_SH"], {}), (["REBLUR_DIFFUSE_SPECULAR_OCCLUSION"], {}),
+                                     (["RELAX_DIFFUSE_SPECULAR_SH"], {})])
 def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, kw):
     """PrePass, TemporalAccumulation and PostBlur write nothing in tiles without geometry (csrc/nrd_reblur.hip k_spatial): whatever
     their planes - and every other internal plane - hold at pixels beyond the denoising range must not matter. Two instances of the
@@ -75,7 +76,7 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
     import numpy as np
 
     rng = np.random.default_rng(7)
-    for roll, (w, h) in (((0.0, (40, 104)), (90.0, (104, 40))) if dens[0] == "REBLUR_DIFFUSE_SPECULAR" else ((0.0, (40, 72)),)):  # (the emulated kernels are slow)
+    for roll, (w, h) in ((0.0, (40, 104)), (90.0, (104, 40))):
         scene = pkg.synth.Scene(w, h, dolly=0.06, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR", roll_deg=roll)
         dd = [api.Denoiser[x] for x in dens]
         st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1, **kw)
@@ -85,7 +86,7 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
         hb = pkg.harness.Harness(emulated, dd, w, h)
         prev_sky = None
         poisoned = 0
-        for f in range(3):
+        for f in range(5):
             fr = scene.frame(f)
             cs = scene.common_settings(api, fr, f, reset=(f == 0))
             sky = np.abs(fr["viewz"].astype(np.float32) * float(cs.viewZScale)) > float(cs.denoisingRange)

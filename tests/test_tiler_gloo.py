@@ -92,7 +92,7 @@ def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
 def test_row_tiling_emulated_kernels_bit_identical(tmp_path, pkg, api, oracle, emulated):
     """the kernel sources themselves (compiled for the host) on two bands: rows stored at a band offset, nrdhip_denoise_rows strips,
     halo rows owned by the neighbour - against the single-instance oracle run"""
-    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 448, "default", "emu", w=32, nframes=2)
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 448, "default", "emu", w=48)
 
 
 @pytest.mark.gpu
@@ -143,7 +143,7 @@ def test_native_tiler_bit_identical(tmp_path, pkg, api, oracle, emulated):
     """the C++ row tiler below the C-ABI (csrc/nrdhip_tiler.cpp: exchange plan, strips-first split, deferred rows) over the
     host-emulated product library, two gloo ranks moving the rows through its transport callbacks - against the single-instance
     oracle run; tall bands so the strips / interior path runs"""
-    parts = run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 704, "default", "emu", "native", w=32, nframes=2)  # 2 tiles wide: the emulated kernels are slow
+    parts = run_tiled_and_compare(tmp_path, pkg, api, oracle, 2, 704, "default", "emu", "native", w=48, nframes=3)
     assert all(int(p["split"][0]) >= 2 * 5 for p in parts)
 
 
