@@ -6,8 +6,8 @@
 // Model: blocks run one after another; threads of a block run sequentially until one of them reaches a block-level
 // primitive (__syncthreads*, __shfl_xor), at which point the block is re-run with one FIBER per HIP thread (ucontext, all on
 // the calling OS thread: a barrier is "yield until every fiber has arrived", ~100 ns per switch instead of a mutex / condition
-// variable hand-off between 256 OS threads; all kernels here are idempotent per block, so the re-run is safe). The sanitizer
-// build (-DHIPEMU_USE_THREADS: ASan does not follow swapcontext) keeps one OS thread per HIP thread and real barriers.
+// variable hand-off between 256 OS threads; all kernels here are idempotent per block, so the re-run is safe). Under AddressSanitizer
+// every stack switch is announced (fiber_switch); -DHIPEMU_USE_THREADS selects the older model: one OS thread per HIP thread, real barriers.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -20,6 +20,17 @@
 #include <vector>
 #ifndef HIPEMU_USE_THREADS
 #include <ucontext.h>
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN_FIBERS 1
+#endif
+#endif
+#if defined(__SANITIZE_ADDRESS__) && !defined(HIPEMU_ASAN_FIBERS)
+#define HIPEMU_ASAN_FIBERS 1
+#endif
+#ifdef HIPEMU_ASAN_FIBERS
+#include <sanitizer/common_interface_defs.h> // ASan must be told about every stack switch
+#endif
 #endif
 
 #define __global__
@@ -142,11 +153,30 @@ struct Fibers {
     int current = -1;
 };
 inline thread_local Fibers* t_fibers = nullptr;
+// stack switch with the AddressSanitizer bookkeeping around it (no-ops in the plain build)
+inline void fiber_switch(ucontext_t* from, ucontext_t* to, const void* toStackBottom, size_t toStackSize, bool fromDies) {
+#ifdef HIPEMU_ASAN_FIBERS
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(fromDies ? nullptr : &fake, toStackBottom, toStackSize);
+    swapcontext(from, to);
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+    (void)toStackBottom;
+    (void)toStackSize;
+    (void)fromDies;
+    swapcontext(from, to);
+#endif
+}
+inline thread_local const void* t_schedStackBottom = nullptr;
+inline thread_local size_t t_schedStackSize = 0;
 inline void fiber_entry() {
+#ifdef HIPEMU_ASAN_FIBERS
+    __sanitizer_finish_switch_fiber(nullptr, &t_schedStackBottom, &t_schedStackSize); // first entry: learn the scheduler's stack
+#endif
     Fibers& f = *t_fibers;
     f.body();
     f.done[f.current] = 1;
-    swapcontext(&f.ctx[f.current], &f.sched); // never resumed
+    fiber_switch(&f.ctx[f.current], &f.sched, t_schedStackBottom, t_schedStackSize, true); // never resumed
 }
 template <typename F>
 void run_block_lockstep(dim3 block, unsigned bx, unsigned by, unsigned bz, F& body) {
@@ -177,7 +207,7 @@ void run_block_lockstep(dim3 block, unsigned bx, unsigned by, unsigned bz, F& bo
             t_threaded = true;
             t_blockIdx = {bx, by, bz};
             t_threadIdx = {(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
-            swapcontext(&f.sched, &f.ctx[i]);
+            fiber_switch(&f.sched, &f.ctx[i], f.stacks.data() + (size_t)i * Fibers::STACK, Fibers::STACK, false);
             if (f.done[i])
                 live--;
         }
@@ -188,7 +218,7 @@ inline void sync() {
     if (!t_threaded)
         throw NeedThreads();
     Fibers& f = *t_fibers;
-    swapcontext(&f.ctx[f.current], &f.sched);
+    fiber_switch(&f.ctx[f.current], &f.sched, t_schedStackBottom, t_schedStackSize, false);
 }
 #endif
 
