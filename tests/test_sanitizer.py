@@ -3,7 +3,8 @@
 emulated-kernel tests in a child process that has the ASan runtime preloaded. The host emulation is the one place where an
 out-of-bounds tap, footprint or LDS staging index faults loudly instead of reading a neighbour's bytes (on the GPU the planes are
 padded by nothing and a stray read is silent): every denoiser family, PrepareInputs with a checkerboard, DRS with rectSize <
-resourceSize changing between frames, a frame narrower and shorter than one 16x16 tile, sky tiles, and the 2-band row tiler."""
+resourceSize changing between frames, a frame narrower and shorter than one 16x16 tile, sky tiles (incl. the run that overwrites
+what they leave unwritten), the orthographic flavour, anti-firefly on SH texels, and the 2-band row tiler."""
 import os
 import subprocess
 import sys
@@ -18,7 +19,14 @@ SELECTION = [
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens0]",   # REBLUR_DIFFUSE_SPECULAR + SIGMA_SHADOW_TRANSLUCENCY + REFERENCE
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens3]",   # RELAX_DIFFUSE_SPECULAR (A-trous LDS windows)
     "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens9]",   # REBLUR_DIFFUSE_SPECULAR_SH
+    "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens6]",   # REBLUR_DIFFUSE_SPECULAR_OCCLUSION
+    "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens10]",  # RELAX_DIFFUSE_SPECULAR_SH
+    "tests/test_kernels_emulated.py::test_emulated_kernels_bit_exact[dens12]",  # REBLUR_DIFFUSE_DIRECTIONAL_OCCLUSION
     "tests/test_kernels_emulated.py::test_emulated_kernels_sky_tiles[dens0]",
+    "tests/test_kernels_emulated.py::test_emulated_kernels_sky_tiles[dens1]",
+    "tests/test_kernels_emulated.py::test_nobody_reads_what_sky_tiles_leave_unwritten[dens0-kw0]",
+    "tests/test_ortho.py::test_ortho_emulated_bit_exact[REBLUR_DIFFUSE_SPECULAR+SIGMA_SHADOW_TRANSLUCENCY+REFERENCE]",
+    "tests/test_settings_variants.py::test_variants_emulated_bit_exact[antifirefly_relax_sh]",
     "tests/test_prepare_inputs.py::test_prepare_inputs_emulated_bit_exact[dens0-WHITE-AREA_5X5]",  # checkerboard + 5x5 hit-distance reconstruction
     "tests/test_prepare_inputs.py::test_prepare_inputs_emulated_bit_exact[dens1-BLACK-None]",
     "tests/test_settings_variants.py::test_variants_emulated_bit_exact[drs_reblur_sigma]",
