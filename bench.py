@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--motion-rows", type=int, default=8, help="row tiling: vertical motion (rows) the stored halo must cover beyond the passes' reach")
     ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras-deadline", type=int, default=240,
+                    help="N > 1: seconds the native-tiler leg and the bit-identity check may take together before rank 0 prints the line of "
+                         "record without them and the run ends (a hang in never-executed transport code must not cost the line)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the HIP-graph replay leg (NRDHIP_FLAG_GRAPH), 1-GPU runs")
     ap.add_argument("--no-upstream-leg", action="store_true", help="skip the timed leg on the NRD_UPSTREAM_FORMULAS build flavour, 1-GPU runs")
     ap.add_argument("--no-full-coverage", action="store_true", help="skip the second timed leg (the same scene without sky), 1-GPU runs")
@@ -283,32 +286,6 @@ def main():
         gathered = [torch.zeros_like(mt) for _ in range(world)]
         dist.all_gather(gathered, mt)
         rank_ms = [round(float(g.item()), 4) for g in gathered]  # GPU-busy ms per frame of every rank (sum of its dispatch times)
-    if tiled and args.tiler == "python" and not args.no_native_leg:
-        # The value of record is the Python tiler's (its transport, PyTorch's RCCL binding, is the proven one). The C++ tiler below
-        # the C-ABI (ncclSend / ncclRecv groups on a side stream) runs the same workload afterwards, reported beside it; whatever
-        # goes wrong there must not cost the line above.
-        try:
-            from nrd_sample_amd.tiler import TiledRunner
-
-            native = TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of, tiler="native",
-                                 motion_rows=args.motion_rows, balance=strong and not args.even_bands)
-            dt_n = timed_run(native)
-            native_leg = {"value": round(w * frame_h * args.steps / dt_n / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_n / args.steps * 1e3, 4),
-                          "transport": "rccl" if backend == "nccl" else "caller callbacks over torch.distributed (%s)" % backend,
-                          "halo_exchange_bytes_per_frame_rank0": int(native.tiler.bytes_exchanged / max(args.warmup + args.steps, 1))}
-            del native
-            torch.cuda.empty_cache()
-        except Exception as e:
-            native_leg = {"error": "%s: %s" % (type(e).__name__, e)}
-    if tiled and strong and not args.no_identity_check:
-        try:
-            from nrd_sample_amd.tiler import verify_tiled_against_single
-
-            ok, detail = verify_tiled_against_single(pkg, hip, dev, dens, w, frame_h, rank, world, settings_of, args.dolly, runner.halo,
-                                                     runner.bounds, tiler=args.tiler)
-            identical = {"identical": ok, "detail": detail}
-        except Exception as e:
-            identical = {"identical": None, "detail": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         pixels_band = w * band_h
         total_pixels = w * frame_h * args.steps
@@ -317,7 +294,7 @@ def main():
         max_accum = max([int(getattr(st, "maxAccumulatedFrameNum", 0)) for st in runner.settings.values()] + [0])
         state = "steady state (accumulation saturated)" if args.warmup >= max_accum else \
             "warm-up %d frames (accumulation saturates at %d)" % (args.warmup, max_accum)
-        tiled = "" if world == 1 and not args.force_tiled else " row-tiled %d x ~%d rows (%s scaling), halo %d rows, %s tiler" % (
+        tiled_desc = "" if world == 1 and not args.force_tiled else " row-tiled %d x ~%d rows (%s scaling), halo %d rows, %s tiler" % (
             world, band_h, args.scaling, runner.halo, args.tiler)
         bpp_contract = contract_bpp(den_names)
         out = {
@@ -325,7 +302,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak" if (world == 1 or not strong) else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s, %dx%d%s, %s" % (args.workload, "+".join(den_names), w, frame_h, tiled, state) +
+            "config": {"workload": "%s: %s, %dx%d%s, %s" % (args.workload, "+".join(den_names), w, frame_h, tiled_desc, state) +
                        (" [camera rolled %g deg: layout probe]" % args.roll if args.roll else "") +
                        (" [recorded preset %s]" % os.path.basename(args.preset) if args.preset else ""),
                        "unique_input_frames": args.unique_frames, "storage_dtype": "f16 planes (f32 viewZ), f32 arithmetic"},
@@ -362,6 +339,59 @@ def main():
             out["config"]["band_split"] = "cost-balanced (geometry tiles + 0.15 x sky tiles of the first frame)" if runner.bounds else "even tile rows"
         if rank_ms is not None:
             out["config"]["rank_ms"] = rank_ms
+
+    # ---- N > 1 extras, every rank takes part: the C++ / RCCL tiler leg and the bit-identity check. Both run code whose transport has
+    # never executed on real multi-GPU hardware; an exception is caught below, and a HANG (a receive that never completes) is bounded by
+    # a watchdog: after --extras-deadline seconds rank 0 prints the line of record as it stands - the value above is complete - with the
+    # unfinished extras marked, and every rank leaves the process. Whatever goes wrong there must not cost the line.
+    import threading
+
+    printed = threading.Lock()
+    watchdog = None
+    if tiled and (not args.no_native_leg or not args.no_identity_check):
+        def give_up():
+            if rank == 0 and printed.acquire(blocking=False):
+                cfg = out["config"]
+                cfg.setdefault("native_tiler", native_leg if native_leg is not None else {"error": "not finished after %d s: skipped by the watchdog" % args.extras_deadline})
+                cfg.setdefault("tiled_bit_identical", None)
+                cfg.setdefault("tiled_bit_identical_detail", "not finished after %d s: skipped by the watchdog" % args.extras_deadline)
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.extras_deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    if tiled and args.tiler == "python" and not args.no_native_leg:
+        # The value of record is the Python tiler's (its transport, PyTorch's RCCL binding, is the proven one). The C++ tiler below
+        # the C-ABI (ncclSend / ncclRecv groups on a side stream) runs the same workload afterwards, reported beside it; whatever
+        # goes wrong there must not cost the line above.
+        try:
+            from nrd_sample_amd.tiler import TiledRunner
+
+            native = TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of, tiler="native",
+                                 motion_rows=args.motion_rows, balance=strong and not args.even_bands)
+            dt_n = timed_run(native)
+            native_leg = {"value": round(w * frame_h * args.steps / dt_n / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_n / args.steps * 1e3, 4),
+                          "transport": "rccl" if backend == "nccl" else "caller callbacks over torch.distributed (%s)" % backend,
+                          "halo_exchange_bytes_per_frame_rank0": int(native.tiler.bytes_exchanged / max(args.warmup + args.steps, 1))}
+            del native
+            torch.cuda.empty_cache()
+        except Exception as e:
+            native_leg = {"error": "%s: %s" % (type(e).__name__, e)}
+    if tiled and strong and not args.no_identity_check:
+        try:
+            from nrd_sample_amd.tiler import verify_tiled_against_single
+
+            ok, detail = verify_tiled_against_single(pkg, hip, dev, dens, w, frame_h, rank, world, settings_of, args.dolly, runner.halo,
+                                                     runner.bounds, tiler=args.tiler)
+            identical = {"identical": ok, "detail": detail}
+        except Exception as e:
+            identical = {"identical": None, "detail": "%s: %s" % (type(e).__name__, e)}
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        if not printed.acquire(blocking=False):  # the watchdog got there first
+            os._exit(0)
         if native_leg is not None:
             out["config"]["native_tiler"] = native_leg
         if identical is not None:
