@@ -1,3 +1,6 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: A/B of prebuilt library variants (_variants/*.so) on BASELINE config 3, printing the SIGMA passes only
+# (tools/ab_variants.sh abbreviates pass names and REBLUR's and SIGMA's collide there).
 for round in 1 2; do
   for v in v0 v2 v3; do
     cp _variants/$v.so nrd-sample_amd/csrc/libnrdhip.so

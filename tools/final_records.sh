@@ -1,3 +1,7 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the records of a build - kernel trace + PMC passes of the default bench command (profile_gpu.sh),
+# the default bench line, every named workload, the sample-side passes, and the 2-rank dry run of the row-tiled bench on the one GPU.
+# Results land under gpurun_out/ (copy the summaries to keep into profiles/). The tag in the file names is edited per build.
 mkdir -p gpurun_out/r3v7
 bash tools/profile_gpu.sh r03v7 reblur_ds_4k > gpurun_out/r3v7/profile.log 2>&1
 timeout 400 python bench.py > gpurun_out/r3v7/bench_default.json 2> gpurun_out/r3v7/bench_default.err
