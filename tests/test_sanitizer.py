@@ -63,3 +63,20 @@ def test_emulated_kernels_under_address_and_ub_sanitizer():
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0, tail
     assert "passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+def test_sanitizer_sees_through_the_emulation_fibers(tmp_path):
+    """the leg above is only worth something if ASan still catches a stray access made from a fiber stack (the emulation runs every HIP
+    thread of a barrier kernel as a ucontext fiber and announces the stack switches): tests/host/asan_fiber_probe.cpp runs clean
+    without arguments and must die with a heap-buffer-overflow report when told to write one element past a plane"""
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang) or not os.path.exists(graft.SANITIZER_RUNTIME):
+        pytest.skip("no clang / ASan runtime in this image")
+    exe = str(tmp_path / "asan_fiber_probe")
+    subprocess.run([clang, "-O1", "-std=c++17", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I" + os.path.join(ROOT, "tests", "hip_emu"), os.path.join(ROOT, "tests", "host", "asan_fiber_probe.cpp"), "-o", exe], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    ok = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and "sum 32640" in ok.stdout, ok.stdout + ok.stderr
+    bad = subprocess.run([exe, "fault"], env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "heap-buffer-overflow" in bad.stderr, bad.stderr[-2000:]
