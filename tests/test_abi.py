@@ -79,6 +79,15 @@ def test_error_convention(request, api, which):
     assert e.value.code == api.Result.INVALID_ARGUMENT and "format" in str(e.value)
     mem = nrd.memory_usage_mb()
     assert abs(mem["persistent"] - 64 * 64 * 16 / 1048576.0) < 1e-6
+    # history counters: unknown identifier / null pointer are INVALID_ARGUMENT; a fresh denoiser reports "no history yet"
+    import ctypes
+    st = api.HistoryState(9, 9, 9, 9)
+    assert b.get_history_state(nrd.handle, int(D.REFERENCE), ctypes.byref(st)) == 0
+    assert (st.frame_counter, st.frames_since_reset, st.history_valid) == (0, 0, 0)
+    assert b.get_history_state(nrd.handle, 4242, ctypes.byref(st)) == int(api.Result.INVALID_ARGUMENT)
+    assert b.set_history_state(nrd.handle, int(D.REFERENCE), None) == int(api.Result.INVALID_ARGUMENT)
+    if which == "emulated":  # NRDHIP_FLAG_GRAPH bookkeeping exists in the product library only
+        assert nrd.graph_stats() == dict(replayed=0, instantiated=0, direct=0)
     nrd.destroy()
 
 
