@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -146,13 +147,15 @@ inline void sync() {
 struct Fibers {
     static constexpr size_t STACK = 256 * 1024;
     std::vector<ucontext_t> ctx;
-    std::vector<char> stacks;
+    std::unique_ptr<char[]> stacks; // (not value-initialised: pages are touched as deep as a fiber really goes)
+    size_t stackCount = 0;
     std::vector<char> done;
     ucontext_t sched;
     std::function<void()> body;
     int current = -1;
 };
 inline thread_local Fibers* t_fibers = nullptr;
+inline thread_local Fibers t_fiberPool;
 // stack switch with the AddressSanitizer bookkeeping around it (no-ops in the plain build)
 inline void fiber_switch(ucontext_t* from, ucontext_t* to, const void* toStackBottom, size_t toStackSize, bool fromDies) {
 #ifdef HIPEMU_ASAN_FIBERS
@@ -180,20 +183,20 @@ inline void fiber_entry() {
 }
 template <typename F>
 void run_block_lockstep(dim3 block, unsigned bx, unsigned by, unsigned bz, F& body) {
-    static thread_local Fibers fibers;
-    Fibers& f = fibers;
+    Fibers& f = t_fiberPool; // one pool per OS thread, shared by every kernel
     t_fibers = &f;
     const int n = (int)(block.x * block.y * block.z);
     g_blockThreads = n;
-    if ((int)f.ctx.size() < n) {
+    if ((int)f.stackCount < n) {
         f.ctx.resize(n);
-        f.stacks.resize((size_t)n * Fibers::STACK);
+        f.stacks.reset(new char[(size_t)n * Fibers::STACK]);
+        f.stackCount = (size_t)n;
     }
     f.done.assign(n, 0);
     f.body = [&body] { body(); };
     for (int i = 0; i < n; i++) {
         getcontext(&f.ctx[i]);
-        f.ctx[i].uc_stack.ss_sp = f.stacks.data() + (size_t)i * Fibers::STACK;
+        f.ctx[i].uc_stack.ss_sp = f.stacks.get() + (size_t)i * Fibers::STACK;
         f.ctx[i].uc_stack.ss_size = Fibers::STACK;
         f.ctx[i].uc_link = &f.sched;
         makecontext(&f.ctx[i], fiber_entry, 0);
@@ -207,7 +210,7 @@ void run_block_lockstep(dim3 block, unsigned bx, unsigned by, unsigned bz, F& bo
             t_threaded = true;
             t_blockIdx = {bx, by, bz};
             t_threadIdx = {(unsigned)i % block.x, ((unsigned)i / block.x) % block.y, (unsigned)i / (block.x * block.y)};
-            fiber_switch(&f.sched, &f.ctx[i], f.stacks.data() + (size_t)i * Fibers::STACK, Fibers::STACK, false);
+            fiber_switch(&f.sched, &f.ctx[i], f.stacks.get() + (size_t)i * Fibers::STACK, Fibers::STACK, false);
             if (f.done[i])
                 live--;
         }
