@@ -1954,6 +1954,18 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of(int t
     return xcd_tile(c, *tx, *ty) ? 1 : 0;
 }
 extern "C" __attribute__((visibility("default"))) unsigned nrdhip_debug_grid_blocks(int tilesX, int tilesY) { return (unsigned)xcd_grid_blocks(tilesX, tilesY); }
+// test / analysis hook, host-emulated build only (tools/gather_locality.py): read and reset the gather trace of the emulation
+// {wave-level gather instructions, distinct 128-byte lines they touched, lane loads}, then switch it on / off
+extern "C" __attribute__((visibility("default"))) void nrdhip_debug_gather_trace(int on, double* out3) {
+    hipemu::GatherTrace& g = hipemu::g_gatherTrace;
+    if (out3) {
+        out3[0] = g.instr;
+        out3[1] = g.lines;
+        out3[2] = g.laneLoads;
+    }
+    g.instr = g.lines = g.laneLoads = 0;
+    g.on = on != 0;
+}
 #endif
 
 void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_prepare_inputs, ); }

@@ -9,6 +9,7 @@
 // variable hand-off between 256 OS threads; all kernels here are idempotent per block, so the re-run is safe). Under AddressSanitizer
 // every stack switch is announced (fiber_switch); -DHIPEMU_USE_THREADS selects the older model: one OS thread per HIP thread, real barriers.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -225,6 +226,47 @@ inline void sync() {
 }
 #endif
 
+// ---- optional gather trace (tools/gather_locality.py): for every wave (64 consecutive threads of a block, as on the GPU) and every
+// buffer gather it executes - the k-th gather of each lane is the same instruction in these straight-line tap loops - the number of
+// distinct 128-byte lines the 64 lanes touch. A hardware-independent measure of how well a pass's taps coalesce.
+struct GatherTrace {
+    bool on = false;
+    std::vector<std::vector<uint64_t>> lanes;
+    double instr = 0, lines = 0, laneLoads = 0;
+};
+inline GatherTrace g_gatherTrace;
+inline thread_local int t_traceLane = -1;
+inline void trace_gather(const void* a) {
+    if (g_gatherTrace.on && t_traceLane >= 0)
+        g_gatherTrace.lanes[(size_t)t_traceLane].push_back((uint64_t)(uintptr_t)a);
+}
+inline void trace_fold_block(int nthreads) {
+    GatherTrace& g = g_gatherTrace;
+    for (int w0 = 0; w0 < nthreads; w0 += 64) {
+        size_t maxk = 0;
+        for (int l = w0; l < w0 + 64 && l < nthreads; l++)
+            maxk = std::max(maxk, g.lanes[(size_t)l].size());
+        for (size_t k = 0; k < maxk; k++) {
+            uint64_t seen[64];
+            int ns = 0, nl = 0;
+            for (int l = w0; l < w0 + 64 && l < nthreads; l++) {
+                if (g.lanes[(size_t)l].size() <= k)
+                    continue;
+                nl++;
+                const uint64_t line = g.lanes[(size_t)l][k] >> 7;
+                bool dup = false;
+                for (int q = 0; q < ns; q++)
+                    dup = dup || seen[q] == line;
+                if (!dup)
+                    seen[ns++] = line;
+            }
+            g.instr += 1;
+            g.lines += ns;
+            g.laneLoads += nl;
+        }
+    }
+}
+
 template <typename F>
 void launch(dim3 grid, dim3 block, F body) {
     for (unsigned bz = 0; bz < grid.z; bz++)
@@ -233,18 +275,29 @@ void launch(dim3 grid, dim3 block, F body) {
                 bool needThreads = false;
                 t_threaded = false;
                 t_blockIdx = {bx, by, bz};
+                const int nthreads = (int)(block.x * block.y * block.z);
+                const bool trace = g_gatherTrace.on;
+                if (trace) {
+                    g_gatherTrace.lanes.resize((size_t)nthreads);
+                    for (auto& l : g_gatherTrace.lanes)
+                        l.clear();
+                }
                 try {
                     for (unsigned tz = 0; tz < block.z && !needThreads; tz++)
                         for (unsigned ty = 0; ty < block.y; ty++)
                             for (unsigned tx = 0; tx < block.x; tx++) {
                                 t_threadIdx = {tx, ty, tz};
+                                t_traceLane = trace ? (int)((tz * block.y + ty) * block.x + tx) : -1;
                                 body();
                             }
                 } catch (NeedThreads&) {
                     needThreads = true;
                 }
+                t_traceLane = -1;
                 if (needThreads)
-                    run_block_lockstep(block, bx, by, bz, body);
+                    run_block_lockstep(block, bx, by, bz, body); // (barrier kernels are not traced: none of them gathers through buffers)
+                else if (trace)
+                    trace_fold_block(nthreads);
             }
 }
 } // namespace hipemu
@@ -275,6 +328,7 @@ typedef unsigned int hipemu_u2v __attribute__((__vector_size__(8)));
 template <typename T>
 inline T hipemu_buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     T v;
+    hipemu::trace_gather(r.p + (unsigned)voff + (unsigned)soff);
     std::memcpy(&v, r.p + (unsigned)voff + (unsigned)soff, sizeof(T));
     return v;
 }
