@@ -212,3 +212,118 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
         if is_spec:
             track = np.where(sky, 0.0, min_hit)
     return f16(out), f16(track)
+
+
+def hash_px_arr(x, y, frame, salt):
+    """hash_px over integer arrays (uint32 wrap-around arithmetic)"""
+    m = np.uint64(0xFFFFFFFF)
+    x, y = x.astype(np.uint64), y.astype(np.uint64)
+    h = ((x * np.uint64(73856093)) & m) ^ ((y * np.uint64(19349663)) & m) ^ np.uint64((frame * 83492791) & 0xFFFFFFFF) ^ np.uint64((salt * 2654435761) & 0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0x5BD1E995)) & m
+    h ^= h >> np.uint64(15)
+    return h
+
+
+MIN_CONVERGED_RADIUS_SCALE, POST_BLUR_RADIUS_SCALE = 0.25, 2.0
+
+
+def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_view, frame_index, denoising_range, s):
+    """REBLUR_DIFFUSE_SPECULAR Blur (post = False) / PostBlur (post = True) of one frame on tap texels: `sig_in` [H, W, 2, 4] fp16 = the
+    signal halves of the tap texels the pass gathers (HistoryFix's for Blur, Blur's for PostBlur), `speeds` [H, W] uint16 = Data1 (diffuse
+    | specular accumulation speed in quarter frames). Differences from the PrePass: the radius comes from the accumulation speed
+    (converged pixels blur less, PostBlur twice as far), the normal-weight lobe narrows with it, Blur rotates its disk per 2x2 pixel
+    quad (PostBlur per frame), a rejected tap enters with weight 0, no hit-distance tracking. Returns [H, W, 2, 4] fp16."""
+    H, W = viewz.shape
+    M = np.asarray(view_to_clip, np.float64)
+    sgn = 1.0 if M[11] > 0 else -1.0
+    pj = np.array([M[0], M[5], M[8], M[9], sgn])
+    fr = np.array([(-sgn - M[8]) / M[0], (sgn - M[9]) / M[5], 2.0 * sgn / M[0], -2.0 * sgn / M[5]])
+    pv = np.array([fr[0] + 0.5 * fr[2] / W, fr[1] + 0.5 * fr[3] / H, fr[2] / W, fr[3] / H])
+    w2v = np.asarray(world_to_view, np.float64).reshape(4, 4).T[:3, :3]
+    unproject = 1.0 / (0.5 * H * abs(pj[1]))
+    min_dim_unproject = min(W, H) * unproject
+    z, n, rough_g, mat = decode_guide(viewz, packed_nr)
+    sky = ~(np.abs(z) <= denoising_range)
+    yy, xx = np.mgrid[0:H, 0:W]
+    Xv = np.stack([z * (pv[2] * xx + pv[0]), z * (pv[3] * yy + pv[1]), z], -1)
+    Nv = n @ w2v.T
+    absz = np.abs(z)
+    frustum = min_dim_unproject * absz
+    geoA = 1.0 / (s["planeDistanceSensitivity"] * frustum)
+    gax, gay = Nv[..., 0] * pv[2] * geoA, Nv[..., 1] * pv[3] * geoA
+    ga0 = (Nv[..., 0] * pv[0] + Nv[..., 1] * pv[1] + Nv[..., 2]) * geoA
+    geoB = -(Nv * Xv).sum(-1) * geoA
+    V = -normalize(Xv)
+    inv = 1.0 / (pj[4] * z)
+    nu = (pj[0] * Xv[..., 0] + pj[2] * z) * inv
+    nv_ = (pj[1] * Xv[..., 1] + pj[3] * z) * inv
+    kuz, kvz = pj[2] - nu * pj[4], pj[3] - nv_ * pj[4]
+    ju, jv = 0.5 * W * inv, -0.5 * H * inv
+    if post:  # one rotation per frame (salt 3)
+        k = np.full((H, W), hash_px(0, 0, frame_index, 3) & 63, np.int64)
+    else:     # one rotation per 2x2 pixel quad (salt 2)
+        k = (hash_px_arr(xx >> 1, yy >> 1, frame_index, 2) & np.uint64(63)).astype(np.int64)
+    ang = 2.0 * np.pi * np.arange(64) / 64.0
+    rot_c, rot_s = np.cos(ang).astype(np.float32).astype(np.float64)[k], np.sin(ang).astype(np.float32).astype(np.float64)[k]
+    reach = int((s["maxBlurRadius"] + s["minBlurRadius"]) * (2.2 if post else 1.1)) + 3
+    out = np.zeros((H, W, 2, 4), np.float64)
+    hp = s["hitDistanceParameters"]
+    A_all = [(speeds & 255).astype(np.float64) * 0.25, (speeds >> 8).astype(np.float64) * 0.25]
+    for sig, is_spec in enumerate((False, True)):
+        plane = sig_in[:, :, sig]
+        center = plane.astype(np.float64)
+        rough = rough_g if is_spec else np.ones_like(rough_g)
+        min_mat = s["minMaterialForSpecular"] if is_spec else s["minMaterialForDiffuse"]
+        hn = hitdist_norm(absz, hp, rough)
+        hdf = np.clip(center[..., 3] * hn / frustum, 0, 1)
+        non_lin = 1.0 / (1.0 + A_all[sig])
+        smc = spec_magic_curve(rough) if is_spec else np.ones_like(rough)
+        r = s["maxBlurRadius"] * (MIN_CONVERGED_RADIUS_SCALE + (1.0 - MIN_CONVERGED_RADIUS_SCALE) * non_lin) * (hdf + (1.0 - hdf) * non_lin) + s["minBlurRadius"]
+        r = r * (POST_BLUR_RADIUS_SCALE if post else 1.0) * smc
+        radius = r if s["maxBlurRadius"] != 0.0 else np.zeros_like(r)
+        active = radius > 0
+        world_radius = radius * unproject * absz
+        T, B = basis(Nv)
+        if is_spec:
+            NoV = (Nv * V).sum(-1, keepdims=True)
+            R = Nv * 2.0 * NoV - V
+            D = normalize(Nv + (R - Nv) * spec_dominant_factor(rough)[..., None])
+            NoD = (Nv * D).sum(-1, keepdims=True)
+            skewed = (NoD[..., 0] < 0.999) & (rough < 0.95)
+            Dr = Nv * 2.0 * NoD - D
+            T2 = normalize(np.cross(Nv, Dr))
+            B2 = np.cross(Dr, T2)
+            T2 = T2 * ((0.5 + 0.5 * rough)[..., None] + (1.0 - (0.5 + 0.5 * rough)[..., None]) * NoD)
+            T, B = np.where(skewed[..., None], T2, T), np.where(skewed[..., None], B2, B)
+        T, B = T * world_radius[..., None], B * world_radius[..., None]
+        jtx, jty = ju * (pj[0] * T[..., 0] + kuz * T[..., 2]), jv * (pj[1] * T[..., 1] + kvz * T[..., 2])
+        jbx, jby = ju * (pj[0] * B[..., 0] + kuz * B[..., 2]), jv * (pj[1] * B[..., 1] + kvz * B[..., 2])
+        angle = np.arctan(3.0 * np.clip(rough, 0, 1) ** 2) * (s["lobeAngleFraction"] + (1.0 - s["lobeAngleFraction"]) * non_lin)
+        normal_w = 1.0 / np.maximum(angle, NORMAL_ANGLE_MIN)
+        hitA = 1.0 / (1e-6 + (1.0 - 1e-6) * np.minimum(non_lin, smc))
+        hitB = -center[..., 3] * hitA
+        roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
+        roughB = -rough * roughA
+        acc, wsum = center.copy(), np.ones((H, W))
+        for t in range(8):
+            ox = POISSON8[t, 0] * rot_c - POISSON8[t, 1] * rot_s
+            oy = POISSON8[t, 0] * rot_s + POISSON8[t, 1] * rot_c
+            fpx = np.floor(ox * jtx + oy * jbx + xx + 0.5)
+            fpy = np.floor(ox * jty + oy * jby + yy + 0.5)
+            in_win = (fpx >= np.maximum(xx - reach, 0)) & (fpx <= np.minimum(xx + reach, W - 1)) & (fpy >= np.maximum(yy - reach, 0)) & (fpy <= np.minimum(yy + reach, H - 1))
+            px, py = np.clip(fpx, 0, W - 1).astype(np.int64), np.clip(fpy, 0, H - 1).astype(np.int64)
+            zs, ns, rs_, ms = z[py, px], n[py, px], rough_g[py, px], mat[py, px]
+            sv = plane[py, px].astype(np.float64)
+            valid = in_win & active & ~sky[py, px] & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
+            w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
+            w = w * smoothstep01(1.0 - 2.0 * np.clip(1.0 - normal_cos(n, ns), 0, 1) * normal_w * normal_w)
+            if is_spec:
+                w = w * smoothstep01(1.0 - np.abs(rs_ * roughA + roughB))
+            ax = np.abs(sv[..., 3] * hitA + hitB)
+            w = w * (s["minHitDistanceWeight"] + (1.0 - s["minHitDistanceWeight"]) * np.clip(1.0 - ax, 0, 1) ** 2)
+            w = np.where(valid, w, 0.0)
+            acc = acc + np.where(valid[..., None], sv, 0.0) * w[..., None]
+            wsum = wsum + w
+        out[:, :, sig] = np.where(sky[..., None], 0.0, acc / wsum[..., None])
+    return f16(out)

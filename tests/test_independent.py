@@ -218,8 +218,22 @@ def test_temporal_passes_independent(pkg, api, oracle, f):
         a, b = (speeds_cur >> shift) & 255, (w_speeds_cur >> shift) & 255
         assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99
 
+    # ---- Blur and PostBlur (fed with the ORACLE's tap texels: HistoryFix's, then Blur's)
+    sb = dict(settings_dict(st), maxBlurRadius=st.maxBlurRadius, minBlurRadius=st.minBlurRadius, lobeAngleFraction=st.lobeAngleFraction)
+    tap_signal = lambda planes: np.stack([np.ascontiguousarray(t[..., 2:4]).view(np.float16).reshape(H, W, 4) for t in planes], 2)
+    hz.nrd.denoise_range([den], 4, 1)
+    taps_b = [hz.pool("REBLUR::Tap_%s_B" % k).copy().view(np.uint32).reshape(H, W, 4) for k in ("Diff", "Spec")]
+    w_blur = ind.blur_pass(False, fr["viewz"], fr["normal_roughness"], tap_signal(taps), speeds_cur, fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
+                           cs.denoisingRange, sb)
+    agree("Blur", tap_signal(taps_b), w_blur, 0.995, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)))
+    for k in range(2):  # the guide part travels through Blur untouched
+        assert np.array_equal(taps_b[k][..., :2], taps[k][..., :2])
+    hz.nrd.denoise_range([den], 5, 1)
+    w_post = ind.blur_pass(True, fr["viewz"], fr["normal_roughness"], tap_signal(taps_b), speeds_cur, fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
+                           cs.denoisingRange, sb)
+    agree("PostBlur", rad("REBLUR::History"), w_post, 0.995, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)))
+
     # ---- TemporalStabilization (fed with the ORACLE's PostBlur output)
-    hz.nrd.denoise_range([den], 4, 2)
     post, stab_prev = rad("REBLUR::History"), lum("REBLUR::StabilizedLuma" + old)
     hz.nrd.denoise_range([den], 6, 1)
     stab = lum("REBLUR::StabilizedLuma" + cur)
