@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import __graft_entry__ as graft  # noqa: E402
 
+GRAPH_LEG_BAND = (7680, 544)  # the band one rank of 8 holds of the 7680x4320 frame (BASELINE config 5): second size of the graph-replay leg
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -446,7 +447,7 @@ def main():
             try:
                 leg = {}
                 side = torch.cuda.Stream(device=dev)
-                for tag, (gw, gh) in (("workload", (w, band_h)), ("band_7680x544", (7680, 544))):
+                for tag, (gw, gh) in (("workload", (w, band_h)), ("band_%dx%d" % GRAPH_LEG_BAND, GRAPH_LEG_BAND)):
                     row = {}
                     for mode in ("direct", "graph"):
                         scene_g = synth.Scene(gw, gh, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
