@@ -192,7 +192,7 @@ def main():
     backend = os.environ.get("NRD_BENCH_DRYRUN_BACKEND", "nccl")
     local = local if backend == "nccl" else local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    dev = "cuda:%d" % local
+    dev = os.environ.get("NRD_BENCH_DEVICE") or "cuda:%d" % local  # (NRD_BENCH_DEVICE=cpu: tests/test_bench_flow.py drives this flow on the emulated kernels)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime

@@ -641,9 +641,11 @@ def verify_tiled_against_single(pkg, backend, device, dens, width, frame_h, rank
     keys = [k for k in ("out_diff", "out_spec") if k in band.outputs]
     bad = []
     for key in keys:
-        own = band.own_rows(band.outputs[key]).contiguous()
+        own = band.own_rows(band.outputs[key])
+        own = own.contiguous() if hasattr(own, "contiguous") else torch.from_numpy(np.ascontiguousarray(own))  # (numpy planes: the CPU backends of the tests)
         if rank == 0:
             ref = single.outputs[key]
+            ref = ref if hasattr(ref, "contiguous") else torch.from_numpy(ref)
             rows = [own] + [None] * (world - 1)
             for r in range(1, world):
                 b0, b1 = band.bounds[r], band.bounds[r + 1]

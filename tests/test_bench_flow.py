@@ -2,34 +2,15 @@
 streams / events / synchronisation replaced by host stand-ins and the workload shrunk to a few tiles. What is checked is the contract of
 the JSON line the driver parses - every key, the roofline and cpu_baseline objects, the extra legs (full coverage, upstream-formulas
 flavour, graph replay) - and that nothing in the flow raises; the numbers themselves mean nothing here."""
-import contextlib
 import json
+import os
+import subprocess
 import sys
-import time
 
 import pytest
 
 
-class FakeEvent:
-    def __init__(self, enable_timing=False):
-        self.t = 0.0
-
-    def record(self, stream=None):
-        self.t = time.perf_counter()
-
-    def elapsed_time(self, other):
-        return max((other.t - self.t) * 1e3, 1e-6)
-
-    def synchronize(self):
-        pass
-
-
-class FakeStream:
-    def __init__(self, device=None):
-        self.cuda_stream = 0
-
-    def synchronize(self):
-        pass
+import bench_worker
 
 
 def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, emulated, emulated_upstream):
@@ -37,15 +18,7 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
 
     import bench
 
-    for name, value in (("is_available", lambda: True), ("device_count", lambda: 1), ("set_device", lambda d: None), ("synchronize", lambda *a: None),
-                        ("empty_cache", lambda: None), ("Event", FakeEvent), ("Stream", FakeStream), ("stream", lambda s: contextlib.nullcontext()),
-                        ("current_stream", lambda *a: FakeStream())):
-        monkeypatch.setattr(torch.cuda, name, value)
-    monkeypatch.setattr(pkg, "hip_backend", lambda device, flavour=None: emulated_upstream if flavour else emulated)
-    real_scene = pkg.synth.Scene
-    monkeypatch.setattr(pkg.synth, "Scene", lambda *a, **kw: real_scene(*a, **dict(kw, device="cpu")))
-    monkeypatch.setitem(bench.WORKLOADS, "reblur_ds_4k", (96, 64, ["REBLUR_DIFFUSE_SPECULAR"]))
-    monkeypatch.setattr(bench, "GRAPH_LEG_BAND", (64, 32))
+    bench_worker.patch_for_cpu(monkeypatch.setattr, pkg, bench, emulated, emulated_upstream, {"reblur_ds_4k": (96, 64, ["REBLUR_DIFFUSE_SPECULAR"])}, (64, 32))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "8", "--warmup", "2", "--unique-frames", "2"])
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
@@ -68,3 +41,38 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
     assert set(c["graph_replay"]) == {"workload", "band_64x32"} and c["graph_replay"]["workload"]["graph_stats"]["direct"] > 0  # (no graphs in the emulation)
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b and b["unit"] == "Mpixels/s"
+
+
+def run_two_ranks(tmp_path, extra):
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_worker.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--unique-frames", "2",
+           "--no-cpu-baseline"] + extra
+    env = dict(os.environ, NRD_BENCH_DRYRUN_BACKEND="gloo", NRD_BENCH_DEVICE="cpu", OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_line_on_the_emulated_backend(emulated, tmp_path):
+    """the N > 1 flow (BASELINE config 5's mode: ONE frame row-tiled into bands, strong scaling) with two gloo ranks on the emulated
+    kernels: the line of record, per-rank GPU-busy times, the balanced bands, the C++ tiler leg and the bit-identity check"""
+    d = run_two_ranks(tmp_path, [])
+    c = d["config"]
+    assert (d["n_gpus"], d["scaling"], d["steps"]) == (2, "strong", 8) and d["value"] > 0
+    assert sum(c["band_rows"]) == 448 and len(c["rank_ms"]) == 2 and all(t > 0 for t in c["rank_ms"])
+    assert c["tiled_bit_identical"] is True, c.get("tiled_bit_identical_detail")
+    assert "value" in c["native_tiler"], c["native_tiler"]
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_two_rank_bench_watchdog_prints_the_line_and_ends_the_run(emulated, tmp_path):
+    """--extras-deadline 0: the watchdog fires while the extras run - rank 0 must still print the complete line of record, with the
+    unfinished extras marked, and every rank must leave with exit code 0"""
+    d = run_two_ranks(tmp_path, ["--extras-deadline", "0"])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(c["rank_ms"]) == 2
+    assert c["tiled_bit_identical"] is None and "watchdog" in c["tiled_bit_identical_detail"]
+    assert "error" in c["native_tiler"] or "value" in c["native_tiler"]
