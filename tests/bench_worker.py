@@ -60,5 +60,6 @@ if __name__ == "__main__":
     import bench
 
     emu = pkg.api.Backend(graft.build_emulated(), "nrdhip_", "cpu")
-    patch_for_cpu(setattr, pkg, bench, emu, emu, {"reblur_ds_8k": (48, 448, ["REBLUR_DIFFUSE_SPECULAR"])}, (64, 32))
+    ww, hh = (int(v) for v in os.environ.get("NRD_TEST_FRAME", "48,448").split(","))
+    patch_for_cpu(setattr, pkg, bench, emu, emu, {"reblur_ds_8k": (ww, hh, ["REBLUR_DIFFUSE_SPECULAR"])}, (64, 32))
     bench.main()

@@ -43,12 +43,12 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
     assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b and b["unit"] == "Mpixels/s"
 
 
-def run_two_ranks(tmp_path, extra):
-    port = 29600 + os.getpid() % 300
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_worker.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--unique-frames", "2",
+def run_two_ranks(tmp_path, extra, world=2, frame="48,448"):
+    port = 29600 + os.getpid() % 300 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_worker.py"), "--gpus", str(world), "--steps", "8", "--warmup", "2", "--unique-frames", "2",
            "--no-cpu-baseline"] + extra
-    env = dict(os.environ, NRD_BENCH_DRYRUN_BACKEND="gloo", NRD_BENCH_DEVICE="cpu", OMP_NUM_THREADS="2")
+    env = dict(os.environ, NRD_BENCH_DRYRUN_BACKEND="gloo", NRD_BENCH_DEVICE="cpu", OMP_NUM_THREADS="2", NRD_TEST_FRAME=frame)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -76,3 +76,19 @@ def test_two_rank_bench_watchdog_prints_the_line_and_ends_the_run(emulated, tmp_
     assert d["n_gpus"] == 2 and d["value"] > 0 and len(c["rank_ms"]) == 2
     assert c["tiled_bit_identical"] is None and "watchdog" in c["tiled_bit_identical_detail"]
     assert "error" in c["native_tiler"] or "value" in c["native_tiler"]
+
+
+def test_four_rank_bench_line_on_the_emulated_backend(emulated, tmp_path):
+    """four bands: interior ranks exchange rows with two neighbours; the line carries four per-rank times and four band heights"""
+    d = run_two_ranks(tmp_path, ["--no-native-leg"], world=4, frame="32,1280")
+    c = d["config"]
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and len(c["rank_ms"]) == 4 and len(c["band_rows"]) == 4 and sum(c["band_rows"]) == 1280
+    assert all(r % 16 == 0 for r in c["band_rows"]) and c["tiled_bit_identical"] is True, c
+
+
+def test_eight_rank_bench_line_on_the_emulated_backend(emulated, tmp_path):
+    """the driver's largest launch shape (N = 8, one rank per GPU there; eight gloo ranks on the host here), native tiler leg included"""
+    d = run_two_ranks(tmp_path, [], world=8, frame="32,2560")
+    c = d["config"]
+    assert d["n_gpus"] == 8 and len(c["rank_ms"]) == 8 and len(c["band_rows"]) == 8 and sum(c["band_rows"]) == 2560
+    assert c["tiled_bit_identical"] is True and "value" in c["native_tiler"], c
