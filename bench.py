@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--motion-rows", type=int, default=8, help="row tiling: vertical motion (rows) the stored halo must cover beyond the passes' reach")
     ap.add_argument("--unique-frames", type=int, default=4, help="distinct noisy input frames cycled through (resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-passes", action="store_true", help="1-GPU runs: one dispatch per pass (NRDHIP_FLAG_SEPARATE_PASSES) instead of the "
+                    "fused REBLUR::PrePassTemporalAccumulation dispatch")
+    ap.add_argument("--no-preroll", action="store_true", help="do not run the untimed pre-roll frames that bring the accumulation to its steady state "
+                    "when --warmup is shorter than the accumulation length (the timed region then sees the wider blur radii of young histories)")
     ap.add_argument("--extras-deadline", type=int, default=240,
                     help="N > 1: seconds the native-tiler leg and the bit-identity check may take together before rank 0 prints the line of "
                          "record without them and the run ends (a hang in never-executed transport code must not cost the line)")
@@ -232,7 +236,7 @@ def main():
             scene_kw = sample_tests.scene_kwargs(preset)
         scene = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
                             roll_deg=args.roll, **scene_kw)
-        hz = Harness(hip, dens, w, band_h)
+        hz = Harness(hip, dens, w, band_h, separate_passes=args.separate_passes)
         st = settings_of(api, scene, dens) if preset is None else sample_tests.denoiser_settings(api, preset, scene, dens, first_frame=False)
         runner = SingleRunner(api, hz, scene, dens, args.unique_frames, st)
         frame_h = band_h
@@ -244,10 +248,21 @@ def main():
                              tiler=args.tiler, motion_rows=args.motion_rows, balance=strong and not args.even_bands)
         band_h = runner.band.layout["own_rows"]
 
+    def accum_length(runner):
+        return max([int(getattr(st, "maxAccumulatedFrameNum", 0)) for st in runner.settings.values()] +
+                   [int(getattr(st, "diffuseMaxAccumulatedFrameNum", 0)) for st in runner.settings.values()] + [0])
+
+    def preroll_frames(runner):
+        """untimed frames in FRONT of the --warmup frames, so that the timed region is the steady state whatever --warmup says: the blur
+        radii shrink with the history length, which saturates after maxAccumulatedFrameNum frames (30 at the sample's operating point) -
+        a run timed after 5 warm-up frames measures wider, slower blurs than the denoiser does from frame 32 on (round 3: 7862 vs 8457)"""
+        return 0 if args.no_preroll else max(0, accum_length(runner) + 2 - args.warmup)
+
     def timed_run(runner):
-        """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns the wall time of the
-        timed region (max over ranks)"""
-        for f in range(args.warmup):
+        """pre-roll to the steady state, W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns
+        the wall time of the timed region (max over ranks)"""
+        pre = preroll_frames(runner)
+        for f in range(pre + args.warmup):
             runner.step(f, reset=(f == 0))
         if hasattr(runner, "finish"):
             runner.finish()
@@ -258,8 +273,8 @@ def main():
         # timed region: exactly K steps, HIP events around every dispatch of every S-th step on the launch stream
         stride = max(args.event_stride, 1)
         t0 = time.perf_counter()
-        for f in range(args.warmup, args.warmup + args.steps):
-            runner.enable_events((f - args.warmup) % stride == 0)
+        for f in range(pre + args.warmup, pre + args.warmup + args.steps):
+            runner.enable_events((f - pre - args.warmup) % stride == 0)
             runner.step(f, reset=False)
         if hasattr(runner, "finish"):
             runner.finish()  # row tiler: halo rows of the last frame's permanent planes still travelling
@@ -292,9 +307,9 @@ def main():
         total_pixels = w * frame_h * args.steps
         value = total_pixels / dt / 1e6
         ms_per_step = dt / args.steps * 1e3
-        max_accum = max([int(getattr(st, "maxAccumulatedFrameNum", 0)) for st in runner.settings.values()] + [0])
-        state = "steady state (accumulation saturated)" if args.warmup >= max_accum else \
-            "warm-up %d frames (accumulation saturates at %d)" % (args.warmup, max_accum)
+        max_accum, pre = accum_length(runner), preroll_frames(runner)
+        state = ("steady state (accumulation saturated%s)" % (": %d untimed pre-roll frames in front of the %d warm-up frames" % (pre, args.warmup) if pre else "")
+                 if pre + args.warmup >= max_accum else "warm-up %d frames (accumulation saturates at %d)" % (args.warmup, max_accum))
         tiled_desc = "" if world == 1 and not args.force_tiled else " row-tiled %d x ~%d rows (%s scaling), halo %d rows, %s tiler" % (
             world, band_h, args.scaling, runner.halo, args.tiler)
         bpp_contract = contract_bpp(den_names)
@@ -335,7 +350,7 @@ def main():
             out["config"]["sky_fraction"] = round(runner.sky_fraction(), 4)
         if hasattr(runner, "tiler"):
             t = runner.tiler
-            out["config"]["halo_exchange_bytes_per_frame_rank0"] = int(t.bytes_exchanged / max(args.warmup + args.steps, 1))
+            out["config"]["halo_exchange_bytes_per_frame_rank0"] = int(t.bytes_exchanged / max(preroll_frames(runner) + args.warmup + args.steps, 1))
             out["config"]["band_rows"] = [b1 - b0 for b0, b1 in zip(runner.band.bounds, runner.band.bounds[1:])]
             out["config"]["band_split"] = "cost-balanced (geometry tiles + 0.15 x sky tiles of the first frame)" if runner.bounds else "even tile rows"
         if rank_ms is not None:
@@ -374,7 +389,7 @@ def main():
             dt_n = timed_run(native)
             native_leg = {"value": round(w * frame_h * args.steps / dt_n / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_n / args.steps * 1e3, 4),
                           "transport": "rccl" if backend == "nccl" else "caller callbacks over torch.distributed (%s)" % backend,
-                          "halo_exchange_bytes_per_frame_rank0": int(native.tiler.bytes_exchanged / max(args.warmup + args.steps, 1))}
+                          "halo_exchange_bytes_per_frame_rank0": int(native.tiler.bytes_exchanged / max(preroll_frames(native) + args.warmup + args.steps, 1))}
             del native
             torch.cuda.empty_cache()
         except Exception as e:
@@ -404,7 +419,7 @@ def main():
                 torch.cuda.empty_cache()
                 scene_fc = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
                                        roll_deg=args.roll, wall_height=float("inf"))
-                hz_fc = Harness(hip, dens, w, band_h)
+                hz_fc = Harness(hip, dens, w, band_h, separate_passes=args.separate_passes)
                 runner_fc = SingleRunner(api, hz_fc, scene_fc, dens, args.unique_frames, settings_of(api, scene_fc, dens))
                 dt_fc = timed_run(runner_fc)
                 pp = runner_fc.pass_times_ms()
@@ -427,7 +442,7 @@ def main():
                 hip_up = pkg.hip_backend(dev, flavour="upstream")
                 scene_up = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
                                        roll_deg=args.roll)
-                hz_up = Harness(hip_up, dens, w, band_h)
+                hz_up = Harness(hip_up, dens, w, band_h, separate_passes=args.separate_passes)
                 runner_up = SingleRunner(api, hz_up, scene_up, dens, args.unique_frames, settings_of(api, scene_up, dens))
                 dt_up = timed_run(runner_up)
                 pp = runner_up.pass_times_ms()

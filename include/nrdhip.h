@@ -42,7 +42,13 @@ enum {
      * hipGraphExecUpdate (it is only re-instantiated when the list changes shape: a CLEAR_AND_RESTART frame with its clears) and is launched
      * on the caller's stream. Needs a capturable stream: on the legacy default stream (NULL) the passes are launched one by one as
      * without the flag. Results are bit-identical either way; nrdhip_graph_stats reports what happened. */
-    NRDHIP_FLAG_GRAPH = 2u
+    NRDHIP_FLAG_GRAPH = 2u,
+    /* one dispatch per pass of the pass graph. By default the REBLUR radiance flavours (REBLUR_DIFFUSE / _SPECULAR / _DIFFUSE_SPECULAR)
+     * run PrePass and TemporalAccumulation as ONE dispatch, "REBLUR::PrePassTemporalAccumulation": TemporalAccumulation reads the
+     * PrePass result at its own pixel only, so it stays in registers and the Tmp1 plane is never touched. Outputs and every other
+     * pool plane are bit-identical either way; the flag exists for callers that want the PrePass result as a plane (tests,
+     * debugging). */
+    NRDHIP_FLAG_SEPARATE_PASSES = 4u
 };
 
 /* == nrd::InstanceCreationDesc + nrd::IntegrationCreationDesc (Source/NRDSample.cpp:924-936).

@@ -369,6 +369,7 @@ class HistoryState(C.Structure):  # nrdhip_history_state
 UNPACK_NORMAL, UNPACK_OCCLUSION, UNPACK_SH, PACK_DIRECTIONAL_OCCLUSION = 0, 1, 2, 3
 FLAG_EXTERNAL_POOLS = 1
 FLAG_GRAPH = 2  # nrdhip_denoise replays one HIP graph per frame (include/nrdhip.h NRDHIP_FLAG_GRAPH)
+FLAG_SEPARATE_PASSES = 4  # one dispatch per pass: no fused REBLUR::PrePassTemporalAccumulation (NRDHIP_FLAG_SEPARATE_PASSES)
 
 
 class NrdError(RuntimeError):
@@ -488,15 +489,17 @@ class Integration:
         self._bound = {}
 
     # nrd::Integration::Recreate(IntegrationCreationDesc, InstanceCreationDesc, device) -> Result
-    def recreate(self, denoisers, resource_width, resource_height, frame_height=0, band_row0=0, band_own_first=0, band_own_rows=0, graph=False):
+    def recreate(self, denoisers, resource_width, resource_height, frame_height=0, band_row0=0, band_own_first=0, band_own_rows=0, graph=False,
+                 separate_passes=False):
         """``denoisers``: list of (identifier, Denoiser). Returns Result (SUCCESS or the failure code), never raises for
-        library-side failures - the sample tests ``!= SUCCESS`` (Source/NRDSample.cpp:982-983)."""
+        library-side failures - the sample tests ``!= SUCCESS`` (Source/NRDSample.cpp:982-983). ``separate_passes``: one dispatch per pass of
+        the pass graph (no fused REBLUR::PrePassTemporalAccumulation) - for callers that want the PrePass result as a plane."""
         self.destroy()
         arr = (DenoiserDesc * len(denoisers))(*[DenoiserDesc(int(i), int(d)) for i, d in denoisers])
         dev = self.backend.device
         device_plus1 = int(dev.split(":")[1]) + 1 if isinstance(dev, str) and dev.startswith("cuda:") else 0  # kernels + checks on the device torch allocates on
         desc = CreateDesc(arr, len(denoisers), resource_width, resource_height, frame_height, band_own_first, band_own_rows, device_plus1,
-                          band_row0, FLAG_EXTERNAL_POOLS | (FLAG_GRAPH if graph else 0))
+                          band_row0, FLAG_EXTERNAL_POOLS | (FLAG_GRAPH if graph else 0) | (FLAG_SEPARATE_PASSES if separate_passes else 0))
         h = C.c_void_p()
         r = self.backend.create(C.byref(desc), C.byref(h))
         if r != 0:

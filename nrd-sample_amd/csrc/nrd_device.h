@@ -316,11 +316,32 @@ struct Guide {
 // dot product of two quantised, not re-normalised vectors is useless for what the normal weights need - 1 - cos at the 1e-4 level for
 // the narrow specular lobes: |n|^2 is off by up to 2e-3, so identical normals would score like a 3 degree bend - while the squared
 // difference of the codes is exact (integers below 2^24 in fp32), zero for equal normals and as fine as the quantisation step.
-NRD_DEV f3 normal_codes(uint32_t nw) { return {(float)(nw & 1023u), (float)((nw >> 10) & 1023u), (float)((nw >> 20) & 1023u)}; }
-NRD_DEV float normal_cos(f3 centreCodes, uint32_t nw) {
-    const f3 c = normal_codes(nw);
-    const float dx = c.x - centreCodes.x, dy = c.y - centreCodes.y, dz = c.z - centreCodes.z;
-    const float d2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
+// Round 4 (profiles/r04_valu_issue.txt: the spatial passes sit on VALU issue, and the three bfe / sub / cvt chains of this distance were
+// a quarter of a tap's cycles): the distance is formed in INTEGERS with packed 16-bit lanes - x and z of a normal word are one
+// `v_and` away from being the two 16-bit lanes {x, z << 4}, so a tap costs and + bfe (y), v_pk_sub_i16, v_sub, v_pk_ashrrev_i16 (lane
+// shifts {0, 4}: exact, 16 dz is a multiple of 16), v_mul_i32_i24 (dy^2), v_dot2c_i32_i16, v_cvt: 8 instructions instead of 12, and
+// the same integer, hence the same float (|d|^2 <= 3 x 1023^2 < 2^24).
+#ifndef NRD_NORMAL_DOT2
+#define NRD_NORMAL_DOT2 1
+#endif
+typedef short nrd_s2 __attribute__((ext_vector_type(2)));
+struct NormalCodes {
+    nrd_s2 xz; // {x, z << 4}
+    int y;
+};
+NRD_DEV NormalCodes normal_codes(uint32_t nw) { return {__builtin_bit_cast(nrd_s2, nw & 0x3ff003ffu), (int)((nw >> 10) & 1023u)}; }
+NRD_DEV float normal_cos(NormalCodes centre, uint32_t nw) {
+    float d2;
+    if (NRD_NORMAL_DOT2) {
+        nrd_s2 d = __builtin_bit_cast(nrd_s2, nw & 0x3ff003ffu) - centre.xz; // {dx, 16 dz}, |16 dz| <= 16368
+        d = d >> nrd_s2{0, 4};
+        const int dy = (int)((nw >> 10) & 1023u) - centre.y;
+        d2 = (float)__builtin_amdgcn_sdot2(d, d, dy * dy, false);
+    } else { // the float form of rounds 1-3 (same value: every term an integer below 2^24)
+        const float dx = (float)(nw & 1023u) - (float)(int)centre.xz.x, dy = (float)((nw >> 10) & 1023u) - (float)centre.y,
+                    dz = (float)((nw >> 20) & 1023u) - (float)((int)centre.xz.y >> 4);
+        d2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    }
     return fma_(d2, -0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f), 1.0f);
 }
 
@@ -439,6 +460,11 @@ NRD_DEV bool project(const float* pj, f3 X, float& u, float& v) {
 }
 
 NRD_DEV bool material_mismatch(uint32_t a, uint32_t b, uint32_t minMaterial) { return a != b && (a > b ? a : b) >= minMaterial; }
+// The same predicate for a tap loop (one pixel against many): "a != b and one of them >= minMaterial" <=> class(a) != class(b) with
+// class(m) = max(m, max(minMaterial, 1) - 1) - every material below the threshold falls into one class. The pixel's class and the
+// floor are computed once; a tap pays shift + max + compare instead of shift + compare + max + compare (+ a scalar or).
+NRD_DEV uint32_t material_floor(uint32_t minMaterial) { return (minMaterial > 1u ? minMaterial : 1u) - 1u; }
+NRD_DEV uint32_t material_class(uint32_t m, uint32_t floor_) { return m > floor_ ? m : floor_; }
 
 // per-pixel geometry of the bilateral passes: plane-distance weight is |zs * (ga0 + gax px + gay gy) + geoB|
 // (orthographic: |zs * geoB + (ga0 + gax px + gay gy)| - geoB holds the z coefficient, ga0 absorbs the plane offset)

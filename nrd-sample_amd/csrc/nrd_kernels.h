@@ -99,6 +99,7 @@ struct ReferenceParams {
     void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s); \
     void launch_reblur_blur_radiance(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s); \
+    void launch_reblur_prepass_temporal_accumulation(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_history_fix(const ReblurParams& p, hipStream_t s); \
     void launch_reblur_temporal_stabilization(const ReblurParams& p, hipStream_t s); \
     void launch_relax_atrous(const AtrousParams& p, hipStream_t s); \

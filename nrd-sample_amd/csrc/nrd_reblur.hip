@@ -38,10 +38,16 @@ NRD_KERNELS_BEGIN
 #define NRD_PRE_DEPTH 2
 #endif
 #ifndef NRD_POST_DEPTH // taps in flight: PostBlur on tap texels
-#define NRD_POST_DEPTH 4
+#define NRD_POST_DEPTH 3 // (round 4: 81 VGPRs at 4 with the packed normal distance - one more than 6 waves per SIMD allow; 3: 73)
+#endif
+#ifndef NRD_POST_WAVES // PostBlur on tap texels: waves per SIMD the register allocator aims for
+#define NRD_POST_WAVES NRD_TAP_WAVES
 #endif
 #ifndef NRD_PRE_WAVES // PrePass: waves per SIMD
 #define NRD_PRE_WAVES 4
+#endif
+#ifndef NRD_FUSED_DEPTH // taps in flight: the PrePass half of the fused PrePass + TemporalAccumulation kernel (115 VGPRs either way: the
+#define NRD_FUSED_DEPTH 5 // reprojection half sets the register count, 4 waves per SIMD; depth 2 / 3 / 4 / 5: 0.3504 / 0.3462 / 0.3515 / 0.3442 ms)
 #endif
 #ifndef NRD_TAP_WAVES // 104 VGPRs at 4 waves; capped at 102 for a fifth wave: Blur 0.202 -> 0.198 ms, PostBlur 0.179 -> 0.1705
 #define NRD_TAP_WAVES 5  // (depth 6 / 8 at 5 waves: equal; depth 12 / 16 at 4 waves: slower - profiles/r03_ab_tap_texels.txt)
@@ -363,19 +369,28 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
 // =====================================================================================================================
 // MODE: 0 = REBLUR radiance, 1 = RELAX radiance, 2 = OCCLUSION (hit distance only), 3 = REBLUR SH, 4 = RELAX SH (compile-time so
 // the unrolled tap loop stays one basic block)
-template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
-// 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
-// carry 16 more registers of tap data and stay at 3
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 0 && MODE == 0) ? NRD_TAP_WAVES : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
+// the per-pixel body of TemporalAccumulation (defined with its kernel below): `ctex` = the pixel's PrePass result as it would sit in
+// Tmp1 (packed fp16 words), `hitDist` = the tracked specular hit distance as it would sit in the hit tracker
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
+NRD_DEV void ta_pixel(const ReblurParams& p, int x, int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], float hitDist);
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
+NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y);
+
+// FUSED (PrePass of the REBLUR radiance flavours only): the pixel goes straight on into TemporalAccumulation - that pass reads the
+// PrePass result at its OWN pixel only (Tmp1, hit tracker), so the result stays in registers: no Tmp1 store + load (32 B/px at two
+// signals), one guide load, one launch and one wave prologue less, and the reprojection's memory round trips overlap with the tap
+// arithmetic of the other waves of the SIMD (profiles/r04_valu_issue.txt: the spatial passes sit on VALU issue,
+// TemporalAccumulation on latency). The values that cross from one half to the other are rounded exactly as the planes would have
+// rounded them (packed fp16 words), so the fused dispatch is bit-identical to the two separate ones.
+template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC, bool FUSED>
+NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, const int tx, const int ty) {
+    static_assert(!FUSED || (VARIANT == 0 && MODE == 0), "only the REBLUR radiance PrePass continues into TemporalAccumulation");
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr bool SH = MODE == 3 || MODE == 4;
     constexpr int sb = SH ? 16 : 8;   // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;  // bytes per texel of the internal radiance planes
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
-    int x, y, tx, ty;
-    if (!my_pixel(c, x, y, tx, ty)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
-        return;                     // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
     const PlaneRef& inP = VARIANT == 1 ? p.tmp1 : p.tmp2; // Blur reads Tmp1, PostBlur reads Tmp2 (PrePass reads the input slots)
     const PlaneRef& outP = VARIANT == 0 ? p.tmp1 : (VARIANT == 1 ? p.tmp2 : p.hist);
     const int reach = VARIANT == 0 ? p.reachPre : (VARIANT == 1 ? p.reachBlur : p.reachPost);
@@ -413,17 +428,21 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
                 st_stream<uint4>(p.tapB[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16, uint4{ctap[sig].x, ctap[sig].y, 0u, 0u});
                 continue;
             }
+            if (FUSED) // nobody reads Tmp1 in the fused frame
+                continue;
             st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb);
             if (SH)
                 st<uint2>(outP, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
         }
         if (VARIANT == 0 && HAS_SPEC)
             st<uint16_t>(p.hitTrack, x, y, 2, (uint16_t)0);
+        if constexpr (FUSED)
+            ta_sky_stores<HAS_DIFF, HAS_SPEC, false, false>(p, x, y);
         return;
     }
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
-    const f3 ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
+    const NormalCodes ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
     f3 V = to_viewer(pg.Xv);
     // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic: no
     // perspective divide and no z terms
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
     const PlaneRef* srcPs[NSIG];
     const PlaneRef* src1Ps[NSIG];
     int srcOffs[NSIG];
-    uint32_t minMats[NSIG];
+    uint32_t matFloor[NSIG], matClass[NSIG]; // material test of the taps (nrd_device.h material_class)
     f4 sum[NSIG], sum1[NSIG];
     float wsum[NSIG], minHit[NSIG], hitNormS[NSIG];
     float jtx[NSIG], jty[NSIG], jbx[NSIG], jby[NSIG], m2w2[NSIG], hitA[NSIG], hitB[NSIG], roughA[NSIG], roughB[NSIG];
@@ -465,7 +484,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         float rough = isSpec ? g.roughness : 1.0f;
-        minMats[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
+        matFloor[sig] = material_floor(isSpec ? p.minMatSpec : p.minMatDiff);
+        matClass[sig] = material_class(g.mat, matFloor[sig]);
         srcPs[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec : &p.inDiff) : &inP;
         srcOffs[sig] = VARIANT == 0 ? 0 : sig * sb;
         f4 center = TAP ? unpack_h4(uint2{ctap[sig].z, ctap[sig].w}) : load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
@@ -557,7 +577,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         // Re-tuned at the end of round 3 (profiles/r03_ab_pipeline_depth.txt): with the 8-byte guide and the tap texels the radiance PrePass
         // is fastest with 2 taps in flight (78 VGPRs, 6 waves per SIMD: -6 % against 5 taps / 4 waves) and PostBlur with 4 (-2.3 %); Blur
         // stays at 8; RELAX's radiance PrePass: 3 (-3 %). The SH and OCCLUSION flavours keep round 2's depths (SH Blur at 3 or 2: +6 %).
-        constexpr int DEPTH_WANTED = (VARIANT == 0 && MODE == 0) ? NRD_PRE_DEPTH : (VARIANT == 0 && MODE == 1) ? 3 : ((VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? (VARIANT == 2 ? NRD_POST_DEPTH : NRD_TAP_DEPTH) : NRD_PIPE_DEPTH));
+        constexpr int DEPTH_WANTED = FUSED ? NRD_FUSED_DEPTH : (VARIANT == 0 && MODE == 0) ? NRD_PRE_DEPTH : (VARIANT == 0 && MODE == 1) ? 3 : ((VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? (VARIANT == 2 ? NRD_POST_DEPTH : NRD_TAP_DEPTH) : NRD_PIPE_DEPTH));
         constexpr int DEPTH = DEPTH_WANTED < NT ? DEPTH_WANTED : NT;
         const PlaneBuf guideB = plane_buf(p.guide, c.yOff);
         PlaneBuf srcB[NSIG], src1B[NSIG];
@@ -589,6 +609,17 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
             const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
             inWin[T] = (cxf == fpx) & (cyf == fpy);
             const int px = (int)cxf, gpy = (int)cyf;
+#ifdef NRD_DIAG_NOLOAD // diagnosis build (timing only, results meaningless): every tap re-uses the centre's texels - all arithmetic, no gathers
+            if constexpr (TAP) {
+                graw[T] = uint4{ctap[sig].x ^ (uint32_t)(px & 1), ctap[sig].y, ctap[sig].z, ctap[sig].w};
+                return;
+            } else if constexpr (MODE == 0) {
+                graw[T] = uint4{f2u(g.z) ^ (uint32_t)(px & 1), g.nw, 0u, 0u};
+                sraw[T] = uint2{f2u(sum[sig].x) ^ (uint32_t)(gpy & 1), f2u(sum[sig].y)};
+                sraw1[T] = uint2{0u, 0u};
+                return;
+            }
+#endif
             if constexpr (TAP) { // ONE gather: {guide part | signal}
                 graw[T] = ldb<uint4>(srcB[sig], px, gpy, 16);
                 return;
@@ -609,6 +640,14 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
         auto consume = [&](const int T) {
             const int sig = T >> 3, t = T & 7;
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+#ifdef NRD_DIAG_NOARITH // diagnosis build (timing only): the gathers and the tap positions stay, the weights go - every tap enters with weight 1
+            {
+                const f4 raw = TAP ? unpack_h4(uint2{graw[T].z, graw[T].w}) : unpack_h4(uint2{graw[T].x ^ sraw[T].x, graw[T].y ^ sraw[T].y});
+                sum[sig] = fma4(raw, inWin[T] ? 1.0f : 0.5f, sum[sig]);
+                wsum[sig] += gaT[T];
+                return;
+            }
+#endif
             Guide gs;
             f4 sv;
             if constexpr (TAP) {
@@ -620,7 +659,12 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
                 gs = decode_guide(uint2{graw[T].x, graw[T].y}, c.denoisingRange);
                 sv = decode_signal(p, sraw[T], occIn);
             }
-            const bool valid = inWin[T] & active[sig] & !gs.sky & !material_mismatch(g.mat, gs.mat, minMats[sig]); // bitwise: one basic block
+#ifndef NRD_MATERIAL_CLASS
+#define NRD_MATERIAL_CLASS 1
+#endif
+            const bool matOk = NRD_MATERIAL_CLASS ? material_class(gs.mat, matFloor[sig]) == matClass[sig]
+                                                  : !material_mismatch(g.mat, gs.mat, isSpec ? p.minMatSpec : p.minMatDiff);
+            const bool valid = inWin[T] & active[sig] & !gs.sky & matOk; // bitwise: one basic block
 #ifdef NRD_DBG_HIST
             if (active[sig]) { // Chebyshev distance of the tap from the centre pixel, buckets <=2, 4, 8, 12, 16, 24, 32, more (taps of both signals)
                 const int t = T & 7;
@@ -703,13 +747,29 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 
                 outw[sig * (sb / 8) + 1] = pack_h4(res1);
         }
         if (VARIANT == 0 && isSpec)
-            st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig]));
+            st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig])); // (fused frame: TemporalStabilization still reads it)
+    }
+    if constexpr (FUSED) { // on into TemporalAccumulation with what Tmp1 and the hit tracker would have held
+        ta_pixel<HAS_DIFF, HAS_SPEC, false, false>(p, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f);
+        return;
     }
     // the signals of the pixel share one texel of the output plane: one store
     if (VARIANT == 0)
         store_texel<RBPT, false>(outP, x, y, outw);
     else if (!(TAP && VARIANT == 1))
         store_texel<RBPT, true>(outP, x, y, outw);
+}
+
+template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
+// 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
+// carry 16 more registers of tap data and stay at 3
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 0 && MODE == 0) ? (VARIANT == 2 ? NRD_POST_WAVES : NRD_TAP_WAVES) : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
+    int x, y, tx, ty;
+    if (!my_pixel(p.c, x, y, tx, ty)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
+        return;                       // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
+    // (round 4: workgroups that take 2 / 4 consecutive tiles with the next tile's centre loads in flight behind the current tile's
+    // arithmetic measured 14 / 24 % SLOWER on Blur and 10 / 18 % on PostBlur - profiles/r04_ab_fusion.txt)
+    spatial_pixel<VARIANT, MODE, HAS_DIFF, HAS_SPEC, false>(p, x, y, tx, ty);
 }
 
 // =====================================================================================================================
@@ -917,8 +977,27 @@ NRD_DEV void blendA(const Footprint& f, const uint16_t (&raw)[4], float& dA, flo
 #ifndef NRD_TA_WAVES // waves per SIMD the compiler budgets TemporalAccumulation's registers for (REBLUR radiance flavours use 107 VGPRs: 4)
 #define NRD_TA_WAVES 4
 #endif
+// what TemporalAccumulation writes at a pixel beyond the denoising range (inside a tile that has geometry)
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WAVES) void k_temporal_accumulation(const ReblurParams p) {
+NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int sb = SH ? 16 : 8;
+    constexpr int RBPT = sb * NSIG;
+    constexpr int LBPT = 2 * NSIG;
+    for (int sig = 0; sig < NSIG; sig++) {
+        st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb);
+        if (SH)
+            st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
+        st<uint16_t>(p.fast, x, y, LBPT, (uint16_t)0, sig * 2);
+        if (RELAX)
+            st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
+    }
+    st<uint16_t>(p.data1Tmp, x, y, 2, (uint16_t)0);
+    st<uint32_t>(p.data2, x, y, 4, 0u);
+}
+
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
+NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], const float hitDist) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
@@ -926,33 +1005,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
     constexpr int LBPT = 2 * NSIG;
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     const FrameConsts& c = p.c;
-    int x, y, tx, ty;
-    if (!my_pixel_w(c, x, y, tx, ty))
-        return;
-    // a tile without geometry: Tmp2, the fast history, Data1Tmp and Data2 of its pixels are read by nobody who has not tested the guide
-    // first (HistoryFix skips the tile, its reconstruction taps and 5x5 windows test the tap's depth; next frame's footprints weigh a
-    // texel beyond the range with an exact 0) - nothing to write (k_spatial has the full argument)
-    if (NRD_SKIP_SKY_TILES && tile_is_sky(p, tx, ty))
-        return;
-    Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
-    if (g.sky) {
-        for (int sig = 0; sig < NSIG; sig++) {
-            st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb);
-            if (SH)
-                st<uint2>(p.tmp2, x, y, RBPT, uint2{0u, 0u}, sig * sb + 8);
-            st<uint16_t>(p.fast, x, y, LBPT, (uint16_t)0, sig * 2);
-            if (RELAX)
-                st<uint16_t>(p.stab, x, y, LBPT, (uint16_t)0, sig * 2);
-        }
-        st<uint16_t>(p.data1Tmp, x, y, 2, (uint16_t)0);
-        st<uint32_t>(p.data2, x, y, 4, 0u);
-        return;
-    }
-    // ---- centre loads
-    uint2 ctex[RBPT / 8];
-    load_texel<RBPT>(p.tmp1, x, y, ctex);
     f4 mvRaw = unpack_h4(ld<uint2>(p.inMV, x, y, 8));
-    float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
     const int gy0 = y + c.yOff;
     float u = ((float)x + 0.5f) * c.invW, v = ((float)gy0 + 0.5f) * c.invH;
     float confD = (HAS_DIFF && c.confAvail) ? sample_confidence(p.confD, u, v) : 1.0f;
@@ -1090,6 +1143,43 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WA
         store_luma(p.stab, x, y, LBPT, m2w);
     st<uint16_t>(p.data1Tmp, x, y, 2, pack_data1(outDiffA, outSpecA));
     st<uint32_t>(p.data2, x, y, 4, data2);
+}
+
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WAVES) void k_temporal_accumulation(const ReblurParams p) {
+    constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
+    constexpr int RBPT = (SH ? 16 : 8) * NSIG;
+    const FrameConsts& c = p.c;
+    int x, y, tx, ty;
+    if (!my_pixel_w(c, x, y, tx, ty))
+        return;
+    // a tile without geometry: Tmp2, the fast history, Data1Tmp and Data2 of its pixels are read by nobody who has not tested the guide
+    // first (HistoryFix skips the tile, its reconstruction taps and 5x5 windows test the tap's depth; next frame's footprints weigh a
+    // texel beyond the range with an exact 0) - nothing to write (k_spatial has the full argument)
+    if (NRD_SKIP_SKY_TILES && tile_is_sky(p, tx, ty))
+        return;
+    Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
+    if (g.sky) {
+        ta_sky_stores<HAS_DIFF, HAS_SPEC, SH, RELAX>(p, x, y);
+        return;
+    }
+    // ---- centre loads
+    uint2 ctex[RBPT / 8];
+    load_texel<RBPT>(p.tmp1, x, y, ctex);
+    const float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
+    ta_pixel<HAS_DIFF, HAS_SPEC, SH, RELAX>(p, x, y, g, ctex, hitDist);
+}
+
+// PrePass + TemporalAccumulation of the REBLUR radiance flavours in ONE launch (spatial_pixel<..., FUSED>)
+#ifndef NRD_FUSED_WAVES
+#define NRD_FUSED_WAVES 4
+#endif
+template <bool HAS_DIFF, bool HAS_SPEC>
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_FUSED_WAVES) void k_prepass_temporal_accumulation(const ReblurParams p) {
+    int x, y, tx, ty;
+    if (!my_pixel(p.c, x, y, tx, ty))
+        return;
+    spatial_pixel<0, 0, HAS_DIFF, HAS_SPEC, true>(p, x, y, tx, ty);
 }
 
 // =====================================================================================================================
@@ -1883,7 +1973,6 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
 }
 
 dim3 grid_for(const FrameConsts& c) { return dim3((unsigned)xcd_grid_blocks(c.tilesX, c.tilesY), 1, 1); }
-
 NRD_KERNELS_END
 
 namespace NRD_PROJ_NS {
@@ -1995,6 +2084,7 @@ void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
     }
 }
 
+void launch_reblur_prepass_temporal_accumulation(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_prepass_temporal_accumulation, ); }
 void launch_reblur_temporal_accumulation(const ReblurParams& p, hipStream_t s) {
     if (p.sh) {
         if (p.relax)

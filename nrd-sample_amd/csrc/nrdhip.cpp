@@ -34,6 +34,7 @@ NRD_FORWARD(launch_reblur_prepare_inputs, ReblurParams)
 NRD_FORWARD(launch_reblur_validation, ReblurParams)
 NRD_FORWARD_I(launch_reblur_spatial, ReblurParams)
 NRD_FORWARD(launch_reblur_temporal_accumulation, ReblurParams)
+NRD_FORWARD(launch_reblur_prepass_temporal_accumulation, ReblurParams)
 NRD_FORWARD(launch_reblur_history_fix, ReblurParams)
 NRD_FORWARD(launch_reblur_temporal_stabilization, ReblurParams)
 NRD_FORWARD(launch_relax_atrous, AtrousParams)
@@ -190,6 +191,10 @@ enum Trans { TILES, TILES_SMOOTH, SHADOW1, PEN1, SHADOW2 };
 
 // REBLUR radiance flavours run Blur / PostBlur on tap texels (guide + signal in one 16-byte texel, nrd_device.h)
 bool tap_texels(const DenoiserState& d) { return d.kind == Kind::REBLUR && !d.sh; } // (OCCLUSION signals travel as {h, 0, 0, h} internally: same kernels)
+// ... and their PrePass and TemporalAccumulation as ONE dispatch, unless the instance was created with NRDHIP_FLAG_SEPARATE_PASSES
+bool fused_prepass(const nrdhip_instance& I, const DenoiserState& d) {
+    return d.kind == Kind::REBLUR && !d.sh && !d.occlusion && !(I.flags & NRDHIP_FLAG_SEPARATE_PASSES);
+}
 
 void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPlane>& trans) {
     using F = nrd::Format;
@@ -682,7 +687,21 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     const PrepareMode pm = prepare_mode(d, s);
     if (pm.any)
         push_prepare_dispatch(d, pm, p, "REBLUR::PrepareInputs", P(rb::GUIDE_A + cur), tb);
-    {
+    if (fused_prepass(I, d)) {
+        // PrePass + TemporalAccumulation in one launch (nrd_reblur.hip spatial_pixel<..., FUSED>): TemporalAccumulation reads the PrePass
+        // result at its own pixel only, so it stays in registers - Tmp1 is neither written nor read, the guide is fetched once
+        Dispatch x{"REBLUR::PrePassTemporalAccumulation", "nrd_reblur_prepass_temporal_accumulation", preHalo,
+                   GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + sp, {}, {}, nullptr};
+        x.read = {P(rb::GUIDE_A + cur)};
+        push_prepass_inputs(d, pm, tb, x.read);
+        for (uint32_t r : {P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1))})
+            x.read.push_back(r);
+        if (c.mixAvail)
+            x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
+        x.written = {T(rb::HITTRACK), T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
+        x.launch = [p](hipStream_t st) { launch_reblur_prepass_temporal_accumulation(p, st); };
+        d.dispatches.push_back(x);
+    } else {
         Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * nr + 8 * nr + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         push_prepass_inputs(d, pm, tb, x.read);
@@ -690,7 +709,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);
     }
-    {
+    if (!fused_prepass(I, d)) {
         Dispatch x{"REBLUR::TemporalAccumulation", "nrd_reblur_temporal_accumulation", 0,
                    GB + 8 + GB + 2 + 8 * nr + 8 * nr + 2 * n + sp + 8 * nr + 2 * n + 2 + 4, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), T(rb::TMP1), P(rb::HIST),

@@ -12,6 +12,7 @@
 // Pass graph: ClassifyTiles(+guide packing) -> PrePass -> TemporalAccumulation -> HistoryFix ->
 // Blur -> PostBlur -> TemporalStabilization (+ split screen). DESIGN.md section "REBLUR" documents every formula.
 #include "orc_core.h"
+#include "../include/nrdhip.h"
 
 namespace orc {
 
@@ -387,6 +388,10 @@ static inline f4 tap_signal(const TapTexel& t) {
     return {f16_to_f32((uint16_t)(t.w2 & 0xffffu)), f16_to_f32((uint16_t)(t.w2 >> 16)), f16_to_f32((uint16_t)(t.w3 & 0xffffu)), f16_to_f32((uint16_t)(t.w3 >> 16))};
 }
 static inline bool tap_texels(const DenoiserState& d) { return d.kind == Kind::REBLUR && !d.sh; } // (OCCLUSION signals travel as {h, 0, 0, h} internally: same planes)
+// REBLUR radiance flavours: PrePass + TemporalAccumulation as one dispatch unless NRDHIP_FLAG_SEPARATE_PASSES (csrc/nrdhip.cpp fused_prepass)
+static inline bool fused_prepass(const Instance& I, const DenoiserState& d) {
+    return d.kind == Kind::REBLUR && !d.sh && !d.occlusion && !(I.flags & NRDHIP_FLAG_SEPARATE_PASSES);
+}
 
 void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1) {
     const Consts& c = k.c;
@@ -735,14 +740,17 @@ static inline float spec_accum_limit(float roughness, float NoV, float parallaxP
 // --------------------------------------------------------------------------------------------------
 // K3 TemporalAccumulation
 // --------------------------------------------------------------------------------------------------
-void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+// `prepassResult`: the plane the PrePass wrote its result to - Tmp1, or the private scratch rows of the fused dispatch (below)
+static void temporal_accumulation_rows(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, const Plane* prepassResult);
+void temporal_accumulation(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { temporal_accumulation_rows(I, d, c, y0, y1, nullptr); }
+static void temporal_accumulation_rows(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, const Plane* prepassResult) {
     Ctx k{I, d, c, (int)(d.frameCounter & 1)};
     const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     (void)sb;
     const nrd::ReblurSettings& s = d.reblur;
     const Plane& G = k.guide();
     const Plane& MV = k.slot(nrd::ResourceType::IN_MV);
-    const Plane& IN = k.trans(T_TMP1);
+    const Plane& IN = prepassResult ? *prepassResult : k.trans(T_TMP1);
     const Plane& OUT = k.trans(T_TMP2);
     const Plane& HIST = k.perm(P_HIST);
     const Plane& FASTP = k.perm(P_FAST_A + (k.cur ^ 1));
@@ -1556,41 +1564,74 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.run = prepare_inputs;
         d.passes.push_back(p);
     }
-    {
+    // the PrePass of rows [y0, y1) into `result` (Tmp1, or the scratch rows of the fused dispatch)
+    static const auto prepass_rows = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, const Plane* result) {
+        Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+        const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
+        SpatialIO io = {};
+        io.reach = reblur_reach(d.reblur).pre;
+        for (int sig = 0; sig < d.nsig; sig++) {
+            bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
+            PrepareMode pm = prepare_mode(d);
+            io.in[sig] = pm.any ? &k.trans(T_PREP_D + (isSpec ? 1 : 0)) : &k.slot(in_slot(d, isSpec));
+            io.in1[sig] = d.sh ? (pm.sh1 ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
+            io.inOff[sig] = 0;
+            io.out[sig] = result;
+            io.outOff[sig] = sig * sb;
+        }
+        spatial_filter(k, PRE, io, y0, y1);
+    };
+    const bool fused = fused_prepass(I, d);
+    std::vector<uint32_t> prepassInputs;
+    for (int si = 0; si < 2; si++) {
+        if (!(si ? d.hasSpec : d.hasDiff))
+            continue;
+        prepassInputs.push_back(pm.any ? T(T_PREP_D + si) : enc_slot(in_slot(d, si != 0)));
+        if (d.sh)
+            prepassInputs.push_back(pm.sh1 ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
+    }
+    if (fused) {
+        // PrePass + TemporalAccumulation as ONE dispatch (csrc/nrd_reblur.hip spatial_pixel<..., FUSED>): TemporalAccumulation reads the
+        // PrePass result at its own pixel only, so the kernel keeps it in registers and Tmp1 is neither written nor read. Here: the
+        // PrePass of the rows goes to private scratch rows with Tmp1's texel layout, TemporalAccumulation reads those - the same
+        // roundings (packed fp16 texels) as through the plane
+        Pass p;
+        p.name = "REBLUR::PrePassTemporalAccumulation";
+        p.kernel = "nrd_reblur_prepass_temporal_accumulation";
+        p.haloRows = (uint16_t)rr.pre;
+        p.bytesPerPixel = GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + (d.hasSpec ? 2 : 0);
+        p.read = {P(P_GUIDE_A + cur)};
+        p.read.insert(p.read.end(), prepassInputs.begin(), prepassInputs.end());
+        for (uint32_t r : {P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))})
+            p.read.push_back(r);
+        if (I.common.isDisocclusionThresholdMixAvailable)
+            p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
+        p.written = {T(T_HITTRACK), T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
+        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
+            if (y1 <= y0)
+                return;
+            Ctx k{I, d, c, (int)(d.frameCounter & 1)};
+            Plane scratch = k.trans(T_TMP1); // same width, texel size and format; own rows
+            scratch.pitch = (uint32_t)scratch.w * scratch.bpt;
+            std::vector<uint8_t> rows((size_t)(y1 - y0) * scratch.pitch, 0);
+            scratch.p = rows.data() - (size_t)y0 * scratch.pitch;
+            prepass_rows(I, d, c, y0, y1, &scratch);
+            temporal_accumulation_rows(I, d, c, y0, y1, &scratch);
+        };
+        d.passes.push_back(p);
+    } else {
         Pass p;
         p.name = "REBLUR::PrePass";
         p.kernel = "nrd_reblur_prepass";
         p.haloRows = (uint16_t)rr.pre;
         p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
-        for (int si = 0; si < 2; si++) {
-            if (!(si ? d.hasSpec : d.hasDiff))
-                continue;
-            p.read.push_back(pm.any ? T(T_PREP_D + si) : enc_slot(in_slot(d, si != 0)));
-            if (d.sh)
-                p.read.push_back(pm.sh1 ? T(T_PREP_D1 + si) : enc_slot(in1_slot(si != 0)));
-        }
+        p.read.insert(p.read.end(), prepassInputs.begin(), prepassInputs.end());
         p.written = {T(T_TMP1), T(T_HITTRACK)};
-        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
-            Ctx k{I, d, c, (int)(d.frameCounter & 1)};
-            const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
-            (void)sb;
-            SpatialIO io = {};
-            io.reach = reblur_reach(d.reblur).pre;
-            for (int sig = 0; sig < d.nsig; sig++) {
-                bool isSpec = (sig == k.sigSpec()) && d.hasSpec;
-                PrepareMode pm = prepare_mode(d);
-                io.in[sig] = pm.any ? &k.trans(T_PREP_D + (isSpec ? 1 : 0)) : &k.slot(in_slot(d, isSpec));
-                io.in1[sig] = d.sh ? (pm.sh1 ? &k.trans(T_PREP_D1 + (isSpec ? 1 : 0)) : &k.slot(in1_slot(isSpec))) : nullptr;
-                io.inOff[sig] = 0;
-                io.out[sig] = &k.trans(T_TMP1);
-                io.outOff[sig] = sig * sb;
-            }
-            spatial_filter(k, PRE, io, y0, y1);
-        };
+        p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { prepass_rows(I, d, c, y0, y1, &I.trans[d.transBase + T_TMP1]); };
         d.passes.push_back(p);
     }
-    {
+    if (!fused) {
         Pass p;
         p.name = "REBLUR::TemporalAccumulation";
         p.kernel = "nrd_reblur_temporal_accumulation";

@@ -338,6 +338,10 @@ inline T hipemu_buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 #define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) hipemu_buf_ld<unsigned int>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, a) hipemu_buf_ld<unsigned short>(r, v, s)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+// v_dot2_i32_i16: a.x * b.x + a.y * b.y + c (no clamp used)
+typedef short hipemu_s2 __attribute__((ext_vector_type(2)));
+static inline int hipemu_sdot2(hipemu_s2 a, hipemu_s2 b, int c) { return (int)a.x * (int)b.x + (int)a.y * (int)b.y + c; }
+#define __builtin_amdgcn_sdot2(a, b, c, clamp) hipemu_sdot2(a, b, c)
 // wave vote: threads run one at a time here, so a "wave" is the thread itself - valid wherever both sides of a wave-uniform
 // branch compute the same result (the only way the product kernels use it)
 #define __builtin_amdgcn_ballot_w64(pred) ((pred) ? 1ull : 0ull)

@@ -32,7 +32,7 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["algorithmic_bytes_contract"] == 352.0 and r["pipeline_frac_contract"] >= 0 and "traffic" in r  # (rounded to 4 decimals: 0 at emulation speed)
-    assert list(d["passes_ms"]) == ["REBLUR::ClassifyTiles", "REBLUR::PrePass", "REBLUR::TemporalAccumulation", "REBLUR::HistoryFix", "REBLUR::Blur",
+    assert list(d["passes_ms"]) == ["REBLUR::ClassifyTiles", "REBLUR::PrePassTemporalAccumulation", "REBLUR::HistoryFix", "REBLUR::Blur",
                                     "REBLUR::PostBlur", "REBLUR::TemporalStabilization"]
     c = d["config"]
     assert "workload" in c and 0.0 <= c["sky_fraction"] <= 1.0

@@ -40,7 +40,7 @@ def oracle_prepass(pkg, api, oracle, f):
     D = api.Denoiser
     scene = pkg.synth.Scene(W, H, dolly=0.03)
     fr = frame(f)
-    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H)
+    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H, separate_passes=True)  # (the PrePass result as a plane: no fused dispatch)
     st = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
     cs = scene.common_settings(api, fr, f, reset=True)
     hz.nrd.new_frame()
@@ -160,7 +160,7 @@ def test_temporal_passes_independent(pkg, api, oracle, f):
     D = api.Denoiser
     den = int(D.REBLUR_DIFFUSE_SPECULAR)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
-    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H)
+    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H, separate_passes=True)  # (pool snapshots between all seven passes)
     st = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
     s = temporal_settings(st)
     for g in range(f):  # the history this frame inherits

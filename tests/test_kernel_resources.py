@@ -73,6 +73,7 @@ def test_headline_kernels_keep_their_occupancy(kernels):
         "k_spatialILi1ELi0ELb1ELb1EE": 5,   # Blur on tap texels, 8 taps in flight
         "k_spatialILi2ELi0ELb1ELb1EE": 6,   # PostBlur, 4 taps in flight
         "k_temporal_accumulationILb1ELb1ELb0ELb0EE": 4,
+        "k_prepass_temporal_accumulationILb1ELb1EE": 4,  # the fused dispatch of record: 5 taps in flight, the reprojection half sets the registers
         "k_history_fixILb1ELb1ELb0EE": 7,
         "k_temporal_stabilizationILb1ELb1ELb0EE": 7,
         "k_classify_tiles": 8,

@@ -34,15 +34,42 @@ def test_emulated_dispatch_lists_match(pkg, api, oracle, emulated):
         hz.nrd.set_common_settings(scene.common_settings(api, fr, 0, reset=True))
         lists.append(hz.nrd.dispatches([int(d) for d in dens]))
     assert [x["name"] for x in lists[0]] == [x["name"] for x in lists[1]]
-    assert len(lists[0]) == 7 + 5 + 1
+    assert len(lists[0]) == 6 + 5 + 1  # (REBLUR: PrePass + TemporalAccumulation are one dispatch)
     for a, b in zip(*lists):
         assert a["written"] == b["written"] and a["read"] == b["read"] and a["halo_rows"] == b["halo_rows"]
         assert abs(a["bytes_per_pixel"] - b["bytes_per_pixel"]) < 1e-4
     total = sum(x["bytes_per_pixel"] for x in lists[1] if x["name"].startswith("REBLUR"))
-    # REBLUR_DIFFUSE_SPECULAR algorithmic bytes / pixel / frame: SURVEY.md 8d estimated ~352 with 8-byte guides; this build
-    # keeps a 16-byte pre-decoded guide texel (+8 B in each of the 8 guide accesses), DESIGN.md "byte accounting"
-    # 408 of round 2 + 16 (HistoryFix writes tap texels) + 16 (Blur writes them; its guide read is gone) - 6 x 8 (the 8-byte guide texel)
-    assert 384 < total < 400
+    # REBLUR_DIFFUSE_SPECULAR algorithmic bytes / pixel / frame: SURVEY.md 8d estimated ~352 with 8-byte guides (this build's guide
+    # texel since round 3): 408 of round 2 + 16 (HistoryFix writes tap texels) + 16 (Blur writes them; its guide read is gone)
+    # - 6 x 8 (the 8-byte guide texel) = 392 with separate passes; the fused PrePass + TemporalAccumulation dispatch neither writes nor
+    # reads Tmp1 (-32), fetches the guide once (-8) and does not read the hit tracker back (-2): 350
+    assert 346 < total < 354
+
+
+@pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["REBLUR_DIFFUSE"], ["REBLUR_SPECULAR"]])
+def test_fused_prepass_is_bit_identical_to_separate_passes(pkg, api, oracle, emulated, dens):
+    """REBLUR radiance flavours run PrePass + TemporalAccumulation as ONE dispatch (csrc/nrd_reblur.hip spatial_pixel<..., FUSED>) unless
+    the instance is created with NRDHIP_FLAG_SEPARATE_PASSES: outputs and every pool plane except the then untouched Tmp1 must be
+    bit-identical, in the kernels and in the oracle, which mirrors both dispatch lists"""
+    w, h = 72, 56
+    scene = pkg.synth.Scene(w, h, dolly=0.04)
+    dd = [api.Denoiser[x] for x in dens]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1, enableAntiFirefly=True)
+    hs = {}
+    for tag, (b, sep) in dict(of=(oracle, False), os=(oracle, True), ef=(emulated, False), es=(emulated, True)).items():
+        hs[tag] = pkg.harness.Harness(b, dd, w, h, separate_passes=sep)
+    names = lambda hz: [x["name"].split("::")[1] for x in hz.nrd.dispatches([int(d) for d in dd])]
+    for f in range(3):
+        fr = scene.frame(f)
+        for hz in hs.values():
+            hz.frame(scene.common_settings(api, fr, f, reset=(f == 0)), hz.upload(fr), st)
+        assert names(hs["ef"])[:3] == ["ClassifyTiles", "PrePassTemporalAccumulation", "HistoryFix"] == names(hs["of"])[:3]
+        assert names(hs["es"])[:4] == ["ClassifyTiles", "PrePass", "TemporalAccumulation", "HistoryFix"] == names(hs["os"])[:4]
+        assert util.compare_all(hs["of"], hs["ef"], exact=True) == []
+        assert util.compare_all(hs["os"], hs["es"], exact=True) == []
+        assert [x for x in util.compare_all(hs["ef"], hs["es"], exact=True) if not x[0].endswith("::Tmp1")] == []
+    import numpy as np
+    assert not np.asarray(hs["ef"].pool("REBLUR::Tmp1")).any() and np.asarray(hs["es"].pool("REBLUR::Tmp1")).any()  # the fused frame never touches it
 
 
 @pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["RELAX_DIFFUSE_SPECULAR_SH"]])

@@ -236,3 +236,23 @@ def test_8k_config5_frame_against_oracle(pkg, api, oracle, hip):
         ho.frame(cs, ho.upload(host), st)
         hg.frame(cs, hg.upload(fr), st)
     assert util.compare_all(ho, hg, exact=True) == []
+
+
+@pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["REBLUR_DIFFUSE"], ["REBLUR_SPECULAR"]])
+def test_fused_prepass_is_bit_identical_to_separate_passes_hip(pkg, api, oracle, hip, dens):
+    """the fused REBLUR::PrePassTemporalAccumulation dispatch (default) against NRDHIP_FLAG_SEPARATE_PASSES on the GPU, and both against
+    the oracle's mirror of the same dispatch list: outputs and every pool plane but the then untouched Tmp1, bit for bit"""
+    w, h = 480, 270
+    scene = pkg.synth.Scene(w, h, dolly=0.02)
+    dd = [api.Denoiser[x] for x in dens]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    hf, hs = pkg.harness.Harness(hip, dd, w, h), pkg.harness.Harness(hip, dd, w, h, separate_passes=True)
+    ho = pkg.harness.Harness(oracle, dd, w, h)
+    oracle.lib.orc_set_threads(ho.nrd.handle, 16)
+    for f in range(4):
+        fr = scene.frame(f)
+        for hz in (hf, hs, ho):
+            hz.frame(scene.common_settings(api, fr, f, reset=(f == 0)), hz.upload(fr), st)
+        assert [x["name"] for x in hf.nrd.dispatches([int(d) for d in dd])][1] == "REBLUR::PrePassTemporalAccumulation"
+        assert [x for x in util.compare_all(hf, hs, exact=True) if not x[0].endswith("::Tmp1")] == [], f
+        assert util.compare_all(ho, hf, exact=True) == [], f

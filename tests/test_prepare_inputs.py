@@ -55,14 +55,15 @@ def test_to_checkerboard_layout(pkg):
 def test_dispatch_list_gains_prepare_pass(pkg, api, oracle):
     D = api.Denoiser
     scene = pkg.synth.Scene(64, 48)
-    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], 64, 48)
-    fr = scene.frame(0)
-    hz.nrd.set_common_settings(scene.common_settings(api, fr, 0, reset=True))
-    assert [x["name"] for x in hz.nrd.dispatches([int(D.REBLUR_DIFFUSE_SPECULAR)])][:2] == ["REBLUR::ClassifyTiles", "REBLUR::PrePass"]
-    s = api.ReblurSettings(checkerboardMode=int(api.CheckerboardMode.WHITE))
-    hz.nrd.set_denoiser_settings(int(D.REBLUR_DIFFUSE_SPECULAR), s)
-    names = [x["name"] for x in hz.nrd.dispatches([int(D.REBLUR_DIFFUSE_SPECULAR)])]
-    assert names[:3] == ["REBLUR::ClassifyTiles", "REBLUR::PrepareInputs", "REBLUR::PrePass"] and len(names) == 8
+    for separate, prepass, total in ((True, "REBLUR::PrePass", 8), (False, "REBLUR::PrePassTemporalAccumulation", 7)):
+        hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], 64, 48, separate_passes=separate)
+        fr = scene.frame(0)
+        hz.nrd.set_common_settings(scene.common_settings(api, fr, 0, reset=True))
+        assert [x["name"] for x in hz.nrd.dispatches([int(D.REBLUR_DIFFUSE_SPECULAR)])][:2] == ["REBLUR::ClassifyTiles", prepass]
+        s = api.ReblurSettings(checkerboardMode=int(api.CheckerboardMode.WHITE))
+        hz.nrd.set_denoiser_settings(int(D.REBLUR_DIFFUSE_SPECULAR), s)
+        names = [x["name"] for x in hz.nrd.dispatches([int(D.REBLUR_DIFFUSE_SPECULAR)])]
+        assert names[:3] == ["REBLUR::ClassifyTiles", "REBLUR::PrepareInputs", prepass] and len(names) == total
 
 
 def test_checkerboard_fixed_point(pkg, api, oracle):
