@@ -220,13 +220,24 @@ public:
         bounds[world] = frameHeight;
         return true;
     }
-    // band of `rank` inside the bounds above: band = {frame height, first stored row, first owned row (local), owned rows}
-    static inline void BandOf(uint16_t frameHeight, int world, int rank, uint32_t haloRows, int32_t band[4], uint16_t& localHeight,
+    // band of `rank` inside the bounds above: band = {frame height, first stored row, first owned row (local), owned rows}. false: the
+    // frame cannot be cut that way - fewer tile rows than `world` bands of at least `haloRows` rows (BandBounds), more than 64 ranks, or
+    // caller-supplied bounds that are not a monotone sequence of multiples of 16 from 0 to the frame height
+    static inline bool BandOf(uint16_t frameHeight, int world, int rank, uint32_t haloRows, int32_t band[4], uint16_t& localHeight,
                               const int32_t* bounds = nullptr) {
         int32_t even[66];
+        if (world < 1 || world > 64 || rank < 0 || rank >= world)
+            return false;
         if (!bounds) {
-            BandBounds(frameHeight, world > 64 ? 64 : world, even);
+            if (!BandBounds(frameHeight, world, even, nullptr, haloRows > 16u ? haloRows : 16u))
+                return false;
             bounds = even;
+        } else {
+            if (bounds[0] != 0 || bounds[world] != (int32_t)frameHeight)
+                return false;
+            for (int r = 0; r < world; r++)
+                if (bounds[r + 1] <= bounds[r] || (r + 1 < world && bounds[r + 1] % 16 != 0))
+                    return false;
         }
         int own0 = bounds[rank], own1 = bounds[rank + 1];
         int row0 = own0 - (int)haloRows < 0 ? 0 : own0 - (int)haloRows;
@@ -236,6 +247,7 @@ public:
         band[2] = own0 - row0;
         band[3] = own1 - own0;
         localHeight = (uint16_t)(row1 - row0);
+        return true;
     }
 
     inline Result Recreate(const IntegrationCreationDesc& integrationDesc, const InstanceCreationDesc& instanceDesc, int device, int rank, int world,
@@ -243,7 +255,8 @@ public:
         DestroyTiler();
         if (world > 64 || rank < 0 || rank >= world)
             return Result::INVALID_ARGUMENT;
-        BandOf(integrationDesc.resourceHeight, world, rank, haloRows, m_Band, m_LocalHeight, bounds);
+        if (!BandOf(integrationDesc.resourceHeight, world, rank, haloRows, m_Band, m_LocalHeight, bounds))
+            return Result::INVALID_ARGUMENT; // (e.g. a 100-row frame over 8 ranks: fewer tile rows than bands)
         IntegrationCreationDesc local = integrationDesc;
         local.resourceHeight = m_LocalHeight;
         Result r = RecreateBand(local, instanceDesc, device, m_Band);

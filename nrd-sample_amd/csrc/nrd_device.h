@@ -296,11 +296,19 @@ NRD_DEV float unorm10_(uint32_t v) {
 // IN_NORMAL_ROUGHNESS as a 10 + 10 bit octahedron and the roughness as 10 bits, 3 x 10 bits and the original roughness code are as fine
 // as that; only the depth loses its 10 low mantissa bits. A decode is a handful of bfe / cvt / fma instead of 3 fp16 converts.
 constexpr int GUIDE_BYTES = 8;
+// A pixel without geometry - |viewZ| beyond the denoising range, Inf, NaN (a viewZ plane filled with 0xFF bytes to say "no hit" is a NaN
+// whose bit pattern would WRAP in the rounding below and come back as depth ~0) - stores ONE canonical depth: the largest finite float
+// with its 10 low bits clear. Finite, so the arithmetic of a tap that lands on it stays free of Inf x 0, and beyond any range.
+constexpr uint32_t GUIDE_SKY_DEPTH = 0x7F7FFC00u;
 NRD_DEV uint32_t qn10(float v) { return (uint32_t)__builtin_floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
-NRD_DEV uint2 encode_guide(float z, uint32_t packedNR) {
+// `geo`: the pixel has geometry - decided on the value that is STORED (the rounding may lift a depth within 2^-13 of the range over
+// it), so that the ClassifyTiles passes flag tiles by the very test every consumer of the texel applies
+NRD_DEV uint2 encode_guide(float z, uint32_t packedNR, float range, bool& geo) {
     f3 n = oct_decode(unorm10_(packedNR & 1023u), unorm10_((packedNR >> 10) & 1023u));
-    return uint2{((f2u(z) + 0x200u) & 0xFFFFFC00u) | ((packedNR >> 20) & 1023u),
-                 qn10(n.x) | (qn10(n.y) << 10) | (qn10(n.z) << 20) | ((packedNR >> 30) << 30)};
+    const uint32_t code = (packedNR >> 20) & 1023u;
+    const uint32_t w0 = ((f2u(z) + 0x200u) & 0xFFFFFC00u) | code;
+    geo = absf(z) <= range && absf(u2f(w0)) <= range;
+    return uint2{geo ? w0 : (GUIDE_SKY_DEPTH | code), qn10(n.x) | (qn10(n.y) << 10) | (qn10(n.z) << 20) | ((packedNR >> 30) << 30)};
 }
 
 struct Guide {

@@ -226,8 +226,9 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
         const int x = (tx0 + k) * 16 + (int)threadIdx.x;
         if (rowValid && x < c.W) {
             const float zs = z[k] * c.viewZScale;
-            st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(zs, nr[k]));
-            if (absf(zs) <= c.denoisingRange)
+            bool geo;
+            st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(zs, nr[k], c.denoisingRange, geo));
+            if (geo)
                 sGeo[k] = 1; // same value from every writer
         }
     }

@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams 
         const uint32_t nr = ld<uint32_t>(p.inNR, x, y, 4);
         const uint16_t penRaw = ld<uint16_t>(p.inPen, x, y, 2);
         float z = zRaw * c.viewZScale;
-        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, nr));
-        if (absf(z) <= c.denoisingRange) {
+        bool geo;
+        st<uint2>(p.guide, x, y, GUIDE_BYTES, encode_guide(z, nr, c.denoisingRange, geo));
+        if (geo) {
             float pen = h2f(penRaw);
             if (pen >= NRD_FP16_MAX)
                 lit = 1;

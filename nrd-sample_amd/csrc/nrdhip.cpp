@@ -133,7 +133,17 @@ struct nrdhip_instance {
     std::string error;
     // NRDHIP_FLAG_GRAPH: one executable graph per identifier list a frame is submitted with (the sample calls Denoise three times a
     // frame - shadow, opaque, reference - each with its own list: Source/NRDSample.cpp:4082, :4126, :4224)
-    std::vector<std::pair<std::vector<uint32_t>, hipGraphExec_t>> graphExecs;
+    // Per list a RING of executable graphs, each with the event recorded behind its last launch: an executable graph is only patched
+    // (hipGraphExecUpdate) or destroyed after the launch that used it last has finished on the device - HIP does not document that an
+    // in-flight launch is immune to an update of its executable graph (CUDA does), and frames are submitted back to back without a sync.
+    struct GraphSlot {
+        static constexpr int RING = 3;
+        std::vector<uint32_t> key;
+        hipGraphExec_t exec[RING] = {nullptr, nullptr, nullptr};
+        hipEvent_t done[RING] = {nullptr, nullptr, nullptr};
+        uint32_t next = 0;
+    };
+    std::vector<GraphSlot> graphExecs;
     uint32_t graphStats[3] = {0, 0, 0}; // replayed frames, instantiations, direct-launch fallbacks
 };
 
@@ -1210,6 +1220,20 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
     return 0;
 }
 
+// every executable graph of the instance, each after the launch that used it last has finished
+static void release_graphs(nrdhip_instance& I) {
+    for (auto& g : I.graphExecs)
+        for (int i = 0; i < nrdhip_instance::GraphSlot::RING; i++) {
+            if (g.done[i]) {
+                (void)hipEventSynchronize(g.done[i]);
+                (void)hipEventDestroy(g.done[i]);
+            }
+            if (g.exec[i])
+                (void)hipGraphExecDestroy(g.exec[i]);
+        }
+    I.graphExecs.clear();
+}
+
 NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
     if (!inst)
         return;
@@ -1220,9 +1244,7 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
                 (void)hipFree(P.p);
     if (inst->transArena)
         (void)hipFree(inst->transArena);
-    for (auto& g : inst->graphExecs)
-        if (g.second)
-            (void)hipGraphExecDestroy(g.second);
+    release_graphs(*inst);
     delete inst;
 }
 
@@ -1521,33 +1543,62 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
         I.graphStats[2]++;
         return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
     }
+    // the capture pass below advances the denoisers' frame counters / ping-pong parity / first-frame flags although no GPU work runs yet:
+    // snapshot them, so that a failure anywhere between capture and launch can hand the SAME frame to the direct path
+    struct Saved {
+        DenoiserState* d;
+        uint32_t frameCounter, framesSinceReset;
+        bool historyValid;
+    };
+    std::vector<Saved> saved;
+    for (auto& d : I.denoisers)
+        saved.push_back({&d, d.frameCounter, d.framesSinceReset, d.historyValid});
+    auto direct_fallback = [&](const char* what, hipError_t err) {
+        (void)hipGetLastError();
+        for (auto& sv : saved) {
+            sv.d->frameCounter = sv.frameCounter;
+            sv.d->framesSinceReset = sv.framesSinceReset;
+            sv.d->historyValid = sv.historyValid;
+        }
+        I.error = std::string(what) + " failed (" + hipGetErrorString(err) + "): frame submitted pass by pass";
+        I.graphStats[2]++;
+        return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    };
     r = nrdhip_denoise_range(inst, ids, n, 0, count, stream);
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(st, &graph);
-    if (r || e != hipSuccess || !graph) {
+    if (r) { // the dispatch list itself is at fault (unbound slot, ...): the direct path would fail the same way
         if (graph)
             (void)hipGraphDestroy(graph);
-        if (!r) {
-            I.error = std::string("HIP stream capture failed: ") + hipGetErrorString(e);
-            r = (int)nrd::Result::FAILURE;
+        for (auto& sv : saved) {
+            sv.d->frameCounter = sv.frameCounter;
+            sv.d->framesSinceReset = sv.framesSinceReset;
+            sv.d->historyValid = sv.historyValid;
         }
         return r;
     }
+    if (e != hipSuccess || !graph) {
+        if (graph)
+            (void)hipGraphDestroy(graph);
+        return direct_fallback("HIP stream capture", e);
+    }
     const std::vector<uint32_t> key(ids, ids + n);
     size_t slot = 0;
-    while (slot < I.graphExecs.size() && I.graphExecs[slot].first != key)
+    while (slot < I.graphExecs.size() && I.graphExecs[slot].key != key)
         slot++;
     if (slot == I.graphExecs.size()) {
         if (I.graphExecs.size() >= 16) { // (a caller cycling through many identifier lists: start over)
-            for (auto& g : I.graphExecs)
-                if (g.second)
-                    (void)hipGraphExecDestroy(g.second);
-            I.graphExecs.clear();
+            release_graphs(I);
             slot = 0;
         }
-        I.graphExecs.push_back({key, nullptr});
+        I.graphExecs.emplace_back();
+        I.graphExecs.back().key = key;
     }
-    hipGraphExec_t& exec = I.graphExecs[slot].second;
+    nrdhip_instance::GraphSlot& G = I.graphExecs[slot];
+    const int ring = (int)(G.next++ % nrdhip_instance::GraphSlot::RING);
+    hipGraphExec_t& exec = G.exec[ring];
+    if (G.done[ring])
+        (void)hipEventSynchronize(G.done[ring]); // the launch that used this executable graph last (RING frames ago) has left the device
     if (exec) {
         hipGraphNode_t bad = nullptr;
         hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
@@ -1562,17 +1613,20 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
         if (e != hipSuccess) {
             exec = nullptr;
             (void)hipGraphDestroy(graph);
-            I.error = std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e);
-            return (int)nrd::Result::FAILURE;
+            return direct_fallback("hipGraphInstantiate", e);
         }
         I.graphStats[1]++;
     }
     e = hipGraphLaunch(exec, st);
     (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) {
-        I.error = std::string("hipGraphLaunch failed: ") + hipGetErrorString(e);
-        return (int)nrd::Result::FAILURE;
-    }
+    if (e != hipSuccess)
+        return direct_fallback("hipGraphLaunch", e);
+    if (!G.done[ring] && hipEventCreateWithFlags(&G.done[ring], hipEventDisableTiming) != hipSuccess)
+        G.done[ring] = nullptr;
+    if (G.done[ring])
+        (void)hipEventRecord(G.done[ring], st);
+    else
+        (void)hipStreamSynchronize(st); // no event to order the next update behind: wait here
     I.graphStats[0]++;
     return 0;
 }

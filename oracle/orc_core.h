@@ -164,12 +164,21 @@ static inline float normal_cos(uint32_t nwCentre, uint32_t nw) {
     return fma_(d2, -0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f), 1.0f);
 }
 static inline uint32_t guide_qn10(float v) { return (uint32_t)floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
-static inline void store_guide(const Plane& G, int x, int y, float z, uint32_t packedNR) {
+// A pixel without geometry (|viewZ| beyond the range, Inf, NaN - e.g. a 0xFF-filled "no hit" plane, whose bits would wrap in the rounding)
+// stores one canonical finite depth; the return value says whether the STORED depth has geometry - the test every consumer applies
+// (csrc/nrd_device.h encode_guide)
+static const uint32_t GUIDE_SKY_DEPTH = 0x7F7FFC00u;
+static inline bool store_guide(const Plane& G, int x, int y, float z, uint32_t packedNR, float range) {
     NormalRoughness nr = unpack_normal_roughness(packedNR);
-    uint32_t w0 = ((f2u(z) + 0x200u) & 0xFFFFFC00u) | ((packedNR >> 20) & 1023u);
+    const uint32_t code = (packedNR >> 20) & 1023u;
+    uint32_t w0 = ((f2u(z) + 0x200u) & 0xFFFFFC00u) | code;
+    const bool geo = absf(z) <= range && absf(u2f(w0)) <= range;
+    if (!geo)
+        w0 = GUIDE_SKY_DEPTH | code;
     uint32_t w1 = guide_qn10(nr.n.x) | (guide_qn10(nr.n.y) << 10) | (guide_qn10(nr.n.z) << 20) | (nr.materialID << 30);
     st_u32(G, x, y, w0, 0);
     st_u32(G, x, y, w1, 4);
+    return geo;
 }
 static inline Guide decode_guide_words(uint32_t w0, uint32_t w1, float range) {
     Guide g;

@@ -80,8 +80,7 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
                     if (x >= c.W || y >= c.resH || y + c.yOff >= c.H || y + c.yOff < 0)
                         continue;
                     float z = ld_f32(inZ, x, y) * zs;
-                    store_guide(G, x, y, z, ld_u32(inNR, x, y));
-                    if (!(absf(z) <= c.denoisingRange))
+                    if (!store_guide(G, x, y, z, ld_u32(inNR, x, y), c.denoisingRange))
                         continue;
                     float pen = ld_h(inPen, x, y);
                     if (pen >= FP16_MAX)

@@ -35,7 +35,10 @@ def smoothstep01(x):
     return x * x * (3.0 - 2.0 * x)
 
 
-def decode_guide(viewz, packed, viewz_scale=1.0, f32_guide=False):
+GUIDE_SKY_DEPTH = 0x7F7FFC00  # canonical stored depth of a pixel without geometry (csrc/nrd_device.h encode_guide)
+
+
+def decode_guide(viewz, packed, viewz_scale=1.0, f32_guide=False, denoising_range=None):
     """ClassifyTiles: viewZ * scale; octahedral normal (10 + 10 bits), linear roughness (10 bits), materialID (2 bits); the guide
     plane stores {depth 22 bit | roughness code, normal 3 x 10 bit | material} and every consumer reads THAT"""
     ox, oy = (packed & 1023) / 1023.0, ((packed >> 10) & 1023) / 1023.0
@@ -53,13 +56,16 @@ def decode_guide(viewz, packed, viewz_scale=1.0, f32_guide=False):
         n = codes * (2.0 / 1023.0) - 1.0
         zb = z.astype(np.float32).view(np.uint32).astype(np.uint64)
         zb = (((zb + 0x200) & 0xFFFFFC00) | ((packed.astype(np.uint64) >> 20) & 1023)).astype(np.uint32)
+        if denoising_range is not None:  # beyond the range (before or after the rounding), Inf, NaN: the canonical sky depth
+            geo = (np.abs(z) <= denoising_range) & (np.abs(zb.view(np.float32).astype(np.float64)) <= denoising_range)
+            zb = np.where(geo, zb, (GUIDE_SKY_DEPTH | ((packed.astype(np.uint64) >> 20) & 1023)).astype(np.uint32))
         z = zb.view(np.float32).astype(np.float64)
     return z, n, rough, (packed >> 30).astype(np.int64)
 
 
-def guide_words(viewz, packed, viewz_scale=1.0):
+def guide_words(viewz, packed, viewz_scale=1.0, denoising_range=None):
     """the two 32-bit words of the guide texel as ClassifyTiles stores them (for a bit-exact comparison with the guide plane)"""
-    z, n, rough, mat = decode_guide(viewz, packed, viewz_scale)
+    z, n, rough, mat = decode_guide(viewz, packed, viewz_scale, denoising_range=denoising_range)
     w0 = z.astype(np.float32).view(np.uint32)
     c = np.round((n + 1.0) * (1023.0 / 2.0)).astype(np.uint32)
     return w0, c[..., 0] | (c[..., 1] << 10) | (c[..., 2] << 20) | (mat.astype(np.uint32) << 30)

@@ -258,9 +258,9 @@ def moments5x5(c, plane, centre, z, skip_centre=False):
     return m1 / k, m2 / k
 
 
-def pack_tap_guide(viewz, packed_nr):
+def pack_tap_guide(viewz, packed_nr, denoising_range=None):
     """guide part of a tap texel = the pixel's guide texel: viewZ rounded to 22 bits | 10-bit roughness code ; 3 x 10-bit normal | material"""
-    return sp.guide_words(viewz, packed_nr)
+    return sp.guide_words(viewz, packed_nr, denoising_range=denoising_range)
 
 
 def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr):
@@ -320,7 +320,7 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr):
         out[:, :, sig] = val
     out[sky] = 0.0
     speeds = np.where(sky, 0, pack_speeds(outA[0], outA[1])).astype(np.uint16)
-    return f16(out), speeds, pack_tap_guide(viewz, packed_nr)
+    return f16(out), speeds, pack_tap_guide(viewz, packed_nr, c.range)
 
 
 def temporal_stabilization(c, s, gcur, mv, hist, speeds, data2, stab_prev, hit_track, history_ok):

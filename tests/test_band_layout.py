@@ -81,3 +81,35 @@ def test_cpp_layout_matches_python(pkg, band_tool):
         for r in range(world):
             L = tiler.band_layout(frame_h, world, r, halo, bounds)
             assert vals[5 * r:5 * r + 5] == [frame_h, L["row0"], L["own_first"], L["own_rows"], L["local_h"]]
+
+
+def test_band_of_refuses_what_cannot_be_cut(tmp_path):
+    """ADVICE r3: nrd::TiledIntegration::BandOf reports failure instead of building a band from uninitialised bounds - fewer tile rows
+    than ranks, bands shorter than the halo, more than 64 ranks, caller bounds that are not monotone multiples of 16 ending at the frame
+    height; Recreate turns that into Result::INVALID_ARGUMENT before anything is allocated"""
+    src = tmp_path / "band_of.cpp"
+    src.write_text(r'''
+#include "NRDIntegration.h"
+#include <cstdio>
+int main() {
+    using T = nrd::TiledIntegration;
+    int32_t band[4]; uint16_t lh = 0; int bad = 0;
+    bad += T::BandOf(100, 8, 0, 16, band, lh) ? 1 : 0;              // 7 tile rows over 8 ranks
+    bad += T::BandOf(1088, 8, 0, 144, band, lh) ? 2 : 0;            // 68 tile rows, 8 bands of >= 9 tile rows each do not fit
+    bad += T::BandOf(4320, 65, 0, 16, band, lh) ? 4 : 0;            // more ranks than the bounds array holds
+    bad += T::BandOf(4320, 8, 8, 16, band, lh) ? 8 : 0;             // rank out of range
+    const int32_t notMonotone[3] = {0, 1088, 1000}, notAligned[3] = {0, 500, 1088}, wrongEnd[3] = {0, 544, 1080}, good[3] = {0, 544, 1088};
+    bad += T::BandOf(1088, 2, 0, 80, band, lh, notMonotone) ? 16 : 0;
+    bad += T::BandOf(1088, 2, 0, 80, band, lh, notAligned) ? 32 : 0;
+    bad += T::BandOf(1088, 2, 0, 80, band, lh, wrongEnd) ? 64 : 0;
+    bad += T::BandOf(1088, 2, 1, 80, band, lh, good) ? 0 : 128;     // ... and accepts a proper cut
+    bad += (band[0] == 1088 && band[1] == 464 && band[2] == 80 && band[3] == 544 && lh == 624) ? 0 : 256;
+    bad += T::BandOf(4320, 8, 7, 80, band, lh) ? 0 : 512;           // the even split of config 5
+    std::printf("%d\n", bad);
+    return bad;
+}
+''')
+    exe = str(tmp_path / "band_of")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout

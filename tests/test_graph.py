@@ -8,7 +8,7 @@ import pytest
 import util
 
 
-def run_pair(pkg, api, backend, dens, frames, w=320, h=192, stream=None, rects=None, split_calls=False):
+def run_pair(pkg, api, backend, dens, frames, w=320, h=192, stream=None, rects=None, split_calls=False, sync_every_frame=True):
     import contextlib
 
     scene = pkg.synth.Scene(w, h, dolly=0.02, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
@@ -35,6 +35,8 @@ def run_pair(pkg, api, backend, dens, frames, w=320, h=192, stream=None, rects=N
             order = [[d] for d in dd] if split_calls else [[d for d in dd]]  # the sample: one Denoise call per denoiser (NRDSample.cpp:4082, :4126, :4224)
             ha.frame(cs, pa, st, order=order)
             hb.frame(cs, pb, st, order=order)
+            if not sync_every_frame and f + 1 < frames:
+                continue  # back-to-back submission: nothing waits for the device between frames
             if stream is not None:
                 stream.synchronize()
             for key in ha.outputs:
@@ -51,11 +53,25 @@ def test_graph_replay_bit_identical(pkg, api, hip, dens):
     import torch
 
     side = torch.cuda.Stream()
-    stats = run_pair(pkg, api, hip, dens, frames=8, stream=side, rects={6: (288, 160)})
-    # 8 frames through the graph; instantiated for frame 0 (with the restart's clears), again for frame 1 (no clears), frame 4
-    # (clears again) and frame 5 - every other frame only patches kernel arguments
-    assert stats["replayed"] == 8 and stats["direct"] == 0, stats
-    assert stats["instantiated"] <= 4, stats
+    stats = run_pair(pkg, api, hip, dens, frames=14, stream=side, rects={6: (288, 160)})
+    # 14 frames through the graph. Every identifier list keeps a ring of 3 executable graphs (one is only patched after the launch that
+    # used it last has finished): instantiated for frames 0 (with the restart's clears), 1, 2 (the other two ring entries), 3 (ring entry
+    # 0 had the clears), 4 (clears again), 7 (the entry frame 4 left with clears) - every other frame only patches kernel arguments
+    assert stats["replayed"] == 14 and stats["direct"] == 0, stats
+    assert stats["instantiated"] <= 6, stats
+
+
+@pytest.mark.gpu
+def test_graph_replay_back_to_back_without_sync(pkg, api, hip):
+    """frames submitted back to back with NO synchronisation in between - frame N's kernels may still be queued when frame
+    N + 1 patches an executable graph. The ring of executable graphs + the event behind each launch must keep every frame on its own
+    constants: final outputs and every pool plane equal the pass-by-pass instance after 12 frames (any frame run with a neighbour's
+    matrices / frame index / ping-pong pointers would leave its mark in the histories)"""
+    import torch
+
+    side = torch.cuda.Stream()
+    stats = run_pair(pkg, api, hip, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW"], frames=12, w=960, h=544, stream=side, sync_every_frame=False)
+    assert stats["replayed"] == 12 and stats["direct"] == 0, stats
 
 
 @pytest.mark.gpu
@@ -65,9 +81,9 @@ def test_graph_replay_one_graph_per_identifier_list(pkg, api, hip):
     import torch
 
     side = torch.cuda.Stream()
-    stats = run_pair(pkg, api, hip, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW", "REFERENCE"], frames=8, stream=side, split_calls=True)
-    assert stats["replayed"] == 8 * 3 and stats["direct"] == 0, stats
-    assert stats["instantiated"] <= 3 * 4, stats  # per list: first frame (restart clears), second frame, the restart at frame 4, the frame after
+    stats = run_pair(pkg, api, hip, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW", "REFERENCE"], frames=14, stream=side, split_calls=True)
+    assert stats["replayed"] == 14 * 3 and stats["direct"] == 0, stats
+    assert stats["instantiated"] <= 3 * 6, stats  # per list: frames 0-4 and 7 (see test_graph_replay_bit_identical), the other 8 patch arguments
 
 
 @pytest.mark.gpu

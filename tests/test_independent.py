@@ -77,7 +77,7 @@ def test_guide_and_prepass_independent(pkg, api, oracle, f):
     fr, cs, st, tmp1, track, guide = oracle_prepass(pkg, api, oracle, f)
     # guide texel {viewZ 22 bit | roughness code, normal 3 x 10 bit | materialID}: depth word and material exact; a normal code may sit
     # one step off where the float32 octahedral decode and the float64 one round to different sides (a handful of texels)
-    w0, w1 = ind.guide_words(fr["viewz"], fr["normal_roughness"])
+    w0, w1 = ind.guide_words(fr["viewz"], fr["normal_roughness"], denoising_range=cs.denoisingRange)
     g = guide.view(np.uint32).reshape(H, W, 2)
     assert np.array_equal(g[..., 0], w0) and np.array_equal(g[..., 1] >> 30, w1 >> 30)
     for sh in (0, 10, 20):

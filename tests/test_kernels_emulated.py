@@ -97,9 +97,12 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
     """PrePass, TemporalAccumulation and PostBlur write nothing in tiles without geometry (csrc/nrd_reblur.hip k_spatial): whatever
     their planes - and every other internal plane - hold at pixels beyond the denoising range must not matter. Two instances of the
     emulated kernels run the same frames; in one of them every internal plane except the guides is overwritten, before every frame,
-    with random FINITE fp16 bit patterns at the pixels that are beyond the range in the previous AND the current frame (a texel that
+    with random fp16 bit patterns at the pixels that are beyond the range in the previous AND the current frame (a texel that
     had geometry a frame ago holds history the reprojection is entitled to). Every output of every frame must be bit-identical: no
-    pass consumes such a texel other than through a test of the guide that selects it out, or with a weight of exactly 0."""
+    pass consumes such a texel other than through a test of the guide that selects it out, or with a weight of exactly 0.
+    The PERMANENT planes get finite patterns only (they are cleared before a denoiser's first frame and only ever written with clamped
+    fp16 values, which is what allows "weight 0 x texel" there); the TRANSIENT planes - one arena aliased across denoisers, so anything
+    may be left in it - get every pattern, NaN and Inf included: a texel of theirs may only ever be SELECTED out."""
     import numpy as np
 
     rng = np.random.default_rng(7)
@@ -128,7 +131,10 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
                             continue
                         arr = p["buf"].view(np.uint16).reshape(h, -1)[:, : w * words].reshape(h, w, words)
                         junk = rng.integers(0, 1 << 16, size=arr.shape, dtype=np.uint16)
-                        junk = np.where((junk & 0x7c00) == 0x7c00, junk & np.uint16(0xbbff), junk)  # no Inf / NaN: finite fp16 only
+                        if pool == 0:
+                            junk = np.where((junk & 0x7c00) == 0x7c00, junk & np.uint16(0xbbff), junk)  # no Inf / NaN: finite fp16 only
+                        else:
+                            junk[..., 0] = np.where(junk[..., 0] % 3 == 0, np.uint16(0x7e00), np.where(junk[..., 0] % 3 == 1, np.uint16(0xfc00), junk[..., 0]))  # NaN, -Inf
                         arr[both] = junk[both]
                         poisoned += int(both.sum())
             prev_sky = sky
@@ -139,3 +145,35 @@ def test_nobody_reads_what_sky_tiles_leave_unwritten(pkg, api, emulated, dens, k
         assert poisoned > 0
         tiles = np.asarray(hb.pool(("RELAX" if dens[0].startswith("RELAX") else "REBLUR") + "::Tiles"))
         assert tiles.max() == 1 and tiles.min() == 0
+
+
+@pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW"], ["RELAX_DIFFUSE_SPECULAR"]])
+def test_no_hit_depth_patterns_are_sky(pkg, api, oracle, emulated, dens):
+    """what a renderer writes into IN_VIEWZ where a ray hit nothing must not matter - 1e5 (the sample, Shared.hlsli:141), +-Inf, a
+    NaN, or a plane cleared with 0xFF bytes (a NaN whose bit pattern used to WRAP in the guide's depth rounding and come back as geometry
+    at depth ~0). ClassifyTiles stores one canonical finite depth for all of them, so every plane and every output is bit-identical to
+    the run with plain far-away depths - in the oracle and in the kernels"""
+    import numpy as np
+
+    w, h = 72, 88
+    scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
+    dd = [api.Denoiser[x] for x in dens]
+    st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    patterns = np.array([0xFFFFFFFF, 0x7F800000, 0xFF800000, 0x7FC00000, 0xFFFFFE00, 0x7F7FFFFF], dtype=np.uint32)
+
+    def mangle(f, fr):
+        cs = scene.common_settings(api, fr, f)
+        sky = np.abs(fr["viewz"].astype(np.float32) * float(cs.viewZScale)) > float(cs.denoisingRange)
+        assert sky.any() and not sky.all()
+        z = fr["viewz"].astype(np.float32).copy().view(np.uint32)
+        yy, xx = np.nonzero(sky)
+        z[yy, xx] = patterns[(xx + 3 * yy + f) % len(patterns)]
+        fr["viewz"] = z.view(np.float32)
+
+    plain = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st)
+    odd = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st, frame_hook=mangle)
+    emu = util.run_frames(api, pkg.harness, emulated, scene, dd, 3, settings=st, frame_hook=mangle)
+    assert util.compare_all(plain, odd, exact=True) == []
+    assert util.compare_all(odd, emu, exact=True) == []
+    for key in ("out_diff", "out_spec"):
+        assert np.isfinite(odd.output(key).astype(np.float32)).all()
