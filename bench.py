@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import __graft_entry__ as graft  # noqa: E402
 
+FLAVOUR_DISTANCE = (1920, 1080, 34)  # width, height, frames of the default-vs-frozen output comparison (config.frozen_formulas.distance_from_default)
 GRAPH_LEG_BAND = (7680, 544)  # the band one rank of 8 holds of the 7680x4320 frame (BASELINE config 5): second size of the graph-replay leg
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -73,7 +74,8 @@ def parse():
                     help="N > 1: seconds the native-tiler leg and the bit-identity check may take together before rank 0 prints the line of "
                          "record without them and the run ends (a hang in never-executed transport code must not cost the line)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the HIP-graph replay leg (NRDHIP_FLAG_GRAPH), 1-GPU runs")
-    ap.add_argument("--no-upstream-leg", action="store_true", help="skip the timed leg on the NRD_UPSTREAM_FORMULAS build flavour, 1-GPU runs")
+    ap.add_argument("--no-frozen-leg", action="store_true", help="skip the timed leg on libnrdhip_frozen.so (the cheaper formulas of rounds 1-3) and "
+                    "the distance of its outputs from the default's, 1-GPU runs")
     ap.add_argument("--no-full-coverage", action="store_true", help="skip the second timed leg (the same scene without sky), 1-GPU runs")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
@@ -434,26 +436,28 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # a reported extra: never lose the headline line to it
                 out["config"]["full_coverage"] = {"error": str(e)}
-        if world == 1 and not args.force_tiled and not args.no_upstream_leg and not args.preset and os.path.exists(pkg.HIP_LIB_UPSTREAM):
-            # the price of the frozen simplifications: the same workload through libnrdhip_upstream.so - the build flavour with the
-            # recalled upstream forms of ledger rows 1, 2, 7, 13 (exp(-3|x|) hit-distance weight, arccosine normal weight, per-pixel Blur
-            # rotation; csrc/nrd_device.h NRD_UPSTREAM_FORMULAS)
+        if world == 1 and not args.force_tiled and not args.no_frozen_leg and not args.preset and os.path.exists(pkg.HIP_LIB_FROZEN):
+            # What the cheaper formulas of rounds 1-3 would buy, and how far their output is from the default's: the same workload through
+            # libnrdhip_frozen.so (csrc/nrd_device.h NRD_UPSTREAM_FORMULAS = 0: compact-support hit-distance weight instead of exp(-3|x|),
+            # normal weight on the squared angle instead of the angle, Blur rotation per 2x2 quad instead of per pixel, RELAX in YCoCg inside)
             try:
-                hip_up = pkg.hip_backend(dev, flavour="upstream")
-                scene_up = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
+                hip_fz = pkg.hip_backend(dev, flavour="frozen")
+                scene_fz = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR",
                                        roll_deg=args.roll)
-                hz_up = Harness(hip_up, dens, w, band_h, separate_passes=args.separate_passes)
-                runner_up = SingleRunner(api, hz_up, scene_up, dens, args.unique_frames, settings_of(api, scene_up, dens))
-                dt_up = timed_run(runner_up)
-                pp = runner_up.pass_times_ms()
-                out["config"]["upstream_formulas"] = {
-                    "value": round(w * frame_h * args.steps / dt_up / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_up / args.steps * 1e3, 4),
-                    "passes_ms": {k: round(v[0], 4) for k, v in pp.items()},
-                    "what": "same workload, libnrdhip_upstream.so: hit-distance weight exp(-3|x|), normal weight on the angle (arccosine), Blur rotation per pixel, RELAX in linear RGB throughout"}
-                del runner_up, hz_up
+                hz_fz = Harness(hip_fz, dens, w, band_h, separate_passes=args.separate_passes)
+                runner_fz = SingleRunner(api, hz_fz, scene_fz, dens, args.unique_frames, settings_of(api, scene_fz, dens))
+                dt_fz = timed_run(runner_fz)
+                pp = runner_fz.pass_times_ms()
+                leg = {"value": round(w * frame_h * args.steps / dt_fz / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_fz / args.steps * 1e3, 4),
+                       "passes_ms": {k: round(v[0], 4) for k, v in pp.items()},
+                       "what": "same workload, libnrdhip_frozen.so: hit-distance weight (1-|x|)^2 instead of exp(-3|x|), normal weight on the squared angle "
+                               "instead of the angle (arccosine), Blur rotation per 2x2 quad instead of per pixel, RELAX in YCoCg inside instead of linear RGB"}
+                del runner_fz, hz_fz
                 torch.cuda.empty_cache()
+                out["config"]["frozen_formulas"] = leg
+                leg["distance_from_default"] = flavour_distance(pkg, api, synth, Harness, hip, hip_fz, dev, dens, den_names, args)
             except Exception as e:
-                out["config"]["upstream_formulas"] = {"error": str(e)}
+                out["config"].setdefault("frozen_formulas", {})["error"] = str(e)
         if world == 1 and not args.force_tiled and not args.no_graph_leg and not args.preset:
             # NRDHIP_FLAG_GRAPH: the frame as ONE HIP graph launch (captured every frame, the executable graph patched with the new kernel
             # arguments) against pass-by-pass launches, both on the same non-default stream and without per-pass events: on the
@@ -571,6 +575,38 @@ def pingpong(n, f):
     period = 2 * (n - 1)
     k = f % period
     return k if k < n else period - k
+
+
+def flavour_distance(pkg, api, synth, Harness, hip_a, hip_b, dev, dens, den_names, args):
+    """PSNR and the share of values more than 1 fp16 ULP apart between the outputs of two build flavours of the library, per OUT_* plane,
+    after `frames` frames (>= the accumulation length) of the same denoisers at 1920x1080 on the bench scene"""
+    import numpy as np
+    import torch
+
+    w, h, frames = FLAVOUR_DISTANCE
+    outs = []
+    for hip_x in (hip_a, hip_b):
+        scene = synth.Scene(w, h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR", roll_deg=args.roll)
+        hz = Harness(hip_x, dens, w, h)
+        runner = SingleRunner(api, hz, scene, dens, args.unique_frames, settings_of(api, scene, dens))
+        for f in range(frames):
+            runner.step(f, reset=(f == 0))
+        torch.cuda.synchronize()
+        outs.append({k: np.asarray(hz.fetch(v)).copy() for k, v in hz.outputs.items()})
+        del runner, hz
+        torch.cuda.empty_cache()
+    res = {"frames": frames, "size": "%dx%d" % (w, h)}
+    for key in ("out_diff", "out_spec"):
+        a16, b16 = outs[0][key].view(np.float16), outs[1][key].view(np.float16)
+        if not a16.any() and not b16.any():
+            continue
+        a, b = a16.astype(np.float64), b16.astype(np.float64)
+        mse = float(np.mean((a - b) ** 2))
+        peak = max(float(np.abs(a).max()), 1e-12)
+        ia, ib = a16.view(np.int16).astype(np.int32), b16.view(np.int16).astype(np.int32)
+        oa, ob = np.where(ia < 0, -32768 - ia, ia), np.where(ib < 0, -32768 - ib, ib)
+        res[key] = {"psnr_db": None if mse == 0 else round(10.0 * np.log10(peak * peak / mse), 2), "ulp_gt1_frac": round(float((np.abs(oa - ob) > 1).mean()), 4)}
+    return res
 
 
 class SingleRunner:

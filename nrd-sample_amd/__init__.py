@@ -15,18 +15,18 @@ from . import api, harness, sample_tests, synth  # noqa: F401
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HIP_LIB = os.path.join(PKG_DIR, "csrc", "libnrdhip.so")
-# the same kernels built with the recalled upstream forms of three frozen simplifications (csrc/nrd_device.h NRD_UPSTREAM_FORMULAS)
-HIP_LIB_UPSTREAM = os.path.join(PKG_DIR, "csrc", "libnrdhip_upstream.so")
+# the same kernels built with the cheaper forms of four formulas that rounds 1-3 had frozen (csrc/nrd_device.h NRD_UPSTREAM_FORMULAS = 0)
+HIP_LIB_FROZEN = os.path.join(PKG_DIR, "csrc", "libnrdhip_frozen.so")
 
 
 def hip_backend(device="cuda:0", flavour=None):
     """The product path. Fails loudly when the HIP library is missing or no GPU is visible - there is no CPU fallback.
-    ``flavour="upstream"``: libnrdhip_upstream.so (bench.py's config.upstream_formulas leg, tests)."""
+    ``flavour="frozen"``: libnrdhip_frozen.so (bench.py's config.frozen_formulas leg, tests)."""
     import torch
 
     if not torch.cuda.is_available():
         raise RuntimeError("nrd-sample_amd: no HIP device visible; the denoiser passes are HIP kernels and have no CPU fallback")
-    b = api.Backend(HIP_LIB_UPSTREAM if flavour == "upstream" else HIP_LIB, "nrdhip_", device)
+    b = api.Backend(HIP_LIB_FROZEN if flavour == "frozen" else HIP_LIB, "nrdhip_", device)
     b.check_abi()
     return b
 

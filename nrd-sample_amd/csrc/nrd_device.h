@@ -225,30 +225,55 @@ NRD_DEV float atan_pos(float x) {
     return inv ? 1.57079633f - p : p;
 }
 
-// NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of four frozen simplifications (oracle/README.md
-// ledger rows 1, 2, 7, 13): hit-distance weight exp(-3 |x|), normal weight on the ANGLE (through an arccosine), Blur rotation per pixel,
-// RELAX in linear RGB throughout (RELAX_LINEAR_RGB below).
-// It exists to put a price on those deviations (bench.py config.upstream_formulas) and as the switch to flip the day External/NRD is
-// vendored; libnrdhip_upstream.so / liboracle_upstream.so are built from the same sources with -DNRD_UPSTREAM_FORMULAS=1.
+// NRD_UPSTREAM_FORMULAS = 1 (the DEFAULT since round 4: libnrdhip.so, liboracle.so): the RECALLED upstream forms of ledger rows 1, 2,
+// 7, 13 (oracle/README.md) - hit-distance weight exp(-3 |x|), normal weight on the ANGLE (through an arccosine), Blur rotation per
+// pixel, RELAX in linear RGB throughout (RELAX_LINEAR_RGB below). NRD_UPSTREAM_FORMULAS = 0 builds the cheaper forms rounds 1-3 had
+// frozen (compact-support hit weight, squared-angle normal weight, rotation per 2x2 quad, YCoCg inside RELAX) as libnrdhip_frozen.so /
+// liboracle_frozen.so: same sources, -DNRD_UPSTREAM_FORMULAS=0; bench.py times it beside the default (config.frozen_formulas) with the
+// distance between the two outputs.
 #ifndef NRD_UPSTREAM_FORMULAS
-#define NRD_UPSTREAM_FORMULAS 0
+#define NRD_UPSTREAM_FORMULAS 1
 #endif
 constexpr bool UPSTREAM_FORMULAS = NRD_UPSTREAM_FORMULAS != 0;
 constexpr int BLUR_ROTATION_SHIFT = UPSTREAM_FORMULAS ? 0 : 1; // Blur's Poisson rotation: per pixel (upstream) / per 2x2 quad (frozen)
 
-// arccosine on [0, 1] (Abramowitz & Stegun 4.4.45, |error| <= 5e-5): sqrt(1 - x) (a0 + a1 x + a2 x^2 + a3 x^3)
+// arccosine on [0, 1] (Abramowitz & Stegun 4.4.45, |error| <= 5e-5): sqrt(1 - x) (a0 + a1 x + a2 x^2 + a3 x^3). The square root takes
+// TWO Newton steps (relative error 4.7e-6, a tenth of the polynomial's own): this function runs once per tap of every spatial pass and
+// the passes are priced in instructions (profiles/r04_valu_issue.txt)
+NRD_DEV float sqrt2_(float x) {
+    const float h = 0.5f * x;
+    float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
+    r = r * fma_(-(h * r), r, 1.5f);
+    r = r * fma_(-(h * r), r, 1.5f);
+    return x * r; // sqrt2_(0) = 0
+}
 NRD_DEV float acos01_poly(float x) {
     x = sat(x);
     float p = -0.0187293f;
     p = fma_(p, x, 0.0742610f);
     p = fma_(p, x, -0.2121144f);
     p = fma_(p, x, 1.5707288f);
-    return sqrt_(1.0f - x) * p;
+    return sqrt2_(1.0f - x) * p;
+}
+// 2^x for x <= 0 (the hit-distance weight's exponent): exp2_poly without its upper clamp and with the power of two applied by v_ldexp_f32
+// instead of an integer add, a shift and a multiply - the same value bit for bit (the scale is exact either way), three instructions less
+NRD_DEV float exp2_poly_neg(float x) {
+    x = fmax2(x, -126.0f);
+    const float fi = __builtin_floorf(x + 0.5f);
+    const float f = x - fi;
+    float p = 1.535336188319500e-4f;
+    p = fma_(p, f, 1.339887440266574e-3f);
+    p = fma_(p, f, 9.618437357674640e-3f);
+    p = fma_(p, f, 5.550332471162809e-2f);
+    p = fma_(p, f, 2.402264791363012e-1f);
+    p = fma_(p, f, 6.931472028550421e-1f);
+    p = fma_(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)fi);
 }
 // hit-distance weight: compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped; upstream flavour: exp(-3 |x|)
 NRD_DEV float exp_weight(float ax) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly(-4.32808512f * ax); // 3 log2(e)
+        return exp2_poly_neg(-4.32808512f * ax); // 3 log2(e); ax >= 0
     float t = sat(1.0f - ax);
     return t * t;
 }

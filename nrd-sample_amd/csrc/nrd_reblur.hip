@@ -31,14 +31,14 @@ NRD_KERNELS_BEGIN
 #define NRD_PIPE_DEPTH_WIDE 5
 #endif
 // Blur / PostBlur on tap texels (one 16-byte gather per tap): taps in flight and waves per SIMD
-#ifndef NRD_TAP_DEPTH
-#define NRD_TAP_DEPTH NRD_PIPE_DEPTH
+#ifndef NRD_TAP_DEPTH // (the default flavour's arccosine / exp2 polynomials hold more registers per tap: 8 taps in flight spill 16 bytes at 5 waves)
+#define NRD_TAP_DEPTH (NRD_UPSTREAM_FORMULAS ? (NRD_ORTHO ? 5 : 6) : NRD_PIPE_DEPTH) // (orthographic flavour: 6 spill 20 bytes)
 #endif
 #ifndef NRD_PRE_DEPTH // taps in flight: REBLUR radiance PrePass
 #define NRD_PRE_DEPTH 2
 #endif
 #ifndef NRD_POST_DEPTH // taps in flight: PostBlur on tap texels
-#define NRD_POST_DEPTH 3 // (round 4: 81 VGPRs at 4 with the packed normal distance - one more than 6 waves per SIMD allow; 3: 73)
+#define NRD_POST_DEPTH (NRD_UPSTREAM_FORMULAS ? 2 : 3) // 6 waves per SIMD either way (75 / 73 VGPRs; one tap more in flight: 82 / 81, 5 waves)
 #endif
 #ifndef NRD_POST_WAVES // PostBlur on tap texels: waves per SIMD the register allocator aims for
 #define NRD_POST_WAVES NRD_TAP_WAVES

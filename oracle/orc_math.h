@@ -205,22 +205,30 @@ static inline float atan_pos(float x) {
 static inline float acos_approx(float x) { return 1.41421356f * sqrtf(sat(1.0f - x)); }
 
 // NRD_UPSTREAM_FORMULAS = 1: the build flavour with the RECALLED upstream forms of ledger rows 1, 2, 7 and 13 (oracle/README.md):
-// hit-distance weight exp(-3 |x|), normal weight on the angle, Blur rotation per pixel, RELAX in linear RGB - liboracle_upstream.so, the checker of
-// libnrdhip_upstream.so (same switch, same formulas: nrd-sample_amd/csrc/nrd_device.h)
-#ifndef NRD_UPSTREAM_FORMULAS
-#define NRD_UPSTREAM_FORMULAS 0
+// hit-distance weight exp(-3 |x|), normal weight on the angle, Blur rotation per pixel, RELAX in linear RGB - liboracle.so (the default since round 4), the checker of
+// libnrdhip.so (same switch, same formulas: nrd-sample_amd/csrc/nrd_device.h)
+#ifndef NRD_UPSTREAM_FORMULAS // (1 = the default since round 4; 0 = the "frozen" flavour: liboracle_frozen.so, the checker of libnrdhip_frozen.so)
+#define NRD_UPSTREAM_FORMULAS 1
 #endif
 static const bool UPSTREAM_FORMULAS = NRD_UPSTREAM_FORMULAS != 0;
 static const int BLUR_ROTATION_SHIFT = NRD_UPSTREAM_FORMULAS ? 0 : 1; // Blur's Poisson rotation: per pixel (upstream) / per 2x2 quad (frozen)
 
 // arccosine on [0, 1] (Abramowitz & Stegun 4.4.45, |error| <= 5e-5)
+// (the square root inside takes TWO Newton steps - relative error 4.7e-6, a tenth of the polynomial's own: csrc/nrd_device.h sqrt2_)
+static inline float sqrt2_(float x) {
+    const float h = 0.5f * x;
+    float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
+    r = r * fma_(-(h * r), r, 1.5f);
+    r = r * fma_(-(h * r), r, 1.5f);
+    return x * r;
+}
 static inline float acos01_poly(float x) {
     x = sat(x);
     float p = -0.0187293f;
     p = fma_(p, x, 0.0742610f);
     p = fma_(p, x, -0.2121144f);
     p = fma_(p, x, 1.5707288f);
-    return sqrt_(1.0f - x) * p;
+    return sqrt2_(1.0f - x) * p;
 }
 // hit-distance weight: compact-support stand-in for exp(-3 |x|): (1 - |x|)^2 clamped (division-free); upstream flavour: exp(-3 |x|)
 static inline float exp_weight(float ax) {

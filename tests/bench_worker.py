@@ -40,17 +40,18 @@ CUDA_STANDINS = (("is_available", lambda: True), ("device_count", lambda: 1), ("
                  ("current_stream", lambda *a: FakeStream()))
 
 
-def patch_for_cpu(setattr_, pkg, bench, emulated, emulated_upstream, workloads, graph_band):
+def patch_for_cpu(setattr_, pkg, bench, emulated, emulated_frozen, workloads, graph_band):
     """setattr_(obj, name, value): monkeypatch.setattr in a test, plain setattr in a worker process"""
     import torch
 
     for name, value in CUDA_STANDINS:
         setattr_(torch.cuda, name, value)
-    setattr_(pkg, "hip_backend", lambda device, flavour=None: emulated_upstream if flavour else emulated)
+    setattr_(pkg, "hip_backend", lambda device, flavour=None: emulated_frozen if flavour else emulated)
     real_scene = pkg.synth.Scene
     setattr_(pkg.synth, "Scene", lambda *a, **kw: real_scene(*a, **dict(kw, device="cpu")))
     setattr_(bench, "WORKLOADS", dict(bench.WORKLOADS, **workloads))
     setattr_(bench, "GRAPH_LEG_BAND", graph_band)
+    setattr_(bench, "FLAVOUR_DISTANCE", (64, 48, 3))
 
 
 if __name__ == "__main__":

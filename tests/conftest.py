@@ -47,22 +47,22 @@ def hip(pkg):
     return pkg.hip_backend("cuda:0")
 
 
-# ---- the NRD_UPSTREAM_FORMULAS build flavour (recalled upstream forms of ledger rows 1, 2, 7; oracle/README.md) ----
+# ---- the NRD_UPSTREAM_FORMULAS=0 build flavour (the cheaper forms of ledger rows 1, 2, 7, 13 that rounds 1-3 had frozen; oracle/README.md) ----
 @pytest.fixture(scope="session")
-def oracle_upstream(pkg):
-    if not os.path.exists(graft.ORACLE_LIB_UPSTREAM):
+def oracle_frozen(pkg):
+    if not os.path.exists(graft.ORACLE_LIB_FROZEN):
         graft.build_oracle()
-    return graft.oracle_backend("upstream")
+    return graft.oracle_backend("frozen")
 
 
 @pytest.fixture(scope="session")
-def emulated_upstream(pkg):
-    path = graft.build_emulated(flavour="upstream")
+def emulated_frozen(pkg):
+    path = graft.build_emulated(flavour="frozen")
     b = pkg.api.Backend(path, "nrdhip_", "cpu")
     b.check_abi()
     return b
 
 
 @pytest.fixture(scope="session")
-def hip_upstream(pkg):
-    return pkg.hip_backend("cuda:0", flavour="upstream")
+def hip_frozen(pkg):
+    return pkg.hip_backend("cuda:0", flavour="frozen")

@@ -1,6 +1,8 @@
 """Generates tests/golden/*.npz with the CPU oracle (the reference holds no golden vectors for this path, SURVEY.md 8c:
 "parity unpinned"; these fixtures pin the build's own oracle against drift and travel to the GPU box).
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py            (the default flavour -> tests/golden/*.npz)
+                         python tests/golden/make_golden.py --frozen   (liboracle_frozen.so -> tests/golden/frozen/*.npz; these are
+                         round 3's files, byte for byte: the frozen flavour's arithmetic has not moved since)
 Inputs are the synthetic scene of nrd-sample_amd/synth.py (64x48, 4 frames, moving camera); outputs are every OUT_* plane
 after every frame."""
 import os
@@ -39,15 +41,20 @@ def settings_for(api, scene, dens):
 
 
 def main():
+    frozen = "--frozen" in sys.argv
     pkg = graft.load_package()
     graft.build_oracle()
     api, synth, harness = pkg.api, pkg.synth, pkg.harness
-    orc = graft.oracle_backend()
+    orc = graft.oracle_backend("frozen" if frozen else None)
     scene = synth.Scene(W, H, dolly=0.03)
     frames = [scene.frame(f) for f in range(FRAMES)]
     out_dir = os.path.dirname(os.path.abspath(__file__))
-    np.savez_compressed(os.path.join(out_dir, "inputs_64x48.npz"),
-                        **{"f%d_%s" % (f, k): frames[f][k] for f in range(FRAMES) for k in INPUT_KEYS})
+    if frozen:
+        out_dir = os.path.join(out_dir, "frozen")
+        os.makedirs(out_dir, exist_ok=True)
+    else:
+        np.savez_compressed(os.path.join(out_dir, "inputs_64x48.npz"),
+                            **{"f%d_%s" % (f, k): frames[f][k] for f in range(FRAMES) for k in INPUT_KEYS})
     for name, dn in CASES.items():
         dens = [api.Denoiser[x] for x in dn]
         hz = harness.Harness(orc, dens, W, H)

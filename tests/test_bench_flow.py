@@ -1,6 +1,6 @@
 """bench.py's default (N = 1) control flow, end to end, without a GPU: main() runs on the host-emulated kernels with torch.cuda's
 streams / events / synchronisation replaced by host stand-ins and the workload shrunk to a few tiles. What is checked is the contract of
-the JSON line the driver parses - every key, the roofline and cpu_baseline objects, the extra legs (full coverage, upstream-formulas
+the JSON line the driver parses - every key, the roofline and cpu_baseline objects, the extra legs (full coverage, frozen-formulas
 flavour, graph replay) - and that nothing in the flow raises; the numbers themselves mean nothing here."""
 import json
 import os
@@ -13,12 +13,12 @@ import pytest
 import bench_worker
 
 
-def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, emulated, emulated_upstream):
+def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, emulated, emulated_frozen):
     import torch
 
     import bench
 
-    bench_worker.patch_for_cpu(monkeypatch.setattr, pkg, bench, emulated, emulated_upstream, {"reblur_ds_4k": (96, 64, ["REBLUR_DIFFUSE_SPECULAR"])}, (64, 32))
+    bench_worker.patch_for_cpu(monkeypatch.setattr, pkg, bench, emulated, emulated_frozen, {"reblur_ds_4k": (96, 64, ["REBLUR_DIFFUSE_SPECULAR"])}, (64, 32))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "8", "--warmup", "2", "--unique-frames", "2"])
     bench.main()
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
@@ -37,7 +37,9 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
     c = d["config"]
     assert "workload" in c and 0.0 <= c["sky_fraction"] <= 1.0
     assert c["full_coverage"]["sky_fraction"] == 0.0 and c["full_coverage"]["value"] > 0
-    assert c["upstream_formulas"]["value"] > 0
+    assert c["frozen_formulas"]["value"] > 0
+    dist_ = c["frozen_formulas"]["distance_from_default"]  # PSNR and the share of values > 1 fp16 ULP apart, per output, default vs frozen flavour
+    assert dist_["frames"] == 3 and all(0.0 <= dist_[k]["ulp_gt1_frac"] <= 1.0 and dist_[k]["psnr_db"] > 20.0 for k in ("out_diff", "out_spec"))
     assert set(c["graph_replay"]) == {"workload", "band_64x32"} and c["graph_replay"]["workload"]["graph_stats"]["direct"] > 0  # (no graphs in the emulation)
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b and b["unit"] == "Mpixels/s"

@@ -72,9 +72,13 @@ def test_reference_accumulation_independent(pkg, api, oracle):
         assert np.abs(hz.pool("REFERENCE::History").view(np.float32).reshape(H, W, 4) - hist).max() <= 2e-7 * max(1.0, float(np.abs(hist).max()))
 
 
+@pytest.mark.parametrize("flavour", ["default", "frozen"])
 @pytest.mark.parametrize("f", [0, 2])
-def test_guide_and_prepass_independent(pkg, api, oracle, f):
-    fr, cs, st, tmp1, track, guide = oracle_prepass(pkg, api, oracle, f)
+def test_guide_and_prepass_independent(request, pkg, api, f, flavour):
+    """both build flavours: the default (hit-distance weight exp(-3|x|), normal weight on the arccosine of the angle - the restatement
+    takes exact exp / arccos where the oracle evaluates its polynomials) and the frozen one ((1 - |x|)^2, squared angle)"""
+    upstream = flavour == "default"
+    fr, cs, st, tmp1, track, guide = oracle_prepass(pkg, api, request.getfixturevalue("oracle" if upstream else "oracle_frozen"), f)
     # guide texel {viewZ 22 bit | roughness code, normal 3 x 10 bit | materialID}: depth word and material exact; a normal code may sit
     # one step off where the float32 octahedral decode and the float64 one round to different sides (a handful of texels)
     w0, w1 = ind.guide_words(fr["viewz"], fr["normal_roughness"], denoising_range=cs.denoisingRange)
@@ -84,7 +88,7 @@ def test_guide_and_prepass_independent(pkg, api, oracle, f):
         d = np.abs(((g[..., 1] >> sh) & 1023).astype(np.int32) - ((w1 >> sh) & 1023).astype(np.int32))
         assert d.max() <= 1 and float((d == 0).mean()) > 0.98
     want, want_track = ind.prepass(fr["viewz"], fr["normal_roughness"], fr["diff"], fr["spec"], fr["view_to_clip"], fr["world_to_view"], cs.frameIndex, cs.denoisingRange,
-                                   settings_dict(st))
+                                   settings_dict(st), exp_hit_weight=upstream, angle_normal_weight=upstream)
     d = ulp16(tmp1, want)
     # float64 vs the oracle's float32: a tap position may floor to the neighbouring texel where the projected offset sits on a pixel
     # boundary - a different (equally valid) tap, not an arithmetic error; everything else must agree to 1 fp16 ULP
@@ -101,12 +105,12 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10.0 * np.log10(max(float(np.abs(b).max()), 1e-9) ** 2 / mse)
 
 
-def test_deviation_ledger_measurements(pkg, api, oracle, capsys):
+def test_deviation_ledger_measurements(pkg, api, oracle_frozen, capsys):
     """How far each knowingly non-upstream formula moves the PrePass output on the golden scene (frames 0 and 2): the numbers quoted
     in oracle/README.md 'deviation ledger'. Asserts only that they stay in the bands written there."""
     rows = {}
     for f in (0, 2):
-        fr, cs, st, tmp1, track, _ = oracle_prepass(pkg, api, oracle, f)
+        fr, cs, st, tmp1, track, _ = oracle_prepass(pkg, api, oracle_frozen, f)
         args = (fr["viewz"], fr["normal_roughness"], fr["diff"], fr["spec"], fr["view_to_clip"], fr["world_to_view"], cs.frameIndex, cs.denoisingRange, settings_dict(st))
         base, _ = ind.prepass(*args)
         for name in ("exp_hit_weight", "angle_normal_weight", "no_reach", "f32_guide"):
@@ -156,11 +160,11 @@ def agree(name, got, want, min_frac, mask=None):
 
 
 @pytest.mark.parametrize("f", [1, 2, 3])
-def test_temporal_passes_independent(pkg, api, oracle, f):
+def test_temporal_passes_independent(pkg, api, oracle_frozen, f):
     D = api.Denoiser
     den = int(D.REBLUR_DIFFUSE_SPECULAR)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
-    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H, separate_passes=True)  # (pool snapshots between all seven passes)
+    hz = pkg.harness.Harness(oracle_frozen, [D.REBLUR_DIFFUSE_SPECULAR], W, H, separate_passes=True)  # (pool snapshots between all seven passes)
     st = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
     s = temporal_settings(st)
     for g in range(f):  # the history this frame inherits
@@ -244,13 +248,13 @@ def test_temporal_passes_independent(pkg, api, oracle, f):
 
 
 @pytest.mark.parametrize("f", [1, 3])
-def test_relax_atrous_iterations_independent(pkg, api, oracle, f):
+def test_relax_atrous_iterations_independent(pkg, api, oracle_frozen, f):
     """one variance-guided A-trous iteration of RELAX_DIFFUSE_SPECULAR, twice: iteration 0 (variance from the accumulated moments +
     the 3x3 spatial estimate of short histories, stride 1) and iteration 1 (stride 2, variance carried in the texel)"""
     D = api.Denoiser
     den = int(D.RELAX_DIFFUSE_SPECULAR)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
-    hz = pkg.harness.Harness(oracle, [D.RELAX_DIFFUSE_SPECULAR], W, H)
+    hz = pkg.harness.Harness(oracle_frozen, [D.RELAX_DIFFUSE_SPECULAR], W, H)
     st = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
     s = {k: getattr(st, k) for k in ("depthThreshold", "spatialVarianceEstimationHistoryThreshold", "specularVarianceBoost", "diffusePhiLuminance",
                                      "specularPhiLuminance", "diffuseMinLuminanceWeight", "specularMinLuminanceWeight", "lobeAngleFraction",
@@ -284,13 +288,13 @@ def test_relax_atrous_iterations_independent(pkg, api, oracle, f):
 
 
 @pytest.mark.parametrize("f", [1, 2, 3])
-def test_sigma_passes_independent(pkg, api, oracle, f):
+def test_sigma_passes_independent(pkg, api, oracle_frozen, f):
     """SIGMA_SHADOW_TRANSLUCENCY: Blur, PostBlur (penumbra-sized tangent-plane blur of the visibility) and TemporalStabilization
     (reprojection with occlusion test, per-channel 5x5 moment clamp, sqrt-encoded RGBA8 history)"""
     D = api.Denoiser
     den = int(D.SIGMA_SHADOW_TRANSLUCENCY)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
-    hz = pkg.harness.Harness(oracle, [D.SIGMA_SHADOW_TRANSLUCENCY], W, H)
+    hz = pkg.harness.Harness(oracle_frozen, [D.SIGMA_SHADOW_TRANSLUCENCY], W, H)
     st = api.SigmaSettings(lightDirection=list(scene.sun))
     s = dict(planeDistanceSensitivity=st.planeDistanceSensitivity, maxStabilizedFrameNum=st.maxStabilizedFrameNum)
     for g in range(f):

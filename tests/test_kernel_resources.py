@@ -69,9 +69,9 @@ def test_headline_kernels_keep_their_occupancy(kernels):
     """REBLUR_DIFFUSE_SPECULAR radiance kernels, perspective flavour: waves per SIMD as tuned (profiles/r03_ab_pipeline_depth.txt,
     r03_ab_tap_texels.txt)"""
     want = {  # (mangled template arguments: k_spatial<VARIANT, MODE, HAS_DIFF, HAS_SPEC>, ...)
-        "k_spatialILi0ELi0ELb1ELb1EE": 6,   # PrePass, 2 taps in flight
-        "k_spatialILi1ELi0ELb1ELb1EE": 5,   # Blur on tap texels, 8 taps in flight
-        "k_spatialILi2ELi0ELb1ELb1EE": 6,   # PostBlur, 4 taps in flight
+        "k_spatialILi0ELi0ELb1ELb1EE": 5,   # PrePass as its own dispatch (NRDHIP_FLAG_SEPARATE_PASSES), 2 taps in flight (frozen flavour: 6 waves)
+        "k_spatialILi1ELi0ELb1ELb1EE": 5,   # Blur on tap texels, 6 taps in flight (frozen flavour: 8)
+        "k_spatialILi2ELi0ELb1ELb1EE": 6,   # PostBlur, 2 taps in flight (frozen flavour: 3)
         "k_temporal_accumulationILb1ELb1ELb0ELb0EE": 4,
         "k_prepass_temporal_accumulationILb1ELb1EE": 4,  # the fused dispatch of record: 5 taps in flight, the reprojection half sets the registers
         "k_history_fixILb1ELb1ELb0EE": 7,
