@@ -353,6 +353,14 @@ def main():
         if hasattr(runner, "tiler"):
             t = runner.tiler
             out["config"]["halo_exchange_bytes_per_frame_rank0"] = int(t.bytes_exchanged / max(preroll_frames(runner) + args.warmup + args.steps, 1))
+            # what the exchange would cost if NOTHING of it overlapped with compute: rank 0 has one neighbour; an interior rank of N >= 3
+            # moves the same volume over EACH of its two links, both directions at once. xGMI: ~50-75 GB/s per direction per link in
+            # practice (MI355X guide: 153 GB/s bidirectional peak per link); DESIGN.md 7 has the per-pass table behind this figure
+            per_neighbour = out["config"]["halo_exchange_bytes_per_frame_rank0"] + int(getattr(t, "input_bytes_per_frame", 0))
+            out["config"]["predicted_exchange_ms"] = {"bytes_per_neighbour_per_frame": per_neighbour,
+                                                      "at_50_GBs_per_direction": round(per_neighbour / 50e9 * 1e3, 3),
+                                                      "at_75_GBs_per_direction": round(per_neighbour / 75e9 * 1e3, 3),
+                                                      "band_compute_ms_rank0": round(sum(v[0] for v in per_pass.values()), 4) if per_pass else None}
             out["config"]["band_rows"] = [b1 - b0 for b0, b1 in zip(runner.band.bounds, runner.band.bounds[1:])]
             out["config"]["band_split"] = "cost-balanced (geometry tiles + 0.15 x sky tiles of the first frame)" if runner.bounds else "even tile rows"
         if rank_ms is not None:

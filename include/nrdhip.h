@@ -89,7 +89,18 @@ typedef struct nrdhip_dispatch_info {
     uint32_t read_num;
     uint32_t read[24];
     float algorithmic_bytes_per_pixel; /* SURVEY.md 8d accounting rule applied to this pass */
+    /* Row tiling, per read plane: how far beyond the rows it computes THIS dispatch reads read[i]. 0 = at the thread's own pixel only;
+     * N = through a spatial footprint of up to N rows (halo_rows is the largest of them); NRDHIP_READ_REPROJECTED = previous-frame
+     * state fetched at motion-displaced positions (the band's motion allowance + one footprint row). A plane a dispatch list does
+     * not annotate reports halo_rows - the conservative answer. */
+    uint16_t read_rows[24];
+    /* NRDHIP_DISPATCH_ALL_ROWS: a pointwise pass over external inputs (the ClassifyTiles passes): it runs on EVERY row a band stores -
+     * owned rows and halo rows alike, the inputs' halo rows being valid after nrdhip_tiler_exchange_inputs - so what it writes is
+     * complete on every rank and is never exchanged */
+    uint32_t flags;
 } nrdhip_dispatch_info;
+enum { NRDHIP_READ_REPROJECTED = 0xFFFFu };
+enum { NRDHIP_DISPATCH_ALL_ROWS = 1u };
 
 /* nrd::Integration::Recreate (Source/NRDSample.cpp:982): create the instance, size its pools. */
 NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** out);
@@ -200,7 +211,14 @@ typedef struct nrdhip_transport {
     int (*send)(void* user, const void* dev_ptr, size_t bytes, int peer_rank, void* hip_stream);
     int (*recv)(void* user, void* dev_ptr, size_t bytes, int peer_rank, void* hip_stream);
     int (*group_end)(void* user, void* hip_stream);
+    /* NRDHIP_TRANSPORT_STREAM_ORDERED: send / recv only ENQUEUE asynchronous work on the stream they are handed and return at once, the
+     * way ncclSend / ncclRecv do. The tiler then treats the transport exactly like RCCL: it hands it its side stream and orders that
+     * stream against the compute stream with the same events (compute -> side stream before an exchange, side stream -> compute before
+     * the next dispatch, a separate event for the deferred rows). Without the flag (0) the callbacks receive the compute stream and
+     * are expected to have finished the transfer when they return (host transports: they synchronise the stream themselves). */
+    uint32_t flags;
 } nrdhip_transport;
+enum { NRDHIP_TRANSPORT_STREAM_ORDERED = 1u };
 /* rows a band must store beyond its owned rows: max read reach of the dispatches of `identifiers` with the settings currently
  * set + `motion_rows` (the largest vertical motion, in rows, reprojection may follow), rounded up to 16 */
 NRDHIP_API int nrdhip_required_halo(nrdhip_instance* inst, const uint32_t* identifiers, uint32_t n, uint32_t motion_rows, uint32_t* out);

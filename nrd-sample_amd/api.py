@@ -310,7 +310,11 @@ class PlaneInfo(C.Structure):
 class DispatchInfo(C.Structure):
     _fields_ = [("name", C.c_char_p), ("kernel", C.c_char_p), ("identifier", _u32), ("grid_width", _u16),
                 ("grid_height", _u16), ("halo_rows", _u16), ("written_num", _u16), ("written", _u32 * 12),
-                ("read_num", _u32), ("read", _u32 * 24), ("algorithmic_bytes_per_pixel", _f)]
+                ("read_num", _u32), ("read", _u32 * 24), ("algorithmic_bytes_per_pixel", _f), ("read_rows", _u16 * 24), ("flags", _u32)]
+
+
+READ_REPROJECTED = 0xFFFF  # nrdhip_dispatch_info.read_rows: previous-frame state read at motion-displaced positions (NRDHIP_READ_REPROJECTED)
+DISPATCH_ALL_ROWS = 1      # nrdhip_dispatch_info.flags: pointwise pass that runs on every stored row of a band (NRDHIP_DISPATCH_ALL_ROWS)
 
 
 class ConfidenceBlurDesc(C.Structure):
@@ -386,7 +390,7 @@ TRANSPORT_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 class Transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("group_begin", TRANSPORT_BEGIN), ("send", TRANSPORT_XFER), ("recv", TRANSPORT_XFER),
-                ("group_end", TRANSPORT_END)]
+                ("group_end", TRANSPORT_END), ("flags", _u32)]  # flags: NRDHIP_TRANSPORT_STREAM_ORDERED = 1
 
 
 class Backend:
@@ -630,6 +634,7 @@ class Integration:
             out.append(dict(name=di.name.decode(), kernel=di.kernel.decode(), identifier=di.identifier,
                             grid=(di.grid_width, di.grid_height), halo_rows=di.halo_rows,
                             written=[di.written[k] for k in range(di.written_num)], read=[di.read[k] for k in range(di.read_num)],
+                            read_rows=[di.read_rows[k] for k in range(di.read_num)], all_rows=bool(di.flags & DISPATCH_ALL_ROWS),
                             bytes_per_pixel=di.algorithmic_bytes_per_pixel))
         return out
 

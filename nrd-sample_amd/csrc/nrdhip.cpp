@@ -94,7 +94,24 @@ struct Dispatch {
     float bpp;
     std::vector<uint32_t> written, read;
     std::function<void(hipStream_t)> launch;
+    // row tiling (nrdhip_dispatch_info::read_rows): planes of `read` this dispatch fetches at the thread's own pixel only / previous-frame
+    // state it fetches at motion-displaced positions / planes it reaches less far into than `halo` (e.g. a 5x5 window inside a pass whose
+    // taps reach 30 rows). Everything else reports `halo`.
+    std::vector<uint32_t> own, reprojected;
+    std::vector<std::pair<uint32_t, uint16_t>> reach;
+    bool allRows = false; // NRDHIP_DISPATCH_ALL_ROWS
 };
+
+// the ClassifyTiles passes run on every row the instance stores (owned + halo rows of a band): pointwise over external inputs whose
+// halo rows the tiler has refreshed, so the guide and the tile planes are complete on every rank without an exchange
+template <typename Params>
+Params on_all_rows(Params q, int resH) {
+    q.c.ownY0 = std::max(0, -q.c.yOff);
+    q.c.ownY1 = std::max(q.c.ownY0, std::min(resH, q.c.H - q.c.yOff));
+    q.c.tileY0 = q.c.ownY0 / 16;
+    q.c.tilesY = (q.c.ownY1 + 15) / 16 - q.c.tileY0;
+    return q;
+}
 
 struct DenoiserState {
     uint32_t identifier = 0;
@@ -691,7 +708,8 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"REBLUR::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
-        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); }; // (plain grid, no direction: does not take part in the alternation)
+        x.allRows = true;
+        { auto q = on_all_rows(p, I.resH); x.launch = [q](hipStream_t st) { launch_reblur_classify_tiles(q, st); }; } // (plain grid, no direction: does not take part in the alternation)
         d.dispatches.push_back(x);
     }
     const PrepareMode pm = prepare_mode(d, s);
@@ -709,6 +727,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         if (c.mixAvail)
             x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {T(rb::HITTRACK), T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
+        x.reprojected = {P(rb::GUIDE_A + (cur ^ 1)), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1))};
         x.launch = [p](hipStream_t st) { launch_reblur_prepass_temporal_accumulation(p, st); };
         d.dispatches.push_back(x);
     } else {
@@ -727,6 +746,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         if (c.mixAvail)
             x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
+        x.reprojected = {P(rb::GUIDE_A + (cur ^ 1)), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1))};
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_accumulation(p, st); };
         d.dispatches.push_back(x);
     }
@@ -736,6 +756,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         // (HistoryFix / TemporalStabilization also look up the Tiles flag of their OWN tile - no reach across tiles or bands, so it
         // is not part of the exchange plan's read sets)
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur)};
+        x.reach = {{P(rb::FAST_A + cur), (uint16_t)2}}; // the 5x5 clamping window; the reconstruction taps read guide, signal and speeds
         if (tap) {
             push_tap_planes(d, tb, rb::TAP_D_A, x.written);
             x.written.push_back(P(rb::DATA1_A + cur));
@@ -754,6 +775,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
             x.written = {T(rb::TMP2)};
         }
+        x.own = {P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 1, st); };
         d.dispatches.push_back(x);
     }
@@ -765,6 +787,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         } else
             x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
         x.written = {P(rb::HIST)};
+        x.own = {P(rb::DATA1_A + cur)};
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 2, st); };
         d.dispatches.push_back(x);
     }
@@ -775,6 +798,8 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.written = {P(rb::STAB_A + cur)};
         push_signal_slots(d, x.written, true);
         push_signal_slots(d, x.read, false);
+        x.own = {P(rb::DATA1_A + cur), T(rb::DATA2), T(rb::HITTRACK)}; // (guide and history: the 5x5 window, = the pass's halo)
+        x.reprojected = {P(rb::STAB_A + (cur ^ 1))};
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_stabilization(p, st); };
         d.dispatches.push_back(x);
     }
@@ -829,7 +854,8 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"RELAX::ClassifyTiles", "nrd_reblur_classify_tiles", 0, 4 + 4 + GB + 1.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         x.written = {P(rb::GUIDE_A + cur), T(rb::TILES)};
-        x.launch = [p](hipStream_t st) { launch_reblur_classify_tiles(p, st); }; // (plain grid, no direction: does not take part in the alternation)
+        x.allRows = true;
+        { auto q = on_all_rows(p, I.resH); x.launch = [q](hipStream_t st) { launch_reblur_classify_tiles(q, st); }; } // (plain grid, no direction: does not take part in the alternation)
         d.dispatches.push_back(x);
     }
     const PrepareMode pm = prepare_mode(d, s);
@@ -851,6 +877,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         if (c.mixAvail)
             x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {T(rb::TMP2), P(rb::FAST_A + cur), P(rb::STAB_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
+        x.reprojected = {P(rb::GUIDE_A + (cur ^ 1)), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1)), P(rb::STAB_A + (cur ^ 1))};
         x.launch = [p](hipStream_t st) { launch_reblur_temporal_accumulation(p, st); };
         d.dispatches.push_back(x);
     }
@@ -858,6 +885,8 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"RELAX::HistoryFix", "nrd_reblur_history_fix", (uint16_t)(2 * s.historyFixBasePixelStride + 2),
                    GB + 2 + 8 * nr + 2 * n + 2 * n + 8 * nr + 2, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur), T(rb::TMP2), T(rb::DATA1_TMP), P(rb::FAST_A + cur), P(rb::STAB_A + cur)}; // moments: antilag
+        x.reach = {{P(rb::FAST_A + cur), (uint16_t)2}};
+        x.own = {P(rb::STAB_A + cur)};
         x.written = {P(rb::HIST), P(rb::DATA1_A + cur)};
         { auto q = directed(p, NRD_REVERSE_HISTORY_FIX != 0); x.launch = [q](hipStream_t st) { launch_reblur_history_fix(q, st); }; }
         d.dispatches.push_back(x);
@@ -979,7 +1008,8 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         Dispatch x{"SIGMA::ClassifyTiles", "nrd_sigma_classify_tiles", 0, 4 + 4 + 2 + GB + 2.0f / 256.0f, {}, {}, nullptr};
         x.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS), enc_slot(RT::IN_PENUMBRA)};
         x.written = {P(sg::GUIDE_A + cur), T(sg::TILES)};
-        x.launch = [p](hipStream_t st) { launch_sigma_classify_tiles(p, st); };
+        x.allRows = true;
+        { auto q = on_all_rows(p, I.resH); x.launch = [q](hipStream_t st) { launch_sigma_classify_tiles(q, st); }; }
         d.dispatches.push_back(x);
     }
     {
@@ -1013,6 +1043,7 @@ void build_sigma(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         if (c.mixAvail)
             x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {P(sg::HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};
+        x.reprojected = {P(sg::GUIDE_A + (cur ^ 1)), P(sg::HIST_A + (cur ^ 1))};
         x.launch = [p](hipStream_t st) { launch_sigma_temporal_stabilization(p, st); };
         d.dispatches.push_back(x);
     }
@@ -1399,8 +1430,19 @@ NRDHIP_API int nrdhip_dispatch_info_get(nrdhip_instance* inst, const uint32_t* i
     for (uint32_t i = 0; i < out->written_num; i++)
         out->written[i] = x.written[i];
     out->read_num = (uint32_t)std::min<size_t>(x.read.size(), 24);
-    for (uint32_t i = 0; i < out->read_num; i++)
+    for (uint32_t i = 0; i < out->read_num; i++) {
         out->read[i] = x.read[i];
+        uint16_t rows = x.halo;
+        if (std::find(x.own.begin(), x.own.end(), x.read[i]) != x.own.end())
+            rows = 0;
+        if (std::find(x.reprojected.begin(), x.reprojected.end(), x.read[i]) != x.reprojected.end())
+            rows = (uint16_t)NRDHIP_READ_REPROJECTED;
+        for (auto& rc : x.reach)
+            if (rc.first == x.read[i])
+                rows = std::min(rc.second, x.halo);
+        out->read_rows[i] = rows;
+    }
+    out->flags = x.allRows ? (uint32_t)NRDHIP_DISPATCH_ALL_ROWS : 0u;
     out->algorithmic_bytes_per_pixel = x.bpp;
     return 0;
 }

@@ -91,6 +91,9 @@ struct nrdhip_tiler {
     int32_t frameH = 0, row0 = 0, ownFirst = 0, ownRows = 0, localH = 0;
     nrdhip_transport tr{};
     bool custom = false;
+    // custom transport whose callbacks complete the transfer before they return (host transports): no side stream, no events. RCCL and
+    // stream-ordered custom transports (NRDHIP_TRANSPORT_STREAM_ORDERED) share ONE ordering path: side stream + the three events below
+    bool hostOrdered() const { return custom && !(tr.flags & NRDHIP_TRANSPORT_STREAM_ORDERED); }
     ncclComm_t comm = nullptr;
     hipStream_t commStream = nullptr;
     hipEvent_t evCompute = nullptr, evComm = nullptr, evDeferred = nullptr;
@@ -99,6 +102,7 @@ struct nrdhip_tiler {
     std::vector<PlanEntry> plan;
     std::vector<uint32_t> planSig; // planes + reach of the dispatches the plan was built from (build_plan)
     uint64_t bytesSent = 0, splitDispatches = 0, exchanges = 0, deferredExchanges = 0;
+    uint32_t reprojRows = 0; // rows of previous-frame state exchanged per surviving permanent plane (build_plan)
     std::string error;
 };
 
@@ -223,8 +227,10 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
             return fail(T, r, "dispatch info");
         sig.push_back(0xffff0000u | d[i].halo_rows);
         sig.insert(sig.end(), d[i].written, d[i].written + d[i].written_num);
-        sig.push_back(0xfffe0000u);
+        sig.push_back(0xfffe0000u | (d[i].flags & 0xffffu));
         sig.insert(sig.end(), d[i].read, d[i].read + d[i].read_num);
+        sig.push_back(0xfffd0000u);
+        sig.insert(sig.end(), d[i].read_rows, d[i].read_rows + d[i].read_num);
         if (d[i].halo_rows > T.halo)
             return fail(T, INVALID, std::string(d[i].name) + " reads " + std::to_string(d[i].halo_rows) + " rows beyond its band, the band stores " +
                                         std::to_string(T.halo) + ": recreate the bands with nrdhip_required_halo() rows");
@@ -233,25 +239,53 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
         return 0;
     T.plan.assign(count, PlanEntry{});
     auto has = [](const uint32_t* v, uint32_t num, uint32_t code) { return std::find(v, v + num, code) != v + num; };
+    // Rows of previous-frame state a band needs beyond its own: the motion allowance the stored halo leaves on top of the widest spatial
+    // reach of the list (nrdhip_required_halo: reach + motion_rows, rounded up to 16) + 2 rows for the bilinear footprint - provided EVERY
+    // read of previous-frame state (a permanent plane read before the list writes it) is a reprojected one or sits at the pixel's own
+    // position; a single spatial reader of last frame's planes and the full halo travels (round 3's rule for every list).
+    uint32_t reproj = 0, maxReach = 0;
+    {
+        bool provable = true;
+        std::vector<uint32_t> writtenSoFar;
+        for (uint32_t i = 0; i < count; i++) {
+            maxReach = std::max<uint32_t>(maxReach, d[i].halo_rows);
+            for (uint32_t k = 0; k < d[i].read_num; k++) {
+                const uint32_t code = d[i].read[k];
+                if ((code >> 16) == 0 && std::find(writtenSoFar.begin(), writtenSoFar.end(), code) == writtenSoFar.end() && d[i].read_rows[k] != 0 &&
+                    d[i].read_rows[k] != NRDHIP_READ_REPROJECTED)
+                    provable = false;
+            }
+            writtenSoFar.insert(writtenSoFar.end(), d[i].written, d[i].written + d[i].written_num);
+        }
+        reproj = provable ? std::min<uint32_t>(T.halo, T.halo - std::min(maxReach, T.halo) + 2u) : T.halo;
+    }
+    T.reprojRows = reproj;
+    // how far dispatch j reads into plane `code` (read_rows: 0 = own pixel, N = spatial footprint, NRDHIP_READ_REPROJECTED)
+    auto reach_into = [&](uint32_t j, uint32_t code) -> uint32_t {
+        for (uint32_t k = 0; k < d[j].read_num; k++)
+            if (d[j].read[k] == code)
+                return d[j].read_rows[k] == NRDHIP_READ_REPROJECTED ? reproj : d[j].read_rows[k];
+        return 0;
+    };
     for (uint32_t i = 0; i < count; i++)
         for (uint32_t k = 0; k < d[i].written_num; k++) {
             const uint32_t code = d[i].written[k];
-            if ((code >> 16) > 1)
-                continue; // output slots are final
+            if ((code >> 16) > 1 || (d[i].flags & NRDHIP_DISPATCH_ALL_ROWS))
+                continue; // output slots are final; a pass over all stored rows (ClassifyTiles) leaves nothing to exchange
             uint32_t rows = 0;
             bool rewritten = false;
             for (uint32_t j = i + 1; j < count; j++) {
                 if (has(d[j].read, d[j].read_num, code))
-                    rows = std::max<uint32_t>(rows, d[j].halo_rows);
+                    rows = std::max<uint32_t>(rows, reach_into(j, code));
                 if (has(d[j].written, d[j].written_num, code)) {
                     rewritten = true;
                     break;
                 }
             }
-            // permanent planes that survive the frame: the next frame reprojects into them at motion-displaced rows - full halo,
-            // but nobody reads those rows before the next frame, so they travel deferred (minus what goes strips-first)
-            if ((code >> 16) == 0 && !rewritten && rows < T.halo)
-                T.plan[i].later.push_back({code, T.halo, rows});
+            // permanent planes that survive the frame: the next frame reprojects into them at motion-displaced rows (`reproj` rows, not the
+            // whole halo), and nobody reads those rows before the next frame, so they travel deferred (minus what goes strips-first)
+            if ((code >> 16) == 0 && !rewritten && rows < reproj)
+                T.plan[i].later.push_back({code, reproj, rows});
             if (rows > 0)
                 T.plan[i].now.push_back({code, rows, 0});
         }
@@ -262,16 +296,24 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
 
 int wait_deferred(nrdhip_tiler& T, hipStream_t stream) {
     if (T.deferredPending) {
-        if (!T.custom && hipStreamWaitEvent(stream, T.evDeferred, 0) != hipSuccess)
+        if (!T.hostOrdered() && hipStreamWaitEvent(stream, T.evDeferred, 0) != hipSuccess)
             return fail(T, FAILURE, "hipStreamWaitEvent");
         T.deferredPending = false;
     }
     return 0;
 }
 
+// the side stream the exchanges run on and the events that order it against the compute stream (RCCL and stream-ordered custom transports)
+int make_side_stream(nrdhip_tiler& T) {
+    if (hipStreamCreateWithFlags(&T.commStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T.evCompute, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&T.evComm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&T.evDeferred, hipEventDisableTiming) != hipSuccess)
+        return fail(T, FAILURE, "side stream / events");
+    return 0;
+}
+
 // comm stream picks up after everything enqueued on the compute stream so far
 int comm_after_compute(nrdhip_tiler& T, hipStream_t stream) {
-    if (T.custom)
+    if (T.hostOrdered())
         return 0; // callbacks receive the compute stream and order themselves (host transports synchronise it)
     if (hipEventRecord(T.evCompute, stream) != hipSuccess || hipStreamWaitEvent(T.commStream, T.evCompute, 0) != hipSuccess)
         return fail(T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
@@ -329,6 +371,13 @@ NRDHIP_API int nrdhip_tiler_create(nrdhip_instance* inst, int rank, int world, c
         }
         T->tr = *transport;
         T->custom = true;
+        if (!T->hostOrdered()) {
+            TilerDeviceScope scope(*T);
+            if (make_side_stream(*T) != 0) {
+                delete T;
+                return FAILURE;
+            }
+        }
     }
     *out = T;
     return 0;
@@ -353,10 +402,7 @@ NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* T, const void* unique_id128)
     ncclResult_t r = g_rccl.CommInitRank(&T->comm, T->world, id, T->rank); // on the instance's HIP device (one rank per GPU)
     if (r != ncclSuccess)
         return fail(*T, FAILURE, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
-    if (hipStreamCreateWithFlags(&T->commStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T->evCompute, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&T->evComm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&T->evDeferred, hipEventDisableTiming) != hipSuccess)
-        return fail(*T, FAILURE, "side stream / events");
-    return 0;
+    return make_side_stream(*T);
 }
 
 NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
@@ -399,8 +445,8 @@ NRDHIP_API int nrdhip_tiler_exchange_inputs(nrdhip_tiler* T, const uint32_t* slo
     hipStream_t st = (hipStream_t)stream;
     int r = comm_after_compute(*T, st);
     if (!r)
-        r = run_ops(*T, ops, T->custom ? st : T->commStream);
-    if (!r && !T->custom && (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess))
+        r = run_ops(*T, ops, T->hostOrdered() ? st : T->commStream);
+    if (!r && !T->hostOrdered() && (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess))
         r = fail(*T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
     T->exchanges++;
     return r;
@@ -433,9 +479,9 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
             if ((r = nrdhip_denoise_range(T->inst, ids, n, i, 1, stream)) != 0)
                 return fail(*T, r, nrdhip_last_error(T->inst));
             if (!ops.empty()) {
-                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, ops, T->custom ? st : T->commStream)) != 0)
+                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, ops, T->hostOrdered() ? st : T->commStream)) != 0)
                     return r;
-                if (!T->custom && (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess))
+                if (!T->hostOrdered() && (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess))
                     return fail(*T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
                 T->exchanges++;
             }
@@ -452,13 +498,13 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
             }
             if (down && (r = nrdhip_denoise_rows(T->inst, ids, n, i, hi, own0 + ownN - hi, first ? NRDHIP_PART_FIRST : 0u, stream)) != 0)
                 return fail(*T, r, nrdhip_last_error(T->inst));
-            if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, ops, T->custom ? st : T->commStream)) != 0)
+            if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, ops, T->hostOrdered() ? st : T->commStream)) != 0)
                 return r;
-            if (!T->custom && hipEventRecord(T->evComm, T->commStream) != hipSuccess)
+            if (!T->hostOrdered() && hipEventRecord(T->evComm, T->commStream) != hipSuccess)
                 return fail(*T, FAILURE, "hipEventRecord");
             if ((r = nrdhip_denoise_rows(T->inst, ids, n, i, lo, hi - lo, NRDHIP_PART_LAST, stream)) != 0)
                 return fail(*T, r, nrdhip_last_error(T->inst));
-            if (!T->custom && hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess)
+            if (!T->hostOrdered() && hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess)
                 return fail(*T, FAILURE, "hipStreamWaitEvent");
             T->exchanges++;
         }
@@ -467,9 +513,9 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
             if ((r = collect(*T, e.later, lops)) != 0)
                 return r;
             if (!lops.empty()) {
-                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, lops, T->custom ? st : T->commStream)) != 0)
+                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, lops, T->hostOrdered() ? st : T->commStream)) != 0)
                     return r;
-                if (!T->custom && hipEventRecord(T->evDeferred, T->commStream) != hipSuccess)
+                if (!T->hostOrdered() && hipEventRecord(T->evDeferred, T->commStream) != hipSuccess)
                     return fail(*T, FAILURE, "hipEventRecord");
                 T->deferredPending = true;
                 T->deferredExchanges++;

@@ -165,35 +165,63 @@ class Tiler:
             return None
         return self.band.nrd.pools[pool][index]
 
+    def reprojection_rows(self, dispatches):
+        """rows of previous-frame state a band needs beyond its own: the motion allowance the stored halo leaves on top of the widest
+        spatial reach of the list (halo = reach + motion_rows rounded up to 16: required_halo) + 2 rows for the bilinear footprint.
+        Only valid when EVERY read of previous-frame state in the list - a permanent plane read before the list writes it - says it is
+        reprojected (or at the pixel's own position): one spatial reader of last frame's planes and the full halo travels, as before."""
+        from . import api
+
+        written = set()
+        for d in dispatches:
+            for code, rows in zip(d["read"], d.get("read_rows", [d["halo_rows"]] * len(d["read"]))):
+                if (code >> 16) == 0 and code not in written and rows not in (0, api.READ_REPROJECTED):
+                    return self.band.halo
+            written.update(d["written"])
+        motion = self.band.halo - max([d["halo_rows"] for d in dispatches] + [0])
+        return max(min(self.band.halo, motion + 2), 0)
+
     def _plan(self, ids, dispatches):
         """for every dispatch: (now, later), two lists of (plane code, rows) over the pool planes it writes.
-        now: boundary rows a LATER DISPATCH OF THIS FRAME reads - the largest halo of the dispatches that read the plane before
-        it is written again; these are exchanged strips-first and waited for before the next dispatch.
-        later: permanent planes that survive the frame get the full halo (next frame's reprojection reads them at
-        motion-displaced rows), but nobody needs those rows before the next frame: their exchange is enqueued after the
-        dispatch and stays in flight behind the rest of the frame (no strips, no wait) - most dispatches end with such a plane
-        (history, fast history, stabilized luma, accumulation speeds), and an 80-row strip is two mostly empty workgroup rounds"""
-        key = tuple((d["name"], tuple(d["written"]), tuple(d["read"]), d["halo_rows"]) for d in dispatches)
+        now: boundary rows a LATER DISPATCH OF THIS FRAME reads - the largest reach INTO THAT PLANE (nrdhip_dispatch_info.read_rows: 0 for
+        a read at the pixel's own position, the window for a 5x5 stencil, the tap reach for a gather) of the dispatches that read it
+        before it is written again; these are exchanged strips-first and waited for before the next dispatch.
+        later: permanent planes that survive the frame are read by the NEXT frame's reprojection at motion-displaced rows - the band's
+        motion allowance + 2 rows (reprojection_rows), not the whole halo (round 3 sent all 80 rows of history, fast history, speeds,
+        stabilized luma and guide: a third of the volume) - and nobody needs those rows before the next frame: their exchange is
+        enqueued after the dispatch and stays in flight behind the rest of the frame (no strips, no wait).
+        Nothing a pass with `all_rows` writes travels at all: the ClassifyTiles passes run on every stored row of the band (their inputs
+        carry valid halo rows), so guide and tile planes are complete on every rank."""
+        from . import api
+
+        key = tuple((d["name"], tuple(d["written"]), tuple(d["read"]), tuple(d.get("read_rows", ())), d.get("all_rows", False), d["halo_rows"]) for d in dispatches)
         if key in self._plan_cache:
             return self._plan_cache[key]
+        reproj = self.reprojection_rows(dispatches)
+
+        def reach_into(r, code):
+            rows = r.get("read_rows")
+            v = rows[r["read"].index(code)] if rows else r["halo_rows"]
+            return reproj if v == api.READ_REPROJECTED else v
+
         plan = []
         for i, d in enumerate(dispatches):
             now, later = [], []
             for code in d["written"]:
-                if (code >> 16) > 1:
-                    continue  # output slots are final
+                if (code >> 16) > 1 or d.get("all_rows"):
+                    continue  # output slots are final; a pass over all stored rows leaves nothing to exchange
                 rows, rewritten = 0, False
                 for r in dispatches[i + 1:]:
                     if code in r["read"]:
-                        rows = max(rows, r["halo_rows"])
+                        rows = max(rows, reach_into(r, code))
                     if code in r["written"]:
                         rewritten = True
                         break
                 if rows > self.band.halo:  # never clamp: a clamped reach is a silently different image
                     raise HaloError("a pass after %s reads %d rows beyond its band, the band stores %d: create the bands with "
                                     "halo=required_halo(dispatches, motion_rows) (probe_halo())" % (d["name"], rows, self.band.halo))
-                if (code >> 16) == 0 and not rewritten and rows < self.band.halo:
-                    later.append((code, self.band.halo, rows))  # the `rows` nearest the band edge travel at once (below)
+                if (code >> 16) == 0 and not rewritten and rows < reproj:
+                    later.append((code, reproj, rows))  # the `rows` nearest the band edge travel at once (below)
                 if rows > 0:
                     now.append((code, rows))
             plan.append((now, later))

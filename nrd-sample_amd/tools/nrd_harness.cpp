@@ -6,7 +6,14 @@
 //   Sample::Denoise ....... ResourceSnapshot::SetResource for every slot, Integration::Denoise (:440-531)
 // Inputs are raw plane files (written by tests/test_cpp_harness.py or any producer); outputs are written back as raw files.
 //
-//   nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl]]
+//   nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl | --async]] [--confidence] [--sh]
+// --async (with --ranks): the in-process fabric as a stream-ordered transport - the tiler then runs its RCCL ordering path (side stream and
+//   events) with device-to-device copies standing in for ncclSend / ncclRecv: what can be verified of that path on a 1-GPU box.
+// --confidence: the history-confidence path of the sample (Source/NRDSample.cpp:3999-4026, :457, :462, :3866): gradient.bin (RGBA16F at
+//   Sample::GetSharcDims(), :596-598) goes through the five ConfidenceBlur passes - Gradient_Ping -> Pong -> Ping ..., the loop of
+//   :4003-4026 - every frame, Gradient_Pong is bound to IN_DIFF_CONFIDENCE and IN_SPEC_CONFIDENCE, isHistoryConfidenceAvailable = true.
+// --sh: NRD_MODE == SH (:464-476): REBLUR_DIFFUSE_SPECULAR_SH with the eight SH slots bound (diff_sh1.bin / spec_sh1.bin are the SH1
+//   inputs, out_diff_sh1.bin / out_spec_sh1.bin are written).
 // --ranks N: the same frames row-tiled across N ranks (nrd::TiledIntegration over the C++ row tiler, nrdhip_tiler_*), one host
 // thread per rank; without --rccl the ranks share GPU 0 and halo rows travel through an in-process mailbox (a stand-in fabric:
 // exercises the exchange plan, the strips / interior split and the band addressing on a 1-GPU box); with --rccl rank r runs on
@@ -131,11 +138,99 @@ static int mbRecv(void* user, void* ptr, size_t bytes, int peer, void*) {
     return hipMemcpy(ptr, msg.data(), bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
 }
 
+// --async: the same in-process fabric as a STREAM-ORDERED transport (NRDHIP_TRANSPORT_STREAM_ORDERED) - send / recv only enqueue work on
+// the stream they are handed and return, like ncclSend / ncclRecv, so that the tiler takes its RCCL ordering path (side stream,
+// evCompute -> side stream, evComm -> compute stream, evDeferred) on the one GPU of the box. A message is a staging buffer of a ring per
+// (source, destination) pair: the sender copies its rows in on ITS stream and records `ready`; the receiver makes ITS stream wait for
+// `ready`, copies the rows out and records `consumed`, which the sender's stream waits for before it overwrites the slot the next time
+// round. The only host-side waits are for a message to have been POSTED (not for the GPU) and for a ring slot's reuse to be known.
+struct AsyncSlot {
+    void* buf = nullptr;
+    size_t cap = 0, bytes = 0;
+    hipEvent_t ready = nullptr, consumed = nullptr;
+    uint64_t posted = 0, taken = 0; // how many times the slot was filled / emptied (host bookkeeping under the fabric's mutex)
+};
+struct AsyncFabric {
+    static constexpr int RING = 32;
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::vector<AsyncSlot>> ring; // (source, destination) -> slots
+    std::map<std::pair<int, int>, uint64_t> sent, received;     // messages posted / taken per pair
+};
+struct AsyncEndpoint {
+    AsyncFabric* fab;
+    int rank;
+};
+static int asSend(void* user, const void* ptr, size_t bytes, int peer, void* stream) {
+    auto* e = (AsyncEndpoint*)user;
+    hipStream_t st = (hipStream_t)stream;
+    AsyncSlot* s;
+    {
+        std::unique_lock<std::mutex> l(e->fab->m);
+        auto& v = e->fab->ring[{e->rank, peer}];
+        if (v.empty())
+            v.resize(AsyncFabric::RING);
+        uint64_t& n = e->fab->sent[{e->rank, peer}];
+        s = &v[n % AsyncFabric::RING];
+        e->fab->cv.wait(l, [&] { return s->taken == s->posted; }); // the receiver has ENQUEUED its copy out of this slot's last use
+        n++;
+    }
+    if (s->cap < bytes) { // (first rounds only; the plan repeats every frame)
+        if (s->buf)
+            (void)hipFree(s->buf);
+        if (hipMalloc(&s->buf, bytes) != hipSuccess)
+            return 1;
+        s->cap = bytes;
+    }
+    if (!s->ready && (hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->consumed, hipEventDisableTiming) != hipSuccess))
+        return 1;
+    if (s->posted && hipStreamWaitEvent(st, s->consumed, 0) != hipSuccess) // ... and that copy has run before the slot is overwritten
+        return 1;
+    if (hipMemcpyAsync(s->buf, ptr, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess || hipEventRecord(s->ready, st) != hipSuccess)
+        return 1;
+    {
+        std::lock_guard<std::mutex> l(e->fab->m);
+        s->bytes = bytes;
+        s->posted++;
+    }
+    e->fab->cv.notify_all();
+    return 0;
+}
+static int asRecv(void* user, void* ptr, size_t bytes, int peer, void* stream) {
+    auto* e = (AsyncEndpoint*)user;
+    hipStream_t st = (hipStream_t)stream;
+    AsyncSlot* s;
+    {
+        std::unique_lock<std::mutex> l(e->fab->m);
+        auto& v = e->fab->ring[{peer, e->rank}];
+        if (v.empty())
+            v.resize(AsyncFabric::RING);
+        uint64_t& n = e->fab->received[{peer, e->rank}];
+        s = &v[n % AsyncFabric::RING];
+        const uint64_t want = n / AsyncFabric::RING + 1; // the slot's (n / RING + 1)-th fill is this message
+        e->fab->cv.wait(l, [&] { return s->posted >= want; });
+        n++;
+        if (s->bytes != bytes)
+            return 1;
+    }
+    if (hipStreamWaitEvent(st, s->ready, 0) != hipSuccess || hipMemcpyAsync(ptr, s->buf, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipEventRecord(s->consumed, st) != hipSuccess)
+        return 1;
+    {
+        std::lock_guard<std::mutex> l(e->fab->m);
+        s->taken++;
+    }
+    e->fab->cv.notify_all();
+    return 0;
+}
+
 struct Shared {
     std::string dir;
     uint16_t w, h;
     int frames, world;
     bool rccl;
+    bool async = false;
+    AsyncFabric fabric;
     Mailbox box;
     uint8_t uniqueId[128];
     std::vector<uint8_t> outDiff, outSpec, outShadow, outSignal; // whole-frame outputs assembled from the ranks' owned rows
@@ -198,7 +293,10 @@ static void rankMain(Shared* S, int rank) {
             return;
     }
     Endpoint ep{&S->box, rank};
-    nrdhip_transport tr{&ep, nullptr, mbSend, mbRecv, nullptr};
+    AsyncEndpoint aep{&S->fabric, rank};
+    nrdhip_transport tr{&ep, nullptr, mbSend, mbRecv, nullptr, 0u};
+    if (S->async)
+        tr = nrdhip_transport{&aep, nullptr, asSend, asRecv, nullptr, NRDHIP_TRANSPORT_STREAM_ORDERED};
     nrd::TiledIntegration m_NRD;
     if (m_NRD.Recreate(desc, instanceCreationDesc, device, rank, S->world, halo, S->rccl ? nullptr : &tr) != nrd::Result::SUCCESS) {
         fprintf(stderr, "rank %d: Recreate failed (bands shorter than the %u-row halo?)\n", rank, halo);
@@ -299,8 +397,9 @@ static void rankMain(Shared* S, int rank) {
     status = 0;
 }
 
-static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int world, bool rccl) {
+static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int world, bool rccl, bool async) {
     Shared S;
+    S.async = async;
     S.dir = dir;
     S.w = w;
     S.h = h;
@@ -347,7 +446,8 @@ static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int w
     };
     if (!save("out_diff.bin", S.outDiff) || !save("out_spec.bin", S.outSpec) || !save("out_shadow.bin", S.outShadow) || !save("out_signal.bin", S.outSignal))
         return 1;
-    printf("row-tiled run: %d ranks, %s transport, %ux%u, %d frames\n", world, rccl ? "RCCL" : "in-process mailbox", w, h, frames);
+    printf("row-tiled run: %d ranks, %s transport, %ux%u, %d frames\n", world,
+           rccl ? "RCCL" : (async ? "in-process stream-ordered (side stream + events, the RCCL ordering path)" : "in-process mailbox"), w, h, frames);
     return 0;
 }
 
@@ -355,32 +455,43 @@ static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int w
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl]]\n");
+        fprintf(stderr, "usage: nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl]] [--confidence] [--sh] [--synthesize]\n");
         return 2;
     }
     std::string dir = argv[1];
     uint16_t w = (uint16_t)atoi(argv[2]), h = (uint16_t)atoi(argv[3]);
     int frames = atoi(argv[4]);
     int ranks = 1;
-    bool rccl = false;
+    bool rccl = false, async = false;
     for (int i = 5; i < argc; i++) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc)
             ranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rccl"))
             rccl = true;
+        else if (!strcmp(argv[i], "--async"))
+            async = true;
     }
-    bool synthesize = false;
-    for (int i = 5; i < argc; i++)
+    bool synthesize = false, confidence = false, sh = false;
+    for (int i = 5; i < argc; i++) {
         if (!strcmp(argv[i], "--synthesize"))
             synthesize = true;
+        else if (!strcmp(argv[i], "--confidence"))
+            confidence = true;
+        else if (!strcmp(argv[i], "--sh"))
+            sh = true;
+    }
+    if ((confidence || sh) && (ranks > 1 || synthesize)) {
+        fprintf(stderr, "--confidence / --sh belong to the 1-rank run on input files\n");
+        return 2;
+    }
     if (ranks > 1)
-        return tiled::run(dir, w, h, frames, ranks, rccl);
+        return tiled::run(dir, w, h, frames, ranks, rccl, async);
     using F = nrd::Format;
     using RT = nrd::ResourceType;
 
     // ---- Sample::Initialize: REBLUR + SIGMA + REFERENCE in one instance ----
     const nrd::DenoiserDesc denoisersDescs[] = {
-        {NRD_ID(REBLUR_DIFFUSE_SPECULAR), nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR},
+        {NRD_ID(REBLUR_DIFFUSE_SPECULAR), sh ? nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR_SH : nrd::Denoiser::REBLUR_DIFFUSE_SPECULAR}, // NRD_MODE (:871-921)
         {NRD_ID(SIGMA_SHADOW), nrd::Denoiser::SIGMA_SHADOW_TRANSLUCENCY}, // SIGMA_VARIANT (:48-52)
         {NRD_ID(REFERENCE), nrd::Denoiser::REFERENCE},
     };
@@ -409,6 +520,23 @@ int main(int argc, char** argv) {
     Texture Diff = makeTexture(w, h, F::RGBA16_SFLOAT, 8), Spec = makeTexture(w, h, F::RGBA16_SFLOAT, 8);
     Texture Unfiltered_Penumbra = makeTexture(w, h, F::R16_SFLOAT, 2), Unfiltered_Translucency = makeTexture(w, h, F::RGBA8_UNORM, 4), Shadow = makeTexture(w, h, F::RGBA8_UNORM, 4);
     Texture Composed = makeTexture(w, h, F::RGBA16_SFLOAT, 8), Validation = makeTexture(w, h, F::RGBA8_UNORM, 4);
+    // SH mode: the second texel of every signal (:2998-3003)
+    Texture Unfiltered_DiffSh, Unfiltered_SpecSh, DiffSh, SpecSh;
+    if (sh) {
+        Unfiltered_DiffSh = makeTexture(w, h, F::RGBA16_SFLOAT, 8), Unfiltered_SpecSh = makeTexture(w, h, F::RGBA16_SFLOAT, 8);
+        DiffSh = makeTexture(w, h, F::RGBA16_SFLOAT, 8), SpecSh = makeTexture(w, h, F::RGBA16_SFLOAT, 8);
+        if (!loadPlane(dir + "/diff_sh1.bin", Unfiltered_DiffSh) || !loadPlane(dir + "/spec_sh1.bin", Unfiltered_SpecSh))
+            return 1;
+    }
+    // history confidence: Gradient_Ping / Gradient_Pong at Sample::GetSharcDims() = 16 * ((renderResolution / SHARC_DOWNSCALE + 15) / 16) (:596-598, :2990)
+    const uint16_t sharcW = (uint16_t)(16u * ((w / 5u + 15u) / 16u)), sharcH = (uint16_t)(16u * ((h / 5u + 15u) / 16u));
+    Texture Gradient_Ping, Gradient_Pong, Gradient_Input;
+    if (confidence) {
+        Gradient_Ping = makeTexture(sharcW, sharcH, F::RGBA16_SFLOAT, 8), Gradient_Pong = makeTexture(sharcW, sharcH, F::RGBA16_SFLOAT, 8);
+        Gradient_Input = makeTexture(sharcW, sharcH, F::RGBA16_SFLOAT, 8); // what SharcUpdate would write into Gradient_Ping every frame
+        if (!loadPlane(dir + "/gradient.bin", Gradient_Input))
+            return 1;
+    }
     if (synthesize) {
         // --synthesize: no input files. A small analytic "path tracer" runs on the host (tilted floor + back wall, hashed noise on
         // radiance and hit distances) and its raw fp32 results go through the producer kernel nrdhip_frontend_pack - the HIP twin of
@@ -498,6 +626,20 @@ int main(int argc, char** argv) {
         resourceSnapshot.SetResource(RT::OUT_DIFF_RADIANCE_HITDIST, GetNrdResource(Diff));
         resourceSnapshot.SetResource(RT::IN_SPEC_RADIANCE_HITDIST, GetNrdResource(Unfiltered_Spec));
         resourceSnapshot.SetResource(RT::OUT_SPEC_RADIANCE_HITDIST, GetNrdResource(Spec));
+        if (confidence) { // one texture on both slots (:457, :462)
+            resourceSnapshot.SetResource(RT::IN_DIFF_CONFIDENCE, GetNrdResource(Gradient_Pong));
+            resourceSnapshot.SetResource(RT::IN_SPEC_CONFIDENCE, GetNrdResource(Gradient_Pong));
+        }
+        if (sh) { // NRD_MODE == SH (:464-476)
+            resourceSnapshot.SetResource(RT::IN_DIFF_SH0, GetNrdResource(Unfiltered_Diff));
+            resourceSnapshot.SetResource(RT::IN_DIFF_SH1, GetNrdResource(Unfiltered_DiffSh));
+            resourceSnapshot.SetResource(RT::OUT_DIFF_SH0, GetNrdResource(Diff));
+            resourceSnapshot.SetResource(RT::OUT_DIFF_SH1, GetNrdResource(DiffSh));
+            resourceSnapshot.SetResource(RT::IN_SPEC_SH0, GetNrdResource(Unfiltered_Spec));
+            resourceSnapshot.SetResource(RT::IN_SPEC_SH1, GetNrdResource(Unfiltered_SpecSh));
+            resourceSnapshot.SetResource(RT::OUT_SPEC_SH0, GetNrdResource(Spec));
+            resourceSnapshot.SetResource(RT::OUT_SPEC_SH1, GetNrdResource(SpecSh));
+        }
         resourceSnapshot.SetResource(RT::IN_PENUMBRA, GetNrdResource(Unfiltered_Penumbra));
         resourceSnapshot.SetResource(RT::IN_TRANSLUCENCY, GetNrdResource(Unfiltered_Translucency));
         resourceSnapshot.SetResource(RT::OUT_SHADOW_TRANSLUCENCY, GetNrdResource(Shadow));
@@ -528,7 +670,31 @@ int main(int argc, char** argv) {
         commonSettings.disocclusionThresholdAlternate = 0.1f;
         commonSettings.frameIndex = (uint32_t)frameIndex;
         commonSettings.accumulationMode = frameIndex == 0 ? nrd::AccumulationMode::CLEAR_AND_RESTART : nrd::AccumulationMode::CONTINUE;
-        commonSettings.isHistoryConfidenceAvailable = false;
+        commonSettings.isHistoryConfidenceAvailable = confidence; // (:3866)
+        if (confidence) {
+            // "History confidence - Blur" (:3999-4026): five passes, step = 1 + i, ping -> pong -> ping ...; the fifth lands in Gradient_Pong
+            if (hipMemcpyAsync(Gradient_Ping.ptr, Gradient_Input.ptr, Gradient_Ping.bytes(), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return 1;
+            nrdhip_confidence_blur_desc cb = {};
+            cb.ping = Gradient_Ping.ptr, cb.pong = Gradient_Pong.ptr, cb.pitch_bytes = Gradient_Ping.pitch;
+            cb.width = sharcW, cb.height = sharcH;
+            const float frustum[4] = {-1.0f, -1.0f / aspect, 2.0f, 2.0f / aspect}; // gCameraFrustum of the projection above (x0, y0, dx, dy at z = 1)
+            memcpy(cb.camera_frustum, frustum, sizeof(frustum));
+            cb.inv_size[0] = 1.0f / (float)sharcW, cb.inv_size[1] = 1.0f / (float)sharcH;
+            cb.rect_width = (float)w;
+            cb.unproject = 1.0f / (0.5f * (float)h * aspect);
+            cb.ortho_mode = 0.0f;
+            cb.frame_index = (uint32_t)frameIndex;
+            cb.max_accumulated_frame_num = 30;
+            cb.relax = 0;
+            for (uint32_t i = 0; i < 5u; i++) { // must be odd
+                cb.first_pass = i, cb.passes_num = 1;
+                if (nrdhip_confidence_blur(&cb, stream) != 0) {
+                    fprintf(stderr, "nrdhip_confidence_blur failed\n");
+                    return 1;
+                }
+            }
+        }
 
         m_NRD.NewFrame();
         m_NRD.SetCommonSettings(commonSettings);
@@ -571,6 +737,10 @@ int main(int argc, char** argv) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     printf("last frame: %.3f ms for SIGMA + REBLUR_DIFFUSE_SPECULAR + REFERENCE at %ux%u\n", ms, w, h);
     if (!savePlane(dir + "/out_diff.bin", Diff) || !savePlane(dir + "/out_spec.bin", Spec) || !savePlane(dir + "/out_shadow.bin", Shadow) || !savePlane(dir + "/out_signal.bin", Composed))
+        return 1;
+    if (sh && (!savePlane(dir + "/out_diff_sh1.bin", DiffSh) || !savePlane(dir + "/out_spec_sh1.bin", SpecSh)))
+        return 1;
+    if (confidence && !savePlane(dir + "/confidence.bin", Gradient_Pong))
         return 1;
     m_NRD.Destroy(); // before the device goes away (:744-748)
     return 0;

@@ -211,6 +211,10 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
 
 static void run_pass(Instance& I, DenoiserState& d, const Consts& c, Pass& p) {
     int y0 = c.ownY0, y1 = c.ownY1;
+    if (p.allRows) { // every row the band stores (csrc/nrdhip.cpp on_all_rows)
+        y0 = std::max(0, -c.yOff);
+        y1 = std::max(y0, std::min(c.resH, c.H - c.yOff));
+    }
     if (p.tileGrid) { // iterate whole tiles covering the owned rows
         y0 = y0 / 16;
         y1 = (y1 + 15) / 16;
@@ -421,8 +425,19 @@ NRDHIP_API int orc_dispatch_info_get(nrdhip_instance* inst, const uint32_t* ids,
     for (uint32_t i = 0; i < out->written_num; i++)
         out->written[i] = p.written[i];
     out->read_num = (uint32_t)std::min<size_t>(p.read.size(), 24);
-    for (uint32_t i = 0; i < out->read_num; i++)
+    for (uint32_t i = 0; i < out->read_num; i++) {
         out->read[i] = p.read[i];
+        uint16_t rows = p.haloRows;
+        if (std::find(p.own.begin(), p.own.end(), p.read[i]) != p.own.end())
+            rows = 0;
+        if (std::find(p.reprojected.begin(), p.reprojected.end(), p.read[i]) != p.reprojected.end())
+            rows = (uint16_t)NRDHIP_READ_REPROJECTED;
+        for (auto& rc : p.reach)
+            if (rc.first == p.read[i])
+                rows = std::min(rc.second, p.haloRows);
+        out->read_rows[i] = rows;
+    }
+    out->flags = p.allRows ? (uint32_t)NRDHIP_DISPATCH_ALL_ROWS : 0u;
     out->algorithmic_bytes_per_pixel = p.bytesPerPixel;
     return 0;
 }

@@ -231,6 +231,12 @@ struct Pass {
     std::vector<uint32_t> read;
     std::function<void(Instance&, DenoiserState&, const Consts&, int y0, int y1)> run; // rows [y0,y1) local
     bool tileGrid = false; // pass iterates over 16x16 tiles rather than pixels
+    // row tiling (nrdhip_dispatch_info::read_rows / flags, csrc/nrdhip.cpp Dispatch): planes of `read` fetched at the pixel's own position
+    // only / previous-frame state fetched at motion-displaced positions / planes reached less far into than haloRows; a pointwise pass
+    // that runs on every stored row of a band (the ClassifyTiles passes)
+    std::vector<uint32_t> own, reprojected;
+    std::vector<std::pair<uint32_t, uint16_t>> reach;
+    bool allRows = false;
 };
 
 struct DenoiserState {

@@ -1537,6 +1537,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
         p.tileGrid = true;
+        p.allRows = true;
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
@@ -1606,6 +1607,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         if (I.common.isDisocclusionThresholdMixAvailable)
             p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_HITTRACK), T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
+        p.reprojected = {P(P_GUIDE_A + (cur ^ 1)), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             if (y1 <= y0)
                 return;
@@ -1640,6 +1642,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         if (I.common.isDisocclusionThresholdMixAvailable)
             p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
+        p.reprojected = {P(P_GUIDE_A + (cur ^ 1)), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))};
         p.run = temporal_accumulation;
         d.passes.push_back(p);
     }
@@ -1650,6 +1653,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
         p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + (tap ? 16 * n : 8 * nr) + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur)};
+        p.reach = {{P(P_FAST_A + cur), (uint16_t)2}}; // the 5x5 clamping window; the reconstruction taps read guide, signal and speeds
         if (tap) {
             push_tap_planes(d, tb, T_TAP_D_A, p.written);
             p.written.push_back(P(P_DATA1_A + cur));
@@ -1663,6 +1667,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::Blur";
         p.kernel = "nrd_reblur_blur";
         p.haloRows = (uint16_t)rr.blur;
+        p.own = {P(P_DATA1_A + cur)};
         if (tap) { // the tap texels carry the guide: no guide plane access
             p.bytesPerPixel = 2 + 16 * n + 16 * n;
             p.read = {P(P_DATA1_A + cur)};
@@ -1694,6 +1699,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PostBlur";
         p.kernel = "nrd_reblur_post_blur";
         p.haloRows = (uint16_t)rr.post;
+        p.own = {P(P_DATA1_A + cur)};
         if (tap) {
             p.bytesPerPixel = 2 + 16 * n + 8 * nr;
             p.read = {P(P_DATA1_A + cur)};
@@ -1724,6 +1730,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::TemporalStabilization";
         p.kernel = "nrd_reblur_temporal_stabilization";
         p.haloRows = 2;
+        p.own = {P(P_DATA1_A + cur), T(T_DATA2), T(T_HITTRACK)}; // (guide and history: the 5x5 window, = the pass's halo)
+        p.reprojected = {P(P_STAB_A + (cur ^ 1))};
         p.bytesPerPixel = GB + 2 + 4 + 8 + 8 * nr + 2 * n + (d.hasSpec ? 2 : 0) + 8 * nr + 2 * n;
         p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_DATA2), enc_slot(RT::IN_MV), P(P_HIST), P(P_STAB_A + (cur ^ 1)), T(T_HITTRACK)};
         p.written = {P(P_STAB_A + cur)};
@@ -1823,6 +1831,7 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS)};
         p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
         p.tileGrid = true;
+        p.allRows = true;
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
@@ -1894,6 +1903,7 @@ void relax_build(Instance& I, DenoiserState& d) {
         if (I.common.isDisocclusionThresholdMixAvailable)
             p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_TMP2), P(P_FAST_A + cur), P(P_STAB_A + cur), T(T_DATA1), T(T_DATA2)};
+        p.reprojected = {P(P_GUIDE_A + (cur ^ 1)), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1)), P(P_STAB_A + (cur ^ 1))};
         p.run = temporal_accumulation;
         d.passes.push_back(p);
     }
@@ -1904,6 +1914,8 @@ void relax_build(Instance& I, DenoiserState& d) {
         p.haloRows = (uint16_t)(2 * s.historyFixBasePixelStride + 2);
         p.bytesPerPixel = GB + 2 + 8 * nr + 2 * n + 2 * n + 8 * nr + 2;
         p.read = {P(P_GUIDE_A + cur), T(T_TMP2), T(T_DATA1), P(P_FAST_A + cur), P(P_STAB_A + cur)};
+        p.reach = {{P(P_FAST_A + cur), (uint16_t)2}};
+        p.own = {P(P_STAB_A + cur)};
         p.written = {P(P_HIST), P(P_DATA1_A + cur)};
         p.run = history_fix;
         d.passes.push_back(p);

@@ -388,6 +388,7 @@ void sigma_build(Instance& I, DenoiserState& d) {
         p.read = {enc_slot(RT::IN_VIEWZ), enc_slot(RT::IN_NORMAL_ROUGHNESS), enc_slot(RT::IN_PENUMBRA)};
         p.written = {P(P_GUIDE_A + cur), T(T_TILES)};
         p.tileGrid = true;
+        p.allRows = true;
         p.run = classify_tiles;
         d.passes.push_back(p);
     }
@@ -439,6 +440,7 @@ void sigma_build(Instance& I, DenoiserState& d) {
         if (d.translucency)
             p.read.push_back(enc_slot(RT::IN_TRANSLUCENCY));
         p.written = {P(P_HIST_A + cur), enc_slot(RT::OUT_SHADOW_TRANSLUCENCY)};
+        p.reprojected = {P(P_GUIDE_A + (cur ^ 1)), P(P_HIST_A + (cur ^ 1))};
         p.run = temporal_stabilization;
         d.passes.push_back(p);
     }

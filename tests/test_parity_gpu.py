@@ -183,8 +183,9 @@ def test_4k_row_window_dispatch_is_identical(pkg, api, hip):
 
 @pytest.mark.parametrize("den", ["REBLUR_DIFFUSE_SPECULAR", "RELAX_DIFFUSE_SPECULAR_SH"])
 def test_4k_against_oracle(pkg, api, oracle, hip, den):
-    """the headline configuration (and BASELINE config 4) at FULL size, 3 frames of the moving-camera scene: every output and every
-    pool plane of the HIP path equals the CPU oracle bit for bit (the oracle needs ~1 s per 4K frame on the box's host cores)"""
+    """the headline configuration (and BASELINE config 4) at FULL size, 2 frames of the moving-camera scene (a restart and a frame that
+    reprojects into it; round 4 dropped the third to keep the GPU suite under 8 minutes): every output and every pool plane of the HIP
+    path equals the CPU oracle bit for bit (the oracle needs ~1 s per 4K frame on the box's host cores)"""
     w, h = 3840, 2160
     scene = pkg.synth.Scene(w, h, dolly=0.01, denoiser="RELAX" if den.startswith("RELAX") else "REBLUR")
     dd = [api.Denoiser[den]]
@@ -192,7 +193,7 @@ def test_4k_against_oracle(pkg, api, oracle, hip, den):
     ho = pkg.harness.Harness(oracle, dd, w, h)
     oracle.lib.orc_set_threads(ho.nrd.handle, 128)
     hg = pkg.harness.Harness(hip, dd, w, h)
-    for f in range(3):
+    for f in range(2):
         fr = scene.frame(f)
         cs = scene.common_settings(api, fr, f, reset=(f == 0))
         ho.frame(cs, ho.upload(fr), st)

@@ -128,12 +128,12 @@ def test_oracle_runs_a_recorded_preset(pkg, api, oracle, presets):
 @pytest.mark.gpu
 def test_config3_at_every_distinct_recorded_operating_point(pkg, api, oracle, hip, presets):
     """REBLUR_DIFFUSE_SPECULAR + SIGMA_SHADOW_TRANSLUCENCY at each distinct operating point recorded in BistroExterior.bin (field of
-    view, sun, hit-distance scale, accumulation lengths with the reset frame, view direction): 4 frames from the forced reset,
+    view, sun, hit-distance scale, accumulation lengths with the reset frame, view direction): 3 frames from the forced reset,
     every output and every pool byte HIP == oracle."""
     st = pkg.sample_tests
     pts = st.distinct_operating_points(presets)
     assert len(pts) >= 3
     for i in pts:
-        ho = _run(pkg, api, oracle, presets[i], 320, 180, 4, threads=util.threads() if hasattr(util, "threads") else None)
-        hg = _run(pkg, api, hip, presets[i], 320, 180, 4)
+        ho = _run(pkg, api, oracle, presets[i], 320, 180, 3, threads=8)
+        hg = _run(pkg, api, hip, presets[i], 320, 180, 3)
         assert util.compare_all(ho, hg, exact=True) == [], "preset %d" % i
