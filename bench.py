@@ -704,6 +704,7 @@ class SingleRunner:
 PASS_KERNEL = {
     "REBLUR::ClassifyTiles": "k_classify_tiles", "REBLUR::PrePass": "k_spatial<0", "REBLUR::Blur": "k_spatial<1",
     "REBLUR::PostBlur": "k_spatial<2", "REBLUR::TemporalAccumulation": "k_temporal_accumulation",
+    "REBLUR::PrePassTemporalAccumulation": "k_prepass_temporal_accumulation", "REBLUR::PrepareInputs": "k_prepare_",
     "REBLUR::HistoryFix": "k_history_fix", "REBLUR::TemporalStabilization": "k_temporal_stabilization",
     "RELAX::ClassifyTiles": "k_classify_tiles", "RELAX::PrePass": "k_spatial<0", "RELAX::TemporalAccumulation": "k_temporal_accumulation",
     "RELAX::HistoryFix": "k_history_fix",

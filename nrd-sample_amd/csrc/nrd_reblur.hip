@@ -30,6 +30,21 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_PIPE_DEPTH_WIDE
 #define NRD_PIPE_DEPTH_WIDE 5
 #endif
+#ifndef NRD_SH_PRE_DEPTH // taps in flight: PrePass of the SH flavours (three gathers per tap: guide, SH0, SH1)
+#define NRD_SH_PRE_DEPTH NRD_PIPE_DEPTH_WIDE
+#endif
+#ifndef NRD_SH_PRE_WAVES
+#define NRD_SH_PRE_WAVES 3
+#endif
+#ifndef NRD_RELAX_SH_PRE_DEPTH // ... of RELAX's SH flavour (BASELINE config 4): 2 taps in flight fit 127 VGPRs = 4 waves per SIMD (5: 145 / 3 waves)
+#define NRD_RELAX_SH_PRE_DEPTH NRD_SH_PRE_DEPTH
+#endif
+#ifndef NRD_RELAX_SH_PRE_WAVES
+#define NRD_RELAX_SH_PRE_WAVES NRD_SH_PRE_WAVES
+#endif
+#ifndef NRD_TA_SH_WAVES // TemporalAccumulation of the SH / RELAX flavours: waves per SIMD the register allocator aims for (1: no bound)
+#define NRD_TA_SH_WAVES 1
+#endif
 // Blur / PostBlur on tap texels (one 16-byte gather per tap): taps in flight and waves per SIMD
 #ifndef NRD_TAP_DEPTH // (the default flavour's arccosine / exp2 polynomials hold more registers per tap: 8 taps in flight spill 16 bytes at 5 waves)
 #define NRD_TAP_DEPTH (NRD_UPSTREAM_FORMULAS ? (NRD_ORTHO ? 5 : 6) : NRD_PIPE_DEPTH) // (orthographic flavour: 6 spill 20 bytes)
@@ -365,6 +380,69 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
     }
 }
 
+// The sample's DEFAULT operating point (Source/NRDSample.cpp:267, :545-548: RESOLUTION_HALF tracing, CheckerboardMode::WHITE, no hit distance
+// reconstruction) as its own kernel: radiance signals of a diffuse + specular denoiser, each on one colour of the checkerboard. Every pixel
+// then does the same thing - it HAS one signal and resolves the other from its left / right neighbours, which carry it - so the work is
+// written without the two-way divergence of the general kernel above (where every wave ran "has data" and "resolve" for both signals: the
+// lanes of a row alternate): three guide texels (x - 1, x, x + 1) and three signal texels, the plane of each picked per lane, all six
+// loads in flight before the first is used; a plain grid of 4-tile runs like ClassifyTiles (no neighbour reuse across tiles worth an XCD
+// traversal, ~700 cycles of scalar prologue less per wave). The arithmetic is the general kernel's, expression by expression.
+__global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
+    const FrameConsts& c = p.c;
+    const int ty = (int)blockIdx.y + c.tileY0;
+    const int y = ty * 16 + (int)threadIdx.y;
+    if (y < c.ownY0 || y >= c.ownY1)
+        return;
+    const int gy0 = y + c.yOff;
+#pragma unroll
+    for (int k = 0; k < NRD_CT_TILES; k++) {
+        const int x = ((int)blockIdx.x * NRD_CT_TILES + k) * 16 + (int)threadIdx.x;
+        if (x >= c.W)
+            continue;
+        // the pixel carries the signal whose phase matches its colour; its neighbours carry the other one
+        const bool ownIsDiff = ((((uint32_t)x ^ (uint32_t)gy0) ^ c.frameIndex) & 1u) == (uint32_t)p.phaseDiff;
+        const PlaneRef& ownIn = ownIsDiff ? p.rawDiff : p.rawSpec;
+        const PlaneRef& otherIn = ownIsDiff ? p.rawSpec : p.rawDiff;
+        const PlaneRef& ownOut = ownIsDiff ? p.inDiff : p.inSpec;
+        const PlaneRef& otherOut = ownIsDiff ? p.inSpec : p.inDiff;
+        const int xl = imax(x - 1, 0), xr = imin(x + 1, c.W - 1);
+        const uint2 g0 = ld_guide(p.guide, x, y), gl = ld_guide(p.guide, xl, y), gr = ld_guide(p.guide, xr, y);
+        const uint2 sOwn = ld<uint2>(ownIn, x >> 1, y, 8), sL = ld<uint2>(otherIn, xl >> 1, y, 8), sR = ld<uint2>(otherIn, xr >> 1, y, 8);
+        const Guide g = decode_guide(g0, c.denoisingRange);
+        if (g.sky) {
+            st<uint2>(ownOut, x, y, 8, uint2{0u, 0u});
+            st<uint2>(otherOut, x, y, 8, uint2{0u, 0u});
+            continue;
+        }
+        const f4 v = unpack_h4(sOwn);
+        // checkerboard resolve of the other signal (k_prepare_inputs, the same expressions)
+        const float invDz = rcp_(0.03f * fmax2(absf(g.z), 1e-6f));
+        float wn[2];
+        bool ok[2];
+        const f4 vn[2] = {unpack_h4(sL), unpack_h4(sR)};
+        const uint2 gn2[2] = {gl, gr};
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const int px = x + (n ? 1 : -1);
+            const Guide gn = decode_guide(gn2[n], c.denoisingRange);
+            ok[n] = px >= 0 && px < c.W && !gn.sky;
+            const float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
+            wn[n] = ok[n] ? w : 0.0f;
+        }
+        if (!(wn[0] + wn[1] > 0.0f)) { // depth edge on both sides: plain mean of whatever exists
+            wn[0] = ok[0] ? 1.0f : 0.0f;
+            wn[1] = ok[1] ? 1.0f : 0.0f;
+        }
+        const float wsum = wn[0] + wn[1];
+        f4 acc = wn[0] > 0.0f ? mul4(vn[0], wn[0]) : f4{0, 0, 0, 0};
+        acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
+        const float inv = rcp_(wsum);
+        const f4 vo = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
+        st<uint2>(ownOut, x, y, 8, pack_h4(v));
+        st<uint2>(otherOut, x, y, 8, pack_h4(vo));
+    }
+}
+
 // =====================================================================================================================
 // Spatial filter: PrePass (VARIANT 0), Blur (1), PostBlur (2)
 // =====================================================================================================================
@@ -578,7 +656,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         // Re-tuned at the end of round 3 (profiles/r03_ab_pipeline_depth.txt): with the 8-byte guide and the tap texels the radiance PrePass
         // is fastest with 2 taps in flight (78 VGPRs, 6 waves per SIMD: -6 % against 5 taps / 4 waves) and PostBlur with 4 (-2.3 %); Blur
         // stays at 8; RELAX's radiance PrePass: 3 (-3 %). The SH and OCCLUSION flavours keep round 2's depths (SH Blur at 3 or 2: +6 %).
-        constexpr int DEPTH_WANTED = FUSED ? NRD_FUSED_DEPTH : (VARIANT == 0 && MODE == 0) ? NRD_PRE_DEPTH : (VARIANT == 0 && MODE == 1) ? 3 : ((VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? (VARIANT == 2 ? NRD_POST_DEPTH : NRD_TAP_DEPTH) : NRD_PIPE_DEPTH));
+        constexpr int DEPTH_WANTED = FUSED ? NRD_FUSED_DEPTH : (VARIANT == 0 && MODE == 0) ? NRD_PRE_DEPTH : (VARIANT == 0 && MODE == 1) ? 3 : (VARIANT == 0 && MODE == 4) ? NRD_RELAX_SH_PRE_DEPTH : (VARIANT == 0 && SH) ? NRD_SH_PRE_DEPTH : ((VARIANT == 0 || SH) ? NRD_PIPE_DEPTH_WIDE : (TAP ? (VARIANT == 2 ? NRD_POST_DEPTH : NRD_TAP_DEPTH) : NRD_PIPE_DEPTH));
         constexpr int DEPTH = DEPTH_WANTED < NT ? DEPTH_WANTED : NT;
         const PlaneBuf guideB = plane_buf(p.guide, c.yOff);
         PlaneBuf srcB[NSIG], src1B[NSIG];
@@ -764,7 +842,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
 template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
 // 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
 // carry 16 more registers of tap data and stay at 3
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? 3 : ((VARIANT != 0 && MODE == 0) ? (VARIANT == 2 ? NRD_POST_WAVES : NRD_TAP_WAVES) : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? (VARIANT == 0 ? (MODE == 4 ? NRD_RELAX_SH_PRE_WAVES : NRD_SH_PRE_WAVES) : 3) : ((VARIANT != 0 && MODE == 0) ? (VARIANT == 2 ? NRD_POST_WAVES : NRD_TAP_WAVES) : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
     int x, y, tx, ty;
     if (!my_pixel(p.c, x, y, tx, ty)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
         return;                       // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
@@ -1147,7 +1225,7 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
 }
 
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? 1 : NRD_TA_WAVES) void k_temporal_accumulation(const ReblurParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAVES : NRD_TA_WAVES) void k_temporal_accumulation(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int RBPT = (SH ? 16 : 8) * NSIG;
     const FrameConsts& c = p.c;
@@ -2058,7 +2136,14 @@ extern "C" __attribute__((visibility("default"))) void nrdhip_debug_gather_trace
 }
 #endif
 
-void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_prepare_inputs, ); }
+void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) {
+    // the sample's default operating point has its own kernel: both radiance signals, complementary checkerboard colours, nothing else to do
+    if (p.checker && p.reconRadius == 0 && !p.prepSh1 && !p.dirOcc && !p.occlusion && p.hasDiff && p.hasSpec && (p.phaseDiff ^ p.phaseSpec) == 1) {
+        hipLaunchKernelGGL(k_prepare_checker, dim3((unsigned)((p.c.tilesX + NRD_CT_TILES - 1) / NRD_CT_TILES), (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
+        return;
+    }
+    NRD_LAUNCH3(k_prepare_inputs, );
+}
 void launch_reblur_validation(const ReblurParams& p, hipStream_t s) { hipLaunchKernelGGL(k_validation, grid_for(p.c), dim3(16, 16, 1), 0, s, p); }
 
 void launch_reblur_spatial(const ReblurParams& p, int variant, hipStream_t s) {
