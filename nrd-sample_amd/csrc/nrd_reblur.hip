@@ -2109,32 +2109,6 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(u
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)((p.c.tilesX + NRD_CT_TILES - 1) / NRD_CT_TILES), (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
 }
-#if defined(NRD_HOST_EMULATION) && !NRD_ORTHO
-// test hook, host-emulated build only (tests/test_tile_traversal.py): the tile that workgroup `block` of a launch over tilesX x
-// tilesY tiles works on (returns 0 when the workgroup is a spare one), and the launch size
-extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of(int tilesX, int tilesY, int tileY0, unsigned block, int reverse, int* tx, int* ty) {
-    FrameConsts c = {};
-    c.reverse = reverse;
-    c.tilesX = tilesX;
-    c.tilesY = tilesY;
-    c.tileY0 = tileY0;
-    hipemu::t_blockIdx = {block, 0u, 0u};
-    return xcd_tile(c, *tx, *ty) ? 1 : 0;
-}
-extern "C" __attribute__((visibility("default"))) unsigned nrdhip_debug_grid_blocks(int tilesX, int tilesY) { return (unsigned)xcd_grid_blocks(tilesX, tilesY); }
-// test / analysis hook, host-emulated build only (tools/gather_locality.py): read and reset the gather trace of the emulation
-// {wave-level gather instructions, distinct 128-byte lines they touched, lane loads}, then switch it on / off
-extern "C" __attribute__((visibility("default"))) void nrdhip_debug_gather_trace(int on, double* out3) {
-    hipemu::GatherTrace& g = hipemu::g_gatherTrace;
-    if (out3) {
-        out3[0] = g.instr;
-        out3[1] = g.lines;
-        out3[2] = g.laneLoads;
-    }
-    g.instr = g.lines = g.laneLoads = 0;
-    g.on = on != 0;
-}
-#endif
 
 void launch_reblur_prepare_inputs(const ReblurParams& p, hipStream_t s) {
     // the sample's default operating point has its own kernel: both radiance signals, complementary checkerboard colours, nothing else to do
