@@ -237,9 +237,13 @@ NRD_DEV float atan_pos(float x) {
 constexpr bool UPSTREAM_FORMULAS = NRD_UPSTREAM_FORMULAS != 0;
 constexpr int BLUR_ROTATION_SHIFT = UPSTREAM_FORMULAS ? 0 : 1; // Blur's Poisson rotation: per pixel (upstream) / per 2x2 quad (frozen)
 
-// arccosine on [0, 1] (Abramowitz & Stegun 4.4.45, |error| <= 5e-5): sqrt(1 - x) (a0 + a1 x + a2 x^2 + a3 x^3). The square root takes
-// TWO Newton steps (relative error 4.7e-6, a tenth of the polynomial's own): this function runs once per tap of every spatial pass and
-// the passes are priced in instructions (profiles/r04_valu_issue.txt)
+// The angle between two normals as upstream's weights take it: Math::AcosApprox(cos) = sqrt(2) sqrt(saturate(1 - cos)) (MathLib, recalled:
+// the library is not vendored in the sample) - the CHORD |n_a - n_b| of the two unit vectors, within 1 % of the arc below 28 degrees and
+// 10 % short of it at 90. On guide normals the chord is (2 / 1023) sqrt(d2) with d2 the squared distance of the 10-bit codes
+// (normal_dist2 below), so a tap pays one square root and nothing else: the A&S 4.4.45 arccosine polynomial the first default-flavour
+// build evaluated here (6 more instructions per tap) was FARTHER from upstream than this. The square root takes TWO Newton steps
+// (relative error 4.7e-6): this runs once per tap of every spatial pass and the passes are priced in instructions
+// (profiles/r04_valu_issue.txt)
 NRD_DEV float sqrt2_(float x) {
     const float h = 0.5f * x;
     float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
@@ -247,27 +251,18 @@ NRD_DEV float sqrt2_(float x) {
     r = r * fma_(-(h * r), r, 1.5f);
     return x * r; // sqrt2_(0) = 0
 }
-NRD_DEV float acos01_poly(float x) {
-    x = sat(x);
-    float p = -0.0187293f;
-    p = fma_(p, x, 0.0742610f);
-    p = fma_(p, x, -0.2121144f);
-    p = fma_(p, x, 1.5707288f);
-    return sqrt2_(1.0f - x) * p;
-}
-// 2^x for x <= 0 (the hit-distance weight's exponent): exp2_poly without its upper clamp and with the power of two applied by v_ldexp_f32
-// instead of an integer add, a shift and a multiply - the same value bit for bit (the scale is exact either way), three instructions less
+// 2^x for x <= 0 (the hit-distance weight's exponent): round-to-nearest split, a DEGREE-4 minimax polynomial on [-0.5, 0.5] (relative
+// error 3.7e-6 - the weight multiplies fp16 signals, 2^-11 - where exp2_poly's degree 6 reaches 1.1e-7: two fma less per signal and tap),
+// the power of two applied by v_ldexp_f32
 NRD_DEV float exp2_poly_neg(float x) {
     x = fmax2(x, -126.0f);
-    const float fi = __builtin_floorf(x + 0.5f);
+    const float fi = __builtin_rintf(x); // v_rndne_f32 (ties to even: f = +-0.5 is inside the fit either way)
     const float f = x - fi;
-    float p = 1.535336188319500e-4f;
-    p = fma_(p, f, 1.339887440266574e-3f);
-    p = fma_(p, f, 9.618437357674640e-3f);
-    p = fma_(p, f, 5.550332471162809e-2f);
-    p = fma_(p, f, 2.402264791363012e-1f);
-    p = fma_(p, f, 6.931472028550421e-1f);
-    p = fma_(p, f, 1.0f);
+    float p = 9.676037356257439e-3f;
+    p = fma_(p, f, 5.592203512787819e-2f);
+    p = fma_(p, f, 2.402210682630539e-1f);
+    p = fma_(p, f, 6.931210160255432e-1f);
+    p = fma_(p, f, 1.0000001192092896f);
     return __builtin_ldexpf(p, (int)fi);
 }
 // hit-distance weight: compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped; upstream flavour: exp(-3 |x|)
@@ -277,20 +272,23 @@ NRD_DEV float exp_weight(float ax) {
     float t = sat(1.0f - ax);
     return t * t;
 }
-// Normal weight. Frozen form: on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; its per-pixel parameter is w2 = 1 / angleMax^2
-// (normal_weight) or -2 w2 (normal_weight_m2: scaling by 2 is exact, so fma(-2 t, w2, 1) and fma(t, -2 w2, 1) round the same exact
-// product - one multiply less per tap). Upstream flavour: smoothstep(1 - acos(cos) / angleMax), parameter = 1 / angleMax for both.
+// Normal weight, from the squared distance d2 of two normals' 10-bit codes (normal_dist2 below; 1 - cos = d2 NORMAL_D2_TO_1MCOS).
+// Frozen form: on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; its per-pixel parameter is w2 = 1 / angleMax^2 (normal_weight)
+// or -2 w2 (normal_weight_m2: scaling by 2 is exact, so fma(-2 t, w2, 1) and fma(t, -2 w2, 1) round the same exact product - one
+// multiply less per tap). Default flavour: smoothstep(1 - angle / angleMax) on the chord (sqrt2_ above), parameter = 1 / angleMax for
+// both; the (2 / 1023) of the chord is folded into the parameter (a per-pixel product the compiler hoists out of the tap loops).
+constexpr float NORMAL_D2_TO_1MCOS = 0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f);
 NRD_DEV float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : normalW * normalW; }
 NRD_DEV float nw_param_m2(float normalW) { return UPSTREAM_FORMULAS ? normalW : -2.0f * (normalW * normalW); }
-NRD_DEV float normal_weight(float cosa, float prm) {
+NRD_DEV float normal_weight(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-acos01_poly(cosa), prm, 1.0f));
-    return smoothstep01(fma_(-2.0f * sat(1.0f - cosa), prm, 1.0f));
+        return smoothstep01(fma_(-sqrt2_(d2), prm * (2.0f / 1023.0f), 1.0f));
+    return smoothstep01(fma_(-2.0f * sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
-NRD_DEV float normal_weight_m2(float cosa, float prm) {
+NRD_DEV float normal_weight_m2(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-acos01_poly(cosa), prm, 1.0f));
-    return smoothstep01(fma_(sat(1.0f - cosa), prm, 1.0f));
+        return smoothstep01(fma_(-sqrt2_(d2), prm * (2.0f / 1023.0f), 1.0f));
+    return smoothstep01(fma_(sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 
 // ---- input decode (once per pixel, in the ClassifyTiles passes) ---------------------------------------------------
@@ -363,7 +361,7 @@ struct NormalCodes {
     int y;
 };
 NRD_DEV NormalCodes normal_codes(uint32_t nw) { return {__builtin_bit_cast(nrd_s2, nw & 0x3ff003ffu), (int)((nw >> 10) & 1023u)}; }
-NRD_DEV float normal_cos(NormalCodes centre, uint32_t nw) {
+NRD_DEV float normal_dist2(NormalCodes centre, uint32_t nw) {
     float d2;
     if (NRD_NORMAL_DOT2) {
         nrd_s2 d = __builtin_bit_cast(nrd_s2, nw & 0x3ff003ffu) - centre.xz; // {dx, 16 dz}, |16 dz| <= 16368
@@ -375,8 +373,9 @@ NRD_DEV float normal_cos(NormalCodes centre, uint32_t nw) {
                     dz = (float)((nw >> 20) & 1023u) - (float)((int)centre.xz.y >> 4);
         d2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
     }
-    return fma_(d2, -0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f), 1.0f);
+    return d2;
 }
+NRD_DEV float normal_cos(NormalCodes centre, uint32_t nw) { return fma_(normal_dist2(centre, nw), -NORMAL_D2_TO_1MCOS, 1.0f); }
 
 NRD_DEV Guide decode_guide(uint2 g, float range) {
     Guide r;

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_prepare_inputs(const ReblurParams p) {
                     if (!(h > 0.0f))
                         continue;
                     float w = geo_weight(pg, (float)px, (float)gy, gs.z);
-                    w *= normal_weight(normal_cos(normal_codes(g.nw), gs.nw), normalW2);
+                    w *= normal_weight(normal_dist2(normal_codes(g.nw), gs.nw), normalW2);
                     if (isSpec)
                         w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                     sum = fma_(h, w, sum);
@@ -758,11 +758,11 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             float w = g_poisson8[t][2];
             w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
             if constexpr (TAP) {
-                w *= normal_weight_m2(normal_cos(ncodes, graw[T].y), m2w2[sig]);
+                w *= normal_weight_m2(normal_dist2(ncodes, graw[T].y), m2w2[sig]);
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_((float)(graw[T].x & 1023u), roughA[sig], roughB[sig])));
             } else {
-                w *= normal_weight_m2(normal_cos(ncodes, gs.nw), m2w2[sig]);
+                w *= normal_weight_m2(normal_dist2(ncodes, gs.nw), m2w2[sig]);
                 if (isSpec)
                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
             }
@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
                             continue;
                         float w = rcp_(1.0f + (float)(i * i + j * j));
                         w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                        w *= p.relax ? pow01(normal_cos(normal_codes(g.nw), gs.nw), p.hfNormalPower) : normal_weight(normal_cos(normal_codes(g.nw), gs.nw), normalW2);
+                        w *= p.relax ? pow01(normal_cos(normal_codes(g.nw), gs.nw), p.hfNormalPower) : normal_weight(normal_dist2(normal_codes(g.nw), gs.nw), normalW2);
                         if (isSpec)
                             w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                         float tA[2];
@@ -1974,14 +1974,14 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
         int px = x + i * stride, gy = y + j * stride + c.yOff;
         Guide gs = decode_guide(graw[k], c.denoisingRange);
         float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
-        float nDot = normal_cos(normal_codes(g.nw), gs.nw);
+        const float nD2 = normal_dist2(normal_codes(g.nw), gs.nw);
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
             bool valid = inside[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
             float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
             w *= geoW;
-            w *= normal_weight_m2(nDot, normalW2[sig]);
+            w *= normal_weight_m2(nD2, normalW2[sig]);
             if (isSpec) {
                 float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                 if (LS)

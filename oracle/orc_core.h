@@ -157,12 +157,12 @@ static const int GUIDE_BYTES = 8;
 // Cosine of the angle between two guide normals from their 10-bit CODES: cos = 1 - |n_a - n_b|^2 / 2 (exact for unit vectors). The dot
 // product of two quantised, not re-normalised vectors cannot resolve 1 - cos at the 1e-4 level the narrow specular lobes ask for (|n|^2
 // is off by up to 2e-3); the squared difference of the codes is exact, zero for equal normals, as fine as the quantisation step.
-static inline float normal_cos(uint32_t nwCentre, uint32_t nw) {
+static inline float normal_dist2(uint32_t nwCentre, uint32_t nw) {
     const float dx = (float)(nw & 1023u) - (float)(nwCentre & 1023u), dy = (float)((nw >> 10) & 1023u) - (float)((nwCentre >> 10) & 1023u),
                 dz = (float)((nw >> 20) & 1023u) - (float)((nwCentre >> 20) & 1023u);
-    const float d2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
-    return fma_(d2, -0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f), 1.0f);
+    return fma_(dz, dz, fma_(dy, dy, dx * dx));
 }
+static inline float normal_cos(uint32_t nwCentre, uint32_t nw) { return fma_(normal_dist2(nwCentre, nw), -NORMAL_D2_TO_1MCOS, 1.0f); }
 static inline uint32_t guide_qn10(float v) { return (uint32_t)floorf(clampf(fma_(v, 511.5f, 512.0f), 0.0f, 1023.0f)); }
 // A pixel without geometry (|viewZ| beyond the range, Inf, NaN - e.g. a 0xFF-filled "no hit" plane, whose bits would wrap in the rounding)
 // stores one canonical finite depth; the return value says whether the STORED depth has geometry - the test every consumer applies

@@ -320,7 +320,7 @@ void prepare_inputs(Instance& I, DenoiserState& d, const Consts& c, int y0, int 
                             if (!(h > 0.0f))
                                 continue;
                             float w = geo_weight(pg, (float)px, (float)gy, gs.z);
-                            w *= normal_weight(normal_cos(g.nw, gs.nw), normalW2);
+                            w *= normal_weight(normal_dist2(g.nw, gs.nw), normalW2);
                             if (isSpec)
                                 w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                             sum = fma_(h, w, sum);
@@ -548,7 +548,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         if (valid) {
                             w = g_poisson8[t][2];
                             w *= geo_weight(pg, fpx, fpy, gs.z);
-                            w *= normal_weight(normal_cos(g.nw, gs.nw), normalW2);
+                            w *= normal_weight(normal_dist2(g.nw, gs.nw), normalW2);
                             if (tap) { // the tap's roughness stays a 10-bit code: the scale of its decode is folded into the per-pixel constant
                                 if (isSpec)
                                     w *= smoothstep01(1.0f - absf(fma_((float)(tt.w0 & 1023u), roughA * (1.0f / 1023.0f), roughB)));
@@ -999,7 +999,7 @@ void history_fix(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1)
                                 float w = rcp_(1.0f + (float)(i * i + j * j));
                                 w *= geo_weight(pg, (float)px, (float)gy, gs.z);
                                 // RELAX: pow(N.Ns, historyFixEdgeStoppingNormalPower) (sample UI Source/NRDSample.cpp:1626) instead of the lobe weight
-                                w *= relax ? pow01(normal_cos(g.nw, gs.nw), d.relax.historyFixEdgeStoppingNormalPower) : normal_weight(normal_cos(g.nw, gs.nw), normalW2);
+                                w *= relax ? pow01(normal_cos(g.nw, gs.nw), d.relax.historyFixEdgeStoppingNormalPower) : normal_weight(normal_dist2(g.nw, gs.nw), normalW2);
                                 if (isSpec)
                                     w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 float tA[2];
@@ -1402,7 +1402,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         if (valid) {
                             w = (i == 0 || j == 0) ? 0.5f : 0.25f;
                             w *= geo_weight(pg, (float)px, (float)gy, gs.z);
-                            w *= normal_weight(normal_cos(g.nw, gs.nw), normalW2);
+                            w *= normal_weight(normal_dist2(g.nw, gs.nw), normalW2);
                             if (isSpec && s.enableRoughnessEdgeStopping) {
                                 float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
                                 w *= relaxEdges ? lerpf(1.0f, rw, roughRelax) : rw;

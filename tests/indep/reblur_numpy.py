@@ -5,7 +5,8 @@ switches to MEASURE the known deviations from the recalled upstream formulas lis
 
 Switches (all False = the frozen algorithm):
   exp_hit_weight ...... hit-distance weight exp(-3 |x|) instead of the compact-support stand-in (1 - |x|)^2
-  angle_normal_weight . normal weight on the angle itself, smoothstep(1 - acos(cos) / angleMax), instead of the squared-angle form
+  angle_normal_weight . normal weight on the angle itself, smoothstep(1 - AcosApprox(cos) / angleMax) with upstream's AcosApprox =
+                        sqrt(2 (1 - cos)) (the chord), instead of the squared-angle form
   no_reach ............ no hard tap reach (the reach exists for row tiling: it bounds what a pass may read beyond a band)
   f32_guide ........... guide kept at decode precision (fp32 depth, normalised fp64 normal) instead of the 8-byte guide texel's 22-bit depth
                         and 3 x 10-bit normal codes
@@ -201,7 +202,7 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
             w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
             cosa = normal_cos(n, ns, f32_guide)
             if angle_normal_weight:
-                w = w * smoothstep01(1.0 - np.arccos(np.clip(cosa, -1, 1)) * normal_w)
+                w = w * smoothstep01(1.0 - np.sqrt(2.0 * np.clip(1.0 - cosa, 0, 1)) * normal_w)  # Math::AcosApprox: the chord
             else:
                 w = w * smoothstep01(1.0 - 2.0 * np.clip(1.0 - cosa, 0, 1) * normal_w * normal_w)
             if is_spec:
