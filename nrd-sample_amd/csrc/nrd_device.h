@@ -291,6 +291,49 @@ NRD_DEV float normal_weight_m2(float d2, float prm) {
     return smoothstep01(fma_(sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 
+// ---- {diffuse, specular} PAIRS of the spatial passes' per-tap arithmetic ------------------------------------------------------
+// gfx950 issues v_pk_{fma, mul, add}_f32 - two IEEE fp32 operations per lane - in 3.4 cycles per wave against 2 x 2.6 for the two
+// plain instructions (profiles/r02_ubench_valu_rate.txt, 4 waves per SIMD): tap t of the diffuse signal and tap t of the specular
+// signal run the same straight-line weight code on different data, so the passes that filter both consume them TOGETHER, one signal
+// per half of a register pair. Every half is the scalar sequence operation for operation (same fma / mul / add, same order): the
+// results are the scalar path's bit for bit. What has no packed form stays scalar on the halves: |x| and clamp source / output
+// modifiers (VOP3P has neither for fp32 sources; the one clamp that sits behind a packed fma is written as the instruction itself),
+// floor / rndne, conversions, v_ldexp.
+typedef float nrd_f2 __attribute__((ext_vector_type(2)));
+NRD_DEV nrd_f2 splat2(float v) { return nrd_f2{v, v}; }
+NRD_DEV nrd_f2 fma2_(nrd_f2 a, nrd_f2 b, nrd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+NRD_DEV nrd_f2 fma2_sat(nrd_f2 a, nrd_f2 b, nrd_f2 c) { // sat(fma(a, b, c)) per half
+#ifdef NRD_HOST_EMULATION
+    const nrd_f2 r = fma2_(a, b, c);
+    return nrd_f2{sat(r.x), sat(r.y)};
+#else
+    nrd_f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#endif
+}
+NRD_DEV nrd_f2 smoothstep01_in01(nrd_f2 x) { return x * x * fma2_(x, splat2(-2.0f), splat2(3.0f)); } // smoothstep01 of halves already in [0, 1]
+NRD_DEV nrd_f2 sqrt2_(nrd_f2 x) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const nrd_f2 h = 0.5f * x;
+    nrd_f2 r = __builtin_bit_cast(nrd_f2, 0x5F3759DFu - (__builtin_bit_cast(u2, x) >> 1));
+    r = r * fma2_(-(h * r), r, splat2(1.5f));
+    r = r * fma2_(-(h * r), r, splat2(1.5f));
+    return x * r;
+}
+// exp2_poly_neg of both halves (x <= 0)
+NRD_DEV nrd_f2 exp2_poly_neg(nrd_f2 x) {
+    x = nrd_f2{fmax2(x.x, -126.0f), fmax2(x.y, -126.0f)};
+    const nrd_f2 fi = nrd_f2{__builtin_rintf(x.x), __builtin_rintf(x.y)};
+    const nrd_f2 f = x - fi;
+    nrd_f2 p = splat2(9.676037356257439e-3f);
+    p = fma2_(p, f, splat2(5.592203512787819e-2f));
+    p = fma2_(p, f, splat2(2.402210682630539e-1f));
+    p = fma2_(p, f, splat2(6.931210160255432e-1f));
+    p = fma2_(p, f, splat2(1.0000001192092896f));
+    return nrd_f2{__builtin_ldexpf(p.x, (int)fi.x), __builtin_ldexpf(p.y, (int)fi.y)};
+}
+
 // ---- input decode (once per pixel, in the ClassifyTiles passes) ---------------------------------------------------
 NRD_DEV f3 oct_decode(float px, float py) {
     float fx = px * 2.0f - 1.0f, fy = py * 2.0f - 1.0f;

@@ -671,9 +671,28 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         bool inWin[NT];
         uint4 graw[NT];
         uint2 sraw[NT], sraw1[NT];
-        auto issue = [&](const int T) {
-            const int sig = T >> 3, t = T & 7;
-            float ox, oy;
+        // Tap order: signal-major (the 8 taps of a signal, then the next signal's) or, when the two signals are consumed as PAIRS
+        // (nrd_device.h nrd_f2), tap-major: {diffuse t, specular t} adjacent. Each signal's sums see its taps in the same order.
+#ifndef NRD_PAIR_SIGNALS
+#define NRD_PAIR_SIGNALS 0
+#endif
+// pairs in flight per kernel family (registers: a pair in flight holds two taps' texels and positions)
+#ifndef NRD_PAIR_DEPTH_TAP
+#define NRD_PAIR_DEPTH_TAP 2
+#endif
+#ifndef NRD_PAIR_DEPTH_POST
+#define NRD_PAIR_DEPTH_POST 1
+#endif
+#ifndef NRD_PAIR_DEPTH_PRE
+#define NRD_PAIR_DEPTH_PRE 1
+#endif
+#ifndef NRD_PAIR_DEPTH_FUSED
+#define NRD_PAIR_DEPTH_FUSED 1
+#endif
+        constexpr bool PAIR = NRD_PAIR_SIGNALS && UPSTREAM_FORMULAS && NSIG == 2 && !SH;
+        auto sig_of = [&](const int T) { return PAIR ? (T & 1) : (T >> 3); };
+        auto tap_of = [&](const int T) { return PAIR ? (T >> 1) : (T & 7); };
+        auto tap_offset = [&](const int t, float& ox, float& oy) {
             if (PER_PIXEL) {
                 ox = g_poisson8[t][0];
                 oy = g_poisson8[t][1];
@@ -681,9 +700,9 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 ox = VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0];
                 oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
             }
-            float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], cx)));
-            float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], cy)));
-            gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
+        };
+        auto gather = [&](const int T, const float fpx, const float fpy) {
+            const int sig = sig_of(T);
             // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
             const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
             inWin[T] = (cxf == fpx) & (cyf == fpy);
@@ -716,59 +735,62 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig]) : uint2{0u, 0u};
             }
         };
-        auto consume = [&](const int T) {
-            const int sig = T >> 3, t = T & 7;
-            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-#ifdef NRD_DIAG_NOARITH // diagnosis build (timing only): the gathers and the tap positions stay, the weights go - every tap enters with weight 1
-            {
-                const f4 raw = TAP ? unpack_h4(uint2{graw[T].z, graw[T].w}) : unpack_h4(uint2{graw[T].x ^ sraw[T].x, graw[T].y ^ sraw[T].y});
-                sum[sig] = fma4(raw, inWin[T] ? 1.0f : 0.5f, sum[sig]);
-                wsum[sig] += gaT[T];
-                return;
-            }
-#endif
-            Guide gs;
-            f4 sv;
+        auto issue = [&](const int T) {
+            const int sig = sig_of(T);
+            float ox, oy;
+            tap_offset(tap_of(T), ox, oy);
+            const float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], cx)));
+            const float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], cy)));
+            gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
+            gather(T, fpx, fpy);
+        };
+        // the positions of tap P of both signals: the same disk sample through each signal's own Jacobian
+        const nrd_f2 jtx2{jtx[0], jtx[NSIG - 1]}, jty2{jty[0], jty[NSIG - 1]}, jbx2{jbx[0], jbx[NSIG - 1]}, jby2{jby[0], jby[NSIG - 1]};
+        auto issue2 = [&](const int P) {
+            float ox, oy;
+            tap_offset(P, ox, oy);
+            const nrd_f2 fx = fma2_(splat2(ox), jtx2, fma2_(splat2(oy), jbx2, splat2(cx)));
+            const nrd_f2 fy = fma2_(splat2(ox), jty2, fma2_(splat2(oy), jby2, splat2(cy)));
+            const nrd_f2 fpx{__builtin_floorf(fx.x), __builtin_floorf(fx.y)}, fpy{__builtin_floorf(fy.x), __builtin_floorf(fy.y)};
+            const nrd_f2 ga = fma2_(splat2(pg.gax), fpx, fma2_(splat2(pg.gay), fpy, splat2(pg.ga0)));
+            gaT[2 * P] = ga.x;
+            gaT[2 * P + 1] = ga.y;
+            gather(2 * P, fpx.x, fpy.x);
+            gather(2 * P + 1, fpx.y, fpy.y);
+        };
+        // a tap's texels -> its guide fields and its signal
+        auto decode = [&](const int T, Guide& gs, f4& sv) {
             if constexpr (TAP) {
                 gs.z = u2f(graw[T].x);
                 gs.mat = graw[T].y >> 30;
+                gs.nw = graw[T].y;
                 gs.sky = !(absf(gs.z) <= c.denoisingRange);
                 sv = unpack_h4(uint2{graw[T].z, graw[T].w});
             } else {
                 gs = decode_guide(uint2{graw[T].x, graw[T].y}, c.denoisingRange);
                 sv = decode_signal(p, sraw[T], occIn);
             }
+            if (relaxIn && !RELAX_LINEAR_RGB)
+                sv = rgb_to_ycocg4(sv);
+        };
 #ifndef NRD_MATERIAL_CLASS
 #define NRD_MATERIAL_CLASS 1
 #endif
+        auto tap_valid = [&](const int T, const Guide& gs) {
+            const int sig = sig_of(T);
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
             const bool matOk = NRD_MATERIAL_CLASS ? material_class(gs.mat, matFloor[sig]) == matClass[sig]
                                                   : !material_mismatch(g.mat, gs.mat, isSpec ? p.minMatSpec : p.minMatDiff);
-            const bool valid = inWin[T] & active[sig] & !gs.sky & matOk; // bitwise: one basic block
-#ifdef NRD_DBG_HIST
-            if (active[sig]) { // Chebyshev distance of the tap from the centre pixel, buckets <=2, 4, 8, 12, 16, 24, 32, more (taps of both signals)
-                const int t = T & 7;
-                float ox = PER_PIXEL ? g_poisson8[t][0] : (VARIANT == 0 ? p.tapsPre[t][0] : p.tapsPost[t][0]);
-                float oy = PER_PIXEL ? g_poisson8[t][1] : (VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1]);
-                float dx = absf(fma_(ox, jtx[sig], oy * jbx[sig])), dy = absf(fma_(ox, jty[sig], oy * jby[sig]));
-                float d = fmax2(dx, dy);
-                int b = d <= 2.f ? 0 : d <= 4.f ? 1 : d <= 8.f ? 2 : d <= 12.f ? 3 : d <= 16.f ? 4 : d <= 24.f ? 5 : d <= 32.f ? 6 : 7;
-                atomicAdd(&g_dbg_hist[VARIANT][b], 1ull);
-            }
-#endif
-            float w = g_poisson8[t][2];
-            w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
-            if constexpr (TAP) {
-                w *= normal_weight_m2(normal_dist2(ncodes, graw[T].y), m2w2[sig]);
-                if (isSpec)
-                    w *= smoothstep01(1.0f - absf(fma_((float)(graw[T].x & 1023u), roughA[sig], roughB[sig])));
-            } else {
-                w *= normal_weight_m2(normal_dist2(ncodes, gs.nw), m2w2[sig]);
-                if (isSpec)
-                    w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA[sig], roughB[sig])));
-            }
-            if (relaxIn && !RELAX_LINEAR_RGB)
-                sv = rgb_to_ycocg4(sv);
-            w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA[sig], hitB[sig]))));
+            return (bool)(inWin[T] & active[sig] & !gs.sky & matOk); // bitwise: one basic block
+        };
+        // roughness weight of a specular tap (the tap texels carry the roughness CODE in the low bits of the depth word)
+        auto rough_weight = [&](const int T, const Guide& gs) {
+            const float r = TAP ? (float)(graw[T].x & 1023u) : gs.roughness;
+            constexpr int SS = HAS_SPEC ? NSIG - 1 : 0; // the specular signal is the last one
+            return smoothstep01(1.0f - absf(fma_(r, roughA[SS], roughB[SS])));
+        };
+        auto accumulate = [&](const int T, const f4 sv, float w, const bool valid) {
+            const int sig = sig_of(T);
             if (VARIANT == 0) {
                 // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): a rejected tap is
                 // selected out component by component
@@ -789,17 +811,87 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 wsum[sig] += w;
             }
         };
+        auto consume = [&](const int T) {
+            const int sig = sig_of(T), t = tap_of(T);
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+#ifdef NRD_DIAG_NOARITH // diagnosis build (timing only): the gathers and the tap positions stay, the weights go - every tap enters with weight 1
+            {
+                const f4 raw = TAP ? unpack_h4(uint2{graw[T].z, graw[T].w}) : unpack_h4(uint2{graw[T].x ^ sraw[T].x, graw[T].y ^ sraw[T].y});
+                sum[sig] = fma4(raw, inWin[T] ? 1.0f : 0.5f, sum[sig]);
+                wsum[sig] += gaT[T];
+                return;
+            }
+#endif
+            Guide gs;
+            f4 sv;
+            decode(T, gs, sv);
+            const bool valid = tap_valid(T, gs);
+#ifdef NRD_DBG_HIST // tools/tap_histogram.py (build with -DNRD_DEBUG_COUNTERS -DNRD_PAIR_SIGNALS=0)
+            if (active[sig]) { // Chebyshev distance of the tap from the centre pixel, buckets <=2, 4, 8, 12, 16, 24, 32, more (taps of both signals)
+                float ox, oy;
+                tap_offset(t, ox, oy);
+                float dx = absf(fma_(ox, jtx[sig], oy * jbx[sig])), dy = absf(fma_(ox, jty[sig], oy * jby[sig]));
+                float d = fmax2(dx, dy);
+                int b = d <= 2.f ? 0 : d <= 4.f ? 1 : d <= 8.f ? 2 : d <= 12.f ? 3 : d <= 16.f ? 4 : d <= 24.f ? 5 : d <= 32.f ? 6 : 7;
+                atomicAdd(&g_dbg_hist[VARIANT][b], 1ull);
+            }
+#endif
+            float w = g_poisson8[t][2];
+            w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
+            w *= normal_weight_m2(normal_dist2(ncodes, gs.nw), m2w2[sig]);
+            if (isSpec)
+                w *= rough_weight(T, gs);
+            w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA[sig], hitB[sig]))));
+            accumulate(T, sv, w, valid);
+        };
+        // tap P of both signals: the weight chain of consume(), operation for operation, on {diffuse, specular} register pairs
+        const nrd_f2 nprm2{m2w2[0] * (2.0f / 1023.0f), m2w2[NSIG - 1] * (2.0f / 1023.0f)}, hitA2{hitA[0], hitA[NSIG - 1]}, hitB2{hitB[0], hitB[NSIG - 1]};
+        auto consume2 = [&](const int P) {
+            const int T0 = 2 * P, T1 = 2 * P + 1;
+            Guide gs0, gs1;
+            f4 sv0, sv1;
+            decode(T0, gs0, sv0);
+            decode(T1, gs1, sv1);
+            const bool valid0 = tap_valid(T0, gs0), valid1 = tap_valid(T1, gs1);
+            const nrd_f2 zs{gs0.z, gs1.z}, ga{gaT[T0], gaT[T1]};
+            const nrd_f2 gp = ORTHO ? fma2_(zs, splat2(pg.geoB), ga) : fma2_(zs, ga, splat2(pg.geoB));
+            nrd_f2 w = splat2(g_poisson8[P][2]) * smoothstep01_in01(nrd_f2{sat(1.0f - absf(gp.x)), sat(1.0f - absf(gp.y))});
+            const nrd_f2 d2{normal_dist2(ncodes, gs0.nw), normal_dist2(ncodes, gs1.nw)};
+            w *= smoothstep01_in01(fma2_sat(-sqrt2_(d2), nprm2, splat2(1.0f)));
+            w.y *= rough_weight(T1, gs1);
+            const nrd_f2 hv = fma2_(nrd_f2{sv0.w, sv1.w}, hitA2, hitB2);
+            const nrd_f2 e = exp2_poly_neg(nrd_f2{-4.32808512f * absf(hv.x), -4.32808512f * absf(hv.y)});
+            w *= fma2_(splat2(1.0f - p.minHitDistanceWeight), e, splat2(p.minHitDistanceWeight));
+            accumulate(T0, sv0, w.x, valid0);
+            accumulate(T1, sv1, w.y, valid1);
+        };
+        if constexpr (PAIR) {
+            constexpr int DP = FUSED ? NRD_PAIR_DEPTH_FUSED : VARIANT == 0 ? NRD_PAIR_DEPTH_PRE : VARIANT == 2 ? NRD_PAIR_DEPTH_POST : NRD_PAIR_DEPTH_TAP;
 #pragma unroll
-        for (int T = 0; T < DEPTH; T++)
-            issue(T);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int P = 0; P < DP; P++)
+                issue2(P);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int T = 0; T < NT; T++) {
-            if (T + DEPTH < NT)
-                issue(T + DEPTH);
+            for (int P = 0; P < 8; P++) {
+                if (P + DP < 8)
+                    issue2(P + DP);
+                __builtin_amdgcn_sched_barrier(0);
+                consume2(P);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int T = 0; T < DEPTH; T++)
+                issue(T);
             __builtin_amdgcn_sched_barrier(0);
-            consume(T);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int T = 0; T < NT; T++) {
+                if (T + DEPTH < NT)
+                    issue(T + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(T);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     uint2 outw[RBPT / 8];

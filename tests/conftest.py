@@ -64,5 +64,14 @@ def emulated_frozen(pkg):
 
 
 @pytest.fixture(scope="session")
+def emulated_paired(pkg):
+    """the kernels built with -DNRD_PAIR_SIGNALS=1 (a shelved build option: profiles/r04_ab_pair_signals.txt)"""
+    path = graft.build_emulated(flavour="paired")
+    b = pkg.api.Backend(path, "nrdhip_", "cpu")
+    b.check_abi()
+    return b
+
+
+@pytest.fixture(scope="session")
 def hip_frozen(pkg):
     return pkg.hip_backend("cuda:0", flavour="frozen")

@@ -72,6 +72,22 @@ def test_fused_prepass_is_bit_identical_to_separate_passes(pkg, api, oracle, emu
     assert not np.asarray(hs["ef"].pool("REBLUR::Tmp1")).any() and np.asarray(hs["es"].pool("REBLUR::Tmp1")).any()  # the fused frame never touches it
 
 
+def test_paired_signals_option_is_bit_identical(pkg, api, oracle, emulated_paired):
+    """-DNRD_PAIR_SIGNALS=1: the spatial passes that filter both signals consume tap t of the diffuse and of the specular signal together,
+    their weight chains on {diffuse, specular} register pairs (v_pk_fma_f32 / v_pk_mul_f32 on gfx950; nrd_device.h nrd_f2). Every half is
+    the scalar sequence operation for operation, so the build must reproduce the oracle bit for bit - fused PrePass, Blur, PostBlur
+    (perspective and orthographic), REBLUR and RELAX. Measured slower than the scalar build on MI355X (profiles/r04_ab_pair_signals.txt),
+    hence an option, not the default."""
+    w, h = 72, 56
+    for den, kw in (("REBLUR_DIFFUSE_SPECULAR", {}), ("REBLUR_DIFFUSE_SPECULAR", dict(ortho=True)), ("RELAX_DIFFUSE_SPECULAR", {})):
+        scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if den.startswith("RELAX") else "REBLUR", **kw)
+        dd = [api.Denoiser[den]]
+        st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+        ho = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st)
+        he = util.run_frames(api, pkg.harness, emulated_paired, scene, dd, 3, settings=st)
+        assert util.compare_all(ho, he, exact=True) == []
+
+
 @pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["RELAX_DIFFUSE_SPECULAR_SH"]])
 def test_emulated_kernels_sky_tiles(pkg, api, oracle, emulated, dens):
     """a frame tall enough that whole tiles are sky: HistoryFix / TemporalStabilization skip their staging on tiles ClassifyTiles
