@@ -459,7 +459,7 @@ def main():
                 leg = {"value": round(w * frame_h * args.steps / dt_fz / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_fz / args.steps * 1e3, 4),
                        "passes_ms": {k: round(v[0], 4) for k, v in pp.items()},
                        "what": "same workload, libnrdhip_frozen.so: hit-distance weight (1-|x|)^2 instead of exp(-3|x|), normal weight on the squared angle "
-                               "instead of the angle (arccosine), Blur rotation per 2x2 quad instead of per pixel, RELAX in YCoCg inside instead of linear RGB"}
+                               "instead of the angle (upstream's AcosApprox: the chord of the two normals), Blur rotation per 2x2 quad instead of per pixel, RELAX in YCoCg inside instead of linear RGB"}
                 del runner_fz, hz_fz
                 torch.cuda.empty_cache()
                 out["config"]["frozen_formulas"] = leg

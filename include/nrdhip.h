@@ -98,9 +98,15 @@ typedef struct nrdhip_dispatch_info {
      * owned rows and halo rows alike, the inputs' halo rows being valid after nrdhip_tiler_exchange_inputs - so what it writes is
      * complete on every rank and is never exchanged */
     uint32_t flags;
+    /* Row tiling, per written plane: written[i] holds 16-byte TAP TEXELS {guide texel | signal} whose first 8 bytes are a copy of the same
+     * pixel's 8-byte texel in pool plane written_prefix[i] (the guide plane, which a NRDHIP_DISPATCH_ALL_ROWS pass completes on every
+     * rank): only the last 8 bytes of each texel have to travel, the receiver puts the first 8 back from its own copy of that plane.
+     * NRDHIP_NO_PLANE: the plane travels as it is. */
+    uint32_t written_prefix[12];
 } nrdhip_dispatch_info;
 enum { NRDHIP_READ_REPROJECTED = 0xFFFFu };
 enum { NRDHIP_DISPATCH_ALL_ROWS = 1u };
+enum { NRDHIP_NO_PLANE = 0xFFFFFFFFu };
 
 /* nrd::Integration::Recreate (Source/NRDSample.cpp:982): create the instance, size its pools. */
 NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** out);

@@ -310,9 +310,11 @@ class PlaneInfo(C.Structure):
 class DispatchInfo(C.Structure):
     _fields_ = [("name", C.c_char_p), ("kernel", C.c_char_p), ("identifier", _u32), ("grid_width", _u16),
                 ("grid_height", _u16), ("halo_rows", _u16), ("written_num", _u16), ("written", _u32 * 12),
-                ("read_num", _u32), ("read", _u32 * 24), ("algorithmic_bytes_per_pixel", _f), ("read_rows", _u16 * 24), ("flags", _u32)]
+                ("read_num", _u32), ("read", _u32 * 24), ("algorithmic_bytes_per_pixel", _f), ("read_rows", _u16 * 24), ("flags", _u32),
+                ("written_prefix", _u32 * 12)]
 
 
+NO_PLANE = 0xFFFFFFFF      # nrdhip_dispatch_info.written_prefix: the plane travels as it is (NRDHIP_NO_PLANE)
 READ_REPROJECTED = 0xFFFF  # nrdhip_dispatch_info.read_rows: previous-frame state read at motion-displaced positions (NRDHIP_READ_REPROJECTED)
 DISPATCH_ALL_ROWS = 1      # nrdhip_dispatch_info.flags: pointwise pass that runs on every stored row of a band (NRDHIP_DISPATCH_ALL_ROWS)
 
@@ -635,6 +637,8 @@ class Integration:
                             grid=(di.grid_width, di.grid_height), halo_rows=di.halo_rows,
                             written=[di.written[k] for k in range(di.written_num)], read=[di.read[k] for k in range(di.read_num)],
                             read_rows=[di.read_rows[k] for k in range(di.read_num)], all_rows=bool(di.flags & DISPATCH_ALL_ROWS),
+                            # tap-texel planes {guide texel | signal}: written plane -> the (guide) plane its texels start with
+                            written_prefix={di.written[k]: di.written_prefix[k] for k in range(di.written_num) if di.written_prefix[k] != NO_PLANE},
                             bytes_per_pixel=di.algorithmic_bytes_per_pixel))
         return out
 

@@ -100,6 +100,7 @@ struct Dispatch {
     std::vector<uint32_t> own, reprojected;
     std::vector<std::pair<uint32_t, uint16_t>> reach;
     bool allRows = false; // NRDHIP_DISPATCH_ALL_ROWS
+    std::vector<std::pair<uint32_t, uint32_t>> prefix; // nrdhip_dispatch_info::written_prefix: {written tap-texel plane, the guide plane its texels start with}
 };
 
 // the ClassifyTiles passes run on every row the instance stores (owned + halo rows of a band): pointwise over external inputs whose
@@ -759,6 +760,8 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         x.reach = {{P(rb::FAST_A + cur), (uint16_t)2}}; // the 5x5 clamping window; the reconstruction taps read guide, signal and speeds
         if (tap) {
             push_tap_planes(d, tb, rb::TAP_D_A, x.written);
+            for (uint32_t code : x.written) // "the tap texels carry the pixel's guide texel as it is" (k_history_fix)
+                x.prefix.push_back({code, P(rb::GUIDE_A + cur)});
             x.written.push_back(P(rb::DATA1_A + cur));
         } else
             x.written = {T(rb::TMP1), P(rb::DATA1_A + cur)};
@@ -771,6 +774,8 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             x.read = {P(rb::DATA1_A + cur)};
             push_tap_planes(d, tb, rb::TAP_D_A, x.read);
             push_tap_planes(d, tb, rb::TAP_D_B, x.written);
+            for (uint32_t code : x.written) // Blur hands the guide part of its input texel on
+                x.prefix.push_back({code, P(rb::GUIDE_A + cur)});
         } else {
             x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
             x.written = {T(rb::TMP2)};
@@ -1443,6 +1448,12 @@ NRDHIP_API int nrdhip_dispatch_info_get(nrdhip_instance* inst, const uint32_t* i
         out->read_rows[i] = rows;
     }
     out->flags = x.allRows ? (uint32_t)NRDHIP_DISPATCH_ALL_ROWS : 0u;
+    for (uint32_t i = 0; i < 12; i++) {
+        out->written_prefix[i] = (uint32_t)NRDHIP_NO_PLANE;
+        for (auto& pf : x.prefix)
+            if (i < out->written_num && pf.first == out->written[i])
+                out->written_prefix[i] = pf.second;
+    }
     out->algorithmic_bytes_per_pixel = x.bpp;
     return 0;
 }

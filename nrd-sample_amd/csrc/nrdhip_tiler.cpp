@@ -34,6 +34,14 @@ namespace {
 
 struct Xfer { // rows of one pool plane: `rows` full-resolution rows next to each band edge, the `skip` nearest the edge already delivered
     uint32_t code, rows, skip;
+    uint32_t prefix = (uint32_t)NRDHIP_NO_PLANE; // tap-texel plane: the guide plane its texels start with (nrdhip_dispatch_info::written_prefix)
+};
+struct Staging { // the signal halves of the tap texels of some rows, packed: what travels instead of the rows themselves
+    const void* key;
+    bool send;
+    int peer;
+    void* ptr;
+    size_t bytes;
 };
 struct PlanEntry {
     std::vector<Xfer> now, later;
@@ -103,6 +111,7 @@ struct nrdhip_tiler {
     std::vector<uint32_t> planSig; // planes + reach of the dispatches the plan was built from (build_plan)
     uint64_t bytesSent = 0, splitDispatches = 0, exchanges = 0, deferredExchanges = 0;
     uint32_t reprojRows = 0; // rows of previous-frame state exchanged per surviving permanent plane (build_plan)
+    std::vector<Staging> staging;
     std::string error;
 };
 
@@ -144,17 +153,64 @@ struct Op {
     uint8_t* ptr;
     size_t bytes;
     int peer;
+    // tap-texel rows (Xfer::prefix): ptr / bytes are the staging buffer; the signal halves are gathered from `plane` before a send and
+    // scattered into it after a receive, which also puts the guide halves back from this rank's own guide plane
+    uint8_t* plane = nullptr;
+    const uint8_t* guide = nullptr;
+    uint32_t pitch = 0, gpitch = 0, width = 0, rows = 0;
 };
+
+// one thread per texel of a run of rows: the last 8 bytes of every 16-byte tap texel -> staging (pack), staging + the same pixel's 8-byte
+// guide texel -> the tap texel (unpack)
+__global__ void k_tap_pack(const uint8_t* plane, uint32_t pitch, uint32_t width, uint2* staging) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, r = blockIdx.y;
+    if (x < width)
+        staging[(size_t)r * width + x] = *reinterpret_cast<const uint2*>(plane + (size_t)r * pitch + (size_t)x * 16u + 8u);
+}
+__global__ void k_tap_unpack(uint8_t* plane, uint32_t pitch, const uint8_t* guide, uint32_t gpitch, uint32_t width, const uint2* staging) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, r = blockIdx.y;
+    if (x < width) {
+        const uint2 g = *reinterpret_cast<const uint2*>(guide + (size_t)r * gpitch + (size_t)x * 8u), v = staging[(size_t)r * width + x];
+        *reinterpret_cast<uint4*>(plane + (size_t)r * pitch + (size_t)x * 16u) = uint4{g.x, g.y, v.x, v.y};
+    }
+}
+
+void* staging_of(nrdhip_tiler& T, const void* key, bool send, int peer, size_t bytes) {
+    for (auto& st : T.staging)
+        if (st.key == key && st.send == send && st.peer == peer && st.bytes == bytes)
+            return st.ptr;
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, bytes) != hipSuccess)
+        return nullptr;
+    T.staging.push_back({key, send, peer, ptr, bytes});
+    return ptr;
+}
 
 // send / recv descriptors of one plane: the `rows` owned rows next to each band edge go to that neighbour's halo; `skip` of them
 // (nearest the edge) were delivered earlier. Order per peer is the same on both sides (NCCL matches sends and receives of a
 // group by order): [send, recv] toward the upper neighbour, then [send, recv] toward the lower one.
-void ops_of(nrdhip_tiler& T, uint8_t* base, uint32_t pitch, uint32_t planeRows, uint32_t div, uint32_t rows, uint32_t skip, std::vector<Op>& ops) {
+bool ops_of(nrdhip_tiler& T, uint8_t* base, uint32_t pitch, uint32_t planeRows, uint32_t div, uint32_t rows, uint32_t skip, std::vector<Op>& ops,
+            const uint8_t* guide = nullptr, uint32_t gpitch = 0, uint32_t width = 0) {
     const uint32_t hskip = skip / div, hrows = std::max<uint32_t>((rows + div - 1) / div, 1u);
     const uint32_t first = (uint32_t)T.ownFirst / div, n = std::max<uint32_t>((uint32_t)T.ownRows / div, 1u);
+    bool ok = true;
     auto push = [&](bool send, uint32_t a, uint32_t b, int peer) {
-        if (b > a)
+        if (b <= a)
+            return;
+        if (!guide) {
             ops.push_back({send, base + (size_t)a * pitch, (size_t)(b - a) * pitch, peer});
+            return;
+        }
+        Op o{send, nullptr, (size_t)(b - a) * width * 8u, peer};
+        o.plane = base + (size_t)a * pitch;
+        o.guide = guide + (size_t)a * gpitch;
+        o.pitch = pitch;
+        o.gpitch = gpitch;
+        o.width = width;
+        o.rows = b - a;
+        o.ptr = (uint8_t*)staging_of(T, o.plane, send, peer, o.bytes);
+        ok = ok && o.ptr;
+        ops.push_back(o);
     };
     if (T.rank > 0) {
         push(true, first + hskip, first + std::min(hrows, n), T.rank - 1);
@@ -164,6 +220,7 @@ void ops_of(nrdhip_tiler& T, uint8_t* base, uint32_t pitch, uint32_t planeRows, 
         push(true, first + n - std::min(hrows, n), first + n - std::min(hskip, n), T.rank + 1);
         push(false, std::min(first + n + hskip, planeRows), std::min(first + n + hrows, planeRows), T.rank + 1);
     }
+    return ok;
 }
 
 // run one batch of transfers on `stream` (RCCL: one group; custom transport: its callbacks in the same order)
@@ -171,8 +228,17 @@ int run_ops(nrdhip_tiler& T, const std::vector<Op>& ops, hipStream_t stream) {
     if (ops.empty())
         return 0;
     for (auto& o : ops)
-        if (o.send)
+        if (o.send) {
             T.bytesSent += o.bytes;
+            if (o.plane) // tap texels: gather the signal halves (same stream as the transfer, ahead of it)
+                hipLaunchKernelGGL(k_tap_pack, dim3((o.width + 255u) / 256u, o.rows, 1), dim3(256, 1, 1), 0, stream, (const uint8_t*)o.plane, o.pitch, o.width, (uint2*)o.ptr);
+        }
+    auto unpack = [&]() { // ... and behind it: received halves + this rank's guide texels -> the halo rows
+        for (auto& o : ops)
+            if (!o.send && o.plane)
+                hipLaunchKernelGGL(k_tap_unpack, dim3((o.width + 255u) / 256u, o.rows, 1), dim3(256, 1, 1), 0, stream, o.plane, o.pitch, o.guide, o.gpitch, o.width, (const uint2*)o.ptr);
+        return 0;
+    };
     if (T.custom) {
         if (T.tr.group_begin && T.tr.group_begin(T.tr.user) != 0)
             return fail(T, FAILURE, "transport group_begin failed");
@@ -183,7 +249,7 @@ int run_ops(nrdhip_tiler& T, const std::vector<Op>& ops, hipStream_t stream) {
         }
         if (T.tr.group_end && T.tr.group_end(T.tr.user, stream) != 0)
             return fail(T, FAILURE, "transport group_end failed");
-        return 0;
+        return unpack();
     }
     if (!T.comm)
         return fail(T, INVALID, "no transport: call nrdhip_tiler_rccl_init or pass callbacks to nrdhip_tiler_create");
@@ -198,16 +264,20 @@ int run_ops(nrdhip_tiler& T, const std::vector<Op>& ops, hipStream_t stream) {
         r = e;
     if (r != ncclSuccess)
         return fail(T, FAILURE, std::string("RCCL: ") + g_rccl.GetErrorString(r));
-    return 0;
+    return unpack();
 }
 
 int collect(nrdhip_tiler& T, const std::vector<Xfer>& list, std::vector<Op>& ops) {
     for (auto& x : list) {
-        nrdhip_plane_info P;
-        uint32_t div;
+        nrdhip_plane_info P, G{};
+        uint32_t div, gdiv = 1;
         if (!plane_of(T, x.code, P, div))
             return fail(T, INVALID, "pool plane of the exchange plan is not bound");
-        ops_of(T, (uint8_t*)P.ptr, P.pitch_bytes, P.height, div, x.rows, x.skip, ops);
+        const bool tap = x.prefix != (uint32_t)NRDHIP_NO_PLANE;
+        if (tap && (!plane_of(T, x.prefix, G, gdiv) || div != 1 || gdiv != 1 || P.bytes_per_texel != 16 || G.bytes_per_texel != 8 || G.height != P.height))
+            return fail(T, INVALID, "tap-texel plane and its guide plane do not match (16 / 8 bytes per texel, same rows)");
+        if (!ops_of(T, (uint8_t*)P.ptr, P.pitch_bytes, P.height, div, x.rows, x.skip, ops, tap ? (const uint8_t*)G.ptr : nullptr, G.pitch_bytes, P.width))
+            return fail(T, FAILURE, "staging buffer allocation failed");
     }
     return 0;
 }
@@ -231,6 +301,8 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
         sig.insert(sig.end(), d[i].read, d[i].read + d[i].read_num);
         sig.push_back(0xfffd0000u);
         sig.insert(sig.end(), d[i].read_rows, d[i].read_rows + d[i].read_num);
+        sig.push_back(0xfffc0000u);
+        sig.insert(sig.end(), d[i].written_prefix, d[i].written_prefix + d[i].written_num);
         if (d[i].halo_rows > T.halo)
             return fail(T, INVALID, std::string(d[i].name) + " reads " + std::to_string(d[i].halo_rows) + " rows beyond its band, the band stores " +
                                         std::to_string(T.halo) + ": recreate the bands with nrdhip_required_halo() rows");
@@ -285,9 +357,9 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
             // permanent planes that survive the frame: the next frame reprojects into them at motion-displaced rows (`reproj` rows, not the
             // whole halo), and nobody reads those rows before the next frame, so they travel deferred (minus what goes strips-first)
             if ((code >> 16) == 0 && !rewritten && rows < reproj)
-                T.plan[i].later.push_back({code, reproj, rows});
+                T.plan[i].later.push_back({code, reproj, rows, d[i].written_prefix[k]});
             if (rows > 0)
-                T.plan[i].now.push_back({code, rows, 0});
+                T.plan[i].now.push_back({code, rows, 0, d[i].written_prefix[k]});
         }
     T.planIds.assign(ids, ids + n);
     T.planSig = sig;
@@ -416,6 +488,8 @@ NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     for (hipEvent_t e : {T->evCompute, T->evComm, T->evDeferred})
         if (e)
             (void)hipEventDestroy(e);
+    for (auto& st : T->staging)
+        (void)hipFree(st.ptr);
     delete T;
 }
 

@@ -142,6 +142,19 @@ class BandHarness(Harness):
         return local_plane[L["own_first"]:L["own_first"] + L["own_rows"]]
 
 
+class _Exchange:
+    """the handles of one batch of sends / receives + what has to happen to the received rows once they are there"""
+
+    def __init__(self, works, post):
+        self.works, self.post = works, post
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for f in self.post:
+            f()
+
+
 class Tiler:
     """Steps a BandHarness dispatch by dispatch, exchanging halo rows after each one."""
 
@@ -153,6 +166,7 @@ class Tiler:
         self._p2p_cache = {}  # dispatch todo -> (P2POp list, bytes sent): pool planes never move, so the row slices are built once
         self._deferred = []   # exchanges of planes only the NEXT frame reads: in flight until the next dispatch list starts
         self._later_todo = []  # ... and their (plane, rows, skip) items while a dispatch list is still running
+        self._staging = {}     # tap-texel planes (nrdhip_dispatch_info.written_prefix): the signal halves of the rows that travel
 
     def _as_tensor(self, buf):
         import torch
@@ -182,7 +196,7 @@ class Tiler:
         return max(min(self.band.halo, motion + 2), 0)
 
     def _plan(self, ids, dispatches):
-        """for every dispatch: (now, later), two lists of (plane code, rows) over the pool planes it writes.
+        """for every dispatch: (now, later), two lists of (plane code, rows[, skip[, guide plane]]) over the pool planes it writes.
         now: boundary rows a LATER DISPATCH OF THIS FRAME reads - the largest reach INTO THAT PLANE (nrdhip_dispatch_info.read_rows: 0 for
         a read at the pixel's own position, the window for a 5x5 stencil, the tap reach for a gather) of the dispatches that read it
         before it is written again; these are exchanged strips-first and waited for before the next dispatch.
@@ -220,61 +234,99 @@ class Tiler:
                 if rows > self.band.halo:  # never clamp: a clamped reach is a silently different image
                     raise HaloError("a pass after %s reads %d rows beyond its band, the band stores %d: create the bands with "
                                     "halo=required_halo(dispatches, motion_rows) (probe_halo())" % (d["name"], rows, self.band.halo))
+                # a plane of tap texels {guide texel | signal} names the guide plane its texels start with (written_prefix): entry + (0, guide)
+                guide = d.get("written_prefix", {}).get(code)
                 if (code >> 16) == 0 and not rewritten and rows < reproj:
-                    later.append((code, reproj, rows))  # the `rows` nearest the band edge travel at once (below)
+                    later.append((code, reproj, rows) + (() if guide is None else (guide,)))  # the `rows` nearest the band edge travel at once (below)
                 if rows > 0:
-                    now.append((code, rows))
+                    now.append((code, rows) + (() if guide is None else (0, guide)))
             plan.append((now, later))
         self._plan_cache[key] = plan
         return plan
 
     def _ops(self, bufs_rows):
-        """send / recv descriptors for [(2-D byte tensor [local rows, pitch], rows-per-texel-row divisor, rows[, skip])]:
+        """send / recv descriptors for [(2-D byte tensor [local rows, pitch], rows-per-texel-row divisor, rows, skip[, guide tensor])]:
         the `rows` owned rows next to each band edge go to that neighbour's halo; `skip` = how many of them (nearest the edge)
-        an earlier exchange already delivered"""
+        an earlier exchange already delivered. Returns (ops, pre, post).
+        An item with a guide tensor is a plane of 16-byte tap texels {guide texel | signal} (written_prefix): only the signal half travels,
+        through a staging tensor - `pre` gathers the halves to send (run before the batch is enqueued), `post` scatters the received
+        halves into the halo rows and puts the guide half back from this rank's own guide plane (run after the wait)."""
         dist, b = self.dist, self.band
         L = b.layout
-        ops = []
-        for item in bufs_rows:
+        ops, pre, post = [], [], []
+        W = b.w
+
+        def texels(t, bpt):  # [rows, pitch] bytes -> [rows, W, bpt]
+            return t.unflatten(1, (t.shape[1] // bpt, bpt))[:, :W]
+
+        def send(t, a, z, peer, guide, key):
+            if z <= a:
+                return
+            if guide is None:
+                ops.append((dist.isend, t[a:z], peer))
+                return
+            st = self._stage(key, (z - a, W, 8), t)
+            src = texels(t[a:z], 16)[:, :, 8:16]
+            pre.append(lambda: st.copy_(src))
+            ops.append((dist.isend, st, peer))
+
+        def recv(t, a, z, peer, guide, key):
+            if z <= a:
+                return
+            if guide is None:
+                ops.append((dist.irecv, t[a:z], peer))
+                return
+            st = self._stage(key, (z - a, W, 8), t)
+            dst, g = texels(t[a:z], 16), texels(guide[a:z], 8)
+
+            def scatter():
+                dst[:, :, 8:16] = st
+                dst[:, :, 0:8] = g
+            post.append(scatter)
+            ops.append((dist.irecv, st, peer))
+
+        for n_item, item in enumerate(bufs_rows):
             t, div, rows = item[:3]
             hskip = (item[3] // div) if len(item) > 3 else 0
+            guide = item[4] if len(item) > 4 else None
             hrows = max((rows + div - 1) // div, 1)
             first, n = L["own_first"] // div, max(L["own_rows"] // div, 1)
             total = t.shape[0]
+            key = (t.data_ptr(), rows, hskip)
             if b.rank > 0:  # upper neighbour: send my first owned rows, receive into my top halo
-                send = t[first + hskip:first + min(hrows, n)]
-                top = first - min(hrows, first)
-                recv = t[top:first - hskip]
-                if send.shape[0] > 0:
-                    ops.append((dist.isend, send, b.rank - 1))
-                if recv.shape[0] > 0:
-                    ops.append((dist.irecv, recv, b.rank - 1))
+                send(t, first + hskip, first + min(hrows, n), b.rank - 1, guide, key + ("su",))
+                recv(t, first - min(hrows, first), first - hskip, b.rank - 1, guide, key + ("ru",))
             if b.rank < b.world - 1:  # lower neighbour
-                send = t[first + n - min(hrows, n):first + n - hskip]
-                bot = min(first + n + hrows, total)
-                recv = t[first + n + hskip:bot]
-                if send.shape[0] > 0:
-                    ops.append((dist.isend, send, b.rank + 1))
-                if recv.shape[0] > 0:
-                    ops.append((dist.irecv, recv, b.rank + 1))
-        return ops
+                send(t, first + n - min(hrows, n), first + n - hskip, b.rank + 1, guide, key + ("sd",))
+                recv(t, first + n + hskip, min(first + n + hrows, total), b.rank + 1, guide, key + ("rd",))
+        return ops, pre, post
+
+    def _stage(self, key, shape, like):
+        import torch
+
+        st = self._staging.get(key)
+        if st is None or tuple(st.shape) != tuple(shape):
+            st = self._staging[key] = torch.empty(shape, dtype=torch.uint8, device=like.device)
+        return st
 
     def exchange_start(self, bufs_rows):
         """enqueue the exchange (RCCL: on the communicator's stream, ordered after the work already on the current stream);
         returns the handles to wait on"""
-        ops = self._ops(bufs_rows)
+        ops, pre, post = self._ops(bufs_rows)
         if not ops:
             return []
         dist = self.dist
         for fn, ten, _ in ops:
             if fn is dist.isend:
                 self.bytes_exchanged += ten.numel() * ten.element_size()
+        for f in pre:
+            f()
         if ops[0][1].is_cuda and dist.get_backend(self.group) != "nccl":
             # only RCCL orders itself after the work already enqueued on the current stream; any other backend (gloo in the
             # tests) must see finished rows
             import torch
             torch.cuda.current_stream().synchronize()
-        return dist.batch_isend_irecv([dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops])
+        return [_Exchange(dist.batch_isend_irecv([dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops]), post)]
 
     def exchange(self, bufs_rows):
         """blocking exchange of the full halo of [(tensor, divisor)] planes (external inputs)"""
@@ -298,27 +350,33 @@ class Tiler:
         hit = self._p2p_cache.get(key)
         if hit is None:
             dist = self.dist
-            ops = self._ops(self.items_of(todo))
+            ops, pre, post = self._ops(self.items_of(todo))
             sent = sum(ten.numel() * ten.element_size() for fn, ten, _ in ops if fn is dist.isend)
             hit = ([dist.P2POp(fn, ten, peer, self.group) for fn, ten, peer in ops], sent,
-                   bool(ops) and ops[0][1].is_cuda and dist.get_backend(self.group) != "nccl")
+                   bool(ops) and ops[0][1].is_cuda and dist.get_backend(self.group) != "nccl", pre, post)
             self._p2p_cache[key] = hit
-        p2p, sent, host_sync = hit
+        p2p, sent, host_sync, pre, post = hit
         if not p2p:
             return []
         self.bytes_exchanged += sent
+        for f in pre:
+            f()
         if host_sync:  # see exchange_start
             import torch
             torch.cuda.current_stream().synchronize()
-        return self.dist.batch_isend_irecv(p2p)
+        return [_Exchange(self.dist.batch_isend_irecv(p2p), post)]
 
     def items_of(self, todo):
         local_h = self.band.layout["local_h"]
         items = []
-        for code, rows, *skip in todo:
+        for code, rows, *rest in todo:  # rest: [skip[, guide plane]]
             p = self._plane_of(code)
             div = 1 if p["height"] == local_h else 16  # pool planes: full resolution, or one texel per 16x16 tile
-            items.append((self._as_tensor(p["buf"]), div, rows, *skip))
+            item = (self._as_tensor(p["buf"]), div, rows, rest[0] if rest else 0)
+            g = rest[1] if len(rest) > 1 else None
+            if g is not None:  # tap texels: the guide half stays at home
+                item += (self._as_tensor(self._plane_of(g)["buf"]),)
+            items.append(item)
         return items
 
     def finish(self):
@@ -441,7 +499,16 @@ class NativeTiler:
                     import torch
                     view = torch.from_numpy(view)
                 return view
-        raise KeyError("transfer range is not inside a plane owned by this process")
+        # not a plane: a staging buffer the C++ tiler allocated itself (the packed signal halves of tap-texel rows)
+        import torch
+
+        if self.band.backend.is_device:
+            class _Raw:  # a raw device range as the CUDA array interface describes it
+                __cuda_array_interface__ = dict(shape=(nbytes,), typestr="|u1", data=(ptr, False), version=2)
+            return torch.as_tensor(_Raw(), device=self.band.backend.device)
+        import ctypes as C
+
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
 
     def _begin(self, user):
         self._works, self._keep = [], []

@@ -438,6 +438,12 @@ NRDHIP_API int orc_dispatch_info_get(nrdhip_instance* inst, const uint32_t* ids,
         out->read_rows[i] = rows;
     }
     out->flags = p.allRows ? (uint32_t)NRDHIP_DISPATCH_ALL_ROWS : 0u;
+    for (uint32_t i = 0; i < 12; i++) {
+        out->written_prefix[i] = (uint32_t)NRDHIP_NO_PLANE;
+        for (auto& pf : p.prefix)
+            if (i < out->written_num && pf.first == out->written[i])
+                out->written_prefix[i] = pf.second;
+    }
     out->algorithmic_bytes_per_pixel = p.bytesPerPixel;
     return 0;
 }

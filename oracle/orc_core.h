@@ -237,6 +237,7 @@ struct Pass {
     std::vector<uint32_t> own, reprojected;
     std::vector<std::pair<uint32_t, uint16_t>> reach;
     bool allRows = false;
+    std::vector<std::pair<uint32_t, uint32_t>> prefix; // nrdhip_dispatch_info::written_prefix: {written tap-texel plane, the guide plane its texels start with}
 };
 
 struct DenoiserState {

@@ -1656,6 +1656,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.reach = {{P(P_FAST_A + cur), (uint16_t)2}}; // the 5x5 clamping window; the reconstruction taps read guide, signal and speeds
         if (tap) {
             push_tap_planes(d, tb, T_TAP_D_A, p.written);
+            for (uint32_t code : p.written) // the tap texels start with the pixel's guide texel as it is
+                p.prefix.push_back({code, P(P_GUIDE_A + cur)});
             p.written.push_back(P(P_DATA1_A + cur));
         } else
             p.written = {T(T_TMP1), P(P_DATA1_A + cur)};
@@ -1673,6 +1675,8 @@ void reblur_build(Instance& I, DenoiserState& d) {
             p.read = {P(P_DATA1_A + cur)};
             push_tap_planes(d, tb, T_TAP_D_A, p.read);
             push_tap_planes(d, tb, T_TAP_D_B, p.written);
+            for (uint32_t code : p.written) // Blur hands the guide part of its input texel on
+                p.prefix.push_back({code, P(P_GUIDE_A + cur)});
         } else {
             p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
             p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};

@@ -1,6 +1,6 @@
 """The two build flavours of the library (csrc/nrd_device.h, oracle/orc_math.h NRD_UPSTREAM_FORMULAS). The DEFAULT (libnrdhip.so,
 liboracle.so; since round 4) carries the recalled upstream forms of ledger rows 1, 2, 7, 13 (oracle/README.md): hit-distance weight
-exp(-3 |x|), normal weight on the angle (arccosine), Blur rotation per pixel, RELAX in linear RGB from input to output. The FROZEN flavour
+exp(-3 |x|), normal weight on the angle (upstream's AcosApprox: the chord of the two normals), Blur rotation per pixel, RELAX in linear RGB from input to output. The FROZEN flavour
 (libnrdhip_frozen.so, liboracle_frozen.so: -DNRD_UPSTREAM_FORMULAS=0) keeps the cheaper forms rounds 1-3 shipped: (1 - |x|)^2, squared
 angle, rotation per 2x2 quad, YCoCg inside RELAX. Same sources; every test of the suite that takes `oracle` / `emulated` / `hip` runs the
 default flavour - here the frozen one is held to ITS oracle just as exactly, and the distance between the two is put on record

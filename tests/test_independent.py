@@ -75,8 +75,8 @@ def test_reference_accumulation_independent(pkg, api, oracle):
 @pytest.mark.parametrize("flavour", ["default", "frozen"])
 @pytest.mark.parametrize("f", [0, 2])
 def test_guide_and_prepass_independent(request, pkg, api, f, flavour):
-    """both build flavours: the default (hit-distance weight exp(-3|x|), normal weight on the arccosine of the angle - the restatement
-    takes exact exp / arccos where the oracle evaluates its polynomials) and the frozen one ((1 - |x|)^2, squared angle)"""
+    """both build flavours: the default (hit-distance weight exp(-3|x|), normal weight on the angle as upstream's AcosApprox takes it, the chord - the
+    restatement takes exact exp / sqrt where the oracle evaluates a polynomial / a Newton iteration) and the frozen one ((1 - |x|)^2, squared angle)"""
     upstream = flavour == "default"
     fr, cs, st, tmp1, track, guide = oracle_prepass(pkg, api, request.getfixturevalue("oracle" if upstream else "oracle_frozen"), f)
     # guide texel {viewZ 22 bit | roughness code, normal 3 x 10 bit | materialID}: depth word and material exact; a normal code may sit

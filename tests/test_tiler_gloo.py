@@ -78,12 +78,13 @@ def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
         deferred = set()
         for i, (now, later) in enumerate(plan):
             assert not (disp[i]["all_rows"] and (now or later)), disp[i]["name"]
-            for code, rows in now:
+            for code, rows, *guide in now:  # (a plane of tap texels carries (0, its guide plane) on top: only the signal half travels)
                 readers = [r for r in disp[i + 1:] if code in r["read"]]
                 assert 0 < rows <= max(r["halo_rows"] for r in readers) <= band.halo, (disp[i]["name"], code, rows)
-            for code, rows, skip in later:
-                assert code >> 16 == 0 and rows == reproj and code in disp[i]["written"]
-                assert skip == dict(now).get(code, 0) < rows  # the rows nearest the edge are not sent twice
+                assert guide == ([0, disp[i]["written_prefix"][code]] if code in disp[i]["written_prefix"] else [])
+            for code, rows, skip, *guide in later:
+                assert code >> 16 == 0 and rows == reproj and code in disp[i]["written"] and not guide
+                assert skip == {e[0]: e[1] for e in now}.get(code, 0) < rows  # the rows nearest the edge are not sent twice
                 deferred.add(code)
         assert plan[-1][0] == []  # nothing after the last dispatch reads its outputs this frame: no strips, no wait
         assert disp[0]["all_rows"] and disp[0]["name"].endswith("ClassifyTiles")
@@ -100,7 +101,9 @@ def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
 def test_exchange_volume_of_the_headline_frame(pkg, api, oracle):
     """bytes per pixel column a band of REBLUR_DIFFUSE_SPECULAR sends to ONE neighbour per frame, plane by plane, from
     the plan - DESIGN.md 7's table. Round 3: 6728 (guide 640, hit tracker 4, Tmp2 480, fast history 320, speeds (tmp) 60, Data2 8, tap
-    texels A 1184 and B 2272, speeds 160, history 1280, stabilized luma 320)."""
+    texels A 1184 and B 2272, speeds 160, history 1280, stabilized luma 320). Round 4: per-plane reach, no guide exchange, previous-frame
+    state over the motion allowance only (4282), then the tap texels' signal half only (their guide half is rebuilt from the receiver's
+    own guide plane): 2554."""
     from nrd_sample_amd import tiler
 
     D = api.Denoiser
@@ -110,20 +113,23 @@ def test_exchange_volume_of_the_headline_frame(pkg, api, oracle):
     disp = band.nrd.dispatches([int(den)])
     assert band.halo == 80 and t.reprojection_rows(disp) == 11
     per_plane = {}
-    for now, later in t._plan([int(den)], disp):
-        for code, rows in now:
+    plan = t._plan([int(den)], disp)
+    guides = []
+    for now, later in plan:
+        for code, rows, *rest in now + later:  # rest: [skip[, guide plane]]; tap texels {guide | signal}: the signal half only (written_prefix)
             p = t._plane_of(code)
-            per_plane[p["name"]] = per_plane.get(p["name"], 0) + rows * p["bpt"]
-        for code, rows, skip in later:
-            p = t._plane_of(code)
-            per_plane[p["name"]] = per_plane.get(p["name"], 0) + (rows - skip) * p["bpt"]
+            skip, guide = (rest + [0])[0], (rest + [None, None])[1]
+            guides += [] if guide is None else [(p["name"], t._plane_of(guide)["name"])]
+            per_plane[p["name"]] = per_plane.get(p["name"], 0) + (rows - skip) * (p["bpt"] if guide is None else 8)
     short = {k.split("::")[1]: v for k, v in per_plane.items()}
     fast = [k for k in short if k.startswith("FastHistory")][0]
     stab = [k for k in short if k.startswith("StabilizedLuma")][0]
     data1 = [k for k in short if k.startswith("Data1_") and k != "Data1_Tmp"][0]
-    assert short == {"Tmp2": 30 * 16, fast: 11 * 4, "Data1_Tmp": 30 * 2, "Tap_Diff_A": 37 * 16, "Tap_Spec_A": 37 * 16, data1: 11 * 2,
-                     "Tap_Diff_B": 71 * 16, "Tap_Spec_B": 71 * 16, "History": 11 * 16, stab: 11 * 4}, short
-    assert sum(short.values()) == 4282  # 36 % less than round 3's 6728; x 7680 columns = 32.9 MB per neighbour and frame at 8K
+    assert len(guides) == 4 and len({g for _, g in guides}) == 1 and guides[0][1].split("::")[1].startswith("Guide")  # the four tap planes start with the current guide
+    assert short == {"Tmp2": 30 * 16, fast: 11 * 4, "Data1_Tmp": 30 * 2, "Tap_Diff_A": 37 * 8, "Tap_Spec_A": 37 * 8, data1: 11 * 2,
+                     "Tap_Diff_B": 71 * 8, "Tap_Spec_B": 71 * 8, "History": 11 * 16, stab: 11 * 4}, short
+    # 62 % less than round 3's 6728 (round 4 first: 4282 with whole tap texels); x 7680 columns = 19.6 MB per neighbour and frame at 8K
+    assert sum(short.values()) == 2554
 
 
 def test_row_tiling_emulated_kernels_bit_identical(tmp_path, pkg, api, oracle, emulated):
