@@ -235,12 +235,20 @@ def hash_px_arr(x, y, frame, salt):
 MIN_CONVERGED_RADIUS_SCALE, POST_BLUR_RADIUS_SCALE = 0.25, 2.0
 
 
-def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_view, frame_index, denoising_range, s):
+def normal_weight(cosa, normal_w, upstream):
+    """frozen flavour: on the squared angle; default (upstream) flavour: on the angle as Math::AcosApprox takes it, sqrt(2 (1 - cos))"""
+    if upstream:
+        return smoothstep01(1.0 - np.sqrt(2.0 * np.clip(1.0 - cosa, 0, 1)) * normal_w)
+    return smoothstep01(1.0 - 2.0 * np.clip(1.0 - cosa, 0, 1) * normal_w * normal_w)
+
+
+def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_view, frame_index, denoising_range, s, upstream=False):
     """REBLUR_DIFFUSE_SPECULAR Blur (post = False) / PostBlur (post = True) of one frame on tap texels: `sig_in` [H, W, 2, 4] fp16 = the
     signal halves of the tap texels the pass gathers (HistoryFix's for Blur, Blur's for PostBlur), `speeds` [H, W] uint16 = Data1 (diffuse
     | specular accumulation speed in quarter frames). Differences from the PrePass: the radius comes from the accumulation speed
     (converged pixels blur less, PostBlur twice as far), the normal-weight lobe narrows with it, Blur rotates its disk per 2x2 pixel
-    quad (PostBlur per frame), a rejected tap enters with weight 0, no hit-distance tracking. Returns [H, W, 2, 4] fp16."""
+    quad (PostBlur per frame), a rejected tap enters with weight 0, no hit-distance tracking. Returns [H, W, 2, 4] fp16.
+    upstream = True: the DEFAULT build flavour - Blur rotates per PIXEL, hit-distance weight exp(-3 |x|), normal weight on the chord."""
     H, W = viewz.shape
     M = np.asarray(view_to_clip, np.float64)
     sgn = 1.0 if M[11] > 0 else -1.0
@@ -270,7 +278,8 @@ def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_vie
     if post:  # one rotation per frame (salt 3)
         k = np.full((H, W), hash_px(0, 0, frame_index, 3) & 63, np.int64)
     else:     # one rotation per 2x2 pixel quad (salt 2)
-        k = (hash_px_arr(xx >> 1, yy >> 1, frame_index, 2) & np.uint64(63)).astype(np.int64)
+        sh = 0 if upstream else 1
+        k = (hash_px_arr(xx >> sh, yy >> sh, frame_index, 2) & np.uint64(63)).astype(np.int64)
     ang = 2.0 * np.pi * np.arange(64) / 64.0
     rot_c, rot_s = np.cos(ang).astype(np.float32).astype(np.float64)[k], np.sin(ang).astype(np.float32).astype(np.float64)[k]
     reach = int((s["maxBlurRadius"] + s["minBlurRadius"]) * (2.2 if post else 1.1)) + 3
@@ -324,11 +333,11 @@ def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_vie
             sv = plane[py, px].astype(np.float64)
             valid = in_win & active & ~sky[py, px] & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
             w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
-            w = w * smoothstep01(1.0 - 2.0 * np.clip(1.0 - normal_cos(n, ns), 0, 1) * normal_w * normal_w)
+            w = w * normal_weight(normal_cos(n, ns), normal_w, upstream)
             if is_spec:
                 w = w * smoothstep01(1.0 - np.abs(rs_ * roughA + roughB))
             ax = np.abs(sv[..., 3] * hitA + hitB)
-            w = w * (s["minHitDistanceWeight"] + (1.0 - s["minHitDistanceWeight"]) * np.clip(1.0 - ax, 0, 1) ** 2)
+            w = w * (s["minHitDistanceWeight"] + (1.0 - s["minHitDistanceWeight"]) * (np.exp(-3.0 * ax) if upstream else np.clip(1.0 - ax, 0, 1) ** 2))
             w = np.where(valid, w, 0.0)
             acc = acc + np.where(valid[..., None], sv, 0.0) * w[..., None]
             wsum = wsum + w

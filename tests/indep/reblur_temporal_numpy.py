@@ -263,7 +263,7 @@ def pack_tap_guide(viewz, packed_nr, denoising_range=None):
     return sp.guide_words(viewz, packed_nr, denoising_range=denoising_range)
 
 
-def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr):
+def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=False):
     """returns signal [H, W, 2, 4] fp16 (what goes into the tap texels), speeds uint16, tap guide words (w0, w1)"""
     H, W = c.H, c.W
     z, n, rough_g, mat = gcur
@@ -299,7 +299,7 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr):
                 ok = fix & inside & (np.abs(zs) <= c.range) & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
                 w = 1.0 / (1.0 + i * i + j * j)
                 w = w * sp.smoothstep01(1.0 - np.abs(zs * (pg["gax"] * px + pg["gay"] * py + pg["ga0"]) + pg["geoB"]))
-                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - sp.normal_cos(n, n[cy, cx]), 0, 1) * normal_w * normal_w)
+                w = w * sp.normal_weight(sp.normal_cos(n, n[cy, cx]), normal_w, upstream)  # (upstream: the default build flavour's form)
                 if is_spec:
                     w = w * sp.smoothstep01(1.0 - np.abs(rough_g[cy, cx] * roughA - rough * roughA))
                 tA = (As if is_spec else Ad)[cy, cx]

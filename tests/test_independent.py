@@ -159,8 +159,13 @@ def agree(name, got, want, min_frac, mask=None):
     return frac
 
 
-@pytest.mark.parametrize("f", [1, 2, 3])
-def test_temporal_passes_independent(pkg, api, oracle_frozen, f):
+@pytest.mark.parametrize("f,flavour", [(1, "frozen"), (2, "frozen"), (3, "frozen"), (2, "default"), (3, "default")])
+def test_temporal_passes_independent(request, pkg, api, f, flavour):
+    """every pass of the REBLUR_DIFFUSE_SPECULAR frame behind the PrePass against its numpy / float64 restatement, each fed the planes the
+    oracle fed its own pass - in BOTH build flavours: the weights of HistoryFix's reconstruction, Blur and PostBlur are the ones that differ
+    (normal weight on the chord, hit-distance weight exp(-3|x|), Blur rotation per pixel in the default build)"""
+    upstream = flavour == "default"
+    oracle_frozen = request.getfixturevalue("oracle" if upstream else "oracle_frozen")
     D = api.Denoiser
     den = int(D.REBLUR_DIFFUSE_SPECULAR)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
@@ -212,7 +217,7 @@ def test_temporal_passes_independent(pkg, api, oracle_frozen, f):
     hz.nrd.denoise_range([den], 3, 1)
     taps = [hz.pool("REBLUR::Tap_%s_A" % k).copy().view(np.uint32).reshape(H, W, 4) for k in ("Diff", "Spec")]
     speeds_cur = hz.pool("REBLUR::Data1" + cur).copy().view(np.uint16).reshape(H, W)
-    w_sig, w_speeds_cur, (w0, w1) = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast, fr["viewz"], fr["normal_roughness"])
+    w_sig, w_speeds_cur, (w0, w1) = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast, fr["viewz"], fr["normal_roughness"], upstream=upstream)
     for k in range(2):
         got = np.ascontiguousarray(taps[k][..., 2:4]).view(np.float16).reshape(H, W, 4)
         agree("HistoryFix signal %d" % k, got, w_sig[:, :, k], 0.99)
@@ -228,13 +233,13 @@ def test_temporal_passes_independent(pkg, api, oracle_frozen, f):
     hz.nrd.denoise_range([den], 4, 1)
     taps_b = [hz.pool("REBLUR::Tap_%s_B" % k).copy().view(np.uint32).reshape(H, W, 4) for k in ("Diff", "Spec")]
     w_blur = ind.blur_pass(False, fr["viewz"], fr["normal_roughness"], tap_signal(taps), speeds_cur, fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
-                           cs.denoisingRange, sb)
+                           cs.denoisingRange, sb, upstream=upstream)
     agree("Blur", tap_signal(taps_b), w_blur, 0.995, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)))
     for k in range(2):  # the guide part travels through Blur untouched
         assert np.array_equal(taps_b[k][..., :2], taps[k][..., :2])
     hz.nrd.denoise_range([den], 5, 1)
     w_post = ind.blur_pass(True, fr["viewz"], fr["normal_roughness"], tap_signal(taps_b), speeds_cur, fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
-                           cs.denoisingRange, sb)
+                           cs.denoisingRange, sb, upstream=upstream)
     agree("PostBlur", rad("REBLUR::History"), w_post, 0.995, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)))
 
     # ---- TemporalStabilization (fed with the ORACLE's PostBlur output)
