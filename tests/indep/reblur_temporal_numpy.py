@@ -387,11 +387,14 @@ def temporal_stabilization(c, s, gcur, mv, hist, speeds, data2, stab_prev, hit_t
 # =====================================================================================================================
 # RELAX: one variance-guided A-trous iteration (3x3 taps at stride 2^it), iteration 0 and the middle iterations
 # =====================================================================================================================
-def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=None):
+def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=None, upstream=False):
     """plane_in [H, W, 2, 4] fp16: iteration 0 = History {Y, Co, Cg, hitT}, later = {Y, Co, Cg, variance}; moments [H, W, 2] fp16
     (second luma moment, iteration 0 only); data2 uint32 (reprojection confidence of the specular history in bits 16..23).
-    Returns the ping-pong texel {Y, Co, Cg, variance} as fp16"""
+    Returns the ping-pong texel {Y, Co, Cg, variance} as fp16.
+    upstream = True: the DEFAULT build flavour - the texels are linear {r, g, b, .} and a luminance is Rec.709 of them, the luminance weight
+    is exp(-3 x), the normal weight sits on the chord of the two normals"""
     H, W = c.H, c.W
+    luma = (lambda v: 0.2126 * v[..., 0] + 0.7152 * v[..., 1] + 0.0722 * v[..., 2]) if upstream else (lambda v: v[..., 0])
     z, n, rough_g, mat = gcur
     sky = ~(np.abs(z) <= c.range)
     yy, xx = np.mgrid[0:H, 0:W]
@@ -403,7 +406,7 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
     out = np.zeros((H, W, 2, 4))
 
     def variance0(sig):
-        Y = pin[:, :, sig, 0]
+        Y = luma(pin[:, :, sig])
         var = np.maximum(moments.astype(np.float64)[..., sig] - Y * Y, 0.0)
         A = As if sig == 1 else Ad
         sy, sy2, cnt = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W))
@@ -427,7 +430,7 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
         var = variance0(sig) if it == 0 else c0[..., 3]
         # what a TAP contributes as its variance: its texel's variance channel; in iteration 0 the tap's temporal variance alone (the
         # spatial estimate and the specular boost belong to the centre pixel)
-        var_all = np.maximum(moments.astype(np.float64)[..., sig] - c0[..., 0] ** 2, 0.0) if it == 0 else var
+        var_all = np.maximum(moments.astype(np.float64)[..., sig] - luma(c0) ** 2, 0.0) if it == 0 else var
         sigma = np.sqrt(var)
         phi = s["specularPhiLuminance"] if is_spec else s["diffusePhiLuminance"]
         min_lw = s["specularMinLuminanceWeight"] if is_spec else s["diffuseMinLuminanceWeight"]
@@ -456,11 +459,12 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
                 sv = pin[cy, cx, sig]
                 w = 0.5 if (i == 0 or j == 0) else 0.25
                 w = w * sp.smoothstep01(1.0 - np.abs(zs * (pg["gax"] * px + pg["gay"] * py + pg["ga0"]) + pg["geoB"]))
-                w = w * sp.smoothstep01(1.0 - 2.0 * np.clip(1.0 - sp.normal_cos(n, n[cy, cx]), 0, 1) * normal_w * normal_w)
+                w = w * sp.normal_weight(sp.normal_cos(n, n[cy, cx]), normal_w, upstream)
                 if is_spec and s["enableRoughnessEdgeStopping"]:
                     rw = sp.smoothstep01(1.0 - np.abs(rough_g[cy, cx] * roughA - rough * roughA))
                     w = w * ((1.0 + (rw - 1.0) * rough_relax) if relax_edges else rw)
-                w = w * np.maximum(np.clip(1.0 - np.abs(sv[..., 0] - c0[..., 0]) * inv_l, 0, 1) ** 2, min_lw)
+                dl = np.abs(luma(sv) - luma(c0)) * inv_l
+                w = w * np.maximum(np.exp(-3.0 * dl) if upstream else np.clip(1.0 - dl, 0, 1) ** 2, min_lw)
                 w = np.where(ok, w, 0.0)
                 acc = acc + sv[..., :3] * w[..., None]
                 acc_var = acc_var + var_all[cy, cx] * w * w

@@ -252,10 +252,13 @@ def test_temporal_passes_independent(request, pkg, api, f, flavour):
     agree("TS stabilized luma", stab, w_stab, 0.99)
 
 
-@pytest.mark.parametrize("f", [1, 3])
-def test_relax_atrous_iterations_independent(pkg, api, oracle_frozen, f):
+@pytest.mark.parametrize("f,flavour", [(1, "frozen"), (3, "frozen"), (1, "default"), (3, "default")])
+def test_relax_atrous_iterations_independent(request, pkg, api, f, flavour):
     """one variance-guided A-trous iteration of RELAX_DIFFUSE_SPECULAR, twice: iteration 0 (variance from the accumulated moments +
-    the 3x3 spatial estimate of short histories, stride 1) and iteration 1 (stride 2, variance carried in the texel)"""
+    the 3x3 spatial estimate of short histories, stride 1) and iteration 1 (stride 2, variance carried in the texel) - both build flavours
+    (default: linear RGB texels, Rec.709 luminance, exp(-3 x) luminance weight, normal weight on the chord)"""
+    upstream = flavour == "default"
+    oracle_frozen = request.getfixturevalue("oracle" if upstream else "oracle_frozen")
     D = api.Denoiser
     den = int(D.RELAX_DIFFUSE_SPECULAR)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
@@ -287,19 +290,19 @@ def test_relax_atrous_iterations_independent(pkg, api, oracle_frozen, f):
     data2 = hz.pool("RELAX::Data2").copy().view(np.uint32).reshape(H, W)
     hz.nrd.denoise_range([den], 4, 1)
     a0 = rad("RELAX::Atrous_A")
-    agree("A-trous iteration 0", a0, tmp.atrous_iteration(c, s, gcur, hist, 0, speeds, moments, data2), 0.99)
+    agree("A-trous iteration 0", a0, tmp.atrous_iteration(c, s, gcur, hist, 0, speeds, moments, data2, upstream=upstream), 0.99)
     hz.nrd.denoise_range([den], 5, 1)
-    agree("A-trous iteration 1", rad("RELAX::Atrous_B"), tmp.atrous_iteration(c, s, gcur, a0, 1, data2=data2), 0.99)
+    agree("A-trous iteration 1", rad("RELAX::Atrous_B"), tmp.atrous_iteration(c, s, gcur, a0, 1, data2=data2, upstream=upstream), 0.99)
 
 
 @pytest.mark.parametrize("f", [1, 2, 3])
-def test_sigma_passes_independent(pkg, api, oracle_frozen, f):
+def test_sigma_passes_independent(pkg, api, oracle, f):
     """SIGMA_SHADOW_TRANSLUCENCY: Blur, PostBlur (penumbra-sized tangent-plane blur of the visibility) and TemporalStabilization
     (reprojection with occlusion test, per-channel 5x5 moment clamp, sqrt-encoded RGBA8 history)"""
     D = api.Denoiser
     den = int(D.SIGMA_SHADOW_TRANSLUCENCY)
     scene = pkg.synth.Scene(W, H, dolly=0.03)
-    hz = pkg.harness.Harness(oracle_frozen, [D.SIGMA_SHADOW_TRANSLUCENCY], W, H)
+    hz = pkg.harness.Harness(oracle, [D.SIGMA_SHADOW_TRANSLUCENCY], W, H)
     st = api.SigmaSettings(lightDirection=list(scene.sun))
     s = dict(planeDistanceSensitivity=st.planeDistanceSensitivity, maxStabilizedFrameNum=st.maxStabilizedFrameNum)
     for g in range(f):
