@@ -241,53 +241,64 @@ constexpr int BLUR_ROTATION_SHIFT = UPSTREAM_FORMULAS ? 0 : 1; // Blur's Poisson
 // the library is not vendored in the sample) - the CHORD |n_a - n_b| of the two unit vectors, within 1 % of the arc below 28 degrees and
 // 10 % short of it at 90. On guide normals the chord is (2 / 1023) sqrt(d2) with d2 the squared distance of the 10-bit codes
 // (normal_dist2 below), so a tap pays one square root and nothing else: the A&S 4.4.45 arccosine polynomial the first default-flavour
-// build evaluated here (6 more instructions per tap) was FARTHER from upstream than this. The square root takes TWO Newton steps
-// (relative error 4.7e-6): this runs once per tap of every spatial pass and the passes are priced in instructions
-// (profiles/r04_valu_issue.txt)
-NRD_DEV float sqrt2_(float x) {
-    const float h = 0.5f * x;
-    float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
-    r = r * fma_(-(h * r), r, 1.5f);
-    r = r * fma_(-(h * r), r, 1.5f);
-    return x * r; // sqrt2_(0) = 0
+// build evaluated here (6 more instructions per tap) was FARTHER from upstream than this.
+// The square root: magic seed + ONE Newton step with tuned constants (J. Kadlec's 0x5F1FFFF9 / 0.703952253 / 2.38924456 variant of
+// the classic sequence): relative error <= 6.5e-4 over every possible d2 (all 3 x 1023^2 integers checked, tests/test_oracle_math.py).
+// That is as fine as its argument deserves - d2 counts quantisation steps of 2 / 1023, a chord of 0.02 (the narrowest lobe) is d2 ~ 100,
+// known to +-5 % - and it runs once per tap of every spatial pass, which are priced in instructions (profiles/r04_valu_issue.txt): 6
+// instructions where the two-step version took 11. Returns sqrt(x) / SQRT1_SCALE: the scale goes into the per-pixel weight parameter.
+constexpr float SQRT1_SCALE = 0.703952253f;
+NRD_DEV float sqrt1_unscaled_(float x) {
+    const float y = u2f(0x5F1FFFF9u - (f2u(x) >> 1));
+    const float u = x * y;
+    return u * fma_(-u, y, 2.38924456f); // sqrt1_unscaled_(0) = 0
 }
-// 2^x for x <= 0 (the hit-distance weight's exponent): round-to-nearest split, a DEGREE-4 minimax polynomial on [-0.5, 0.5] (relative
-// error 3.7e-6 - the weight multiplies fp16 signals, 2^-11 - where exp2_poly's degree 6 reaches 1.1e-7: two fma less per signal and tap),
-// the power of two applied by v_ldexp_f32
+constexpr float NORMAL_CHORD_SCALE = (2.0f / 1023.0f) * SQRT1_SCALE; // chord of two guide normals = NORMAL_CHORD_SCALE * sqrt1_unscaled_(d2)
+// 2^x for x <= 0 (the hit-distance weight's exponent): round-to-nearest-even split (v_rndne_f32), a DEGREE-3 minimax polynomial on
+// [-0.5, 0.5] (relative error 8.0e-5, a sixth of an fp16 ULP of the signals the weight multiplies; exp2_poly's degree 6 reaches 1.1e-7:
+// three fma less per tap), the power of two applied by v_ldexp_f32
 NRD_DEV float exp2_poly_neg(float x) {
     x = fmax2(x, -126.0f);
     const float fi = __builtin_rintf(x); // v_rndne_f32 (ties to even: f = +-0.5 is inside the fit either way)
     const float f = x - fi;
-    float p = 9.676037356257439e-3f;
-    p = fma_(p, f, 5.592203512787819e-2f);
-    p = fma_(p, f, 2.402210682630539e-1f);
-    p = fma_(p, f, 6.931210160255432e-1f);
-    p = fma_(p, f, 1.0000001192092896f);
+    float p = 5.519811809062958e-2f;
+    p = fma_(p, f, 2.4267692863941193e-1f);
+    p = fma_(p, f, 6.932618021965027e-1f);
+    p = fma_(p, f, 9.999227523803711e-1f);
     return __builtin_ldexpf(p, (int)fi);
 }
 // hit-distance weight: compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped; upstream flavour: exp(-3 |x|)
+constexpr float EXP_WEIGHT_SCALE = UPSTREAM_FORMULAS ? 4.32808512f : 1.0f; // 3 log2(e)
 NRD_DEV float exp_weight(float ax) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly_neg(-4.32808512f * ax); // 3 log2(e); ax >= 0
+        return exp2_poly_neg(-EXP_WEIGHT_SCALE * ax); // ax >= 0
     float t = sat(1.0f - ax);
+    return t * t;
+}
+// the same weight of |v| when the caller has EXP_WEIGHT_SCALE folded into v (the spatial passes' taps: v = fma(hitT, a, b) with per-pixel
+// a, b - one multiply less per tap)
+NRD_DEV float exp_weight_prescaled(float v) {
+    if (UPSTREAM_FORMULAS)
+        return exp2_poly_neg(-absf(v));
+    float t = sat(1.0f - absf(v));
     return t * t;
 }
 // Normal weight, from the squared distance d2 of two normals' 10-bit codes (normal_dist2 below; 1 - cos = d2 NORMAL_D2_TO_1MCOS).
 // Frozen form: on the squared angle (angle^2 ~ 2 (1 - cos)), sqrt-free; its per-pixel parameter is w2 = 1 / angleMax^2 (normal_weight)
 // or -2 w2 (normal_weight_m2: scaling by 2 is exact, so fma(-2 t, w2, 1) and fma(t, -2 w2, 1) round the same exact product - one
-// multiply less per tap). Default flavour: smoothstep(1 - angle / angleMax) on the chord (sqrt2_ above), parameter = 1 / angleMax for
-// both; the (2 / 1023) of the chord is folded into the parameter (a per-pixel product the compiler hoists out of the tap loops).
+// multiply less per tap). Default flavour: smoothstep(1 - angle / angleMax) on the chord (sqrt1_unscaled_ above), parameter = 1 / angleMax for
+// both; the chord's scale (NORMAL_CHORD_SCALE) is folded into the parameter (a per-pixel product the compiler hoists out of the tap loops).
 constexpr float NORMAL_D2_TO_1MCOS = 0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f);
 NRD_DEV float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : normalW * normalW; }
 NRD_DEV float nw_param_m2(float normalW) { return UPSTREAM_FORMULAS ? normalW : -2.0f * (normalW * normalW); }
 NRD_DEV float normal_weight(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-sqrt2_(d2), prm * (2.0f / 1023.0f), 1.0f));
+        return smoothstep01(fma_(-sqrt1_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
     return smoothstep01(fma_(-2.0f * sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 NRD_DEV float normal_weight_m2(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-sqrt2_(d2), prm * (2.0f / 1023.0f), 1.0f));
+        return smoothstep01(fma_(-sqrt1_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
     return smoothstep01(fma_(sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 
@@ -313,24 +324,21 @@ NRD_DEV nrd_f2 fma2_sat(nrd_f2 a, nrd_f2 b, nrd_f2 c) { // sat(fma(a, b, c)) per
 #endif
 }
 NRD_DEV nrd_f2 smoothstep01_in01(nrd_f2 x) { return x * x * fma2_(x, splat2(-2.0f), splat2(3.0f)); } // smoothstep01 of halves already in [0, 1]
-NRD_DEV nrd_f2 sqrt2_(nrd_f2 x) {
+NRD_DEV nrd_f2 sqrt1_unscaled_(nrd_f2 x) {
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    const nrd_f2 h = 0.5f * x;
-    nrd_f2 r = __builtin_bit_cast(nrd_f2, 0x5F3759DFu - (__builtin_bit_cast(u2, x) >> 1));
-    r = r * fma2_(-(h * r), r, splat2(1.5f));
-    r = r * fma2_(-(h * r), r, splat2(1.5f));
-    return x * r;
+    const nrd_f2 y = __builtin_bit_cast(nrd_f2, 0x5F1FFFF9u - (__builtin_bit_cast(u2, x) >> 1));
+    const nrd_f2 u = x * y;
+    return u * fma2_(-u, y, splat2(2.38924456f));
 }
 // exp2_poly_neg of both halves (x <= 0)
 NRD_DEV nrd_f2 exp2_poly_neg(nrd_f2 x) {
     x = nrd_f2{fmax2(x.x, -126.0f), fmax2(x.y, -126.0f)};
     const nrd_f2 fi = nrd_f2{__builtin_rintf(x.x), __builtin_rintf(x.y)};
     const nrd_f2 f = x - fi;
-    nrd_f2 p = splat2(9.676037356257439e-3f);
-    p = fma2_(p, f, splat2(5.592203512787819e-2f));
-    p = fma2_(p, f, splat2(2.402210682630539e-1f));
-    p = fma2_(p, f, splat2(6.931210160255432e-1f));
-    p = fma2_(p, f, splat2(1.0000001192092896f));
+    nrd_f2 p = splat2(5.519811809062958e-2f);
+    p = fma2_(p, f, splat2(2.4267692863941193e-1f));
+    p = fma2_(p, f, splat2(6.932618021965027e-1f));
+    p = fma2_(p, f, splat2(9.999227523803711e-1f));
     return nrd_f2{__builtin_ldexpf(p.x, (int)fi.x), __builtin_ldexpf(p.y, (int)fi.y)};
 }
 

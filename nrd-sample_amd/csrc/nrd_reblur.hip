@@ -627,7 +627,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
         m2w2[sig] = nw_param_m2(normalW);
         float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
-        hitA[sig] = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
+        hitA[sig] = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
         hitB[sig] = -center.w * hitA[sig];
         roughA[sig] = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
         roughB[sig] = -rough * roughA[sig];
@@ -841,11 +841,11 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             w *= normal_weight_m2(normal_dist2(ncodes, gs.nw), m2w2[sig]);
             if (isSpec)
                 w *= rough_weight(T, gs);
-            w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA[sig], hitB[sig]))));
+            w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight_prescaled(fma_(sv.w, hitA[sig], hitB[sig])));
             accumulate(T, sv, w, valid);
         };
         // tap P of both signals: the weight chain of consume(), operation for operation, on {diffuse, specular} register pairs
-        const nrd_f2 nprm2{m2w2[0] * (2.0f / 1023.0f), m2w2[NSIG - 1] * (2.0f / 1023.0f)}, hitA2{hitA[0], hitA[NSIG - 1]}, hitB2{hitB[0], hitB[NSIG - 1]};
+        const nrd_f2 nprm2{m2w2[0] * NORMAL_CHORD_SCALE, m2w2[NSIG - 1] * NORMAL_CHORD_SCALE}, hitA2{hitA[0], hitA[NSIG - 1]}, hitB2{hitB[0], hitB[NSIG - 1]};
         auto consume2 = [&](const int P) {
             const int T0 = 2 * P, T1 = 2 * P + 1;
             Guide gs0, gs1;
@@ -857,10 +857,10 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             const nrd_f2 gp = ORTHO ? fma2_(zs, splat2(pg.geoB), ga) : fma2_(zs, ga, splat2(pg.geoB));
             nrd_f2 w = splat2(g_poisson8[P][2]) * smoothstep01_in01(nrd_f2{sat(1.0f - absf(gp.x)), sat(1.0f - absf(gp.y))});
             const nrd_f2 d2{normal_dist2(ncodes, gs0.nw), normal_dist2(ncodes, gs1.nw)};
-            w *= smoothstep01_in01(fma2_sat(-sqrt2_(d2), nprm2, splat2(1.0f)));
+            w *= smoothstep01_in01(fma2_sat(-sqrt1_unscaled_(d2), nprm2, splat2(1.0f)));
             w.y *= rough_weight(T1, gs1);
             const nrd_f2 hv = fma2_(nrd_f2{sv0.w, sv1.w}, hitA2, hitB2);
-            const nrd_f2 e = exp2_poly_neg(nrd_f2{-4.32808512f * absf(hv.x), -4.32808512f * absf(hv.y)});
+            const nrd_f2 e = exp2_poly_neg(nrd_f2{-absf(hv.x), -absf(hv.y)});
             w *= fma2_(splat2(1.0f - p.minHitDistanceWeight), e, splat2(p.minHitDistanceWeight));
             accumulate(T0, sv0, w.x, valid0);
             accumulate(T1, sv1, w.y, valid1);

@@ -603,6 +603,15 @@ NRDHIP_API float orc_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
 NRDHIP_API float orc_exp2(float x) { return exp2_poly(x); }
 NRDHIP_API float orc_log2(float x) { return log2_poly(x); }
 NRDHIP_API float orc_atan(float x) { return atan_pos(x); }
+// (arrays: the accuracy tests of the default flavour's per-tap sequences run over millions of arguments)
+NRDHIP_API void orc_sqrt1_array(const float* x, float* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++)
+        out[i] = sqrt1_unscaled_(x[i]) * SQRT1_SCALE;
+}
+NRDHIP_API void orc_exp2_neg_array(const float* x, float* out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++)
+        out[i] = exp2_poly_neg(x[i]);
+}
 NRDHIP_API uint32_t orc_pack_nr(float nx, float ny, float nz, float roughness, uint32_t mat) { return pack_normal_roughness({nx, ny, nz}, roughness, mat); }
 NRDHIP_API void orc_unpack_nr(uint32_t p, float* out5) {
     NormalRoughness r = unpack_normal_roughness(p);

@@ -215,41 +215,49 @@ static const int BLUR_ROTATION_SHIFT = NRD_UPSTREAM_FORMULAS ? 0 : 1; // Blur's 
 
 // The angle between two normals as upstream's weights take it: Math::AcosApprox(cos) = sqrt(2) sqrt(saturate(1 - cos)) (MathLib, recalled)
 // = the CHORD of the two unit vectors = (2 / 1023) sqrt(d2) on guide normals, d2 = squared distance of the 10-bit codes (orc_core.h
-// normal_dist2). The square root takes TWO Newton steps - relative error 4.7e-6 (csrc/nrd_device.h sqrt2_)
-static inline float sqrt2_(float x) {
-    const float h = 0.5f * x;
-    float r = u2f(0x5F3759DFu - (f2u(x) >> 1));
-    r = r * fma_(-(h * r), r, 1.5f);
-    r = r * fma_(-(h * r), r, 1.5f);
-    return x * r;
+// normal_dist2). The square root: magic seed + ONE Newton step with tuned constants, relative error <= 6.5e-4 - as fine as the quantised
+// d2 deserves (csrc/nrd_device.h sqrt1_unscaled_); returns sqrt(x) / SQRT1_SCALE
+static const float SQRT1_SCALE = 0.703952253f;
+static inline float sqrt1_unscaled_(float x) {
+    const float y = u2f(0x5F1FFFF9u - (f2u(x) >> 1));
+    const float u = x * y;
+    return u * fma_(-u, y, 2.38924456f);
 }
-// 2^x for x <= 0, degree-4 polynomial after a round-to-nearest split (relative error 3.7e-6): csrc/nrd_device.h exp2_poly_neg
+static const float NORMAL_CHORD_SCALE = (2.0f / 1023.0f) * SQRT1_SCALE;
+// 2^x for x <= 0, degree-3 polynomial after a round-to-nearest split (relative error 8.0e-5): csrc/nrd_device.h exp2_poly_neg
 static inline float exp2_poly_neg(float x) {
     x = fmax2(x, -126.0f);
     const float fi = rintf(x); // round to nearest even (the default rounding mode; the kernels: v_rndne_f32)
     const float f = x - fi;
-    float p = 9.676037356257439e-3f;
-    p = fma_(p, f, 5.592203512787819e-2f);
-    p = fma_(p, f, 2.402210682630539e-1f);
-    p = fma_(p, f, 6.931210160255432e-1f);
-    p = fma_(p, f, 1.0000001192092896f);
+    float p = 5.519811809062958e-2f;
+    p = fma_(p, f, 2.4267692863941193e-1f);
+    p = fma_(p, f, 6.932618021965027e-1f);
+    p = fma_(p, f, 9.999227523803711e-1f);
     return ldexpf(p, (int)fi);
 }
 // hit-distance weight: compact-support stand-in for exp(-3 |x|): (1 - |x|)^2 clamped (division-free); upstream flavour: exp(-3 |x|)
+static const float EXP_WEIGHT_SCALE = UPSTREAM_FORMULAS ? 4.32808512f : 1.0f; // 3 log2(e)
 static inline float exp_weight(float ax) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly_neg(-4.32808512f * ax); // 3 log2(e)
+        return exp2_poly_neg(-EXP_WEIGHT_SCALE * ax);
     float t = sat(1.0f - ax);
+    return t * t;
+}
+// the same weight of |v| with EXP_WEIGHT_SCALE already folded into v (the spatial passes' taps)
+static inline float exp_weight_prescaled(float v) {
+    if (UPSTREAM_FORMULAS)
+        return exp2_poly_neg(-absf(v));
+    float t = sat(1.0f - absf(v));
     return t * t;
 }
 // normal weight from the squared distance d2 of two normals' 10-bit codes (orc_core.h normal_dist2; 1 - cos = d2 NORMAL_D2_TO_1MCOS).
 // Frozen: on the SQUARED angle, angle^2 ~ 2 (1 - cos) (sqrt-free), parameter w2 = 1 / angleMax^2; default flavour: smoothstep(1 - angle /
-// angleMax) on the chord (sqrt2_ above), parameter 1 / angleMax
+// angleMax) on the chord (sqrt1_unscaled_ above), parameter 1 / angleMax
 static const float NORMAL_D2_TO_1MCOS = 0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0f);
 static inline float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : normalW * normalW; }
 static inline float normal_weight(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-sqrt2_(d2), prm * (2.0f / 1023.0f), 1.0f));
+        return smoothstep01(fma_(-sqrt1_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
     return smoothstep01(fma_(-2.0f * sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 

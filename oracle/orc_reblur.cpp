@@ -507,7 +507,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                     float normalW2 = nw_param(normalW);
                     float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
-                    float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc)));
+                    float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
                     float hitB = -center.w * hitA;
                     float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
@@ -554,7 +554,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                                     w *= smoothstep01(1.0f - absf(fma_((float)(tt.w0 & 1023u), roughA * (1.0f / 1023.0f), roughB)));
                             } else if (isSpec)
                                 w *= smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                            w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight(absf(fma_(sv.w, hitA, hitB))));
+                            w *= lerpf(s.minHitDistanceWeight, 1.0f, exp_weight_prescaled(fma_(sv.w, hitA, hitB)));
                         }
                         sum = fma4(sv, w, sum);
                         if (sh)

@@ -107,6 +107,29 @@ def test_ycocg_roundtrip_and_hitdist_norm(lib, pkg):
         assert abs(lib.orc_hitdist_norm(z, hp, r) / ref - 1) < 1e-5
 
 
+def test_per_tap_sequences_of_the_default_flavour(oracle):
+    """the two approximations a spatial tap of the default build pays for (csrc/nrd_device.h == oracle/orc_math.h): the one-step square
+    root of the normal weight's chord over EVERY squared code distance that can occur (0 .. 3 x 1023^2): relative error <= 6.6e-4, exact
+    at 0, monotone enough to be a distance (never negative); the degree-3 exp2 of the hit-distance weight on [-126, 0]: relative error
+    <= 8.1e-5, and what lies below the clamp stays at 2^-126"""
+    L = oracle.lib
+    fp = ctypes.POINTER(ctypes.c_float)
+    for fn in (L.orc_sqrt1_array, L.orc_exp2_neg_array):
+        fn.restype = None
+        fn.argtypes = [fp, fp, ctypes.c_uint32]
+    x = np.arange(0, 3 * 1023 * 1023 + 1, dtype=np.float32)
+    out = np.empty_like(x)
+    L.orc_sqrt1_array(x.ctypes.data_as(fp), out.ctypes.data_as(fp), x.size)
+    ref = np.sqrt(x.astype(np.float64))
+    assert out[0] == 0.0 and (out >= 0).all()
+    assert np.abs(out[1:].astype(np.float64) / ref[1:] - 1.0).max() <= 6.6e-4
+    e = np.concatenate([np.linspace(-126.0, 0.0, 2000001), [-200.0, -1e9]]).astype(np.float32)
+    got = np.empty_like(e)
+    L.orc_exp2_neg_array(e.ctypes.data_as(fp), got.ctypes.data_as(fp), e.size)
+    want = np.exp2(np.maximum(e.astype(np.float64), -126.0))
+    assert np.abs(got.astype(np.float64) / want - 1.0).max() <= 8.1e-5
+
+
 def test_unorm10_decode_sequence_is_the_ieee_quotient():
     """nrd_device.h unorm10_: q = x * r; q' = fma(fma(-q, 1023, x), r, q) with r = fl(1/1023) equals the correctly rounded x / 1023
     (what the oracle's `/` computes) for every 10-bit x - checked in exact rational arithmetic with one rounding per operation"""
