@@ -191,6 +191,12 @@ def test_native_tiler_bit_identical(tmp_path, pkg, api, oracle, emulated):
     assert all(int(p["split"][0]) >= 2 * 5 for p in parts)
 
 
+def test_native_tiler_three_ranks_bit_identical(tmp_path, pkg, api, oracle, emulated):
+    """... and with an INTERIOR rank: both neighbours, so every tap-texel exchange packs and unpacks signal halves in both directions
+    (four staging buffers per plane) in one transfer group"""
+    run_tiled_and_compare(tmp_path, pkg, api, oracle, 3, 1056, "default", "emu", "native", w=32, nframes=2)
+
+
 def test_halo_is_enforced_not_clamped(tmp_path, pkg, api, oracle, emulated):
     """RELAX with 8 A-trous iterations reads 128 rows beyond a band. With the default 80-row halo both tilers must REFUSE
     (ADVICE r1 / VERDICT r1 weak 6: the silent clamp produced a different image); with the probed halo the tiled result is
