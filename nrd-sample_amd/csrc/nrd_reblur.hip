@@ -1099,14 +1099,17 @@ NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const ui
     float planeRef = dot3(NvPrev, XvPrev);
     float g0 = ORTHO ? fma_(NvPrev.x, c.pvPrev[0], NvPrev.y * c.pvPrev[1]) : fma_(NvPrev.x, c.pvPrev[0], fma_(NvPrev.y, c.pvPrev[1], NvPrev.z));
     float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
+    const uint32_t mfloor = material_floor(minMat), mclass = material_class(mat, mfloor);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
-        bool ok = fp.sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
+        bool ok = fp.sane & (tx >= 0) & (tx < c.Wprev) & (gy >= 0) & (gy < c.Hprev) & (ty >= 0) & (ty < c.resH);
         Guide gp = decode_guide(graw[i], c.denoisingRange);
         float lin = fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
         float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin; // N . X of the previous-frame texel
-        ok = ok && !gp.sky && absf(plane - planeRef) <= threshold && dot3(N, gp.n) > PREV_NORMAL_COS && !material_mismatch(mat, gp.mat, minMat);
+        // (bitwise: every operand is a plain comparison; the short-circuit form compiles to an exec-mask detour per operand)
+        const bool planeOk = absf(plane - planeRef) <= threshold, normalOk = dot3(N, gp.n) > PREV_NORMAL_COS, matOk = material_class(gp.mat, mfloor) == mclass;
+        ok = ok & !gp.sky & planeOk & normalOk & matOk;
         f.w[i] = ok ? bw[i] : 0.0f;
         f.wsum += f.w[i];
         f.bits |= ok ? (1u << i) : 0u;
@@ -1833,8 +1836,11 @@ __global__ __launch_bounds__(256) void k_validation(const ReblurParams p) {
 // in LDS once - every texel is read by up to 9 pixels - and the taps become LDS reads at compile-time offsets: no per-tap
 // address arithmetic, no bounds tests (a texel outside the frame / the held rows is staged with viewZ = NaN, i.e. as sky).
 // LS = 0 (strides >= 8, window too large for LDS at a useful occupancy): coalesced global gathers, batched.
+#ifndef NRD_ATROUS_WAVES // waves per SIMD the register allocator aims for in the iterations behind the first (the first holds the moments too: 3)
+#define NRD_ATROUS_WAVES 4
+#endif
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool FIRST, int LS>
-__global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES) void k_relax_atrous(const AtrousParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
@@ -1952,14 +1958,15 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     float c0Y[NSIG]; // luminance of the centre texel
     f3 sum[NSIG];
     float sumVar[NSIG], wsum[NSIG], invL[NSIG], normalW2[NSIG], minLw[NSIG];
-    uint32_t minMat[NSIG];
+    uint32_t matFloor[NSIG], matClass[NSIG]; // material test of the taps (nrd_device.h material_class)
     float roughA = 0.0f, roughB = 0.0f, roughRelax = 1.0f;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         const int si = isSpec ? 1 : 0;
         float rough = isSpec ? g.roughness : 1.0f;
-        minMat[sig] = isSpec ? p.minMatSpec : p.minMatDiff;
+        matFloor[sig] = material_floor(isSpec ? p.minMatSpec : p.minMatDiff);
+        matClass[sig] = material_class(g.mat, matFloor[sig]);
         minLw[sig] = p.minLw[si];
         c0[sig] = unpack_h4(ctex[sig * SW]);
         c0Y[sig] = signal_luma(c0[sig], true);
@@ -2030,8 +2037,8 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
     // the 8 taps in row-major order as a software pipeline (like k_spatial): DEPTH taps in flight, tap k is consumed right after tap
     // k + DEPTH is issued, so the arithmetic of a tap runs under the loads of the next ones (LDS flavours: the reads of a batch)
     constexpr int TI[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, TJ[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-#ifndef NRD_ATROUS_DEPTH
-#define NRD_ATROUS_DEPTH 4
+#ifndef NRD_ATROUS_DEPTH // taps in flight of the SH gather flavour: 2 keep it at 126 VGPRs = 4 waves per SIMD (4: 132 / 3 waves; profiles/r04_ab_atrous_mask.txt)
+#define NRD_ATROUS_DEPTH 2
 #endif
     constexpr int DEPTH = LS ? (SH ? 4 : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
     uint2 graw[8];
@@ -2070,7 +2077,10 @@ __global__ __launch_bounds__(256) void k_relax_atrous(const AtrousParams p) {
 #pragma unroll
         for (int sig = 0; sig < NSIG; sig++) {
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            bool valid = inside[k] && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat[sig]); // rejected taps are selected out below
+            // (bitwise: one basic block - the short-circuit form compiles to an exec-mask detour per operand; the material test as class
+            // equality, nrd_device.h material_class) rejected taps are selected out below
+            const bool matOk = material_class(gs.mat, matFloor[sig]) == matClass[sig];
+            const bool valid = inside[k] & !gs.sky & matOk;
             float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
             w *= geoW;
             w *= normal_weight_m2(nD2, normalW2[sig]);

@@ -372,11 +372,12 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(COPY ? 8 : 2) void k_sigma_te
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
-            bool ok = !(ttx < 0 || ttx >= c.Wprev || gy < 0 || gy >= c.Hprev || tty < 0 || tty >= c.resH);
+            bool ok = (ttx >= 0) & (ttx < c.Wprev) & (gy >= 0) & (gy < c.Hprev) & (tty >= 0) & (tty < c.resH); // (bitwise: one basic block)
             Guide gp = decode_guide(fg[i], c.denoisingRange);
             float lin = fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
             float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin;
-            ok = ok && !gp.sky && absf(plane - planeRef) <= threshold && dot3(g.n, gp.n) > PREV_NORMAL_COS;
+            const bool planeOk = absf(plane - planeRef) <= threshold, normalOk = dot3(g.n, gp.n) > PREV_NORMAL_COS;
+            ok = ok & !gp.sky & planeOk & normalOk;
             // a rejected texel is selected out (the history plane holds RGBA8: any bit pattern decodes to finite values, but the sums
             // must see exactly the texels the oracle adds)
             const f4 acc = fma4(decode_shadow(fh[i]), bw[i], sum);
