@@ -119,6 +119,22 @@ def spec_dominant_factor(r):
     return s * (np.sqrt(s) + r)
 
 
+def plane_terms(viewz, packed_nr, view_to_clip, world_to_view, plane_distance_sensitivity):
+    """(gax, gay, ga0, geoB) of the plane-distance weight |zs (gax px + gay py + ga0) + geoB| of every centre pixel (perspective camera)"""
+    H, W = viewz.shape
+    M = np.asarray(view_to_clip, np.float64)
+    sgn = 1.0 if M[11] > 0 else -1.0
+    fr = np.array([(-sgn - M[8]) / M[0], (sgn - M[9]) / M[5], 2.0 * sgn / M[0], -2.0 * sgn / M[5]])
+    pv = np.array([fr[0] + 0.5 * fr[2] / W, fr[1] + 0.5 * fr[3] / H, fr[2] / W, fr[3] / H])
+    w2v = np.asarray(world_to_view, np.float64).reshape(4, 4).T[:3, :3]
+    z, n, _, _ = decode_guide(viewz, packed_nr)
+    yy, xx = np.mgrid[0:H, 0:W]
+    Xv = np.stack([z * (pv[2] * xx + pv[0]), z * (pv[3] * yy + pv[1]), z], -1)
+    Nv = n @ w2v.T
+    geoA = 1.0 / (plane_distance_sensitivity * min(W, H) / (0.5 * H * abs(M[5])) * np.abs(z))
+    return Nv[..., 0] * pv[2] * geoA, Nv[..., 1] * pv[3] * geoA, (Nv[..., 0] * pv[0] + Nv[..., 1] * pv[1] + Nv[..., 2]) * geoA, -(Nv * Xv).sum(-1) * geoA
+
+
 def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_index, denoising_range, s, exp_hit_weight=False,
             angle_normal_weight=False, no_reach=False, f32_guide=False):
     """REBLUR_DIFFUSE_SPECULAR PrePass of one frame (perspective, no jitter, radiance mode, full frame). `s`: dict of the

@@ -341,3 +341,42 @@ def test_sigma_passes_independent(pkg, api, oracle, f):
     want = tmp.sigma_temporal_stabilization(c, s, gcur, gprev, fr["mv"], sh2, tiles, hist_prev, True)
     want = np.stack([(want >> (8 * i)) & 255 for i in range(4)], -1).astype(np.int32)
     assert float((np.abs(hist - want) <= 1).mean()) > 0.99 and float((hist == want).mean()) > 0.97
+
+
+@pytest.mark.parametrize("recon,radius", [(None, 0), ("AREA_3X3", 1), ("AREA_5X5", 2)])
+def test_prepare_inputs_independent(pkg, api, oracle, recon, radius):
+    """PrepareInputs at the sample's default operating point (checkerboard WHITE: both signals on complementary colours of half-width
+    inputs) with and without the hit-distance reconstruction, 40 % of the hit distances punched out: the dense planes the oracle hands to
+    the PrePass against tests/indep/prepare_numpy.py, frames 0 and 1 (the checkerboard phase flips with the frame index)"""
+    import prepare_numpy as prep
+
+    D = api.Denoiser
+    den = int(D.REBLUR_DIFFUSE_SPECULAR)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    hz = pkg.harness.Harness(oracle, [D.REBLUR_DIFFUSE_SPECULAR], W, H)
+    st = api.ReblurSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1, checkerboardMode=int(api.CheckerboardMode.WHITE),
+                            hitDistanceReconstructionMode=int(getattr(api.HitDistanceReconstructionMode, recon or "OFF")))
+    s = dict(minMaterialForDiffuse=0, minMaterialForSpecular=1, lobeAngleFraction=st.lobeAngleFraction, roughnessFraction=st.roughnessFraction)
+    rng = np.random.default_rng(5)
+    for f in range(2):
+        fr = frame(f)
+        for key in ("diff", "spec"):
+            a = np.array(fr[key])
+            a[rng.random(a.shape[:2]) < 0.4, 3] = 0
+            fr[key] = a
+        fr.update(pkg.harness.to_checkerboard(fr, f, white=True))
+        cs = scene.common_settings(api, fr, f, reset=(f == 0))
+        hz.nrd.new_frame()
+        hz.nrd.set_common_settings(cs)
+        hz.bind(hz.upload(fr))
+        hz.nrd.set_denoiser_settings(den, st)
+        names = [d["name"].split("::")[1] for d in hz.nrd.dispatches([den])]
+        assert names[:2] == ["ClassifyTiles", "PrepareInputs"]
+        hz.nrd.denoise_range([den], 0, 2)
+        geo = ind.plane_terms(fr["viewz"], fr["normal_roughness"], fr["view_to_clip"], fr["world_to_view"], st.planeDistanceSensitivity)
+        for key, plane, phase, is_spec in (("diff", "REBLUR::Prepared_Diff", 1, False), ("spec", "REBLUR::Prepared_Spec", 0, True)):
+            got = hz.pool(plane).copy().view(np.float16).reshape(H, W, 4)
+            half = np.asarray(fr[key]).view(np.float16).reshape(H, -1, 4)
+            want = prep.prepare_inputs(fr["viewz"], fr["normal_roughness"], half, phase, cs.frameIndex, cs.denoisingRange, is_spec, radius, geo, s)
+            agree("PrepareInputs %s frame %d" % (key, f), got, want, 0.995)
+        hz.nrd.denoise_range([den], 2, len(names) - 2)  # finish the frame: the next one starts from a consistent instance
