@@ -210,7 +210,9 @@ NRDHIP_API const char* nrdhip_last_error(nrdhip_instance* inst);
 typedef struct nrdhip_tiler nrdhip_tiler;
 /* caller-supplied transport (tests, hosts with their own fabric layer): all calls of one exchange arrive between group_begin
  * and group_end (both optional), sends and receives toward one peer in matching order on both sides. `hip_stream` is the
- * stream the rows were produced on - a host transport synchronises it before reading. Return 0 on success. */
+ * stream the rows were produced on - a host transport synchronises it before reading. `dev_ptr` is device memory of this rank: rows of a
+ * pool plane or of a bound slot, or a staging buffer of the tiler (the packed signal halves of tap-texel rows, nrdhip_dispatch_info::
+ * written_prefix) - a transport must not assume it lies inside a plane the caller allocated. Return 0 on success. */
 typedef struct nrdhip_transport {
     void* user;
     int (*group_begin)(void* user);
