@@ -150,6 +150,26 @@ NRD_DEV f3 normalize3(f3 a) {
     return mul3(a, inv);
 }
 
+// ---- build flavour NRD_HW_TRANSCENDENTALS (libnrdhip_hwt.so) ----------------------------------------------------------------------
+// The software sequences above and the polynomials below exist so that the CPU oracle can repeat every result bit for bit. What the
+// reference's HLSL executes at those places are the GPU's transcendental instructions, and on gfx950 they are the cheaper choice:
+// v_rcp_f32 / v_sqrt_f32 / v_exp_f32 issue in ~8 cycles per wave against 18 (rcp_), 31 (sqrt_), 13 (sqrt1_unscaled_) and 21
+// (exp2_poly_neg) for the sequences (profiles/r02_ubench_valu_rate.txt), and the spatial passes are VALU-issue bound
+// (profiles/r04v4_valu_issue_final_build.txt). This flavour uses the instructions (1 ULP each, more accurate than the one-step root
+// and the degree-3 exponential they replace) in the WEIGHT-CLASS arithmetic of the spatial filters only: per-tap weights (normal chord,
+// hit-distance / luminance exponential), their per-pixel parameters (1 / angle, 1 / plane distance scale, roughness and hit distance
+// scales, sigma of A-trous) and the final 1 / weight sum. Everything a DISCRETE decision hangs on keeps the exact sequences: the
+// projection Jacobian and blur radius (tap coordinates -> floor), reprojection, footprint validity, accumulation speeds (u8 codes),
+// HistoryFix strides - so this flavour and its checker (liboracle_hwt.so: the same places with IEEE 1 / x, sqrtf, exp2f) gather the
+// same texels and differ by rounding of weights only. Parity bar of the flavour: <= 1 ULP fp16 / PSNR >= 60 dB, not bit identity
+// (tests/test_hw_transcendentals.py; measured distance: profiles/r05_ab_hw_transcendentals.txt).
+#ifndef NRD_HW_TRANSCENDENTALS
+#define NRD_HW_TRANSCENDENTALS 0
+#endif
+constexpr bool HW_TRANSCENDENTALS = NRD_HW_TRANSCENDENTALS != 0;
+NRD_DEV float wrcp_(float x) { return HW_TRANSCENDENTALS ? __builtin_amdgcn_rcpf(x) : rcp_(x); }     // weight-class 1 / x, x > 0
+NRD_DEV float wsqrt_(float x) { return HW_TRANSCENDENTALS ? __builtin_amdgcn_sqrtf(x) : sqrt_(x); } // weight-class sqrt(x), x >= 0
+
 // ---- fp16 (hardware RNE converts, denormals on) ------------------------------------------------------------------
 #define NRD_FP16_MAX 65504.0f
 NRD_DEV float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -214,7 +234,7 @@ NRD_DEV float pow01(float x, float y) {
 
 NRD_DEV float atan_pos(float x) {
     bool inv = x > 1.0f;
-    float t = inv ? rcp_(x) : x;
+    float t = inv ? wrcp_(x) : x; // (only consumer: spec_lobe_half_angle -> the normal weight's parameter)
     float s = t * t;
     float p = 0.0208351f;
     p = fma_(p, s, -0.0851330f);
@@ -253,7 +273,9 @@ NRD_DEV float sqrt1_unscaled_(float x) {
     const float u = x * y;
     return u * fma_(-u, y, 2.38924456f); // sqrt1_unscaled_(0) = 0
 }
-constexpr float NORMAL_CHORD_SCALE = (2.0f / 1023.0f) * SQRT1_SCALE; // chord of two guide normals = NORMAL_CHORD_SCALE * sqrt1_unscaled_(d2)
+// chord of two guide normals = NORMAL_CHORD_SCALE * chord_unscaled_(d2); hwt flavour: v_sqrt_f32, no scale to undo
+constexpr float NORMAL_CHORD_SCALE = (2.0f / 1023.0f) * (HW_TRANSCENDENTALS ? 1.0f : SQRT1_SCALE);
+NRD_DEV float chord_unscaled_(float d2) { return HW_TRANSCENDENTALS ? __builtin_amdgcn_sqrtf(d2) : sqrt1_unscaled_(d2); }
 // 2^x for x <= 0 (the hit-distance weight's exponent): round-to-nearest-even split (v_rndne_f32), a DEGREE-3 minimax polynomial on
 // [-0.5, 0.5] (relative error 8.0e-5, a sixth of an fp16 ULP of the signals the weight multiplies; exp2_poly's degree 6 reaches 1.1e-7:
 // three fma less per tap), the power of two applied by v_ldexp_f32
@@ -267,11 +289,12 @@ NRD_DEV float exp2_poly_neg(float x) {
     p = fma_(p, f, 9.999227523803711e-1f);
     return __builtin_ldexpf(p, (int)fi);
 }
+NRD_DEV float exp2_neg(float x) { return HW_TRANSCENDENTALS ? __builtin_amdgcn_exp2f(x) : exp2_poly_neg(x); } // hwt flavour: v_exp_f32
 // hit-distance weight: compact-support stand-in for exp(-3|x|) (division-free): (1 - |x|)^2 clamped; upstream flavour: exp(-3 |x|)
 constexpr float EXP_WEIGHT_SCALE = UPSTREAM_FORMULAS ? 4.32808512f : 1.0f; // 3 log2(e)
 NRD_DEV float exp_weight(float ax) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly_neg(-EXP_WEIGHT_SCALE * ax); // ax >= 0
+        return exp2_neg(-EXP_WEIGHT_SCALE * ax); // ax >= 0
     float t = sat(1.0f - ax);
     return t * t;
 }
@@ -279,7 +302,7 @@ NRD_DEV float exp_weight(float ax) {
 // a, b - one multiply less per tap)
 NRD_DEV float exp_weight_prescaled(float v) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly_neg(-absf(v));
+        return exp2_neg(-absf(v));
     float t = sat(1.0f - absf(v));
     return t * t;
 }
@@ -293,53 +316,13 @@ NRD_DEV float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : nor
 NRD_DEV float nw_param_m2(float normalW) { return UPSTREAM_FORMULAS ? normalW : -2.0f * (normalW * normalW); }
 NRD_DEV float normal_weight(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-sqrt1_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
+        return smoothstep01(fma_(-chord_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
     return smoothstep01(fma_(-2.0f * sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 NRD_DEV float normal_weight_m2(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-sqrt1_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
+        return smoothstep01(fma_(-chord_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
     return smoothstep01(fma_(sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
-}
-
-// ---- {diffuse, specular} PAIRS of the spatial passes' per-tap arithmetic ------------------------------------------------------
-// gfx950 issues v_pk_{fma, mul, add}_f32 - two IEEE fp32 operations per lane - in 3.4 cycles per wave against 2 x 2.6 for the two
-// plain instructions (profiles/r02_ubench_valu_rate.txt, 4 waves per SIMD): tap t of the diffuse signal and tap t of the specular
-// signal run the same straight-line weight code on different data, so the passes that filter both consume them TOGETHER, one signal
-// per half of a register pair. Every half is the scalar sequence operation for operation (same fma / mul / add, same order): the
-// results are the scalar path's bit for bit. What has no packed form stays scalar on the halves: |x| and clamp source / output
-// modifiers (VOP3P has neither for fp32 sources; the one clamp that sits behind a packed fma is written as the instruction itself),
-// floor / rndne, conversions, v_ldexp.
-typedef float nrd_f2 __attribute__((ext_vector_type(2)));
-NRD_DEV nrd_f2 splat2(float v) { return nrd_f2{v, v}; }
-NRD_DEV nrd_f2 fma2_(nrd_f2 a, nrd_f2 b, nrd_f2 c) { return __builtin_elementwise_fma(a, b, c); }
-NRD_DEV nrd_f2 fma2_sat(nrd_f2 a, nrd_f2 b, nrd_f2 c) { // sat(fma(a, b, c)) per half
-#ifdef NRD_HOST_EMULATION
-    const nrd_f2 r = fma2_(a, b, c);
-    return nrd_f2{sat(r.x), sat(r.y)};
-#else
-    nrd_f2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-#endif
-}
-NRD_DEV nrd_f2 smoothstep01_in01(nrd_f2 x) { return x * x * fma2_(x, splat2(-2.0f), splat2(3.0f)); } // smoothstep01 of halves already in [0, 1]
-NRD_DEV nrd_f2 sqrt1_unscaled_(nrd_f2 x) {
-    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    const nrd_f2 y = __builtin_bit_cast(nrd_f2, 0x5F1FFFF9u - (__builtin_bit_cast(u2, x) >> 1));
-    const nrd_f2 u = x * y;
-    return u * fma2_(-u, y, splat2(2.38924456f));
-}
-// exp2_poly_neg of both halves (x <= 0)
-NRD_DEV nrd_f2 exp2_poly_neg(nrd_f2 x) {
-    x = nrd_f2{fmax2(x.x, -126.0f), fmax2(x.y, -126.0f)};
-    const nrd_f2 fi = nrd_f2{__builtin_rintf(x.x), __builtin_rintf(x.y)};
-    const nrd_f2 f = x - fi;
-    nrd_f2 p = splat2(5.519811809062958e-2f);
-    p = fma2_(p, f, splat2(2.4267692863941193e-1f));
-    p = fma2_(p, f, splat2(6.932618021965027e-1f));
-    p = fma2_(p, f, splat2(9.999227523803711e-1f));
-    return nrd_f2{__builtin_ldexpf(p.x, (int)fi.x), __builtin_ldexpf(p.y, (int)fi.y)};
 }
 
 // ---- input decode (once per pixel, in the ClassifyTiles passes) ---------------------------------------------------
@@ -562,7 +545,7 @@ NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, 
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
     p.frustumSize = c.minRectDimMulUnproject * zpersp(p.absZ);
-    float geoA = rcp_(planeDistSensitivity * p.frustumSize);
+    float geoA = wrcp_(planeDistSensitivity * p.frustumSize);
     p.gax = p.Nv.x * c.pv[2] * geoA;
     p.gay = p.Nv.y * c.pv[3] * geoA;
     if (ORTHO) {
@@ -580,7 +563,7 @@ NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, 
 NRD_DEV float strand_normal_relax(const FrameConsts& c, uint32_t mat, float absZ) {
     if (mat != c.strandMat)
         return 1.0f;
-    return lerpf(0.25f, 1.0f, sat(c.strandThickness * rcp_(c.unproject * zpersp(absZ))));
+    return lerpf(0.25f, 1.0f, sat(c.strandThickness * wrcp_(c.unproject * zpersp(absZ))));
 }
 // plane-distance term of a tap from its precomputed linear part ga = ga0 + gax px + gay gy
 NRD_DEV float geo_plane(const PixelGeo& p, float ga, float zs) { return ORTHO ? fma_(zs, p.geoB, ga) : fma_(zs, ga, p.geoB); }
@@ -613,7 +596,6 @@ template <typename T>
 struct nt_native {
     typedef T type;
 };
-#ifndef NRD_HOST_EMULATION
 template <>
 struct nt_native<uint2> {
     typedef unsigned int type __attribute__((ext_vector_type(2)));
@@ -622,24 +604,15 @@ template <>
 struct nt_native<uint4> {
     typedef unsigned int type __attribute__((ext_vector_type(4)));
 };
-#endif
 template <typename T>
 NRD_DEV T ld_stream(const PlaneRef& P, int x, int y, int bpt, int off = 0) {
-#ifdef NRD_HOST_EMULATION
-    return ld<T>(P, x, y, bpt, off);
-#else
     typedef typename nt_native<T>::type N;
     return __builtin_bit_cast(T, __builtin_nontemporal_load(reinterpret_cast<const N*>(P.p + texel_offset(P, x, y, bpt, off))));
-#endif
 }
 template <typename T>
 NRD_DEV void st_stream(const PlaneRef& P, int x, int y, int bpt, T v, int off = 0) {
-#ifdef NRD_HOST_EMULATION
-    st<T>(P, x, y, bpt, v, off);
-#else
     typedef typename nt_native<T>::type N;
     __builtin_nontemporal_store(__builtin_bit_cast(N, v), reinterpret_cast<N*>(P.p + texel_offset(P, x, y, bpt, off)));
-#endif
 }
 
 // Gathers of the spatial passes go through buffer instructions: a raw V# (base = the plane's first texel, no stride, no bounds -
@@ -761,17 +734,22 @@ NRD_DEV bool ring_pos(int tid, int& lx, int& ly) {
     return true;
 }
 
-// One 16-bit word of a per-tile plane through the SCALAR data path (same address for the whole workgroup; constant address space:
+// One 8- / 16-bit word of a per-tile plane through the SCALAR data path (same address for the whole workgroup; constant address space:
 // s_load_dword of the aligned word that holds it): the flag does not queue in the in-order vector memory counter with the workgroup's loads
-NRD_DEV uint32_t ld_tile_u16(const PlaneRef& P, int tx, int ty) {
-#ifdef NRD_HOST_EMULATION
-    return (uint32_t)ld<uint16_t>(P, tx, ty, 2);
-#else
-    const uintptr_t a = (uintptr_t)P.p + texel_offset(P, tx, ty, 2, 0);
-    typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
-    const uint32_t w = *(const_u32_ptr)(a & ~(uintptr_t)3);
-    return (w >> ((uint32_t)(a & 2) * 8u)) & 0xffffu;
+#ifndef NRD_SCALAR_AS // (the host emulation of the tests defines it away, like NRD_WAVES_PER_EU)
+#define NRD_SCALAR_AS __attribute__((address_space(4)))
 #endif
+NRD_DEV uint32_t ld_scalar_word(uintptr_t a) {
+    typedef const NRD_SCALAR_AS uint32_t* const_u32_ptr;
+    return *(const_u32_ptr)(a & ~(uintptr_t)3);
+}
+NRD_DEV uint32_t ld_tile_u16(const PlaneRef& P, int tx, int ty) {
+    const uintptr_t a = (uintptr_t)P.p + texel_offset(P, tx, ty, 2, 0);
+    return (ld_scalar_word(a) >> ((uint32_t)(a & 2) * 8u)) & 0xffffu;
+}
+NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) {
+    const uintptr_t a = (uintptr_t)P.p + texel_offset(P, tx, ty, 1, 0);
+    return (ld_scalar_word(a) >> ((uint32_t)(a & 3) * 8u)) & 0xffu;
 }
 
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) { // one 16 x 16 workgroup per tile

@@ -68,11 +68,6 @@ NRD_KERNELS_BEGIN
 #define NRD_TAP_WAVES 5  // (depth 6 / 8 at 5 waves: equal; depth 12 / 16 at 4 waves: slower - profiles/r03_ab_tap_texels.txt)
 #endif
 
-#if defined(NRD_DEBUG_COUNTERS) && !NRD_ORTHO // diagnosis build only (tools/tap_histogram.py): histogram of tap distances per spatial pass
-__device__ unsigned long long g_dbg_hist[3][8];
-#define NRD_DBG_HIST 1
-#endif
-
 constexpr float MAX_ACCUM = 63.0f;
 constexpr float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
 constexpr float POST_BLUR_RADIUS_SCALE = 2.0f;
@@ -158,21 +153,7 @@ NRD_DEV void store_texel(const PlaneRef& P, int x, int y, const uint2 (&t)[BYTES
 
 // REBLUR / RELAX::Tiles (written by ClassifyTiles): 1 = no pixel of the 16x16 tile has geometry. One byte per tile, same address for
 // the whole workgroup: a scalar value
-#ifndef NRD_SCALAR_TILE_FLAG
-#define NRD_SCALAR_TILE_FLAG 1
-#endif
-NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty) {
-#if defined(NRD_HOST_EMULATION) || !NRD_SCALAR_TILE_FLAG
-    return __builtin_amdgcn_readfirstlane((int)ld<uint8_t>(tiles, tx, ty, 1)) != 0;
-#else
-    // through the SCALAR data path (constant address space: s_load_dword of the aligned word that holds the byte): the flag then does not
-    // queue behind - or in front of - the vector loads of the workgroup in the in-order vector memory counter
-    const uintptr_t a = (uintptr_t)tiles.p + texel_offset(tiles, tx, ty, 1, 0);
-    typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
-    const uint32_t w = *(const_u32_ptr)(a & ~(uintptr_t)3);
-    return ((w >> ((uint32_t)(a & 3) * 8u)) & 0xffu) != 0u;
-#endif
-}
+NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty) { return ld_tile_u8(tiles, tx, ty) != 0u; }
 NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty) { return tile_is_sky(p.tiles, tx, ty); }
 
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
@@ -623,13 +604,14 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             jby[sig] = d;
         }
         float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
-        float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+        // (weight-class reciprocals from here on - wrcp_: the hwt flavour's v_rcp_f32; everything above feeds the tap coordinates and stays exact)
+        float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN));
         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
         m2w2[sig] = nw_param_m2(normalW);
-        float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
-        hitA[sig] = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
+        float hitScale = relaxIn ? wrcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
+        hitA[sig] = hitScale * wrcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
         hitB[sig] = -center.w * hitA[sig];
-        roughA[sig] = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
+        roughA[sig] = wrcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
         roughB[sig] = -rough * roughA[sig];
         if (TAP)
             roughA[sig] = roughA[sig] * (1.0f / 1023.0f); // applies to the tap's roughness CODE
@@ -671,27 +653,9 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         bool inWin[NT];
         uint4 graw[NT];
         uint2 sraw[NT], sraw1[NT];
-        // Tap order: signal-major (the 8 taps of a signal, then the next signal's) or, when the two signals are consumed as PAIRS
-        // (nrd_device.h nrd_f2), tap-major: {diffuse t, specular t} adjacent. Each signal's sums see its taps in the same order.
-#ifndef NRD_PAIR_SIGNALS
-#define NRD_PAIR_SIGNALS 0
-#endif
-// pairs in flight per kernel family (registers: a pair in flight holds two taps' texels and positions)
-#ifndef NRD_PAIR_DEPTH_TAP
-#define NRD_PAIR_DEPTH_TAP 2
-#endif
-#ifndef NRD_PAIR_DEPTH_POST
-#define NRD_PAIR_DEPTH_POST 1
-#endif
-#ifndef NRD_PAIR_DEPTH_PRE
-#define NRD_PAIR_DEPTH_PRE 1
-#endif
-#ifndef NRD_PAIR_DEPTH_FUSED
-#define NRD_PAIR_DEPTH_FUSED 1
-#endif
-        constexpr bool PAIR = NRD_PAIR_SIGNALS && UPSTREAM_FORMULAS && NSIG == 2 && !SH;
-        auto sig_of = [&](const int T) { return PAIR ? (T & 1) : (T >> 3); };
-        auto tap_of = [&](const int T) { return PAIR ? (T >> 1) : (T & 7); };
+        // Tap order: signal-major (the 8 taps of a signal, then the next signal's)
+        auto sig_of = [&](const int T) { return T >> 3; };
+        auto tap_of = [&](const int T) { return T & 7; };
         auto tap_offset = [&](const int t, float& ox, float& oy) {
             if (PER_PIXEL) {
                 ox = g_poisson8[t][0];
@@ -707,17 +671,6 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
             inWin[T] = (cxf == fpx) & (cyf == fpy);
             const int px = (int)cxf, gpy = (int)cyf;
-#ifdef NRD_DIAG_NOLOAD // diagnosis build (timing only, results meaningless): every tap re-uses the centre's texels - all arithmetic, no gathers
-            if constexpr (TAP) {
-                graw[T] = uint4{ctap[sig].x ^ (uint32_t)(px & 1), ctap[sig].y, ctap[sig].z, ctap[sig].w};
-                return;
-            } else if constexpr (MODE == 0) {
-                graw[T] = uint4{f2u(g.z) ^ (uint32_t)(px & 1), g.nw, 0u, 0u};
-                sraw[T] = uint2{f2u(sum[sig].x) ^ (uint32_t)(gpy & 1), f2u(sum[sig].y)};
-                sraw1[T] = uint2{0u, 0u};
-                return;
-            }
-#endif
             if constexpr (TAP) { // ONE gather: {guide part | signal}
                 graw[T] = ldb<uint4>(srcB[sig], px, gpy, 16);
                 return;
@@ -744,20 +697,6 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
             gather(T, fpx, fpy);
         };
-        // the positions of tap P of both signals: the same disk sample through each signal's own Jacobian
-        const nrd_f2 jtx2{jtx[0], jtx[NSIG - 1]}, jty2{jty[0], jty[NSIG - 1]}, jbx2{jbx[0], jbx[NSIG - 1]}, jby2{jby[0], jby[NSIG - 1]};
-        auto issue2 = [&](const int P) {
-            float ox, oy;
-            tap_offset(P, ox, oy);
-            const nrd_f2 fx = fma2_(splat2(ox), jtx2, fma2_(splat2(oy), jbx2, splat2(cx)));
-            const nrd_f2 fy = fma2_(splat2(ox), jty2, fma2_(splat2(oy), jby2, splat2(cy)));
-            const nrd_f2 fpx{__builtin_floorf(fx.x), __builtin_floorf(fx.y)}, fpy{__builtin_floorf(fy.x), __builtin_floorf(fy.y)};
-            const nrd_f2 ga = fma2_(splat2(pg.gax), fpx, fma2_(splat2(pg.gay), fpy, splat2(pg.ga0)));
-            gaT[2 * P] = ga.x;
-            gaT[2 * P + 1] = ga.y;
-            gather(2 * P, fpx.x, fpy.x);
-            gather(2 * P + 1, fpx.y, fpy.y);
-        };
         // a tap's texels -> its guide fields and its signal
         auto decode = [&](const int T, Guide& gs, f4& sv) {
             if constexpr (TAP) {
@@ -773,14 +712,9 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             if (relaxIn && !RELAX_LINEAR_RGB)
                 sv = rgb_to_ycocg4(sv);
         };
-#ifndef NRD_MATERIAL_CLASS
-#define NRD_MATERIAL_CLASS 1
-#endif
         auto tap_valid = [&](const int T, const Guide& gs) {
             const int sig = sig_of(T);
-            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            const bool matOk = NRD_MATERIAL_CLASS ? material_class(gs.mat, matFloor[sig]) == matClass[sig]
-                                                  : !material_mismatch(g.mat, gs.mat, isSpec ? p.minMatSpec : p.minMatDiff);
+            const bool matOk = material_class(gs.mat, matFloor[sig]) == matClass[sig];
             return (bool)(inWin[T] & active[sig] & !gs.sky & matOk); // bitwise: one basic block
         };
         // roughness weight of a specular tap (the tap texels carry the roughness CODE in the low bits of the depth word)
@@ -814,28 +748,10 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         auto consume = [&](const int T) {
             const int sig = sig_of(T), t = tap_of(T);
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-#ifdef NRD_DIAG_NOARITH // diagnosis build (timing only): the gathers and the tap positions stay, the weights go - every tap enters with weight 1
-            {
-                const f4 raw = TAP ? unpack_h4(uint2{graw[T].z, graw[T].w}) : unpack_h4(uint2{graw[T].x ^ sraw[T].x, graw[T].y ^ sraw[T].y});
-                sum[sig] = fma4(raw, inWin[T] ? 1.0f : 0.5f, sum[sig]);
-                wsum[sig] += gaT[T];
-                return;
-            }
-#endif
             Guide gs;
             f4 sv;
             decode(T, gs, sv);
             const bool valid = tap_valid(T, gs);
-#ifdef NRD_DBG_HIST // tools/tap_histogram.py (build with -DNRD_DEBUG_COUNTERS -DNRD_PAIR_SIGNALS=0)
-            if (active[sig]) { // Chebyshev distance of the tap from the centre pixel, buckets <=2, 4, 8, 12, 16, 24, 32, more (taps of both signals)
-                float ox, oy;
-                tap_offset(t, ox, oy);
-                float dx = absf(fma_(ox, jtx[sig], oy * jbx[sig])), dy = absf(fma_(ox, jty[sig], oy * jby[sig]));
-                float d = fmax2(dx, dy);
-                int b = d <= 2.f ? 0 : d <= 4.f ? 1 : d <= 8.f ? 2 : d <= 12.f ? 3 : d <= 16.f ? 4 : d <= 24.f ? 5 : d <= 32.f ? 6 : 7;
-                atomicAdd(&g_dbg_hist[VARIANT][b], 1ull);
-            }
-#endif
             float w = g_poisson8[t][2];
             w *= smoothstep01(1.0f - absf(geo_plane(pg, gaT[T], gs.z))); // == geo_weight(pg, fpx, fpy, gs.z)
             w *= normal_weight_m2(normal_dist2(ncodes, gs.nw), m2w2[sig]);
@@ -844,42 +760,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight_prescaled(fma_(sv.w, hitA[sig], hitB[sig])));
             accumulate(T, sv, w, valid);
         };
-        // tap P of both signals: the weight chain of consume(), operation for operation, on {diffuse, specular} register pairs
-        const nrd_f2 nprm2{m2w2[0] * NORMAL_CHORD_SCALE, m2w2[NSIG - 1] * NORMAL_CHORD_SCALE}, hitA2{hitA[0], hitA[NSIG - 1]}, hitB2{hitB[0], hitB[NSIG - 1]};
-        auto consume2 = [&](const int P) {
-            const int T0 = 2 * P, T1 = 2 * P + 1;
-            Guide gs0, gs1;
-            f4 sv0, sv1;
-            decode(T0, gs0, sv0);
-            decode(T1, gs1, sv1);
-            const bool valid0 = tap_valid(T0, gs0), valid1 = tap_valid(T1, gs1);
-            const nrd_f2 zs{gs0.z, gs1.z}, ga{gaT[T0], gaT[T1]};
-            const nrd_f2 gp = ORTHO ? fma2_(zs, splat2(pg.geoB), ga) : fma2_(zs, ga, splat2(pg.geoB));
-            nrd_f2 w = splat2(g_poisson8[P][2]) * smoothstep01_in01(nrd_f2{sat(1.0f - absf(gp.x)), sat(1.0f - absf(gp.y))});
-            const nrd_f2 d2{normal_dist2(ncodes, gs0.nw), normal_dist2(ncodes, gs1.nw)};
-            w *= smoothstep01_in01(fma2_sat(-sqrt1_unscaled_(d2), nprm2, splat2(1.0f)));
-            w.y *= rough_weight(T1, gs1);
-            const nrd_f2 hv = fma2_(nrd_f2{sv0.w, sv1.w}, hitA2, hitB2);
-            const nrd_f2 e = exp2_poly_neg(nrd_f2{-absf(hv.x), -absf(hv.y)});
-            w *= fma2_(splat2(1.0f - p.minHitDistanceWeight), e, splat2(p.minHitDistanceWeight));
-            accumulate(T0, sv0, w.x, valid0);
-            accumulate(T1, sv1, w.y, valid1);
-        };
-        if constexpr (PAIR) {
-            constexpr int DP = FUSED ? NRD_PAIR_DEPTH_FUSED : VARIANT == 0 ? NRD_PAIR_DEPTH_PRE : VARIANT == 2 ? NRD_PAIR_DEPTH_POST : NRD_PAIR_DEPTH_TAP;
-#pragma unroll
-            for (int P = 0; P < DP; P++)
-                issue2(P);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int P = 0; P < 8; P++) {
-                if (P + DP < 8)
-                    issue2(P + DP);
-                __builtin_amdgcn_sched_barrier(0);
-                consume2(P);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+        {
 #pragma unroll
             for (int T = 0; T < DEPTH; T++)
                 issue(T);
@@ -898,7 +779,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-        float invw = rcp_(wsum[sig]);
+        float invw = wrcp_(wsum[sig]);
         f4 res = mul4(sum[sig], invw), res1 = mul4(sum1[sig], invw);
         if (VARIANT == 0 && isSpec && p.prepassTrackOnly) { // pass-through: the centre is fetched again instead of being kept live across the tap loop
             res = load_signal(p, *srcPs[sig], x, y, srcBpt, srcOffs[sig], occIn);
@@ -2005,12 +1886,12 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
                 var = fma_(var, p.specularVarianceBoost, var);
         } else
             var = c0[sig].w;
-        float sigma = sqrt_(var);
-        invL[sig] = 0.3333f * rcp_(fma_(p.phi[si], sigma, 1e-4f));
+        float sigma = wsqrt_(var);
+        invL[sig] = 0.3333f * wrcp_(fma_(p.phi[si], sigma, 1e-4f));
         float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
         if (isSpec)
             angle += p.lobeSlack;
-        float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+        float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN));
         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
         if (p.confDriven) { // confidenceDriven*: low history confidence relaxes the luminance / normal edge stopping of both signals
             float conf = sample_confidence(isSpec ? p.confS : p.confD, u, ((float)gy0 + 0.5f) * c.invH);
@@ -2026,7 +1907,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
         }
         normalW2[sig] = nw_param_m2(normalW); // holds -2 w^2 (normal_weight_m2)
         if (isSpec) {
-            roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
+            roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
             roughB = -rough * roughA;
         }
         sum[sig] = {c0[sig].x, c0[sig].y, c0[sig].z};
@@ -2134,7 +2015,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-        float inv = rcp_(wsum[sig]);
+        float inv = wrcp_(wsum[sig]);
         f3 o = mul3(sum[sig], inv);
         float ov = sumVar[sig] * inv * inv;
         if (last) {
@@ -2195,19 +2076,7 @@ namespace NRD_PROJ_NS {
 
 #if NRD_PART == 1
 void launch_reblur_blur_radiance(const ReblurParams& p, hipStream_t s) { NRD_LAUNCH3(k_spatial, 1, 0, ); }
-#ifdef NRD_DBG_HIST
-extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p1(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_hist), sizeof(g_dbg_hist));
-}
-#endif
 #else
-#ifdef NRD_DBG_HIST
-extern "C" __attribute__((visibility("default"))) int nrdhip_debug_counters_p0(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_hist), sizeof(g_dbg_hist));
-}
-#endif
 void launch_reblur_classify_tiles(const ReblurParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_classify_tiles, dim3((unsigned)((p.c.tilesX + NRD_CT_TILES - 1) / NRD_CT_TILES), (unsigned)p.c.tilesY, 1), dim3(16, 16, 1), 0, s, p);
 }

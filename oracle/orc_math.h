@@ -62,6 +62,16 @@ static inline float rsqrt_(float x) {
     return r;
 }
 static inline float sqrt_(float x) { return x * rsqrt_(x); } // sqrt_(0) = 0
+// NRD_HW_TRANSCENDENTALS = 1 (liboracle_hwt.so, the checker of libnrdhip_hwt.so; csrc/nrd_device.h has the rule): the WEIGHT-CLASS
+// reciprocals / square roots / exponentials of the spatial filters are the GPU's transcendental instructions there (1 ULP each); here
+// they are the correctly rounded IEEE results at the same places - the two sides then differ by roundings of weights only, and the
+// flavour's parity bar is <= 1 ULP fp16 instead of bit identity. Everything a discrete decision hangs on keeps the exact sequences.
+#ifndef NRD_HW_TRANSCENDENTALS
+#define NRD_HW_TRANSCENDENTALS 0
+#endif
+static const bool HW_TRANSCENDENTALS = NRD_HW_TRANSCENDENTALS != 0;
+static inline float wrcp_(float x) { return HW_TRANSCENDENTALS ? 1.0f / x : rcp_(x); }
+static inline float wsqrt_(float x) { return HW_TRANSCENDENTALS ? sqrtf(x) : sqrt_(x); }
 static inline float lerpf(float a, float b, float t) { return fma_(b - a, t, a); }
 static inline float smoothstep01(float x) { x = sat(x); return x * x * (3.0f - 2.0f * x); }
 static inline float absf(float x) { return __builtin_fabsf(x); }
@@ -190,7 +200,7 @@ static inline float pow01(float x, float y) {
 // atan(x), x >= 0 (Abramowitz-Stegun 4.4.49 on [0,1], reflected above 1)
 static inline float atan_pos(float x) {
     bool inv = x > 1.0f;
-    float t = inv ? rcp_(x) : x;
+    float t = inv ? wrcp_(x) : x;
     float s = t * t;
     float p = 0.0208351f;
     p = fma_(p, s, -0.0851330f);
@@ -223,7 +233,8 @@ static inline float sqrt1_unscaled_(float x) {
     const float u = x * y;
     return u * fma_(-u, y, 2.38924456f);
 }
-static const float NORMAL_CHORD_SCALE = (2.0f / 1023.0f) * SQRT1_SCALE;
+static const float NORMAL_CHORD_SCALE = (2.0f / 1023.0f) * (HW_TRANSCENDENTALS ? 1.0f : SQRT1_SCALE);
+static inline float chord_unscaled_(float d2) { return HW_TRANSCENDENTALS ? sqrtf(d2) : sqrt1_unscaled_(d2); }
 // 2^x for x <= 0, degree-3 polynomial after a round-to-nearest split (relative error 8.0e-5): csrc/nrd_device.h exp2_poly_neg
 static inline float exp2_poly_neg(float x) {
     x = fmax2(x, -126.0f);
@@ -235,18 +246,19 @@ static inline float exp2_poly_neg(float x) {
     p = fma_(p, f, 9.999227523803711e-1f);
     return ldexpf(p, (int)fi);
 }
+static inline float exp2_neg(float x) { return HW_TRANSCENDENTALS ? exp2f(x) : exp2_poly_neg(x); }
 // hit-distance weight: compact-support stand-in for exp(-3 |x|): (1 - |x|)^2 clamped (division-free); upstream flavour: exp(-3 |x|)
 static const float EXP_WEIGHT_SCALE = UPSTREAM_FORMULAS ? 4.32808512f : 1.0f; // 3 log2(e)
 static inline float exp_weight(float ax) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly_neg(-EXP_WEIGHT_SCALE * ax);
+        return exp2_neg(-EXP_WEIGHT_SCALE * ax);
     float t = sat(1.0f - ax);
     return t * t;
 }
 // the same weight of |v| with EXP_WEIGHT_SCALE already folded into v (the spatial passes' taps)
 static inline float exp_weight_prescaled(float v) {
     if (UPSTREAM_FORMULAS)
-        return exp2_poly_neg(-absf(v));
+        return exp2_neg(-absf(v));
     float t = sat(1.0f - absf(v));
     return t * t;
 }
@@ -257,7 +269,7 @@ static const float NORMAL_D2_TO_1MCOS = 0.5f * (2.0f / 1023.0f) * (2.0f / 1023.0
 static inline float nw_param(float normalW) { return UPSTREAM_FORMULAS ? normalW : normalW * normalW; }
 static inline float normal_weight(float d2, float prm) {
     if (UPSTREAM_FORMULAS)
-        return smoothstep01(fma_(-sqrt1_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
+        return smoothstep01(fma_(-chord_unscaled_(d2), prm * NORMAL_CHORD_SCALE, 1.0f));
     return smoothstep01(fma_(-2.0f * sat(1.0f - fma_(d2, -NORMAL_D2_TO_1MCOS, 1.0f)), prm, 1.0f));
 }
 

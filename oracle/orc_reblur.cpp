@@ -156,7 +156,7 @@ static inline PixelGeo pixel_geo(const Consts& c, const Guide& g, int x, int gy,
     p.absZ = absf(g.z);
     p.ortho = c.ortho;
     p.frustumSize = c.minRectDimMulUnproject * (c.ortho ? 1.0f : p.absZ);
-    float geoA = rcp_(planeDistSensitivity * p.frustumSize);
+    float geoA = wrcp_(planeDistSensitivity * p.frustumSize);
     p.gax = p.Nv.x * c.pv[2] * geoA;
     p.gay = p.Nv.y * c.pv[3] * geoA;
     if (c.ortho) {
@@ -178,7 +178,7 @@ static inline float geo_weight(const PixelGeo& p, float px, float gy, float zs) 
 static inline float strand_normal_relax(const Consts& c, uint32_t mat, float absZ) {
     if (mat != c.strandMat)
         return 1.0f;
-    return lerpf(0.25f, 1.0f, sat(c.strandThickness * rcp_(c.unproject * (c.ortho ? 1.0f : absZ))));
+    return lerpf(0.25f, 1.0f, sat(c.strandThickness * wrcp_(c.unproject * (c.ortho ? 1.0f : absZ))));
 }
 // unit vector from the view-space point toward the viewer
 static inline f3 to_viewer(const Consts& c, f3 Xv) {
@@ -503,13 +503,13 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
                     float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
                     float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
-                    float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                    float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN)); // (weight-class from here on: orc_math.h NRD_HW_TRANSCENDENTALS)
                     normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                     float normalW2 = nw_param(normalW);
-                    float hitScale = relaxIn ? rcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
-                    float hitA = hitScale * rcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
+                    float hitScale = relaxIn ? wrcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
+                    float hitA = hitScale * wrcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
                     float hitB = -center.w * hitA;
-                    float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
+                    float roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                     float roughB = -rough * roughA;
                     if (variant == BLUR) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk
                         const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
@@ -564,7 +564,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                             minHit = fmin2(minHit, sv.w * hitNorm);
                     }
                 }
-                float invw = rcp_(wsum);
+                float invw = wrcp_(wsum);
                 f4 res = mul4(sum, invw), res1 = mul4(sum1, invw);
                 // usePrepassOnlyForSpecularMotionEstimation: the specular signal passes through, only the tracked hit distance is filtered
                 if (variant == PRE && isSpec && k.d.kind == Kind::REBLUR && s.usePrepassOnlyForSpecularMotionEstimation) {
@@ -1352,14 +1352,14 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         var = fma_(var, s.specularVarianceBoost, var);
                 } else
                     var = c0.w;
-                float sigma = sqrt_(var);
+                float sigma = wsqrt_(var);
                 float phi = isSpec ? s.specularPhiLuminance : s.diffusePhiLuminance;
                 float minLw = isSpec ? s.specularMinLuminanceWeight : s.diffuseMinLuminanceWeight;
-                float invL = 0.3333f * rcp_(fma_(phi, sigma, 1e-4f));
+                float invL = 0.3333f * wrcp_(fma_(phi, sigma, 1e-4f));
                 float angle = spec_lobe_half_angle(rough) * s.lobeAngleFraction;
                 if (isSpec)
                     angle += s.specularLobeAngleSlack * 0.017453292f; // degrees
-                float normalW = rcp_(fmax2(angle, NORMAL_ANGLE_MIN));
+                float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN));
                 normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                 // confidenceDriven*: low history confidence (IN_*_CONFIDENCE) relaxes the luminance / normal edge stopping of both signals
                 if (s.confidenceDrivenRelaxationMultiplier > 0.0f && c.confAvail) {
@@ -1378,7 +1378,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                     roughRelax = lerpf(1.0f, conf, sat(s.roughnessEdgeStoppingRelaxation));
                 }
                 float normalW2 = nw_param(normalW);
-                float roughA = rcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
+                float roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
                 float roughB = -rough * roughA;
                 f3 sum = {c0.x, c0.y, c0.z};
                 float sumVar = var, wsum = 1.0f;
@@ -1415,7 +1415,7 @@ void atrous(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int 
                         sumVar = fma_(vs, w * w, sumVar);
                         wsum += w;
                     }
-                float inv = rcp_(wsum);
+                float inv = wrcp_(wsum);
                 f3 o = mul3(sum, inv);
                 float ov = sumVar * inv * inv;
                 if (last) {

@@ -64,14 +64,26 @@ def emulated_frozen(pkg):
 
 
 @pytest.fixture(scope="session")
-def emulated_paired(pkg):
-    """the kernels built with -DNRD_PAIR_SIGNALS=1 (a shelved build option: profiles/r04_ab_pair_signals.txt)"""
-    path = graft.build_emulated(flavour="paired")
+def hip_frozen(pkg):
+    return pkg.hip_backend("cuda:0", flavour="frozen")
+
+
+# ---- the NRD_HW_TRANSCENDENTALS=1 build flavour (v_rcp_f32 / v_sqrt_f32 / v_exp_f32 in the weight arithmetic of the spatial filters) ----
+@pytest.fixture(scope="session")
+def oracle_hwt(pkg):
+    if not os.path.exists(graft.ORACLE_LIB_HWT):
+        graft.build_oracle()
+    return graft.oracle_backend("hwt")
+
+
+@pytest.fixture(scope="session")
+def emulated_hwt(pkg):
+    path = graft.build_emulated(flavour="hwt")
     b = pkg.api.Backend(path, "nrdhip_", "cpu")
     b.check_abi()
     return b
 
 
 @pytest.fixture(scope="session")
-def hip_frozen(pkg):
-    return pkg.hip_backend("cuda:0", flavour="frozen")
+def hip_hwt(pkg):
+    return pkg.hip_backend("cuda:0", flavour="hwt")

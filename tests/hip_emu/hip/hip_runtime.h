@@ -41,6 +41,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define NRD_WAVES_PER_EU(n)
+#define NRD_SCALAR_AS // (nrd_device.h: the constant address space of the scalar tile-flag loads)
 #define __shared__ static
 
 struct dim3 {
@@ -60,7 +61,6 @@ struct float2 {
     float x, y;
 };
 
-#define NRD_HOST_EMULATION 1 // host-side sources that talk to RCCL / dlopen compile that part out (nrdhip_tiler.cpp)
 typedef int hipError_t;
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
@@ -340,6 +340,10 @@ inline T hipemu_buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 #define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) hipemu_buf_ld<unsigned int>(r, v, s)
 #define __builtin_amdgcn_raw_buffer_load_b16(r, v, s, a) hipemu_buf_ld<unsigned short>(r, v, s)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+// the transcendental instructions of the NRD_HW_TRANSCENDENTALS flavour (1 ULP on the device; here: the correctly rounded IEEE results)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sqrtf(x) __builtin_sqrtf(x)
+#define __builtin_amdgcn_exp2f(x) __builtin_exp2f(x)
 // v_dot2_i32_i16: a.x * b.x + a.y * b.y + c (no clamp used)
 typedef short hipemu_s2 __attribute__((ext_vector_type(2)));
 static inline int hipemu_sdot2(hipemu_s2 a, hipemu_s2 b, int c) { return (int)a.x * (int)b.x + (int)a.y * (int)b.y + c; }

@@ -72,19 +72,17 @@ def test_fused_prepass_is_bit_identical_to_separate_passes(pkg, api, oracle, emu
     assert not np.asarray(hs["ef"].pool("REBLUR::Tmp1")).any() and np.asarray(hs["es"].pool("REBLUR::Tmp1")).any()  # the fused frame never touches it
 
 
-def test_paired_signals_option_is_bit_identical(pkg, api, oracle, emulated_paired):
-    """-DNRD_PAIR_SIGNALS=1: the spatial passes that filter both signals consume tap t of the diffuse and of the specular signal together,
-    their weight chains on {diffuse, specular} register pairs (v_pk_fma_f32 / v_pk_mul_f32 on gfx950; nrd_device.h nrd_f2). Every half is
-    the scalar sequence operation for operation, so the build must reproduce the oracle bit for bit - fused PrePass, Blur, PostBlur
-    (perspective and orthographic), REBLUR and RELAX. Measured slower than the scalar build on MI355X (profiles/r04_ab_pair_signals.txt),
-    hence an option, not the default."""
+def test_hw_transcendentals_flavour_places_agree(pkg, api, oracle_hwt, emulated_hwt):
+    """-DNRD_HW_TRANSCENDENTALS=1 on both sides: the kernels' transcendental builtins are IEEE 1 / x, sqrtf, exp2f under the host emulation -
+    exactly what liboracle_hwt.so computes at those places - so the two must agree bit for bit: every weight-class site is switched on BOTH
+    sides and nowhere else (on the GPU the instructions are 1 ULP: tests/test_hw_transcendentals.py holds that build to the 1-ULP-fp16 bar)"""
     w, h = 72, 56
-    for den, kw in (("REBLUR_DIFFUSE_SPECULAR", {}), ("REBLUR_DIFFUSE_SPECULAR", dict(ortho=True)), ("RELAX_DIFFUSE_SPECULAR", {})):
+    for den, kw in (("REBLUR_DIFFUSE_SPECULAR", {}), ("REBLUR_DIFFUSE_SPECULAR", dict(ortho=True)), ("RELAX_DIFFUSE_SPECULAR_SH", {}), ("REBLUR_DIFFUSE_SPECULAR_SH", {})):
         scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if den.startswith("RELAX") else "REBLUR", **kw)
         dd = [api.Denoiser[den]]
         st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
-        ho = util.run_frames(api, pkg.harness, oracle, scene, dd, 3, settings=st)
-        he = util.run_frames(api, pkg.harness, emulated_paired, scene, dd, 3, settings=st)
+        ho = util.run_frames(api, pkg.harness, oracle_hwt, scene, dd, 3, settings=st)
+        he = util.run_frames(api, pkg.harness, emulated_hwt, scene, dd, 3, settings=st)
         assert util.compare_all(ho, he, exact=True) == []
 
 

@@ -1,4 +1,4 @@
-"""Runs ON THE GPU BOX with a library built with -DNRD_DEBUG_COUNTERS (tools/build_variant.sh hist "-DNRD_DEBUG_COUNTERS"):
+"""Runs ON THE GPU BOX with a library built with -DNRD_DEBUG_COUNTERS (tools/build_variant.sh hist "-DNRD_DEBUG_COUNTERS" tools/variants/lab_diag_hist_pair.patch):
 distribution of tap distances (Chebyshev, pixels) in the three spatial passes of the default bench workload, over all frames
 (warm-up included) and over the steady state only."""
 import ctypes as C, os, sys
