@@ -179,6 +179,15 @@ NRDHIP_API int nrdhip_bind_pool(nrdhip_instance* inst, uint32_t pool, uint32_t i
  * nrdhip_slot_info - the plane currently bound to a resource slot (ptr NULL = unbound). */
 NRDHIP_API int nrdhip_denoiser_kind(nrdhip_instance* inst, uint32_t identifier, uint32_t* kind);
 NRDHIP_API int nrdhip_get_band(nrdhip_instance* inst, int32_t out[5]);
+/* Row tiling: the LOCAL rows [first_local_row, first_local_row + rows) on which the previous frame's permanent planes are current on this
+ * instance (rows = 0: every stored row - a whole-frame instance, the default). A row tiler refreshes only the rows of last frame's state
+ * that reprojection may reach (owned rows +- the motion allowance of nrdhip_required_halo + 2), not the whole stored halo; with the
+ * window set, a reprojection footprint (surface or virtual motion) that lands beyond it is REJECTED like one that leaves the frame - the
+ * pixel restarts its history - instead of reading rows no exchange has written this frame. `motion_rows` of nrdhip_required_halo must
+ * therefore bound the vertical displacement of BOTH the surface motion and the specular virtual motion for the tiled frame to stay
+ * bit-identical to the single-GPU frame; beyond it the result is deterministic and self-consistent, but no longer identical.
+ * No counterpart in the reference (single adapter). Both row tilers (nrdhip_tiler_*, nrd-sample_amd/tiler.py) set it from their plan. */
+NRDHIP_API int nrdhip_set_history_rows(nrdhip_instance* inst, int32_t first_local_row, uint32_t rows);
 /* HIP device ordinal the instance was created for (nrdhip_create_desc::device_plus1 - 1), -1 = "whatever is current at each call" */
 NRDHIP_API int nrdhip_get_device(nrdhip_instance* inst);
 NRDHIP_API int nrdhip_slot_info(nrdhip_instance* inst, uint32_t slot, nrdhip_plane_info* out);
@@ -193,7 +202,7 @@ NRDHIP_API const char* nrdhip_denoiser_string(uint32_t denoiser);
 /* sizeof() of the ABI structs as compiled, for binding self-checks:
  * 0 CommonSettings, 1 ReblurSettings, 2 RelaxSettings, 3 SigmaSettings, 4 ReferenceSettings,
  * 5 nrdhip_create_desc, 6 nrdhip_plane_info, 7 nrdhip_dispatch_info, 8 nrdhip_confidence_blur_desc, 9 nrdhip_unpack_desc,
- * 10 nrdhip_taa_desc, 11 nrdhip_frontend_pack_desc, 12 nrdhip_compose_desc */
+ * 10 nrdhip_taa_desc, 11 nrdhip_frontend_pack_desc, 12 nrdhip_compose_desc, 13 nrdhip_transport */
 NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which);
 /* last error text of the instance (or of creation when inst == NULL) */
 NRDHIP_API const char* nrdhip_last_error(nrdhip_instance* inst);

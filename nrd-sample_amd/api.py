@@ -414,6 +414,7 @@ class Backend:
         self._sig("denoise", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
         self._sig("get_history_state", C.c_int, [C.c_void_p, _u32, C.POINTER(HistoryState)])
         self._sig("set_history_state", C.c_int, [C.c_void_p, _u32, C.POINTER(HistoryState)])
+        self._sig("set_history_rows", C.c_int, [C.c_void_p, C.c_int32, _u32])
         if hasattr(self.lib, self.prefix + "graph_stats"):  # product library (the CPU oracle of the tests has no graphs)
             self._sig("graph_stats", C.c_int, [C.c_void_p, C.POINTER(_u32)])
         self._sig("dispatch_count", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.POINTER(_u32)])
@@ -470,6 +471,8 @@ class Backend:
             got = self.sizeof(i)
             if got != C.sizeof(cls):
                 raise RuntimeError("ABI mismatch: sizeof(%s) python=%d library=%d" % (cls.__name__, C.sizeof(cls), got))
+        if self.has_tiler and self.sizeof(13) != C.sizeof(Transport):  # (copied by value in nrdhip_tiler_create: a stale layout would hand it garbage flags)
+            raise RuntimeError("ABI mismatch: sizeof(nrdhip_transport) python=%d library=%d" % (C.sizeof(Transport), self.sizeof(13)))
         return True
 
     @property
@@ -550,6 +553,11 @@ class Integration:
 
     def new_frame(self):
         self._check(self.backend.new_frame(self.handle), "NewFrame")
+
+    def set_history_rows(self, first_local_row, rows):
+        """row tiling: the local rows on which last frame's permanent planes are current (include/nrdhip.h nrdhip_set_history_rows); rows = 0: all"""
+        self._check(self.backend.set_history_rows(self.handle, int(first_local_row), int(rows)), "set_history_rows")
+        self.history_rows = (int(first_local_row), int(rows))
 
     def set_common_settings(self, cs):
         self._check(self.backend.set_common(self.handle, C.byref(cs), C.sizeof(cs)), "SetCommonSettings")

@@ -73,6 +73,9 @@ struct FrameConsts {
     int tilesX, tilesY; // tile grid covering the owned rows: tile row 0 starts at local row tileY0 * 16
     int tileY0;
     int reverse; // 1: every XCD walks its tile sequence backwards (consecutive passes alternate: the reader starts where the writer ended)
+    int prevY0, prevY1; // local rows [prevY0, prevY1) on which the PREVIOUS frame's planes are current (nrdhip_set_history_rows; whole planes
+                        // on a single GPU). A row tiler refreshes only the rows reprojection may reach; a footprint texel outside is rejected
+                        // like one outside the frame - a disocclusion - instead of being read from rows no exchange has written this frame
     float rot[64][2];
 };
 

@@ -984,7 +984,7 @@ NRD_DEV Footprint foot_weights(const FrameConsts& c, const FootPos& fp, const ui
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
-        bool ok = fp.sane & (tx >= 0) & (tx < c.Wprev) & (gy >= 0) & (gy < c.Hprev) & (ty >= 0) & (ty < c.resH);
+        bool ok = fp.sane & (tx >= 0) & (tx < c.Wprev) & (gy >= 0) & (gy < c.Hprev) & (ty >= c.prevY0) & (ty < c.prevY1);
         Guide gp = decode_guide(graw[i], c.denoisingRange);
         float lin = fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));
         float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin; // N . X of the previous-frame texel

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(COPY ? 8 : 2) void k_sigma_te
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int ttx = ix + (i & 1), gy = iy + (i >> 1), tty = gy - c.yOff;
-            bool ok = (ttx >= 0) & (ttx < c.Wprev) & (gy >= 0) & (gy < c.Hprev) & (tty >= 0) & (tty < c.resH); // (bitwise: one basic block)
+            bool ok = (ttx >= 0) & (ttx < c.Wprev) & (gy >= 0) & (gy < c.Hprev) & (tty >= c.prevY0) & (tty < c.prevY1); // (bitwise: one basic block)
             Guide gp = decode_guide(fg[i], c.denoisingRange);
             float lin = fma_(gx, (float)ttx, fma_(gyc, (float)gy, g0));
             float plane = ORTHO ? fma_(gp.z, NvPrev.z, lin) : gp.z * lin;

@@ -139,6 +139,7 @@ inline uint32_t enc_slot(nrd::ResourceType t) { return (2u << 16) | (uint32_t)t;
 
 struct nrdhip_instance {
     int resW = 0, resH = 0, frameH = 0, yOff = 0, ownY0 = 0, ownRows = 0;
+    int histY0 = 0, histRows = 0; // nrdhip_set_history_rows (0 rows = every stored row)
     int device = -1; // HIP device ordinal the pools live on and the kernels run on (-1: whatever is current at each call)
     uint32_t flags = 0;
     nrd::CommonSettings common;
@@ -329,6 +330,8 @@ bool derive_consts(const nrdhip_instance& I, FrameConsts& c, std::string& err) {
     c.ownY1 = std::min(c.ownY1, I.resH);
     if (c.ownY1 < c.ownY0)
         c.ownY1 = c.ownY0;
+    c.prevY0 = I.histRows ? std::max(I.histY0, 0) : 0;
+    c.prevY1 = I.histRows ? std::min(I.histY0 + I.histRows, I.resH) : I.resH;
     c.tilesX = (c.W + 15) / 16;
     c.tileY0 = c.ownY0 / 16;
     c.tilesY = (c.ownY1 + 15) / 16 - c.tileY0;
@@ -1345,6 +1348,14 @@ NRDHIP_API int nrdhip_denoiser_kind(nrdhip_instance* inst, uint32_t identifier, 
 
 NRDHIP_API int nrdhip_get_device(nrdhip_instance* inst) { return inst ? inst->device : -1; }
 
+NRDHIP_API int nrdhip_set_history_rows(nrdhip_instance* inst, int32_t first_local_row, uint32_t rows) {
+    if (!inst)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    inst->histY0 = first_local_row;
+    inst->histRows = (int)rows;
+    return 0;
+}
+
 NRDHIP_API int nrdhip_get_band(nrdhip_instance* inst, int32_t out[5]) {
     if (!inst || !out)
         return (int)nrd::Result::INVALID_ARGUMENT;
@@ -1760,6 +1771,7 @@ NRDHIP_API uint32_t nrdhip_sizeof(uint32_t which) {
         case 10: return sizeof(nrdhip_taa_desc);
         case 11: return sizeof(nrdhip_frontend_pack_desc);
         case 12: return sizeof(nrdhip_compose_desc);
+        case 13: return sizeof(nrdhip_transport);
     }
     return 0;
 }

@@ -332,6 +332,13 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
         reproj = provable ? std::min<uint32_t>(T.halo, T.halo - std::min(maxReach, T.halo) + 2u) : T.halo;
     }
     T.reprojRows = reproj;
+    {
+        // the kernels must not trust previous-frame rows the plan below never refreshes: tell the instance which local rows are current
+        // (owned rows +- reproj); a footprint beyond them is rejected instead of being read from stale halo rows
+        int32_t band[5];
+        if (nrdhip_get_band(T.inst, band) != 0 || nrdhip_set_history_rows(T.inst, band[2] - (int32_t)reproj, (uint32_t)band[3] + 2u * reproj) != 0)
+            return fail(T, FAILURE, "nrdhip_set_history_rows");
+    }
     // how far dispatch j reads into plane `code` (read_rows: 0 = own pixel, N = spatial footprint, NRDHIP_READ_REPROJECTED)
     auto reach_into = [&](uint32_t j, uint32_t code) -> uint32_t {
         for (uint32_t k = 0; k < d[j].read_num; k++)
@@ -437,7 +444,9 @@ NRDHIP_API int nrdhip_tiler_create(nrdhip_instance* inst, int rank, int world, c
         return INVALID; // a band shorter than its halo cannot feed its neighbour's halo from owned rows
     }
     if (transport) {
-        if (!transport->send || !transport->recv) {
+        // (the struct is copied by value: a caller built against an older header or one that did not zero-initialise it would hand over
+        // garbage flags - an unknown bit is refused rather than read as "stream-ordered"; nrdhip_sizeof(13) lets bindings check the layout)
+        if (!transport->send || !transport->recv || (transport->flags & ~(uint32_t)NRDHIP_TRANSPORT_STREAM_ORDERED)) {
             delete T;
             return INVALID;
         }

@@ -209,9 +209,15 @@ class Tiler:
         from . import api
 
         key = tuple((d["name"], tuple(d["written"]), tuple(d["read"]), tuple(d.get("read_rows", ())), d.get("all_rows", False), d["halo_rows"]) for d in dispatches)
+        L = self.band.layout
         if key in self._plan_cache:
-            return self._plan_cache[key]
+            plan, reproj = self._plan_cache[key]
+            self.band.nrd.set_history_rows(L["own_first"] - reproj, L["own_rows"] + 2 * reproj)
+            return plan
         reproj = self.reprojection_rows(dispatches)
+        # the kernels must not trust previous-frame rows this plan never refreshes: a footprint beyond owned rows +- reproj is rejected
+        # (a disocclusion) instead of being read from stale halo rows (include/nrdhip.h nrdhip_set_history_rows)
+        self.band.nrd.set_history_rows(L["own_first"] - reproj, L["own_rows"] + 2 * reproj)
 
         def reach_into(r, code):
             rows = r.get("read_rows")
@@ -241,7 +247,7 @@ class Tiler:
                 if rows > 0:
                     now.append((code, rows) + (() if guide is None else (0, guide)))
             plan.append((now, later))
-        self._plan_cache[key] = plan
+        self._plan_cache[key] = (plan, reproj)
         return plan
 
     def _ops(self, bufs_rows):

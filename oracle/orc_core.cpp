@@ -20,7 +20,7 @@ const float g_poisson8[8][3] = {
     {0.7836658f, -0.4208784f, 0.5932f},  {0.1564120f, -0.8198990f, 0.6314f}};
 
 // CommonSettings -> per-frame constants. Column-major 4x4 input (NRDSample.cpp:3836-3839).
-bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err) {
+bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err, int histY0, int histRows) {
     c = Consts();
     c.W = cs.rectSize[0];
     c.H = cs.rectSize[1];
@@ -47,6 +47,8 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
     c.ownY1 = std::min(c.ownY1, resH);
     if (c.ownY1 < c.ownY0)
         c.ownY1 = c.ownY0;
+    c.prevY0 = histRows ? std::max(histY0, 0) : 0;
+    c.prevY1 = histRows ? std::min(histY0 + histRows, resH) : resH;
     c.invW = 1.0f / (float)c.W;
     c.invH = 1.0f / (float)c.H;
     c.invWprev = 1.0f / (float)c.Wprev;
@@ -322,6 +324,13 @@ NRDHIP_API int orc_create(const nrdhip_create_desc* desc, nrdhip_instance** out)
 
 NRDHIP_API void orc_destroy(nrdhip_instance* inst) { delete inst; }
 NRDHIP_API int orc_new_frame(nrdhip_instance*) { return 0; }
+NRDHIP_API int orc_set_history_rows(nrdhip_instance* inst, int32_t first_local_row, uint32_t rows) {
+    if (!inst)
+        return (int)nrd::Result::INVALID_ARGUMENT;
+    inst->I.histY0 = first_local_row;
+    inst->I.histRows = (int)rows;
+    return 0;
+}
 
 NRDHIP_API int orc_set_threads(nrdhip_instance* inst, int threads) {
     inst->I.threads = threads < 1 ? 1 : threads;
@@ -492,7 +501,7 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
             return (int)nrd::Result::INVALID_ARGUMENT;
         }
     Consts c;
-    if (!derive_consts(I.common, I.resW, I.resH, I.frameH, I.yOff, I.ownY0, I.ownRows, c, I.error))
+    if (!derive_consts(I.common, I.resW, I.resH, I.frameH, I.yOff, I.ownY0, I.ownRows, c, I.error, I.histY0, I.histRows))
         return (int)nrd::Result::INVALID_ARGUMENT;
     std::vector<Flat> fl;
     int r = flatten(I, ids, n, fl);

@@ -87,6 +87,7 @@ struct Consts {
     int resW = 0, resH = 0;   // local plane size
     int yOff = 0;             // global row stored at local row 0 (row tiling), else 0
     int ownY0 = 0, ownY1 = 0; // local rows this instance produces [ownY0, ownY1)
+    int prevY0 = 0, prevY1 = 0; // local rows on which the previous frame's planes are current (orc_set_history_rows; default: all stored rows)
     float invW = 0, invH = 0, invWprev = 0, invHprev = 0;
     // orthographic projections (the sample's "Ortho" camera, Source/NRDSample.cpp:1214, :1971): Xv.xy = uv * d + o (no z factor),
     // pj = {m0, m5, m12, m13, 1}; the trailing element of fr / pv / pj is the flag (1 = orthographic) for the helpers below
@@ -109,7 +110,7 @@ struct Consts {
     float rot[64][2] = {};
 };
 
-bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err);
+bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err, int histY0 = 0, int histRows = 0);
 
 // view position from uv and (signed) viewZ
 static inline f3 reconstruct(const float* fr, float u, float v, float z) {
@@ -260,6 +261,7 @@ struct DenoiserState {
 
 struct Instance {
     int resW = 0, resH = 0, frameH = 0, yOff = 0, ownY0 = 0, ownRows = 0;
+    int histY0 = 0, histRows = 0; // orc_set_history_rows (0 rows = all)
     uint32_t flags = 0;
     int threads = 1;
     nrd::CommonSettings common;

@@ -649,7 +649,7 @@ static inline Footprint footprint(const Ctx& k, float pu, float pv, f3 NvPrev, f
     float gx = NvPrev.x * c.pvPrev[2], gyc = NvPrev.y * c.pvPrev[3];
     for (int i = 0; i < 4; i++) {
         int tx = f.ix + (i & 1), gy = f.iy + (i >> 1), ty = gy - c.yOff;
-        bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= 0 && ty < c.resH;
+        bool ok = sane && tx >= 0 && tx < c.Wprev && gy >= 0 && gy < c.Hprev && ty >= c.prevY0 && ty < c.prevY1;
         if (ok) {
             Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
             float lin = fma_(gx, (float)tx, fma_(gyc, (float)gy, g0));

@@ -325,7 +325,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                     float wsum = 0.0f;
                     for (int i = 0; i < 4; i++) {
                         int tx = ix + (i & 1), gy = iy + (i >> 1), ty = gy - c.yOff;
-                        if (tx < 0 || tx >= c.Wprev || gy < 0 || gy >= c.Hprev || ty < 0 || ty >= c.resH)
+                        if (tx < 0 || tx >= c.Wprev || gy < 0 || gy >= c.Hprev || ty < c.prevY0 || ty >= c.prevY1)
                             continue;
                         Guide gp = load_guide(GP, tx, ty, c.denoisingRange);
                         if (gp.sky)

@@ -21,7 +21,8 @@ def bench_settings(api, scene, dens):
 
 
 def run_pair(pkg, api, oracle, hip, dens, w, h, threads, exact=True, dolly=0.004):
-    scene = pkg.synth.Scene(w, h, dolly=dolly, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
+    # (frames are rendered on the GPU - a 1080p frame takes numpy ~2 s - and copied to the host for the oracle)
+    scene = pkg.synth.Scene(w, h, dolly=dolly, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR", device="cuda:0")
     dd = [api.Denoiser[x] for x in dens]
     st = bench_settings(api, scene, dd)
     ho = pkg.harness.Harness(oracle, dd, w, h)
@@ -31,7 +32,7 @@ def run_pair(pkg, api, oracle, hip, dens, w, h, threads, exact=True, dolly=0.004
     for f in range(FRAMES):
         fr = scene.frame(f)
         cs = scene.common_settings(api, fr, f, reset=(f == 0))
-        ho.frame(cs, ho.upload(fr), st)
+        ho.frame(cs, ho.upload(util.host_frame(fr)), st)
         hg.frame(cs, hg.upload(fr), st)
         if f >= FIRST_CHECKED:
             bad = util.compare_all(ho, hg, exact=exact, ulp=1)

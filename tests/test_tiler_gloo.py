@@ -75,6 +75,9 @@ def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
         reproj = t.reprojection_rows(disp)
         reach = max(d["halo_rows"] for d in disp)
         assert reproj == band.halo - reach + 2 < band.halo  # every read of last frame's state in these lists is a reprojected one
+        # ... and the instance is told that last frame's planes are current on owned rows +- reproj ONLY: its reprojection rejects footprints
+        # beyond them instead of reading halo rows no exchange refreshes (tests/test_history_rows.py: the kernels honour the window)
+        assert band.nrd.history_rows == (band.layout["own_first"] - reproj, band.layout["own_rows"] + 2 * reproj)
         deferred = set()
         for i, (now, later) in enumerate(plan):
             assert not (disp[i]["all_rows"] and (now or later)), disp[i]["name"]

@@ -58,6 +58,13 @@ def run_frames(api, harness_mod, backend, scene, denoisers, nframes, settings=No
     return h
 
 
+def host_frame(fr):
+    """a frame rendered on the GPU (synth.Scene(device="cuda:0"): torch tensors) as the numpy planes the CPU oracle takes"""
+    host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in fr.items()}
+    host["normal_roughness"] = host["normal_roughness"].view(np.uint32)
+    return host
+
+
 def compare_all(ha, hb, exact=True, ulp=1):
     """compare outputs and every pool plane of two harnesses; returns list of (name, detail) mismatches"""
     bad = []
