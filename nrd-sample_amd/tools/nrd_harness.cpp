@@ -6,9 +6,15 @@
 //   Sample::Denoise ....... ResourceSnapshot::SetResource for every slot, Integration::Denoise (:440-531)
 // Inputs are raw plane files (written by tests/test_cpp_harness.py or any producer); outputs are written back as raw files.
 //
-//   nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl | --async]] [--confidence] [--sh]
+//   nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl | --async [--latency-us L] [--solo R]]] [--confidence] [--sh]
 // --async (with --ranks): the in-process fabric as a stream-ordered transport - the tiler then runs its RCCL ordering path (side stream and
 //   events) with device-to-device copies standing in for ncclSend / ncclRecv: what can be verified of that path on a 1-GPU box.
+// --latency-us L (with --async): every exchange group of the stream-ordered transport starts with a kernel that spins L microseconds on the
+//   stream the tiler hands it - a stand-in for the xGMI / RCCL latency this 1-GPU box does not have. Results must not change (ordering).
+// --solo R (with --ranks N --async): ONLY rank R runs, against a loopback transport (its sends land in a scratch buffer, its receives copy
+//   that buffer back after the injected latency): TIMING ONLY - the halo rows hold this rank's own data, outputs are not written. With the
+//   GPU to itself the rank's frame time shows whether the strips-first schedule really hides an exchange behind the interior of its
+//   dispatch (evCompute / evComm / evDeferred ordering): tests/test_cpp_harness.py compares frame times at L = 0 and L > 0.
 // --confidence: the history-confidence path of the sample (Source/NRDSample.cpp:3999-4026, :457, :462, :3866): gradient.bin (RGBA16F at
 //   Sample::GetSharcDims(), :596-598) goes through the five ConfidenceBlur passes - Gradient_Ping -> Pong -> Ping ..., the loop of
 //   :4003-4026 - every frame, Gradient_Pong is bound to IN_DIFF_CONFIDENCE and IN_SPEC_CONFIDENCE, isHistoryConfidenceAvailable = true.
@@ -144,6 +150,62 @@ static int mbRecv(void* user, void* ptr, size_t bytes, int peer, void*) {
 // (source, destination) pair: the sender copies its rows in on ITS stream and records `ready`; the receiver makes ITS stream wait for
 // `ready`, copies the rows out and records `consumed`, which the sender's stream waits for before it overwrites the slot the next time
 // round. The only host-side waits are for a message to have been POSTED (not for the GPU) and for a ring slot's reuse to be known.
+// injected link latency: spins on the device for `ticks` of the constant-rate wall clock (hipDeviceAttributeWallClockRate, kHz)
+__global__ void k_delay(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+static long long g_delayTicks = 0; // 0 = no injected latency
+static void setLatencyUs(int us) {
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+    g_delayTicks = (long long)us * (long long)khz / 1000;
+}
+
+// --solo: loopback transport of a single rank (timing only). A send lands in a scratch buffer per (peer, message index of the group), a
+// receive copies the buffer of the same index back, behind the injected latency of its group - all on the stream the tiler hands over.
+struct LoopbackEndpoint {
+    std::map<std::pair<int, int>, std::pair<void*, size_t>> scratch; // (peer, index in group) -> buffer
+    int sendIndex = 0, recvIndex = 0;
+    bool delayed = false;
+    uint64_t groups = 0;
+};
+static int lbBegin(void* user) {
+    auto* e = (LoopbackEndpoint*)user;
+    e->sendIndex = e->recvIndex = 0;
+    e->delayed = false;
+    e->groups++;
+    return 0;
+}
+static void* lbBuffer(LoopbackEndpoint* e, int peer, int index, size_t bytes) {
+    auto& b = e->scratch[{peer, index}];
+    if (b.second < bytes) {
+        if (b.first)
+            (void)hipFree(b.first);
+        if (hipMalloc(&b.first, bytes) != hipSuccess)
+            return nullptr;
+        (void)hipMemset(b.first, 0, bytes);
+        b.second = bytes;
+    }
+    return b.first;
+}
+static int lbSend(void* user, const void* ptr, size_t bytes, int peer, void* stream) {
+    auto* e = (LoopbackEndpoint*)user;
+    void* b = lbBuffer(e, peer, e->sendIndex++, bytes);
+    return b && hipMemcpyAsync(b, ptr, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+static int lbRecv(void* user, void* ptr, size_t bytes, int peer, void* stream) {
+    auto* e = (LoopbackEndpoint*)user;
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->delayed && g_delayTicks > 0) {
+        hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, g_delayTicks);
+        e->delayed = true;
+    }
+    void* b = lbBuffer(e, peer, e->recvIndex++, bytes);
+    return b && hipMemcpyAsync(ptr, b, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : 1;
+}
+
 struct AsyncSlot {
     void* buf = nullptr;
     size_t cap = 0, bytes = 0;
@@ -160,7 +222,12 @@ struct AsyncFabric {
 struct AsyncEndpoint {
     AsyncFabric* fab;
     int rank;
+    bool delayed = false; // --latency-us: the first receive of a group carries the injected latency
 };
+static int asBegin(void* user) {
+    ((AsyncEndpoint*)user)->delayed = false;
+    return 0;
+}
 static int asSend(void* user, const void* ptr, size_t bytes, int peer, void* stream) {
     auto* e = (AsyncEndpoint*)user;
     hipStream_t st = (hipStream_t)stream;
@@ -213,6 +280,10 @@ static int asRecv(void* user, void* ptr, size_t bytes, int peer, void* stream) {
         if (s->bytes != bytes)
             return 1;
     }
+    if (!e->delayed && g_delayTicks > 0) {
+        hipLaunchKernelGGL(k_delay, dim3(1), dim3(1), 0, st, g_delayTicks);
+        e->delayed = true;
+    }
     if (hipStreamWaitEvent(st, s->ready, 0) != hipSuccess || hipMemcpyAsync(ptr, s->buf, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess ||
         hipEventRecord(s->consumed, st) != hipSuccess)
         return 1;
@@ -230,6 +301,7 @@ struct Shared {
     int frames, world;
     bool rccl;
     bool async = false;
+    int solo = -1; // --solo R: only rank R runs, loopback transport, timing only
     AsyncFabric fabric;
     Mailbox box;
     uint8_t uniqueId[128];
@@ -294,9 +366,12 @@ static void rankMain(Shared* S, int rank) {
     }
     Endpoint ep{&S->box, rank};
     AsyncEndpoint aep{&S->fabric, rank};
+    LoopbackEndpoint lep;
     nrdhip_transport tr{&ep, nullptr, mbSend, mbRecv, nullptr, 0u};
     if (S->async)
-        tr = nrdhip_transport{&aep, nullptr, asSend, asRecv, nullptr, NRDHIP_TRANSPORT_STREAM_ORDERED};
+        tr = nrdhip_transport{&aep, asBegin, asSend, asRecv, nullptr, NRDHIP_TRANSPORT_STREAM_ORDERED};
+    if (S->solo >= 0)
+        tr = nrdhip_transport{&lep, lbBegin, lbSend, lbRecv, nullptr, NRDHIP_TRANSPORT_STREAM_ORDERED};
     nrd::TiledIntegration m_NRD;
     if (m_NRD.Recreate(desc, instanceCreationDesc, device, rank, S->world, halo, S->rccl ? nullptr : &tr) != nrd::Result::SUCCESS) {
         fprintf(stderr, "rank %d: Recreate failed (bands shorter than the %u-row halo?)\n", rank, halo);
@@ -338,7 +413,13 @@ static void rankMain(Shared* S, int rank) {
         rs.SetResource(RT::IN_SIGNAL, GetNrdResource(Composed));
         rs.SetResource(RT::OUT_SIGNAL, GetNrdResource(Composed));
     };
+    hipEvent_t evT0 = nullptr, evT1 = nullptr;
+    (void)hipEventCreate(&evT0);
+    (void)hipEventCreate(&evT1);
+    const int timedFrom = S->frames > 8 ? 4 : S->frames; // (frame time is reported for runs of more than 8 frames: the first 4 are warm-up)
     for (int frameIndex = 0; frameIndex < S->frames; frameIndex++) {
+        if (frameIndex == timedFrom)
+            (void)hipEventRecord(evT0, stream);
         nrd::CommonSettings commonSettings = {};
         float aspect = (float)w / (float)h;
         float proj[16] = {1, 0, 0, 0, 0, aspect, 0, 0, 0, 0, 1, 1, 0, 0, -0.05f, 0};
@@ -383,9 +464,23 @@ static void rankMain(Shared* S, int rank) {
             }
         }
     }
-    if (m_NRD.Finish(stream) != nrd::Result::SUCCESS || hipStreamSynchronize(stream) != hipSuccess)
+    if (m_NRD.Finish(stream) != nrd::Result::SUCCESS || hipEventRecord(evT1, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
         return;
     const int own0 = m_NRD.OwnFirst(), ownN = m_NRD.OwnRows(), g0 = row0 + own0;
+    if (S->frames > timedFrom) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, evT0, evT1);
+        uint64_t ts[4] = {};
+        nrdhip_tiler_stats(m_NRD.GetTiler(), ts);
+        printf("rank %d: %.4f ms per frame over %d frames (GPU time on the compute stream, exchanges included), %.1f in-frame + %.1f deferred exchanges per frame, "
+               "injected latency %lld ticks per exchange%s\n", rank, ms / (float)(S->frames - timedFrom), S->frames - timedFrom, (double)ts[2] / S->frames, (double)ts[3] / S->frames,
+               g_delayTicks, S->solo >= 0 ? " [solo: loopback transport, timing only]" : "");
+    }
+    if (S->solo >= 0) {
+        m_NRD.Destroy();
+        status = 0;
+        return;
+    }
     if (!fetchOwned(Diff, own0, ownN, g0, S->outDiff) || !fetchOwned(Spec, own0, ownN, g0, S->outSpec) || !fetchOwned(Shadow, own0, ownN, g0, S->outShadow) ||
         !fetchOwned(Composed, own0, ownN, g0, S->outSignal))
         return;
@@ -397,9 +492,10 @@ static void rankMain(Shared* S, int rank) {
     status = 0;
 }
 
-static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int world, bool rccl, bool async) {
+static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int world, bool rccl, bool async, int solo, int latencyUs) {
     Shared S;
     S.async = async;
+    S.solo = solo;
     S.dir = dir;
     S.w = w;
     S.h = h;
@@ -421,6 +517,22 @@ static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int w
             fprintf(stderr, "ncclGetUniqueId failed\n");
             return 1;
         }
+    }
+    if (latencyUs > 0)
+        setLatencyUs(latencyUs);
+    if (solo >= 0) { // one rank against the loopback transport: timing only, nothing to assemble
+        if (solo >= world || !async) {
+            fprintf(stderr, "--solo R needs --ranks N > R and --async\n");
+            return 2;
+        }
+        std::thread t(rankMain, &S, solo);
+        t.join();
+        if (S.status[solo]) {
+            fprintf(stderr, "rank %d failed\n", solo);
+            return 1;
+        }
+        printf("row-tiled run: rank %d of %d alone, loopback stream-ordered transport, %ux%u, %d frames, %d us injected per exchange\n", solo, world, w, h, frames, latencyUs);
+        return 0;
     }
     S.outDiff.assign((size_t)w * 8 * h, 0);
     S.outSpec.assign((size_t)w * 8 * h, 0);
@@ -455,7 +567,7 @@ static int run(const std::string& dir, uint16_t w, uint16_t h, int frames, int w
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl]] [--confidence] [--sh] [--synthesize]\n");
+        fprintf(stderr, "usage: nrd_harness <dir> <width> <height> <frames> [--ranks N [--rccl | --async [--latency-us L] [--solo R]]] [--confidence] [--sh] [--synthesize]\n");
         return 2;
     }
     std::string dir = argv[1];
@@ -463,9 +575,14 @@ int main(int argc, char** argv) {
     int frames = atoi(argv[4]);
     int ranks = 1;
     bool rccl = false, async = false;
+    int solo = -1, latencyUs = 0;
     for (int i = 5; i < argc; i++) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc)
             ranks = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--solo") && i + 1 < argc)
+            solo = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--latency-us") && i + 1 < argc)
+            latencyUs = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--rccl"))
             rccl = true;
         else if (!strcmp(argv[i], "--async"))
@@ -485,7 +602,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     if (ranks > 1)
-        return tiled::run(dir, w, h, frames, ranks, rccl, async);
+        return tiled::run(dir, w, h, frames, ranks, rccl, async, solo, latencyUs);
     using F = nrd::Format;
     using RT = nrd::ResourceType;
 
