@@ -361,6 +361,24 @@ def main():
                                                       "at_50_GBs_per_direction": round(per_neighbour / 50e9 * 1e3, 3),
                                                       "at_75_GBs_per_direction": round(per_neighbour / 75e9 * 1e3, 3),
                                                       "band_compute_ms_rank0": round(sum(v[0] for v in per_pass.values()), 4) if per_pass else None}
+            if per_pass and hasattr(t, "_plan"):
+                # the same bytes dispatch by dispatch against the measured interior each exchange can hide behind (strips-first schedule):
+                # what the frame SHOULD cost on real links - the figure a SCALE run is to be compared with (nrd-sample_amd/tiler.py)
+                try:
+                    from nrd_sample_amd.tiler import exchange_overlap_model, plan_bytes
+
+                    disp = runner.band.nrd.dispatches(ids)
+                    planes = {(pool << 16) | i: p["bpt"] for pool in (0, 1) for i, p in enumerate(runner.band.nrd.pools[pool])}
+                    pb = plan_bytes(t._plan(ids, disp), planes, w)
+                    pm = [per_pass[d["name"]][0] for d in disp]
+                    nb = 1 if world <= 2 else 2
+                    out["config"]["exchange_overlap_model"] = {
+                        "%d_GBs_%d_us" % (gbs, lat): {k: v for k, v in exchange_overlap_model([d["name"] for d in disp], pm, pb, band_h, nb, gbs, lat).items() if k != "per_dispatch" or (gbs, lat) == (50, 20)}
+                        for gbs, lat in ((50, 20), (75, 10), (35, 50))}
+                    out["config"]["exchange_overlap_model"]["note"] = ("rank 0's measured dispatch times (ms, strips + interior) and plan bytes; an interior band (2 neighbours) "
+                                                                       "for N > 2; xGMI rate per direction per link and end-to-end latency per exchange group are ASSUMED")
+                except Exception as e:
+                    out["config"]["exchange_overlap_model"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["config"]["band_rows"] = [b1 - b0 for b0, b1 in zip(runner.band.bounds, runner.band.bounds[1:])]
             out["config"]["band_split"] = "cost-balanced (geometry tiles + 0.15 x sky tiles of the first frame)" if runner.bounds else "even tile rows"
         if rank_ms is not None:

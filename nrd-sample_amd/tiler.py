@@ -122,6 +122,48 @@ def probe_halo(backend, denoisers, settings=None, motion_rows=DEFAULT_MOTION_ROW
         nrd.destroy()
 
 
+def plan_bytes(plan, planes, width, neighbours=1):
+    """bytes ONE band sends to ONE neighbour per dispatch of a plan (Tiler._plan): [(strips-first bytes, strip rows, deferred bytes)].
+    `planes`: code -> bytes per texel of the pool plane (tap-texel planes with a guide prefix send their 8-byte signal half only)."""
+    out = []
+    for now, later in plan:
+        nb = sum((8 if len(e) > 3 else planes[e[0]]) * (e[1] - (e[2] if len(e) > 2 else 0)) * width for e in now)
+        lb = sum((8 if len(e) > 3 else planes[e[0]]) * (e[1] - e[2]) * width for e in later)
+        strip = (max([e[1] for e in now] + [0]) + 15) // 16 * 16
+        out.append((nb * neighbours, strip, lb * neighbours))
+    return out
+
+
+def exchange_overlap_model(names, pass_ms, bytes_per_dispatch, own_rows, neighbours, link_gbs=50.0, latency_us=20.0):
+    """What a row-tiled frame should cost on real links, dispatch by dispatch, with the strips-first schedule of both tilers
+    (csrc/nrdhip_tiler.cpp nrdhip_tiler_denoise, Tiler._run_dispatch_now) - the number a first SCALE_rNN.json run is to be compared with.
+      pass_ms[i]            GPU time of dispatch i on the band (strips + interior; measured on one GPU)
+      bytes_per_dispatch[i] (bytes sent strips-first to ONE neighbour, strip rows, bytes sent deferred to ONE neighbour)  [plan_bytes]
+      neighbours            1 for the first / last band, 2 for an interior band (each neighbour has its own xGMI link: transfers to the two
+                            run side by side, so the exchange TIME does not grow with it - only the share of the band that is strips does)
+    Per dispatch with a strips-first exchange: the strips (`neighbours` x strip rows of `own_rows`) run first, then the rows travel
+    (latency + bytes / link rate per direction) WHILE the interior runs; the next dispatch waits for both, so the dispatch costs
+    strips + max(interior, exchange) and `unhidden` = max(0, exchange - interior). Deferred rows (read by the next frame only) queue on
+    the same side stream behind the frame's exchanges; they cost nothing unless their total exceeds what is left of the frame."""
+    rows, total, unhidden_total, deferred_ms = [], 0.0, 0.0, 0.0
+    for name, ms, (now_b, strip, later_b) in zip(names, pass_ms, bytes_per_dispatch):
+        x = (latency_us * 1e-3 + now_b / (link_gbs * 1e9) * 1e3) if now_b else 0.0
+        split = now_b > 0 and own_rows >= 4 * strip
+        strips_ms = ms * min(neighbours * strip / max(own_rows, 1), 1.0) if split else (ms if now_b else 0.0)
+        interior_ms = ms - strips_ms if split else (0.0 if now_b else ms)
+        unhidden = max(0.0, x - interior_ms) if now_b else 0.0
+        deferred_ms += (latency_us * 1e-3 + later_b / (link_gbs * 1e9) * 1e3) if later_b else 0.0
+        rows.append({"dispatch": name, "compute_ms": round(ms, 4), "strips_first_bytes": int(now_b), "exchange_ms": round(x, 4),
+                     "interior_ms": round(interior_ms, 4), "unhidden_ms": round(unhidden, 4)})
+        total += ms + unhidden
+        unhidden_total += unhidden
+    compute = sum(pass_ms)
+    return {"link_GBs_per_direction": link_gbs, "latency_us_per_exchange": latency_us, "compute_ms": round(compute, 4), "unhidden_exchange_ms": round(unhidden_total, 4),
+            "deferred_exchange_ms": round(deferred_ms, 4), "deferred_fits_behind_frame": deferred_ms <= total,
+            "predicted_frame_ms": round(total + max(0.0, deferred_ms - total), 4), "serial_frame_ms": round(compute + sum(r["exchange_ms"] for r in rows) + deferred_ms, 4),
+            "per_dispatch": rows}
+
+
 class BandHarness(Harness):
     """Harness for one row band: planes are local_h rows tall, CommonSettings describe the whole frame."""
 

@@ -101,6 +101,36 @@ def test_exchange_plan_defers_rows_only_the_next_frame_reads(pkg, api, oracle):
         assert deferred <= set(written_last)
 
 
+def test_exchange_overlap_model(pkg, api, oracle):
+    """tiler.exchange_overlap_model / plan_bytes: the per-dispatch prediction bench.py prints for a tiled run (config.exchange_overlap_model)
+    - bytes straight from the plan (the 2554 B per pixel column of DESIGN.md 7), every exchange hidden up to the interior of ITS dispatch"""
+    from nrd_sample_amd import tiler
+
+    den = api.Denoiser.REBLUR_DIFFUSE_SPECULAR
+    band = tiler.BandHarness(oracle, [den], 128, 1280, 1, 4)
+    t = tiler.Tiler(band, None)
+    disp = band.nrd.dispatches([int(den)])
+    planes = {(pool << 16) | i: p["bpt"] for pool in (0, 1) for i, p in enumerate(band.nrd.pools[pool])}
+    pb = tiler.plan_bytes(t._plan([int(den)], disp), planes, 7680)
+    assert sum(b[0] + b[2] for b in pb) == 2554 * 7680
+    names = [d["name"] for d in disp]
+    ms = [0.02, 0.18, 0.055, 0.10, 0.095, 0.06]  # a 544-row band of the 8K frame (1-GPU pass times x 544 / 4320)
+    m = tiler.exchange_overlap_model(names, ms, pb, 544, 2, 50.0, 20.0)
+    assert m["compute_ms"] <= m["predicted_frame_ms"] <= m["serial_frame_ms"]
+    assert abs(m["predicted_frame_ms"] - (m["compute_ms"] + m["unhidden_exchange_ms"])) < 1e-3 and m["deferred_fits_behind_frame"]
+    by = {r["dispatch"].split("::")[1]: r for r in m["per_dispatch"]}
+    assert by["ClassifyTiles"]["exchange_ms"] == 0 and by["TemporalStabilization"]["exchange_ms"] == 0  # nothing a later dispatch of the frame reads
+    assert by["Blur"]["unhidden_ms"] > 0 and by["PostBlur"]["unhidden_ms"] == 0  # 71 rows of tap texels against Blur's interior; 2 rows of history
+    # a fabric without latency and with unlimited rate hides everything; a slow one approaches the serial cost
+    fast = tiler.exchange_overlap_model(names, ms, pb, 544, 2, 1e6, 0.0)
+    assert abs(fast["predicted_frame_ms"] - fast["compute_ms"]) < 1e-3
+    slow = tiler.exchange_overlap_model(names, ms, pb, 544, 2, 5.0, 100.0)
+    assert slow["predicted_frame_ms"] > 0.75 * slow["serial_frame_ms"]  # (the deferred rows still travel behind the frame)
+    # a band too short for strips + interior runs whole and then waits: nothing hidden
+    short = tiler.exchange_overlap_model(names, ms, pb, 200, 2, 50.0, 20.0)
+    assert short["unhidden_exchange_ms"] >= m["unhidden_exchange_ms"]
+
+
 def test_exchange_volume_of_the_headline_frame(pkg, api, oracle):
     """bytes per pixel column a band of REBLUR_DIFFUSE_SPECULAR sends to ONE neighbour per frame, plane by plane, from
     the plan - DESIGN.md 7's table. Round 3: 6728 (guide 640, hit tracker 4, Tmp2 480, fast history 320, speeds (tmp) 60, Data2 8, tap
