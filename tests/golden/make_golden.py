@@ -1,6 +1,8 @@
 """Generates tests/golden/*.npz with the CPU oracle (the reference holds no golden vectors for this path, SURVEY.md 8c:
 "parity unpinned"; these fixtures pin the build's own oracle against drift and travel to the GPU box).
-Run from the repo root:  python tests/golden/make_golden.py            (the default flavour -> tests/golden/*.npz)
+Run from the repo root:  python tests/golden/make_golden.py --why "what formula moved"   (the default flavour -> tests/golden/*.npz; a fixture
+                         whose CONTENT changes is only overwritten with --why, and gets a line in tests/golden/CHANGELOG.md with its distance
+                         from the file it replaces - tests/golden/changelog.py; tests/test_golden.py checks every committed fixture has one)
                          python tests/golden/make_golden.py --frozen   (liboracle_frozen.so -> tests/golden/frozen/*.npz; these are
                          round 3's files, byte for byte: the frozen flavour's arithmetic has not moved since)
 Inputs are the synthetic scene of nrd-sample_amd/synth.py (64x48, 4 frames, moving camera); outputs are every OUT_* plane
@@ -13,6 +15,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import changelog  # noqa: E402
 
 CASES = {
     "reblur_ds_sigma_reference": ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY", "REFERENCE"],
@@ -42,6 +47,7 @@ def settings_for(api, scene, dens):
 
 def main():
     frozen = "--frozen" in sys.argv
+    why = sys.argv[sys.argv.index("--why") + 1] if "--why" in sys.argv else None
     pkg = graft.load_package()
     graft.build_oracle()
     api, synth, harness = pkg.api, pkg.synth, pkg.harness
@@ -67,7 +73,26 @@ def main():
             for k, v in hz.outputs.items():
                 blob["f%d_%s" % (f, k)] = hz.fetch(v).copy()
             blob["f%d_signal" % f] = hz.fetch(planes["signal"]).copy()
-        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **blob)
+        path = os.path.join(out_dir, name + ".npz")
+        if not frozen:  # no silent regeneration of the default fixtures: what moved, and how far
+            tmp = path + ".new.npz"
+            np.savez_compressed(tmp, **blob)
+            new = np.load(tmp)
+            new_hash = changelog.content_hash(new)
+            old = np.load(path) if os.path.exists(path) else None
+            old_hash = changelog.content_hash(old) if old is not None else None
+            if old_hash == new_hash:
+                os.remove(tmp)
+                print(name, "unchanged (%s)" % new_hash)
+                continue
+            if not why:
+                os.remove(tmp)
+                raise SystemExit("%s would change (%s -> %s): re-run with --why \"what formula moved\" (tests/golden/CHANGELOG.md gets the distance)" % (name, old_hash, new_hash))
+            changelog.append(name, new_hash, old_hash, why, changelog.distance(new, old, FRAMES) if old is not None else {})
+            os.replace(tmp, path)
+            print(name, "written (%s), CHANGELOG.md updated" % new_hash)
+            continue
+        np.savez_compressed(path, **blob)
         print(name, "written")
 
 

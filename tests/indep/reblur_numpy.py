@@ -10,6 +10,12 @@ Switches (all False = the frozen algorithm):
   no_reach ............ no hard tap reach (the reach exists for row tiling: it bounds what a pass may read beyond a band)
   f32_guide ........... guide kept at decode precision (fp32 depth, normalised fp64 normal) instead of the 8-byte guide texel's 22-bit depth
                         and 3 x 10-bit normal codes
+Measurement-only switches on top of the DEFAULT flavour (exp_hit_weight = angle_normal_weight = True), ledger rows 16-18 - what the default
+build's cheap evaluations move against the exact functions this restatement otherwise takes:
+  one_step_sqrt ....... the chord's square root as the build evaluates it: magic seed + ONE tuned Newton step (relative error <= 6.5e-4)
+  poly3_exp2 .......... the hit-distance weight's exponential as the build evaluates it: round-to-nearest split + degree-3 polynomial (8.0e-5)
+  arc_normal_weight ... the true angle acos(cos) instead of the chord sqrt(2 (1 - cos)) (upstream's AcosApprox IS the chord: this row measures
+                        what the substitution the recalled shader makes is worth, not a deviation of this build)
 """
 import numpy as np
 
@@ -135,8 +141,27 @@ def plane_terms(viewz, packed_nr, view_to_clip, world_to_view, plane_distance_se
     return Nv[..., 0] * pv[2] * geoA, Nv[..., 1] * pv[3] * geoA, (Nv[..., 0] * pv[0] + Nv[..., 1] * pv[1] + Nv[..., 2]) * geoA, -(Nv * Xv).sum(-1) * geoA
 
 
+def sqrt_one_step(x):
+    """sqrt(x) the way csrc/nrd_device.h sqrt1_unscaled_ evaluates it (float32): seed 0x5F1FFFF9 - (bits >> 1), one Newton step with the
+    tuned constants 0.703952253 / 2.38924456 - restated here to MEASURE it (ledger row 16), not to share it"""
+    x = np.asarray(x, np.float32)
+    y = (np.uint32(0x5F1FFFF9) - (x.view(np.uint32) >> np.uint32(1))).view(np.float32)
+    u = x * y
+    r = np.float32(0.703952253) * (u * (np.float32(2.38924456) - u * y))
+    return np.where(x > 0, r, 0.0).astype(np.float64)
+
+
+def exp2_poly3(x):
+    """2^x, x <= 0, the way csrc/nrd_device.h exp2_poly_neg evaluates it: round-to-nearest-even split, degree-3 polynomial (ledger row 17)"""
+    x = np.maximum(np.asarray(x, np.float64), -126.0)
+    fi = np.rint(x)
+    f = x - fi
+    p = ((5.519811809062958e-2 * f + 2.4267692863941193e-1) * f + 6.932618021965027e-1) * f + 9.999227523803711e-1
+    return np.ldexp(p, fi.astype(np.int64))
+
+
 def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_index, denoising_range, s, exp_hit_weight=False,
-            angle_normal_weight=False, no_reach=False, f32_guide=False):
+            angle_normal_weight=False, no_reach=False, f32_guide=False, one_step_sqrt=False, poly3_exp2=False, arc_normal_weight=False):
     """REBLUR_DIFFUSE_SPECULAR PrePass of one frame (perspective, no jitter, radiance mode, full frame). `s`: dict of the
     ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16)."""
     H, W = viewz.shape
@@ -217,14 +242,18 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
             valid = in_win & active & ~sky[py, px] & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
             w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
             cosa = normal_cos(n, ns, f32_guide)
-            if angle_normal_weight:
+            if arc_normal_weight:
+                w = w * smoothstep01(1.0 - np.arccos(np.clip(cosa, -1, 1)) * normal_w)  # the true angle (measurement only)
+            elif angle_normal_weight and one_step_sqrt:
+                w = w * smoothstep01(1.0 - sqrt_one_step(2.0 * np.clip(1.0 - cosa, 0, 1)) * normal_w)
+            elif angle_normal_weight:
                 w = w * smoothstep01(1.0 - np.sqrt(2.0 * np.clip(1.0 - cosa, 0, 1)) * normal_w)  # Math::AcosApprox: the chord
             else:
                 w = w * smoothstep01(1.0 - 2.0 * np.clip(1.0 - cosa, 0, 1) * normal_w * normal_w)
             if is_spec:
                 w = w * smoothstep01(1.0 - np.abs(rs_ * roughA + roughB))
             ax = np.abs(sv[..., 3] * hitA + hitB)
-            e = np.exp(-3.0 * ax) if exp_hit_weight else np.clip(1.0 - ax, 0, 1) ** 2
+            e = (exp2_poly3(-4.32808512 * ax) if poly3_exp2 else np.exp(-3.0 * ax)) if exp_hit_weight else np.clip(1.0 - ax, 0, 1) ** 2
             w = w * (s["minHitDistanceWeight"] + (1.0 - s["minHitDistanceWeight"]) * e)
             w = np.where(valid, w, 0.0)
             acc = acc + np.where(valid[..., None], sv, 0.0) * w[..., None]

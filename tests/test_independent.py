@@ -93,8 +93,8 @@ def test_guide_and_prepass_independent(request, pkg, api, f, flavour):
     # float64 vs the oracle's float32: a tap position may floor to the neighbouring texel where the projected offset sits on a pixel
     # boundary - a different (equally valid) tap, not an arithmetic error; everything else must agree to 1 fp16 ULP
     frac_off = float((d > 1).any(axis=(2, 3)).mean())
-    assert frac_off < 0.02, frac_off
-    assert float((d <= 1).mean()) > 0.995
+    print("AGREE PrePass frame %d %s: pixels with a value beyond 1 ULP %.3f %%, values within 1 ULP %.4f %%, max %d ULP" % (f, flavour, 100 * frac_off, 100 * float((d <= 1).mean()), int(d.max())))
+    assert frac_off == 0.0 and int(d.max()) <= 1, (frac_off, int(d.max()))  # stated bar (round 5): EVERY value within 1 fp16 ULP on the golden frames
     dt = ulp16(track, want_track)
     assert float((dt <= 1).mean()) > 0.98
 
@@ -125,6 +125,32 @@ def test_deviation_ledger_measurements(pkg, api, oracle_frozen, capsys):
     with capsys.disabled():
         for k, v in rows.items():
             print("deviation %-20s max %5d ULP fp16, %.1f %% of values move > 1 ULP, max relative %.3f, PSNR %.1f dB" % (k, v["max_ulp"], 100 * v["frac_changed"], v["max_rel"], v["psnr"]))
+    # ---- rows 16-18: the DEFAULT flavour's cheap evaluations against the exact functions (round 4's A/B records carried
+    # speed only). Base = the default flavour with exact sqrt / exp; each switch changes ONE evaluation.
+    rows2 = {}
+    for f in (0, 2):
+        fr, cs, st, tmp1, track, _ = oracle_prepass(pkg, api, oracle_frozen, f)
+        args = (fr["viewz"], fr["normal_roughness"], fr["diff"], fr["spec"], fr["view_to_clip"], fr["world_to_view"], cs.frameIndex, cs.denoisingRange, settings_dict(st))
+        base, _ = ind.prepass(*args, exp_hit_weight=True, angle_normal_weight=True)
+        for name in ("one_step_sqrt", "poly3_exp2", "arc_normal_weight"):
+            alt, _ = ind.prepass(*args, exp_hit_weight=True, angle_normal_weight=True, **{name: True})
+            d = ulp16(base, alt)
+            rel = np.abs(alt.astype(np.float64) - base.astype(np.float64)) / np.maximum(np.abs(base.astype(np.float64)), 1e-3)
+            r = rows2.setdefault(name, dict(max_ulp=0, differ=0.0, frac_changed=0.0, max_rel=0.0, psnr=199.0))
+            r["max_ulp"] = max(r["max_ulp"], int(d.max()))
+            r["differ"] = max(r["differ"], float((d > 0).mean()))
+            r["frac_changed"] = max(r["frac_changed"], float((d > 1).mean()))
+            r["max_rel"] = max(r["max_rel"], float(rel[..., :3].max()))
+            r["psnr"] = min(r["psnr"], psnr(alt[..., :3], base[..., :3]) if (alt != base).any() else 199.0)
+    with capsys.disabled():
+        for k, v in rows2.items():
+            print("default-flavour evaluation %-18s max %4d ULP fp16, %.3f %% of values differ, %.4f %% by > 1 ULP, max relative %.5f, PSNR %.1f dB" % (
+                k, v["max_ulp"], 100 * v["differ"], 100 * v["frac_changed"], v["max_rel"], v["psnr"]))
+    # the cheap evaluations stay far inside what "1 ULP fp16 / 60 dB" tolerates; the chord-for-arc substitution (upstream's own) is the big one
+    # (measured: 1 ULP / 0.16 % differ / 122 dB; 1 ULP / 0.60 % / 107 dB; 5 ULP / 0.15 % beyond 1 ULP / 113 dB - oracle/README.md rows 16-18)
+    assert rows2["one_step_sqrt"]["max_ulp"] <= 1 and rows2["one_step_sqrt"]["differ"] < 0.004 and rows2["one_step_sqrt"]["psnr"] > 115.0
+    assert rows2["poly3_exp2"]["max_ulp"] <= 1 and rows2["poly3_exp2"]["differ"] < 0.012 and rows2["poly3_exp2"]["psnr"] > 100.0
+    assert rows2["arc_normal_weight"]["max_ulp"] <= 8 and rows2["arc_normal_weight"]["frac_changed"] < 0.004 and rows2["arc_normal_weight"]["psnr"] > 105.0
     # the 8-byte guide (22-bit depth, 3 x 10-bit normal): the 1e-3 normal step tilts the tap basis enough to move ~3 % of the taps (30-pixel
     # radius) onto the neighbouring texel - a different, equally valid sample of a noisy input, not a weight error (the depth alone: 65 dB)
     assert rows["f32_guide"]["psnr"] > 45.0 and rows["f32_guide"]["frac_changed"] < 0.06
@@ -150,12 +176,16 @@ def temporal_settings(st):
                 antilagSigmaScale=st.antilagSettings.luminanceSigmaScale, antilagSensitivity=st.antilagSettings.luminanceSensitivity)
 
 
-def agree(name, got, want, min_frac, mask=None):
+def agree(name, got, want, min_frac, mask=None, max_ulp=None):
+    """the stated bar of an independent restatement ("a stated max ULP + fraction", not ">= 99 %"): at least `min_frac` of
+    the values within 1 fp16 ULP and, where `max_ulp` is given, NO value farther than that"""
     d = ulp16(got, want)
     if mask is not None:
         d = d[mask]
     frac = float((d <= 1).mean())
+    print("AGREE %-40s within 1 ULP %.4f %%, within 2 ULP %.4f %%, max %d ULP" % (name, 100 * frac, 100 * float((d <= 2).mean()), int(d.max())))
     assert frac >= min_frac, "%s: only %.2f %% of the values within 1 fp16 ULP (max %d)" % (name, 100 * frac, int(d.max()))
+    assert max_ulp is None or int(d.max()) <= max_ulp, "%s: max %d ULP fp16 (bar %d)" % (name, int(d.max()), max_ulp)
     return frac
 
 
@@ -201,8 +231,8 @@ def test_temporal_passes_independent(request, pkg, api, f, flavour):
     data2 = hz.pool("REBLUR::Data2").copy().view(np.uint32).reshape(H, W)
     w_tmp2, w_fast, w_speeds, w_data2, info = tmp.temporal_accumulation(c, s, gcur, gprev, fr["mv"], tmp1, hist, fast_prev, speeds_prev, track, fr["confidence"], True)
     assert info["smb_ok"][geo].mean() > 0.8 and info["vmb_ok"][geo].mean() > 0.5  # the test exercises both footprints, not the fallbacks
-    agree("TA radiance", tmp2, w_tmp2, 0.99)
-    agree("TA fast history", fast, w_fast, 0.99)
+    agree("TA radiance", tmp2, w_tmp2, 1.0, max_ulp=1)
+    agree("TA fast history", fast, w_fast, 1.0, max_ulp=1)
     # validity bits of the 2 x 4 footprint texels: the surface-motion ones must agree; the virtual-motion footprint tests texels against
     # the SURFACE's plane, which puts whole rows of them next to the threshold (the ground / wall seam of this scene) where float32 and
     # float64 decide differently for a percent of the pixels
@@ -220,7 +250,7 @@ def test_temporal_passes_independent(request, pkg, api, f, flavour):
     w_sig, w_speeds_cur, (w0, w1) = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast, fr["viewz"], fr["normal_roughness"], upstream=upstream)
     for k in range(2):
         got = np.ascontiguousarray(taps[k][..., 2:4]).view(np.float16).reshape(H, W, 4)
-        agree("HistoryFix signal %d" % k, got, w_sig[:, :, k], 0.99)
+        agree("HistoryFix signal %d" % k, got, w_sig[:, :, k], 1.0, max_ulp=1)
         assert np.array_equal(taps[k][..., 0], w0), "guide part of the tap texels: depth | roughness word"
         assert float((taps[k][..., 1] == w1).mean()) > 0.98 and np.array_equal(taps[k][..., 1] >> 30, w1 >> 30), "guide part of the tap texels: normal | material word"
     for shift in (0, 8):
@@ -234,13 +264,13 @@ def test_temporal_passes_independent(request, pkg, api, f, flavour):
     taps_b = [hz.pool("REBLUR::Tap_%s_B" % k).copy().view(np.uint32).reshape(H, W, 4) for k in ("Diff", "Spec")]
     w_blur = ind.blur_pass(False, fr["viewz"], fr["normal_roughness"], tap_signal(taps), speeds_cur, fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
                            cs.denoisingRange, sb, upstream=upstream)
-    agree("Blur", tap_signal(taps_b), w_blur, 0.995, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)))
+    agree("Blur", tap_signal(taps_b), w_blur, 1.0, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)), max_ulp=1)
     for k in range(2):  # the guide part travels through Blur untouched
         assert np.array_equal(taps_b[k][..., :2], taps[k][..., :2])
     hz.nrd.denoise_range([den], 5, 1)
     w_post = ind.blur_pass(True, fr["viewz"], fr["normal_roughness"], tap_signal(taps_b), speeds_cur, fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
                            cs.denoisingRange, sb, upstream=upstream)
-    agree("PostBlur", rad("REBLUR::History"), w_post, 0.995, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)))
+    agree("PostBlur", rad("REBLUR::History"), w_post, 1.0, mask=np.broadcast_to(geo[..., None, None], (H, W, 2, 4)), max_ulp=1)
 
     # ---- TemporalStabilization (fed with the ORACLE's PostBlur output)
     post, stab_prev = rad("REBLUR::History"), lum("REBLUR::StabilizedLuma" + old)
@@ -248,8 +278,11 @@ def test_temporal_passes_independent(request, pkg, api, f, flavour):
     stab = lum("REBLUR::StabilizedLuma" + cur)
     out = np.stack([hz.output("out_diff"), hz.output("out_spec")], 2)
     w_out, w_stab = tmp.temporal_stabilization(c, s, gcur, fr["mv"], post, speeds_cur, data2, stab_prev, track, True)
-    agree("TS output", out, w_out, 0.99)
-    agree("TS stabilized luma", stab, w_stab, 0.99)
+    # (measured 99.80-99.88 % / 99.74-99.84 %: the remainder are pixels whose virtual-motion footprint validates differently in float32
+    # and float64 - its texels are tested against the SURFACE's plane, which parks rows of them on the threshold; a different footprint is
+    # another history sample, hence hundreds of ULP at those pixels and none in between)
+    agree("TS output", out, w_out, 0.997)
+    agree("TS stabilized luma", stab, w_stab, 0.996)
 
 
 @pytest.mark.parametrize("f,flavour", [(1, "frozen"), (3, "frozen"), (1, "default"), (3, "default")])
@@ -290,9 +323,9 @@ def test_relax_atrous_iterations_independent(request, pkg, api, f, flavour):
     data2 = hz.pool("RELAX::Data2").copy().view(np.uint32).reshape(H, W)
     hz.nrd.denoise_range([den], 4, 1)
     a0 = rad("RELAX::Atrous_A")
-    agree("A-trous iteration 0", a0, tmp.atrous_iteration(c, s, gcur, hist, 0, speeds, moments, data2, upstream=upstream), 0.99)
+    agree("A-trous iteration 0", a0, tmp.atrous_iteration(c, s, gcur, hist, 0, speeds, moments, data2, upstream=upstream), 1.0, max_ulp=1)
     hz.nrd.denoise_range([den], 5, 1)
-    agree("A-trous iteration 1", rad("RELAX::Atrous_B"), tmp.atrous_iteration(c, s, gcur, a0, 1, data2=data2, upstream=upstream), 0.99)
+    agree("A-trous iteration 1", rad("RELAX::Atrous_B"), tmp.atrous_iteration(c, s, gcur, a0, 1, data2=data2, upstream=upstream), 1.0, max_ulp=1)
 
 
 @pytest.mark.parametrize("f", [1, 2, 3])
@@ -329,12 +362,12 @@ def test_sigma_passes_independent(pkg, api, oracle, f):
     hz.nrd.denoise_range([den], 2, 1)
     sh1 = hz.pool("SIGMA::Shadow1").copy().view(np.float16).reshape(H, W, 4)
     pen1 = hz.pool("SIGMA::Penumbra1").copy().view(np.float16).reshape(H, W)
-    agree("SIGMA Blur shadow", sh1, w_sh1, 0.99)
-    agree("SIGMA Blur penumbra", pen1, w_pen1, 0.99)
+    agree("SIGMA Blur shadow", sh1, w_sh1, 1.0, max_ulp=1)
+    agree("SIGMA Blur penumbra", pen1, w_pen1, 1.0, max_ulp=1)
     w_sh2, _ = tmp.sigma_blur(c, s, z, n, tiles, pen1, sh1, cs.frameIndex, 1)
     hz.nrd.denoise_range([den], 3, 1)
     sh2 = hz.pool("SIGMA::Shadow2").copy().view(np.float16).reshape(H, W, 4)
-    agree("SIGMA PostBlur shadow", sh2, w_sh2, 0.99)
+    agree("SIGMA PostBlur shadow", sh2, w_sh2, 1.0, max_ulp=1)
     hist_prev = hz.pool("SIGMA::History" + old).copy().view(np.uint32).reshape(H, W)
     hz.nrd.denoise_range([den], 4, 1)
     hist = hz.pool("SIGMA::History" + cur).copy().view(np.uint8).reshape(H, W, 4).astype(np.int32)
@@ -378,5 +411,5 @@ def test_prepare_inputs_independent(pkg, api, oracle, recon, radius):
             got = hz.pool(plane).copy().view(np.float16).reshape(H, W, 4)
             half = np.asarray(fr[key]).view(np.float16).reshape(H, -1, 4)
             want = prep.prepare_inputs(fr["viewz"], fr["normal_roughness"], half, phase, cs.frameIndex, cs.denoisingRange, is_spec, radius, geo, s)
-            agree("PrepareInputs %s frame %d" % (key, f), got, want, 0.995)
+            agree("PrepareInputs %s frame %d" % (key, f), got, want, 0.9998, max_ulp=2)
         hz.nrd.denoise_range([den], 2, len(names) - 2)  # finish the frame: the next one starts from a consistent instance
