@@ -74,8 +74,9 @@ def parse():
                     help="N > 1: seconds the native-tiler leg and the bit-identity check may take together before rank 0 prints the line of "
                          "record without them and the run ends (a hang in never-executed transport code must not cost the line)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the HIP-graph replay leg (NRDHIP_FLAG_GRAPH), 1-GPU runs")
-    ap.add_argument("--no-frozen-leg", action="store_true", help="skip the timed leg on libnrdhip_frozen.so (the cheaper formulas of rounds 1-3) and "
-                    "the distance of its outputs from the default's, 1-GPU runs")
+    ap.add_argument("--no-frozen-leg", action="store_true", help="skip the timed legs on the other build flavours - libnrdhip_frozen.so (the cheaper formulas of "
+                    "rounds 1-3) and libnrdhip_hwt.so (hardware transcendentals in the weight arithmetic) - and the distance of their outputs from the default's, 1-GPU runs")
+    ap.add_argument("--no-young-leg", action="store_true", help="skip the leg timed WITHOUT the pre-roll (young histories, wider blurs: the regime rounds 1-3 timed), 1-GPU runs")
     ap.add_argument("--no-full-coverage", action="store_true", help="skip the second timed leg (the same scene without sky), 1-GPU runs")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (exercises the tiler)")
     ap.add_argument("--dolly", type=float, default=0.002, help="camera translation per frame (scene units)")
@@ -334,6 +335,8 @@ def main():
             out["config"]["algorithmic_bytes_per_pixel"] = round(sum_bpp, 2)
             out["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, dom_name),
+                               # a live run cannot collect counters: the figure comes from a committed rocprofv3 --pmc table - which, and of which build
+                               "traffic_source": traffic_source(args.workload, pkg.HIP_LIB),
                                # whole pass chain on both denominators: the as-built plane layout and the contract's rule
                                "algorithmic_bytes_as_built": round(sum_bpp, 2), "pipeline_frac": round(sum_bpp * pixels_band / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "algorithmic_bytes_contract": bpp_contract,
@@ -484,6 +487,46 @@ def main():
                 leg["distance_from_default"] = flavour_distance(pkg, api, synth, Harness, hip, hip_fz, dev, dens, den_names, args)
             except Exception as e:
                 out["config"].setdefault("frozen_formulas", {})["error"] = str(e)
+        if world == 1 and not args.force_tiled and not args.no_frozen_leg and not args.preset and os.path.exists(pkg.HIP_LIB_HWT):
+            # The OPTIONAL flavour with the GPU's transcendental instructions in the weight arithmetic of the spatial filters (libnrdhip_hwt.so,
+            # csrc/nrd_device.h NRD_HW_TRANSCENDENTALS): timed beside the default; not bit-reproducible on a CPU and measured NOT to hold the
+            # 1-ULP bar against its checker at isolated pixels (profiles/r05_ab_hw_transcendentals.txt), hence not the library of record
+            try:
+                hip_hw = pkg.hip_backend(dev, flavour="hwt")
+                scene_hw = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR", roll_deg=args.roll)
+                hz_hw = Harness(hip_hw, dens, w, band_h, separate_passes=args.separate_passes)
+                runner_hw = SingleRunner(api, hz_hw, scene_hw, dens, args.unique_frames, settings_of(api, scene_hw, dens))
+                dt_hw = timed_run(runner_hw)
+                pp = runner_hw.pass_times_ms()
+                leg = {"value": round(w * frame_h * args.steps / dt_hw / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_hw / args.steps * 1e3, 4),
+                       "passes_ms": {k: round(v[0], 4) for k, v in pp.items()},
+                       "what": "same workload, libnrdhip_hwt.so: v_rcp_f32 / v_sqrt_f32 / v_exp_f32 in the weight-class arithmetic of the spatial filters (tap weights, their "
+                               "per-pixel parameters, 1 / weight sum); everything a discrete decision hangs on keeps the exact sequences. OPTIONAL: fails the 1-ULP bar at isolated pixels"}
+                del runner_hw, hz_hw
+                torch.cuda.empty_cache()
+                out["config"]["hw_transcendentals"] = leg
+                leg["distance_from_default"] = flavour_distance(pkg, api, synth, Harness, hip, hip_hw, dev, dens, den_names, args)
+            except Exception as e:
+                out["config"].setdefault("hw_transcendentals", {})["error"] = str(e)
+        if world == 1 and not args.force_tiled and not args.no_young_leg and not args.preset and not args.no_preroll:
+            # the pre-roll is a METHODOLOGY change of round 4 (rounds 1-3 timed right behind the warm-up frames: young histories,
+            # wider blur radii, slower frames). The same workload once more without it, so that both regimes stand in one line of record.
+            try:
+                scene_y = synth.Scene(w, band_h, dolly=args.dolly, device=dev, denoiser="RELAX" if den_names[0].startswith("RELAX") else "REBLUR", roll_deg=args.roll)
+                hz_y = Harness(hip, dens, w, band_h, separate_passes=args.separate_passes)
+                runner_y = SingleRunner(api, hz_y, scene_y, dens, args.unique_frames, settings_of(api, scene_y, dens))
+                args.no_preroll = True
+                try:
+                    dt_y = timed_run(runner_y)
+                finally:
+                    args.no_preroll = False
+                out["config"]["without_preroll"] = {"value": round(w * frame_h * args.steps / dt_y / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(dt_y / args.steps * 1e3, 4),
+                                                    "what": "timed right behind the %d warm-up frames (histories %d..%d frames old of %d: wider blurs) - the regime rounds 1-3 reported"
+                                                            % (args.warmup, args.warmup, args.warmup + args.steps, accum_length(runner_y))}
+                del runner_y, hz_y
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["config"]["without_preroll"] = {"error": str(e)}
         if world == 1 and not args.force_tiled and not args.no_graph_leg and not args.preset:
             # NRDHIP_FLAG_GRAPH: the frame as ONE HIP graph launch (captured every frame, the executable graph patched with the new kernel
             # arguments) against pass-by-pass launches, both on the same non-default stream and without per-pass events: on the
@@ -729,6 +772,32 @@ PASS_KERNEL = {
 }
 
 
+def _traffic_files(workload):
+    import glob
+    import re
+
+    def build_order(path):  # r01v6 < r01v8 < r01v10 < r02v1: numeric, not alphabetical
+        return [int(n) for n in re.findall(r"\d+", os.path.basename(path).split("_hbm_traffic_")[0])]
+
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_%s.json" % workload)), key=build_order)
+
+
+def traffic_source(workload, lib_path):
+    """where roofline.traffic comes from: the committed counter table (newest for the workload), the library it was collected on and whether
+    that is the library this run times (a lookup must not pass for a measurement of the build at hand)"""
+    import hashlib
+    import json
+
+    files = _traffic_files(workload)
+    if not files:
+        return None
+    on = json.load(open(files[-1])).get("_measured_on", {})
+    mine = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:12] if os.path.exists(lib_path) else None
+    return {"table": "profiles/" + os.path.basename(files[-1]), "collected_with": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_gpu.sh); not measured in this run",
+            "table_library_sha256_12": on.get("library_sha256_12"), "timed_library_sha256_12": mine,
+            "same_build": (on.get("library_sha256_12") == mine) if on.get("library_sha256_12") else None}
+
+
 def measured_traffic(workload, pass_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the gfx950 correction of
     MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc runs, tools/profile_gpu.sh); None if that workload / kernel
@@ -737,17 +806,12 @@ def measured_traffic(workload, pass_name):
     import json
 
     prefix = PASS_KERNEL.get(pass_name)
-    import re
-
-    def build_order(path):  # r01v6 < r01v8 < r01v10 < r02v1: numeric, not alphabetical
-        return [int(n) for n in re.findall(r"\d+", os.path.basename(path).split("_hbm_traffic_")[0])]
-
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_hbm_traffic_%s.json" % workload)), key=build_order)
+    files = _traffic_files(workload)
     if not prefix or not files:
         return None
     table = json.load(open(files[-1]))
     for k, v in table.items():
-        if k.startswith(prefix):
+        if k.startswith(prefix) and not k.startswith("_"):
             return round(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
     return None
 

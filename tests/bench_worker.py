@@ -46,7 +46,7 @@ def patch_for_cpu(setattr_, pkg, bench, emulated, emulated_frozen, workloads, gr
 
     for name, value in CUDA_STANDINS:
         setattr_(torch.cuda, name, value)
-    setattr_(pkg, "hip_backend", lambda device, flavour=None: emulated_frozen if flavour else emulated)
+    setattr_(pkg, "hip_backend", lambda device, flavour=None: emulated_frozen if flavour == "frozen" else emulated)  # (the hwt leg runs on the default emulation: control flow only)
     real_scene = pkg.synth.Scene
     setattr_(pkg.synth, "Scene", lambda *a, **kw: real_scene(*a, **dict(kw, device="cpu")))
     setattr_(bench, "WORKLOADS", dict(bench.WORKLOADS, **workloads))

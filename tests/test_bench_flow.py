@@ -40,6 +40,10 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
     assert c["frozen_formulas"]["value"] > 0
     dist_ = c["frozen_formulas"]["distance_from_default"]  # PSNR and the share of values > 1 fp16 ULP apart, per output, default vs frozen flavour
     assert dist_["frames"] == 3 and all(0.0 <= dist_[k]["ulp_gt1_frac"] <= 1.0 and dist_[k]["psnr_db"] > 20.0 for k in ("out_diff", "out_spec"))
+    assert c["hw_transcendentals"]["value"] > 0 and "distance_from_default" in c["hw_transcendentals"]  # the optional flavour's leg
+    assert c["without_preroll"]["value"] > 0 and "warm-up" in c["without_preroll"]["what"]  # both timing regimes in one line
+    ts = r["traffic_source"]  # a table lookup is labelled as one: which table, of which library, and whether that is the library timed here
+    assert ts is None or (ts["table"].startswith("profiles/") and "same_build" in ts and ts["timed_library_sha256_12"])
     assert set(c["graph_replay"]) == {"workload", "band_64x32"} and c["graph_replay"]["workload"]["graph_stats"]["direct"] > 0  # (no graphs in the emulation)
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b and b["unit"] == "Mpixels/s"

@@ -21,7 +21,7 @@ try:
     for r in range(a.rounds):
         for v in a.variants:
             shutil.copy(os.path.join(ROOT, "_variants", v + ".so"), LIB)
-            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", a.workload, "--no-cpu-baseline", "--no-frozen-leg", "--no-graph-leg"] + \
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", a.workload, "--no-cpu-baseline", "--no-frozen-leg", "--no-young-leg", "--no-graph-leg"] + \
                   ([] if a.full_coverage else ["--no-full-coverage"]) + a.bench_args.split()
             try:
                 out = subprocess.run(cmd, capture_output=True, text=True, timeout=300).stdout

@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r04}; WL=${2:-reblur_ds_4k}
 ROOT=$(pwd); export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --workload $WL --steps 16 --warmup 32 --no-cpu-baseline --no-full-coverage --no-frozen-leg --no-graph-leg ${BENCH_ARGS:-}"
+CMD="python $ROOT/bench.py --workload $WL --steps 16 --warmup 32 --no-cpu-baseline --no-full-coverage --no-frozen-leg --no-young-leg --no-graph-leg ${BENCH_ARGS:-}"
 i=0
 for set in \
   "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \

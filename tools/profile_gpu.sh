@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r01}; WL=${2:-reblur_ds_4k}; STEPS=${3:-48}; WARM=${4:-32}  # defaults = the default bench.py command
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/profiles; mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline --no-full-coverage --no-frozen-leg --no-graph-leg"
+CMD="python $ROOT/bench.py --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline --no-full-coverage --no-frozen-leg --no-young-leg --no-graph-leg"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o k -- $CMD > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum"; do

@@ -59,5 +59,9 @@ with open(os.path.join(out, "%s_pmc_%s.csv" % (tag, wl)), "w") as o:
         write = mean.get("WRITE_SIZE", float("nan")) * 1024 / px
         o.write('"%s",%d,%s,%.1f,%.1f\n' % (k, n, ",".join("%.0f" % mean[c] for c in counters), fetch, write))
         summary[k] = {"fetch_bytes_per_launch": mean.get("FETCH_SIZE", 0) * 2048, "write_bytes_per_launch": mean.get("WRITE_SIZE", 0) * 1024}
+# which build the counters were collected on: bench.py labels roofline.traffic with it and says whether the library it TIMES is the same one
+import hashlib
+lib = os.path.join(root, "nrd-sample_amd", "csrc", "libnrdhip.so")
+summary["_measured_on"] = {"library_sha256_12": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:12] if os.path.exists(lib) else None, "tag": tag, "workload": wl}
 json.dump(summary, open(os.path.join(out, "%s_hbm_traffic_%s.json" % (tag, wl)), "w"), indent=1)
 print(open(os.path.join(out, "%s_pmc_%s.csv" % (tag, wl))).read())
