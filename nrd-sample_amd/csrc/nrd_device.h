@@ -739,21 +739,14 @@ NRD_DEV bool ring_pos(int tid, int& lx, int& ly) {
 
 // One 8- / 16-bit word of a per-tile plane through the SCALAR data path (same address for the whole workgroup; constant address space:
 // s_load_dword of the aligned word that holds it): the flag does not queue in the in-order vector memory counter with the workgroup's loads
-#ifndef NRD_SCALAR_AS // (the host emulation of the tests defines it away, like NRD_WAVES_PER_EU)
-#define NRD_SCALAR_AS __attribute__((address_space(4)))
+#ifndef NRD_TILE_TEXEL // (the host emulation of the tests substitutes a plain 1- / 2-byte read - the aligned word may end up to 3 bytes behind
+                       // the plane, which a device allocation always covers and an instrumented host heap does not; like NRD_WAVES_PER_EU)
+#define NRD_TILE_TEXEL(addr, bytes)                                                                                           \
+    ((*(const __attribute__((address_space(4))) uint32_t*)((addr) & ~(uintptr_t)3) >> ((uint32_t)((addr) & (uintptr_t)(4 - (bytes))) * 8u)) & \
+     ((bytes) == 1 ? 0xffu : 0xffffu))
 #endif
-NRD_DEV uint32_t ld_scalar_word(uintptr_t a) {
-    typedef const NRD_SCALAR_AS uint32_t* const_u32_ptr;
-    return *(const_u32_ptr)(a & ~(uintptr_t)3);
-}
-NRD_DEV uint32_t ld_tile_u16(const PlaneRef& P, int tx, int ty) {
-    const uintptr_t a = (uintptr_t)P.p + texel_offset(P, tx, ty, 2, 0);
-    return (ld_scalar_word(a) >> ((uint32_t)(a & 2) * 8u)) & 0xffffu;
-}
-NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) {
-    const uintptr_t a = (uintptr_t)P.p + texel_offset(P, tx, ty, 1, 0);
-    return (ld_scalar_word(a) >> ((uint32_t)(a & 3) * 8u)) & 0xffu;
-}
+NRD_DEV uint32_t ld_tile_u16(const PlaneRef& P, int tx, int ty) { return NRD_TILE_TEXEL((uintptr_t)P.p + texel_offset(P, tx, ty, 2, 0), 2); }
+NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE_TEXEL((uintptr_t)P.p + texel_offset(P, tx, ty, 1, 0), 1); }
 
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) { // one 16 x 16 workgroup per tile
     const int b = (int)blockIdx.x;

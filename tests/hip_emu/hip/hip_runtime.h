@@ -41,7 +41,8 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define NRD_WAVES_PER_EU(n)
-#define NRD_SCALAR_AS // (nrd_device.h: the constant address space of the scalar tile-flag loads)
+// nrd_device.h: the scalar-path read of a per-tile texel (an aligned dword on the device) as the plain 1- / 2-byte read it stands for
+#define NRD_TILE_TEXEL(addr, bytes) ((bytes) == 1 ? (uint32_t)*(const uint8_t*)(addr) : (uint32_t)*(const uint16_t*)(addr))
 #define __shared__ static
 
 struct dim3 {
