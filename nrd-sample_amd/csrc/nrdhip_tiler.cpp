@@ -104,8 +104,19 @@ struct nrdhip_tiler {
     bool hostOrdered() const { return custom && !(tr.flags & NRDHIP_TRANSPORT_STREAM_ORDERED); }
     ncclComm_t comm = nullptr;
     hipStream_t commStream = nullptr;
-    hipEvent_t evCompute = nullptr, evComm = nullptr, evDeferred = nullptr;
-    bool deferredPending = false;
+    hipEvent_t evCompute = nullptr, evComm = nullptr;
+    // Rows only the NEXT frame reads (permanent planes that survive the frame) travel as ONE group behind the last dispatch of their list -
+    // round 5: six groups per REBLUR frame, each queued IN FRONT of the next dispatch's strips-first exchange on the in-order side stream,
+    // put 13 latencies on a frame's critical path where 7 belong (profiles/r05_exchange_overlap_solo.json) - and are awaited by the SAME
+    // list's next call, right before its first dispatch that reads previous-frame state: another list's call (SIGMA, then REBLUR, then
+    // REFERENCE inside one frame) does not wait for them. One event per identifier list.
+    struct DeferredSlot {
+        std::vector<uint32_t> ids;
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+    };
+    std::vector<DeferredSlot> deferred;
+    uint32_t firstPrevRead = 0; // first dispatch of the planned list that reads a permanent plane before the list writes it
     std::vector<uint32_t> planIds;
     std::vector<PlanEntry> plan;
     std::vector<uint32_t> planSig; // planes + reach of the dispatches the plan was built from (build_plan)
@@ -319,12 +330,15 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
     {
         bool provable = true;
         std::vector<uint32_t> writtenSoFar;
+        T.firstPrevRead = count;
         for (uint32_t i = 0; i < count; i++) {
             maxReach = std::max<uint32_t>(maxReach, d[i].halo_rows);
             for (uint32_t k = 0; k < d[i].read_num; k++) {
                 const uint32_t code = d[i].read[k];
-                if ((code >> 16) == 0 && std::find(writtenSoFar.begin(), writtenSoFar.end(), code) == writtenSoFar.end() && d[i].read_rows[k] != 0 &&
-                    d[i].read_rows[k] != NRDHIP_READ_REPROJECTED)
+                const bool previous = (code >> 16) == 0 && std::find(writtenSoFar.begin(), writtenSoFar.end(), code) == writtenSoFar.end();
+                if (previous)
+                    T.firstPrevRead = std::min(T.firstPrevRead, i);
+                if (previous && d[i].read_rows[k] != 0 && d[i].read_rows[k] != NRDHIP_READ_REPROJECTED)
                     provable = false;
             }
             writtenSoFar.insert(writtenSoFar.end(), d[i].written, d[i].written + d[i].written_num);
@@ -373,19 +387,30 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
     return 0;
 }
 
-int wait_deferred(nrdhip_tiler& T, hipStream_t stream) {
-    if (T.deferredPending) {
-        if (!T.hostOrdered() && hipStreamWaitEvent(stream, T.evDeferred, 0) != hipSuccess)
+int wait_deferred(nrdhip_tiler& T, nrdhip_tiler::DeferredSlot& slot, hipStream_t stream) {
+    if (slot.pending) {
+        if (!T.hostOrdered() && hipStreamWaitEvent(stream, slot.ev, 0) != hipSuccess)
             return fail(T, FAILURE, "hipStreamWaitEvent");
-        T.deferredPending = false;
+        slot.pending = false;
     }
     return 0;
+}
+nrdhip_tiler::DeferredSlot* deferred_slot(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
+    for (auto& s : T.deferred)
+        if (s.ids.size() == n && std::equal(s.ids.begin(), s.ids.end(), ids))
+            return &s;
+    nrdhip_tiler::DeferredSlot s;
+    s.ids.assign(ids, ids + n);
+    if (!T.hostOrdered() && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+    T.deferred.push_back(s);
+    return &T.deferred.back();
 }
 
 // the side stream the exchanges run on and the events that order it against the compute stream (RCCL and stream-ordered custom transports)
 int make_side_stream(nrdhip_tiler& T) {
     if (hipStreamCreateWithFlags(&T.commStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&T.evCompute, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&T.evComm, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&T.evDeferred, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&T.evComm, hipEventDisableTiming) != hipSuccess)
         return fail(T, FAILURE, "side stream / events");
     return 0;
 }
@@ -494,7 +519,10 @@ NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
         g_rccl.CommDestroy(T->comm);
     if (T->commStream)
         (void)hipStreamDestroy(T->commStream);
-    for (hipEvent_t e : {T->evCompute, T->evComm, T->evDeferred})
+    for (auto& slot : T->deferred)
+        if (slot.ev)
+            (void)hipEventDestroy(slot.ev);
+    for (hipEvent_t e : {T->evCompute, T->evComm})
         if (e)
             (void)hipEventDestroy(e);
     for (auto& st : T->staging)
@@ -545,10 +573,16 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
     int r = build_plan(*T, ids, n);
     if (r)
         return r;
-    if ((r = wait_deferred(*T, st)) != 0) // a new dispatch list: last frame's permanent planes must have arrived
-        return r;
+    nrdhip_tiler::DeferredSlot* slot = deferred_slot(*T, ids, n);
+    if (!slot)
+        return fail(*T, FAILURE, "hipEventCreate");
     const bool up = T->rank > 0, down = T->rank < T->world - 1;
+    std::vector<Xfer> laterAll;
     for (uint32_t i = 0; i < T->plan.size(); i++) {
+        // the rows THIS list sent behind its previous call must have arrived before its first reader of previous-frame state runs
+        // (the dispatches in front of it - ClassifyTiles - run while they are still travelling)
+        if (i == T->firstPrevRead && (r = wait_deferred(*T, *slot, st)) != 0)
+            return r;
         const PlanEntry& e = T->plan[i];
         uint32_t strip = 0;
         for (auto& x : e.now)
@@ -591,18 +625,21 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
                 return fail(*T, FAILURE, "hipStreamWaitEvent");
             T->exchanges++;
         }
-        if (!e.later.empty()) {
-            std::vector<Op> lops;
-            if ((r = collect(*T, e.later, lops)) != 0)
+        laterAll.insert(laterAll.end(), e.later.begin(), e.later.end());
+    }
+    if (T->firstPrevRead >= T->plan.size() && (r = wait_deferred(*T, *slot, st)) != 0) // (a list without a reader of previous-frame state)
+        return r;
+    if (!laterAll.empty()) { // ONE group behind the last dispatch: nothing of it is read before this list's next call
+        std::vector<Op> lops;
+        if ((r = collect(*T, laterAll, lops)) != 0)
+            return r;
+        if (!lops.empty()) {
+            if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, lops, T->hostOrdered() ? st : T->commStream)) != 0)
                 return r;
-            if (!lops.empty()) {
-                if ((r = comm_after_compute(*T, st)) != 0 || (r = run_ops(*T, lops, T->hostOrdered() ? st : T->commStream)) != 0)
-                    return r;
-                if (!T->hostOrdered() && hipEventRecord(T->evDeferred, T->commStream) != hipSuccess)
-                    return fail(*T, FAILURE, "hipEventRecord");
-                T->deferredPending = true;
-                T->deferredExchanges++;
-            }
+            if (!T->hostOrdered() && hipEventRecord(slot->ev, T->commStream) != hipSuccess)
+                return fail(*T, FAILURE, "hipEventRecord");
+            slot->pending = true;
+            T->deferredExchanges++;
         }
     }
     return 0;
@@ -613,7 +650,10 @@ NRDHIP_API int nrdhip_tiler_finish(nrdhip_tiler* T, void* stream) {
     if (!T)
         return INVALID;
     TilerDeviceScope scope(*T);
-    return wait_deferred(*T, (hipStream_t)stream);
+    for (auto& slot : T->deferred)
+        if (int r = wait_deferred(*T, slot, (hipStream_t)stream))
+            return r;
+    return 0;
 }
 
 NRDHIP_API int nrdhip_tiler_stats(nrdhip_tiler* T, uint64_t out[4]) {

@@ -206,7 +206,7 @@ class Tiler:
         self.split_dispatches = 0  # dispatches run as boundary strips + interior with the exchange in flight
         self._plan_cache = {}
         self._p2p_cache = {}  # dispatch todo -> (P2POp list, bytes sent): pool planes never move, so the row slices are built once
-        self._deferred = []   # exchanges of planes only the NEXT frame reads: in flight until the next dispatch list starts
+        self._deferred = {}   # dispatch list -> exchanges of planes only the NEXT frame reads: in flight until that list's next call
         self._later_todo = []  # ... and their (plane, rows, skip) items while a dispatch list is still running
         self._staging = {}     # tap-texel planes (nrdhip_dispatch_info.written_prefix): the signal halves of the rows that travel
 
@@ -427,11 +427,13 @@ class Tiler:
             items.append(item)
         return items
 
-    def finish(self):
-        """wait for the exchanges still in flight (rows only the next frame reads)"""
-        for w in self._deferred:
-            w.wait()
-        self._deferred = []
+    def finish(self, ids=None):
+        """wait for the exchanges still in flight (rows only the next frame reads): all of them, or (`ids`) those the dispatch list `ids` sent
+        behind its previous call - another list's call inside the same frame (SIGMA, then REBLUR, then REFERENCE) does not wait for them"""
+        keys = list(self._deferred) if ids is None else [tuple(ids)]
+        for k in keys:
+            for w in self._deferred.pop(k, []):
+                w.wait()
 
     def run_dispatch(self, ids, i, plan_entry, last=None):
         """one dispatch + the halo exchange of what it wrote. When the band is tall enough the rows a neighbour needs are
@@ -439,7 +441,7 @@ class Tiler:
         the copies overlap the compute instead of serialising with it (nrdhip_denoise_rows). Rows that only the next frame
         reads follow without strips and without a wait (see _plan)."""
         if i == 0:
-            self.finish()  # a new dispatch list: last frame's permanent planes must have arrived
+            self.finish(ids)  # this list's next call: the permanent planes it sent behind its last call must have arrived
             self._later_todo = []
         todo, later = plan_entry
         self._run_dispatch_now(ids, i, todo)
@@ -448,7 +450,7 @@ class Tiler:
         # millisecond of GPU work); `last` unknown: sent right away
         self._later_todo += later
         if (last is None or last) and self._later_todo:
-            self._deferred += self.exchange_start_cached(self._later_todo)
+            self._deferred.setdefault(tuple(ids), []).extend(self.exchange_start_cached(self._later_todo))
             self._later_todo = []
 
     def _run_dispatch_now(self, ids, i, todo):
