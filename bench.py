@@ -264,7 +264,20 @@ def main():
     def timed_run(runner):
         """pre-roll to the steady state, W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns
         the wall time of the timed region (max over ranks)"""
+        import gc
+
         pre = preroll_frames(runner)
+        # no cyclic garbage collection inside a timed region: a generation-2 pass of a torch-sized heap stops the launch thread for ~35 ms
+        # (measured round 5, tools/hwt_leg_probe.py: one HistoryFix event pair 22 ms wide, the next frames 10 % slower while the idled
+        # GPU's clocks ramp up again) - it struck whichever leg happened to cross the allocation threshold
+        gc.collect()
+        gc.disable()
+        try:
+            return _timed_run(runner, pre)
+        finally:
+            gc.enable()
+
+    def _timed_run(runner, pre):
         for f in range(pre + args.warmup):
             runner.step(f, reset=(f == 0))
         if hasattr(runner, "finish"):
