@@ -76,6 +76,12 @@ struct FrameConsts {
     int prevY0, prevY1; // local rows [prevY0, prevY1) on which the PREVIOUS frame's planes are current (nrdhip_set_history_rows; whole planes
                         // on a single GPU). A row tiler refreshes only the rows reprojection may reach; a footprint texel outside is rejected
                         // like one outside the frame - a disocclusion - instead of being read from rows no exchange has written this frame
+    // Tile order table of the launch grid (nrdhip.cpp tile_table, built once per tilesX x tilesY with xcd_tile_kj on the host): entry
+    // j * 8 + k = the j-th tile of XCD k as tx | ty << 16 (ty relative to tileY0), 0xffffffff = spare workgroup. One scalar load replaces
+    // the ~230 scalar / VALU instructions (five integer divisions) xcd_tile_kj costs every wave; nullptr = compute it (strips of a row
+    // tiler whose shape has no table yet, launches recorded inside a graph capture before the table exists)
+    const uint32_t* tileTable;
+    int tilesPerXcd; // entries per XCD in tileTable = launch blocks / 8
     float rot[64][2];
 };
 
@@ -104,8 +110,8 @@ NRD_DEV float smoothstep01(float x) {
     return x * x * fma_(x, -2.0f, 3.0f); // == 3 - 2x rounded once: 2x is exact, so this is bit-identical to "3.0f - 2.0f * x"
 }
 NRD_DEV float absf(float x) { return __builtin_fabsf(x); } // a free source modifier (|x|) on the consuming instruction
-NRD_DEV int imin(int a, int b) { return a < b ? a : b; }
-NRD_DEV int imax(int a, int b) { return a > b ? a : b; }
+NRD_HD int imin(int a, int b) { return a < b ? a : b; }
+NRD_HD int imax(int a, int b) { return a > b ? a : b; }
 
 NRD_DEV f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 NRD_DEV f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -693,7 +699,7 @@ NRD_HD int xcd_grid_blocks(int tilesX, int tilesY) { // launch size: 8 x (larges
     const int rows = xcd_rows(tilesY);
     return xcd_cols(tilesX) * rows * ((tilesY + rows - 1) / rows) * 8;
 }
-NRD_DEV bool xcd_tile_kj(const FrameConsts& c, const int k, const int jIn, int& tx, int& ty) { // j-th tile of XCD k
+NRD_HD bool xcd_tile_kj(const FrameConsts& c, const int k, const int jIn, int& tx, int& ty) { // j-th tile of XCD k
     const int cols = xcd_cols(c.tilesX), rows = xcd_rows(c.tilesY);
     const int perBlock = cols * rows;
     // c.reverse: the launch walks the XCD's tile sequence back to front. A pass that reads what the previous one wrote then starts in
@@ -748,9 +754,27 @@ NRD_DEV bool ring_pos(int tid, int& lx, int& ly) {
 NRD_DEV uint32_t ld_tile_u16(const PlaneRef& P, int tx, int ty) { return NRD_TILE_TEXEL((uintptr_t)P.p + texel_offset(P, tx, ty, 2, 0), 2); }
 NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE_TEXEL((uintptr_t)P.p + texel_offset(P, tx, ty, 1, 0), 1); }
 
+// One dword through the scalar data path (uniform address, read-only for the launch): constant address space = s_load_dword
+#ifndef NRD_SCALAR_U32 // (the host emulation of the tests reads the plain word)
+#define NRD_SCALAR_U32(ptr) (*(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(ptr))
+#endif
+#ifndef NRD_TILE_TABLE // 0: every wave computes its tile (xcd_tile_kj) - the A/B switch of profiles/r05_ab_tile_table.txt
+#define NRD_TILE_TABLE 1
+#endif
+// the j-th tile of XCD k in this launch's direction: from the table when the launch has one
+NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty) {
+    if (NRD_TILE_TABLE && c.tileTable) {
+        const int jd = c.reverse ? c.tilesPerXcd - 1 - j : j;
+        const uint32_t e = NRD_SCALAR_U32(c.tileTable + (jd * 8 + k));
+        tx = (int)(e & 0xffffu);
+        ty = (int)(e >> 16) + c.tileY0;
+        return e != 0xffffffffu;
+    }
+    return xcd_tile_kj(c, k, j, tx, ty);
+}
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) { // one 16 x 16 workgroup per tile
     const int b = (int)blockIdx.x;
-    return xcd_tile_kj(c, b & 7, b >> 3, tx, ty);
+    return xcd_tile_of(c, b & 7, b >> 3, tx, ty);
 }
 
 } // namespace nrdhip

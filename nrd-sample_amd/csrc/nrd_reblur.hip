@@ -174,7 +174,7 @@ NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
 NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
 #if NRD_WG64
     const int b = (int)blockIdx.x, jj = b >> 3;
-    if (!xcd_tile_kj(c, b & 7, jj >> 2, tx, ty))
+    if (!xcd_tile_of(c, b & 7, jj >> 2, tx, ty))
         return false;
     x = tx * 16 + (int)threadIdx.x;
     y = ty * 16 + (jj & 3) * 4 + (int)threadIdx.y;

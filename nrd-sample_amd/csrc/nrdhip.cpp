@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -111,6 +112,8 @@ Params on_all_rows(Params q, int resH) {
     q.c.ownY1 = std::max(q.c.ownY0, std::min(resH, q.c.H - q.c.yOff));
     q.c.tileY0 = q.c.ownY0 / 16;
     q.c.tilesY = (q.c.ownY1 + 15) / 16 - q.c.tileY0;
+    q.c.tileTable = nullptr; // (the table of the owned rows' grid does not describe this one; the ClassifyTiles passes launch plain 2-D grids)
+    q.c.tilesPerXcd = 0;
     return q;
 }
 
@@ -164,6 +167,14 @@ struct nrdhip_instance {
     };
     std::vector<GraphSlot> graphExecs;
     uint32_t graphStats[3] = {0, 0, 0}; // replayed frames, instantiations, direct-launch fallbacks
+    // tile order tables of the launch grids this instance has used (FrameConsts::tileTable), keyed by {tilesX, tilesY}: device memory,
+    // built once per shape (a full frame has one; a row tiler adds one per strip shape), freed with the instance
+    struct TileTable {
+        uint32_t* dev = nullptr;
+        std::vector<uint32_t> host; // stays alive: the upload is an asynchronous copy on the launch stream
+    };
+    std::map<std::pair<int, int>, TileTable> tileTables;
+    bool capturing = false; // inside nrdhip_denoise's stream capture: no allocation / copy may be issued (a missing table stays missing)
 };
 
 namespace {
@@ -1062,7 +1073,47 @@ struct Flat {
     uint32_t index;
 };
 
-int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Flat>& out) {
+// The tile order of a launch over tilesX x tilesY tiles (nrd_device.h xcd_tile_kj, forward direction, tile rows relative to tileY0) as a
+// device table: entry j * 8 + k = tx | ty << 16 of the j-th tile of XCD k, 0xffffffff for the spare workgroups of the rounded-up grid.
+// nullptr when the shape has no table and none may be made now (inside a stream capture) or the allocation fails: the kernels then
+// compute the tile themselves - same order, same result.
+// The upload is stream-ordered on the stream the kernels are launched on (no device-wide synchronisation in the middle of a row tiler's
+// overlapped exchange schedule).
+const uint32_t* tile_table(nrdhip_instance& I, int tilesX, int tilesY, hipStream_t st) {
+    if (tilesX <= 0 || tilesY <= 0 || tilesX > 0xffff || tilesY > 0xfffe)
+        return nullptr;
+    auto it = I.tileTables.find({tilesX, tilesY});
+    if (it != I.tileTables.end())
+        return it->second.dev;
+    if (I.capturing)
+        return nullptr;
+    const int blocks = xcd_grid_blocks(tilesX, tilesY);
+    nrdhip_instance::TileTable& T = I.tileTables[{tilesX, tilesY}];
+    std::vector<uint32_t>& host = T.host;
+    host.assign((size_t)blocks, 0xffffffffu);
+    FrameConsts c;
+    std::memset(&c, 0, sizeof(c));
+    c.tilesX = tilesX;
+    c.tilesY = tilesY;
+    for (int b = 0; b < blocks; b++) {
+        int tx, ty;
+        if (xcd_tile_kj(c, b & 7, b >> 3, tx, ty))
+            host[(size_t)b] = (uint32_t)tx | ((uint32_t)ty << 16);
+    }
+    uint32_t* dev = nullptr;
+    if (hipMalloc((void**)&dev, host.size() * sizeof(uint32_t)) != hipSuccess ||
+        hipMemcpyAsync(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+        (void)hipGetLastError();
+        if (dev)
+            (void)hipFree(dev);
+        dev = nullptr; // (remembered: the shape is not tried again every frame)
+    }
+    T.dev = dev;
+    return dev;
+}
+
+// forLaunch: the lists are about to be launched (the HIP device of the instance is current): their grids get their tile tables
+int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Flat>& out, bool forLaunch = false, hipStream_t st = nullptr) {
     out.clear();
     if (!I.commonSet) {
         I.error = "SetCommonSettings has not been called";
@@ -1071,6 +1122,10 @@ int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Fla
     FrameConsts c;
     if (!derive_consts(I, c, I.error))
         return (int)nrd::Result::INVALID_ARGUMENT;
+    if (forLaunch) {
+        c.tileTable = tile_table(I, c.tilesX, c.tilesY, st);
+        c.tilesPerXcd = xcd_grid_blocks(c.tilesX, c.tilesY) / 8;
+    }
     bool reset = I.common.accumulationMode != nrd::AccumulationMode::CONTINUE;
     for (uint32_t i = 0; i < n; i++) {
         DenoiserState* d = find(I, ids[i]);
@@ -1283,6 +1338,9 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
                 (void)hipFree(P.p);
     if (inst->transArena)
         (void)hipFree(inst->transArena);
+    for (auto& t : inst->tileTables)
+        if (t.second.dev)
+            (void)hipFree(t.second.dev);
     release_graphs(*inst);
     delete inst;
 }
@@ -1515,7 +1573,7 @@ static int denoise_parts(nrdhip_instance* inst, const uint32_t* ids, uint32_t n,
                 return (int)nrd::Result::INVALID_ARGUMENT;
             }
     std::vector<Flat> fl;
-    int r = flatten(I, ids, n, fl);
+    int r = flatten(I, ids, n, fl, true, st);
     if (r)
         return r;
     if (first > fl.size() || first + count > fl.size())
@@ -1602,6 +1660,17 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
     nrdhip_instance& I = *inst;
     hipStream_t st = (hipStream_t)stream;
     DeviceScope scope(I.device);
+    { // the tile table of the frame's grid is made BEFORE the capture begins (an allocation + copy; nothing of the kind may run inside it)
+        FrameConsts c;
+        std::string err;
+        if (I.commonSet && derive_consts(I, c, err))
+            (void)tile_table(I, c.tilesX, c.tilesY, st);
+    }
+    struct CaptureFlag {
+        bool& f;
+        explicit CaptureFlag(bool& b) : f(b) { f = true; }
+        ~CaptureFlag() { f = false; }
+    };
     if (!st || hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         I.graphStats[2]++;
@@ -1628,7 +1697,10 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
         I.graphStats[2]++;
         return nrdhip_denoise_range(inst, ids, n, 0, count, stream);
     };
-    r = nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    {
+        CaptureFlag capturing(I.capturing);
+        r = nrdhip_denoise_range(inst, ids, n, 0, count, stream);
+    }
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(st, &graph);
     if (r) { // the dispatch list itself is at fault (unbound slot, ...): the direct path would fail the same way

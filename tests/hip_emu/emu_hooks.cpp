@@ -16,6 +16,20 @@ extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of(int t
     hipemu::t_blockIdx = {block, 0u, 0u};
     return xcd_tile(c, *tx, *ty) ? 1 : 0;
 }
+// the same through a tile order table (FrameConsts::tileTable: `table` = entries j * 8 + k of the FORWARD launch with tile rows relative to
+// tileY0, as nrdhip.cpp tile_table builds it) - the lookup path of xcd_tile: direction and tileY0 are applied on top of the table
+extern "C" __attribute__((visibility("default"))) int nrdhip_debug_tile_of_table(const uint32_t* table, int tilesX, int tilesY, int tileY0, unsigned block, int reverse, int* tx,
+                                                                              int* ty) {
+    FrameConsts c = {};
+    c.reverse = reverse;
+    c.tilesX = tilesX;
+    c.tilesY = tilesY;
+    c.tileY0 = tileY0;
+    c.tileTable = table;
+    c.tilesPerXcd = xcd_grid_blocks(tilesX, tilesY) / 8;
+    hipemu::t_blockIdx = {block, 0u, 0u};
+    return xcd_tile(c, *tx, *ty) ? 1 : 0;
+}
 extern "C" __attribute__((visibility("default"))) unsigned nrdhip_debug_grid_blocks(int tilesX, int tilesY) { return (unsigned)xcd_grid_blocks(tilesX, tilesY); }
 // read and reset the gather trace of the emulation {wave-level gather instructions, distinct 128-byte lines they touched, lane loads},
 // then switch it on / off

@@ -43,6 +43,7 @@
 #define NRD_WAVES_PER_EU(n)
 // nrd_device.h: the scalar-path read of a per-tile texel (an aligned dword on the device) as the plain 1- / 2-byte read it stands for
 #define NRD_TILE_TEXEL(addr, bytes) ((bytes) == 1 ? (uint32_t)*(const uint8_t*)(addr) : (uint32_t)*(const uint16_t*)(addr))
+#define NRD_SCALAR_U32(ptr) (*(const uint32_t*)(ptr)) // nrd_device.h: a dword through the scalar data path
 #define __shared__ static
 
 struct dim3 {
@@ -386,6 +387,15 @@ inline hipError_t hipMalloc(void** p, size_t n) {
 }
 inline hipError_t hipFree(void* p) {
     std::free(p);
+    return hipSuccess;
+}
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+    std::memcpy(dst, src, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) {
+    std::memcpy(dst, src, n);
     return hipSuccess;
 }
 inline hipError_t hipMemset(void* p, int v, size_t n) {

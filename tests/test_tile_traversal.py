@@ -12,6 +12,9 @@ def emu_lib(emulated):
     lib = emulated.lib
     lib.nrdhip_debug_tile_of.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     lib.nrdhip_debug_tile_of.restype = ctypes.c_int
+    lib.nrdhip_debug_tile_of_table.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int)]
+    lib.nrdhip_debug_tile_of_table.restype = ctypes.c_int
     lib.nrdhip_debug_grid_blocks.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.nrdhip_debug_grid_blocks.restype = ctypes.c_uint
     return lib
@@ -81,3 +84,22 @@ def test_reverse_walks_each_xcd_back_to_front(emu_lib):
         r = [(x, y) for b, x, y in rev if b % 8 == k]
         assert r == f[::-1]
     assert min(y for b, x, y in rev if b < 8 * 240) >= tiles_y - 17 - 8  # the first 240 workgroups of every XCD: the bottom block row
+
+
+@pytest.mark.parametrize("tiles", [(1, 1), (7, 9), (9, 17), (30, 34), (61, 5), (240, 135)])
+def test_tile_table_lookup_equals_the_computed_traversal(emu_lib, tiles):
+    """FrameConsts::tileTable (one scalar load per wave instead of xcd_tile_kj's five integer divisions): a table holding the FORWARD order
+    with tile rows relative to tileY0 - what nrdhip.cpp tile_table uploads - must hand every workgroup the tile the computation hands it,
+    in both directions and for any first tile row, spare workgroups included"""
+    tiles_x, tiles_y = tiles
+    n = emu_lib.nrdhip_debug_grid_blocks(tiles_x, tiles_y)
+    tx, ty = ctypes.c_int(), ctypes.c_int()
+    table = (ctypes.c_uint32 * n)()
+    for b in range(n):
+        ok = emu_lib.nrdhip_debug_tile_of(tiles_x, tiles_y, 0, b, 0, ctypes.byref(tx), ctypes.byref(ty))
+        table[b] = (tx.value | (ty.value << 16)) if ok else 0xFFFFFFFF
+    for tile_y0, reverse in ((0, 0), (5, 0), (0, 1), (11, 1)):
+        for b in range(n):
+            want = (emu_lib.nrdhip_debug_tile_of(tiles_x, tiles_y, tile_y0, b, reverse, ctypes.byref(tx), ctypes.byref(ty)), tx.value, ty.value)
+            got = (emu_lib.nrdhip_debug_tile_of_table(table, tiles_x, tiles_y, tile_y0, b, reverse, ctypes.byref(tx), ctypes.byref(ty)), tx.value, ty.value)
+            assert got[0] == want[0] and (not want[0] or got[1:] == want[1:]), (b, tile_y0, reverse, want, got)
