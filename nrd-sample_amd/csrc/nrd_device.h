@@ -81,6 +81,10 @@ struct FrameConsts {
     // the ~230 scalar / VALU instructions (five integer divisions) xcd_tile_kj costs every wave; nullptr = compute it (strips of a row
     // tiler whose shape has no table yet, launches recorded inside a graph capture before the table exists)
     const uint32_t* tileTable;
+    // The per-tile flag of ClassifyTiles in the SAME order (one byte per table entry, written by this frame's ClassifyTiles through the
+    // inverse table): a wave loads its table entry and its flag side by side - one scalar round trip - instead of entry, then flag at
+    // (tx, ty). nullptr = read the Tiles plane (a launch whose grid is not the one ClassifyTiles ran on: strips of a row tiler)
+    const uint8_t* tileFlags;
     int tilesPerXcd; // entries per XCD in tileTable = launch blocks / 8
     float rot[64][2];
 };
@@ -761,20 +765,35 @@ NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE
 #ifndef NRD_TILE_TABLE // 0: every wave computes its tile (xcd_tile_kj) - the A/B switch of profiles/r05_ab_tile_table.txt
 #define NRD_TILE_TABLE 1
 #endif
-// the j-th tile of XCD k in this launch's direction: from the table when the launch has one
-NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty) {
+#ifndef NRD_TILE_FLAGS // 0: the tile flag always comes from the Tiles plane (a scalar load that depends on the table entry)
+#define NRD_TILE_FLAGS 1
+#endif
+// the j-th tile of XCD k in this launch's direction: from the table when the launch has one. `tflag` = the tile's ClassifyTiles flag when
+// the launch carries the flags in table order (FrameConsts::tileFlags), -1 when it must be read from the Tiles plane
+NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty, int& tflag) {
+    tflag = -1;
     if (NRD_TILE_TABLE && c.tileTable) {
         const int jd = c.reverse ? c.tilesPerXcd - 1 - j : j;
         const uint32_t e = NRD_SCALAR_U32(c.tileTable + (jd * 8 + k));
+        if (NRD_TILE_FLAGS && c.tileFlags)
+            tflag = (int)NRD_TILE_TEXEL((uintptr_t)c.tileFlags + (uint32_t)(jd * 8 + k), 1);
         tx = (int)(e & 0xffffu);
         ty = (int)(e >> 16) + c.tileY0;
         return e != 0xffffffffu;
     }
     return xcd_tile_kj(c, k, j, tx, ty);
 }
-NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) { // one 16 x 16 workgroup per tile
+NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty) {
+    int tflag;
+    return xcd_tile_of(c, k, j, tx, ty, tflag);
+}
+NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty, int& tflag) { // one 16 x 16 workgroup per tile
     const int b = (int)blockIdx.x;
-    return xcd_tile_of(c, b & 7, b >> 3, tx, ty);
+    return xcd_tile_of(c, b & 7, b >> 3, tx, ty, tflag);
+}
+NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
+    int tflag;
+    return xcd_tile(c, tx, ty, tflag);
 }
 
 } // namespace nrdhip

@@ -53,6 +53,10 @@ struct ReblurParams {
     // tapA: HistoryFix -> Blur, tapB: Blur -> PostBlur
     int tapTex;
     PlaneRef tapA[2], tapB[2];
+    // ClassifyTiles only: the tile flags once more in LAUNCH order (FrameConsts::tileFlags of the passes behind it) through the inverse of
+    // the tile table (tile -> forward launch index); nullptr when those passes launch over another grid than ClassifyTiles
+    uint8_t* tileFlagsOut;
+    const uint32_t* tileInv;
 };
 
 // one RELAX A-trous iteration (nrd_reblur.hip k_relax_atrous)

@@ -153,16 +153,21 @@ NRD_DEV void store_texel(const PlaneRef& P, int x, int y, const uint2 (&t)[BYTES
 
 // REBLUR / RELAX::Tiles (written by ClassifyTiles): 1 = no pixel of the 16x16 tile has geometry. One byte per tile, same address for
 // the whole workgroup: a scalar value
-NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty) { return ld_tile_u8(tiles, tx, ty) != 0u; }
-NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty) { return tile_is_sky(p.tiles, tx, ty); }
+// (`tflag`: the flag as xcd_tile delivered it with the tile - launches that carry the flags in table order - or -1: read the plane)
+NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty, int tflag) { return (tflag >= 0 ? (uint32_t)tflag : ld_tile_u8(tiles, tx, ty)) != 0u; }
+NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty, int tflag) { return tile_is_sky(p.tiles, tx, ty, tflag); }
 
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
-NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
-    if (!xcd_tile(c, tx, ty))
+NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty, int& tflag) {
+    if (!xcd_tile(c, tx, ty, tflag))
         return false;
     x = tx * 16 + (int)threadIdx.x;
     y = ty * 16 + (int)threadIdx.y;
     return x < c.W && y >= c.ownY0 && y < c.ownY1;
+}
+NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
+    int tflag;
+    return my_pixel(c, x, y, tx, ty, tflag);
 }
 
 // TemporalAccumulation runs one WAVE per workgroup (16 x 4 pixels, a quarter of a tile; the four quarters of a tile are consecutive
@@ -171,17 +176,21 @@ NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
 #ifndef NRD_WG64
 #define NRD_WG64 1
 #endif
-NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
+NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty, int& tflag) {
 #if NRD_WG64
     const int b = (int)blockIdx.x, jj = b >> 3;
-    if (!xcd_tile_of(c, b & 7, jj >> 2, tx, ty))
+    if (!xcd_tile_of(c, b & 7, jj >> 2, tx, ty, tflag))
         return false;
     x = tx * 16 + (int)threadIdx.x;
     y = ty * 16 + (jj & 3) * 4 + (int)threadIdx.y;
     return x < c.W && y >= c.ownY0 && y < c.ownY1;
 #else
-    return my_pixel(c, x, y, tx, ty);
+    return my_pixel(c, x, y, tx, ty, tflag);
 #endif
+}
+NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) {
+    int tflag;
+    return my_pixel_w(c, x, y, tx, ty, tflag);
 }
 
 // =====================================================================================================================
@@ -229,8 +238,13 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
         }
     }
     __syncthreads();
-    if (tid < NRD_CT_TILES && tx0 + tid < c.tilesX)
+    if (tid < NRD_CT_TILES && tx0 + tid < c.tilesX) {
         st<uint8_t>(p.tiles, tx0 + tid, ty, 1, sGeo[tid] ? 0 : 1);
+        // ... and once more where the workgroup that will work on this tile finds it next to its table entry (FrameConsts::tileFlags; only
+        // when the other passes' grid is this grid: nrdhip.cpp tile_flags)
+        if (p.tileFlagsOut)
+            p.tileFlagsOut[p.tileInv[(uint32_t)(ty - c.tileY0) * (uint32_t)c.tilesX + (uint32_t)(tx0 + tid)]] = sGeo[tid] ? 0 : 1;
+    }
 }
 
 // =====================================================================================================================
@@ -375,6 +389,25 @@ __global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
     if (y < c.ownY0 || y >= c.ownY1)
         return;
     const int gy0 = y + c.yOff;
+    // The loads of ALL the run's pixels go out before the first result is stored: the output planes may alias the inputs as far as the
+    // compiler can tell, so with load - compute - store per pixel the four pixels of a thread were four dependent memory round trips
+    // (0.077 ms at 4K for 32 bytes per pixel: 3.4 TB/s); the positions are clamped, the loads unconditional
+    uint2 g0[NRD_CT_TILES], gl[NRD_CT_TILES], gr[NRD_CT_TILES], sOwn[NRD_CT_TILES], sL[NRD_CT_TILES], sR[NRD_CT_TILES];
+#pragma unroll
+    for (int k = 0; k < NRD_CT_TILES; k++) {
+        const int x = imin(((int)blockIdx.x * NRD_CT_TILES + k) * 16 + (int)threadIdx.x, c.W - 1);
+        const bool ownIsDiff = ((((uint32_t)x ^ (uint32_t)gy0) ^ c.frameIndex) & 1u) == (uint32_t)p.phaseDiff;
+        const PlaneRef& ownIn = ownIsDiff ? p.rawDiff : p.rawSpec;
+        const PlaneRef& otherIn = ownIsDiff ? p.rawSpec : p.rawDiff;
+        const int xl = imax(x - 1, 0), xr = imin(x + 1, c.W - 1);
+        g0[k] = ld_guide(p.guide, x, y);
+        gl[k] = ld_guide(p.guide, xl, y);
+        gr[k] = ld_guide(p.guide, xr, y);
+        sOwn[k] = ld<uint2>(ownIn, x >> 1, y, 8);
+        sL[k] = ld<uint2>(otherIn, xl >> 1, y, 8);
+        sR[k] = ld<uint2>(otherIn, xr >> 1, y, 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < NRD_CT_TILES; k++) {
         const int x = ((int)blockIdx.x * NRD_CT_TILES + k) * 16 + (int)threadIdx.x;
@@ -382,26 +415,21 @@ __global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
             continue;
         // the pixel carries the signal whose phase matches its colour; its neighbours carry the other one
         const bool ownIsDiff = ((((uint32_t)x ^ (uint32_t)gy0) ^ c.frameIndex) & 1u) == (uint32_t)p.phaseDiff;
-        const PlaneRef& ownIn = ownIsDiff ? p.rawDiff : p.rawSpec;
-        const PlaneRef& otherIn = ownIsDiff ? p.rawSpec : p.rawDiff;
         const PlaneRef& ownOut = ownIsDiff ? p.inDiff : p.inSpec;
         const PlaneRef& otherOut = ownIsDiff ? p.inSpec : p.inDiff;
-        const int xl = imax(x - 1, 0), xr = imin(x + 1, c.W - 1);
-        const uint2 g0 = ld_guide(p.guide, x, y), gl = ld_guide(p.guide, xl, y), gr = ld_guide(p.guide, xr, y);
-        const uint2 sOwn = ld<uint2>(ownIn, x >> 1, y, 8), sL = ld<uint2>(otherIn, xl >> 1, y, 8), sR = ld<uint2>(otherIn, xr >> 1, y, 8);
-        const Guide g = decode_guide(g0, c.denoisingRange);
+        const Guide g = decode_guide(g0[k], c.denoisingRange);
         if (g.sky) {
             st<uint2>(ownOut, x, y, 8, uint2{0u, 0u});
             st<uint2>(otherOut, x, y, 8, uint2{0u, 0u});
             continue;
         }
-        const f4 v = unpack_h4(sOwn);
+        const f4 v = unpack_h4(sOwn[k]);
         // checkerboard resolve of the other signal (k_prepare_inputs, the same expressions)
         const float invDz = rcp_(0.03f * fmax2(absf(g.z), 1e-6f));
         float wn[2];
         bool ok[2];
-        const f4 vn[2] = {unpack_h4(sL), unpack_h4(sR)};
-        const uint2 gn2[2] = {gl, gr};
+        const f4 vn[2] = {unpack_h4(sL[k]), unpack_h4(sR[k])};
+        const uint2 gn2[2] = {gl[k], gr[k]};
 #pragma unroll
         for (int n = 0; n < 2; n++) {
             const int px = x + (n ? 1 : -1);
@@ -443,7 +471,7 @@ NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y);
 // TemporalAccumulation on latency). The values that cross from one half to the other are rounded exactly as the planes would have
 // rounded them (packed fp16 words), so the fused dispatch is bit-identical to the two separate ones.
 template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC, bool FUSED>
-NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, const int tx, const int ty) {
+NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, const int tx, const int ty, const int tflag) {
     static_assert(!FUSED || (VARIANT == 0 && MODE == 0), "only the REBLUR radiance PrePass continues into TemporalAccumulation");
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr bool SH = MODE == 3 || MODE == 4;
@@ -467,7 +495,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
     // that only ever holds finite values). So they write nothing - a pixel beyond the denoising range used to cost these two passes
     // 34 + 48 bytes of traffic, a third of what a pixel with geometry costs. Blur must keep the tap texels of the tile current (PostBlur's
     // taps take their sky test from the guide inside the texel): it copies the guide texel in, without reading HistoryFix's texels.
-    if (NRD_SKIP_SKY_TILES && (VARIANT != 1 || TAP) && tile_is_sky(p, tx, ty)) {
+    if (NRD_SKIP_SKY_TILES && (VARIANT != 1 || TAP) && tile_is_sky(p, tx, ty, tflag)) {
         if (VARIANT == 1) {
             const uint2 gsky = ld_guide(p.guide, x, y);
             for (int sig = 0; sig < NSIG; sig++)
@@ -816,12 +844,12 @@ template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
 // 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
 // carry 16 more registers of tap data and stay at 3
 __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? (VARIANT == 0 ? (MODE == 4 ? NRD_RELAX_SH_PRE_WAVES : NRD_SH_PRE_WAVES) : 3) : ((VARIANT != 0 && MODE == 0) ? (VARIANT == 2 ? NRD_POST_WAVES : NRD_TAP_WAVES) : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
-    int x, y, tx, ty;
-    if (!my_pixel(p.c, x, y, tx, ty)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
-        return;                       // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
+    int x, y, tx, ty, tflag;
+    if (!my_pixel(p.c, x, y, tx, ty, tflag)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
+        return;                              // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
     // (round 4: workgroups that take 2 / 4 consecutive tiles with the next tile's centre loads in flight behind the current tile's
     // arithmetic measured 14 / 24 % SLOWER on Blur and 10 / 18 % on PostBlur - profiles/r04_ab_fusion.txt)
-    spatial_pixel<VARIANT, MODE, HAS_DIFF, HAS_SPEC, false>(p, x, y, tx, ty);
+    spatial_pixel<VARIANT, MODE, HAS_DIFF, HAS_SPEC, false>(p, x, y, tx, ty, tflag);
 }
 
 // =====================================================================================================================
@@ -1205,13 +1233,13 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAV
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int RBPT = (SH ? 16 : 8) * NSIG;
     const FrameConsts& c = p.c;
-    int x, y, tx, ty;
-    if (!my_pixel_w(c, x, y, tx, ty))
+    int x, y, tx, ty, tflag;
+    if (!my_pixel_w(c, x, y, tx, ty, tflag))
         return;
     // a tile without geometry: Tmp2, the fast history, Data1Tmp and Data2 of its pixels are read by nobody who has not tested the guide
     // first (HistoryFix skips the tile, its reconstruction taps and 5x5 windows test the tap's depth; next frame's footprints weigh a
     // texel beyond the range with an exact 0) - nothing to write (k_spatial has the full argument)
-    if (NRD_SKIP_SKY_TILES && tile_is_sky(p, tx, ty))
+    if (NRD_SKIP_SKY_TILES && tile_is_sky(p, tx, ty, tflag))
         return;
     Guide g = decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
@@ -1231,10 +1259,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAV
 #endif
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_FUSED_WAVES) void k_prepass_temporal_accumulation(const ReblurParams p) {
-    int x, y, tx, ty;
-    if (!my_pixel(p.c, x, y, tx, ty))
+    int x, y, tx, ty, tflag;
+    if (!my_pixel(p.c, x, y, tx, ty, tflag))
         return;
-    spatial_pixel<0, 0, HAS_DIFF, HAS_SPEC, true>(p, x, y, tx, ty);
+    spatial_pixel<0, 0, HAS_DIFF, HAS_SPEC, true>(p, x, y, tx, ty, tflag);
 }
 
 // =====================================================================================================================
@@ -1284,8 +1312,8 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     __shared__ float tile[NSIG][400];    // fast luma history
     __shared__ float tileCur[NSIG][400]; // incoming luma (anti-firefly only)
     const FrameConsts& c = p.c;
-    int tx, ty;
-    if (!xcd_tile(c, tx, ty))
+    int tx, ty, tflag;
+    if (!xcd_tile(c, tx, ty, tflag))
         return;
     // the centre loads of the pixel do not depend on the staged tiles: issued first, they travel with the staging loads (this
     // kernel spent 72 % of its wave time in s_waitcnt: staging round trip, barrier, then the centre round trip)
@@ -1307,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
         st<uint16_t>(p.data1, x, y, 2, (uint16_t)0);
     };
     // a tile without geometry (ClassifyTiles: Tiles = 1; block-uniform): every pixel takes the sky path - no staging, no barrier
-    if (tile_is_sky(p, tx, ty)) {
+    if (tile_is_sky(p, tx, ty, tflag)) {
         if (live)
             sky_out(tapTex ? ld_guide(p.guide, x, y) : uint2{0u, 0u});
         return;
@@ -1516,8 +1544,15 @@ NRD_DEV bool blend_stab(const FootPos& fp, const uint32_t (&raw)[4], int half, u
     return fp.sane && wsum > 0.0f;
 }
 
+#ifndef NRD_TS_WAVES // waves per SIMD the register allocator aims for in TemporalStabilization (0: no bound - 49 VGPRs / 106 SGPRs = 7)
+#define NRD_TS_WAVES 0
+#endif
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH>
+#if NRD_TS_WAVES
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_TS_WAVES) void k_temporal_stabilization(const ReblurParams p) {
+#else
 __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurParams p) {
+#endif
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
@@ -1526,8 +1561,8 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     __shared__ float tile[NSIG][400];
     const FrameConsts& c = p.c;
-    int tx, ty;
-    if (!xcd_tile(c, tx, ty))
+    int tx, ty, tflag;
+    if (!xcd_tile(c, tx, ty, tflag))
         return;
     // Memory round trips are what this kernel waits for (64 % of its wave time sat in s_waitcnt): the centre loads of the pixel do
     // not depend on the staged tile, so they are issued FIRST and travel together with the staging loads - one round trip, then
@@ -1552,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_temporal_stabilization(const ReblurPara
         }
     };
     // a tile without geometry (ClassifyTiles: Tiles = 1; block-uniform): every pixel takes the sky path - no staging, no barrier
-    if (tile_is_sky(p, tx, ty)) {
+    if (tile_is_sky(p, tx, ty, tflag)) {
         if (live)
             sky_out();
         return;
@@ -1736,7 +1771,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
     const FrameConsts& c = p.c;
     // rows / columns a tap may land on: inside the frame and inside the rows this instance holds
     const int loY = imax(0, -c.yOff), hiY = imin(c.resH, c.H - c.yOff) - 1;
-    int x, y, tx, ty;
+    int x, y, tx, ty, tflag;
     uint16_t d1raw = 0;
     uint32_t d2raw = 0;
     const bool last = p.last != 0;
@@ -1759,9 +1794,9 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
         }
     };
     if (LS) {
-        if (!xcd_tile(c, tx, ty))
+        if (!xcd_tile(c, tx, ty, tflag))
             return;
-        if (tile_is_sky(p.tiles, tx, ty)) { // a tile without geometry (block-uniform): the per-pixel sky stores, no staging, no barrier
+        if (tile_is_sky(p.tiles, tx, ty, tflag)) { // a tile without geometry (block-uniform): the per-pixel sky stores, no staging, no barrier
             x = tx * 16 + (int)threadIdx.x;
             y = ty * 16 + (int)threadIdx.y;
             if (x < c.W && y >= c.ownY0 && y < c.ownY1)

@@ -113,6 +113,7 @@ Params on_all_rows(Params q, int resH) {
     q.c.tileY0 = q.c.ownY0 / 16;
     q.c.tilesY = (q.c.ownY1 + 15) / 16 - q.c.tileY0;
     q.c.tileTable = nullptr; // (the table of the owned rows' grid does not describe this one; the ClassifyTiles passes launch plain 2-D grids)
+    q.c.tileFlags = nullptr;
     q.c.tilesPerXcd = 0;
     return q;
 }
@@ -132,6 +133,8 @@ struct DenoiserState {
     nrd::SigmaSettings sigma;
     nrd::ReferenceSettings reference;
     std::vector<Dispatch> dispatches;
+    // ClassifyTiles' per-tile flags in launch order (FrameConsts::tileFlags), one device buffer per grid shape this denoiser ran on
+    std::map<std::pair<int, int>, uint8_t*> tileFlags;
 };
 
 inline uint32_t enc_perm(uint32_t i) { return i; }
@@ -170,9 +173,11 @@ struct nrdhip_instance {
     // tile order tables of the launch grids this instance has used (FrameConsts::tileTable), keyed by {tilesX, tilesY}: device memory,
     // built once per shape (a full frame has one; a row tiler adds one per strip shape), freed with the instance
     struct TileTable {
-        uint32_t* dev = nullptr;
+        uint32_t* dev = nullptr; // [blocks] launch index -> tile, then [tilesX * tilesY] tile -> forward launch index (the inverse)
+        uint32_t blocks = 0;
         std::vector<uint32_t> host; // stays alive: the upload is an asynchronous copy on the launch stream
     };
+    hipStream_t tableStream = nullptr; // the stream the current dispatch lists are launched on (uploads / clears of the tables above)
     std::map<std::pair<int, int>, TileTable> tileTables;
     bool capturing = false; // inside nrdhip_denoise's stream capture: no allocation / copy may be issued (a missing table stays missing)
 };
@@ -467,6 +472,39 @@ Params directed(Params q, bool reverse) {
     return q;
 }
 
+// ClassifyTiles' flags in launch order for the passes behind it (FrameConsts::tileFlags): usable when those passes launch over the grid
+// ClassifyTiles runs on (one instance holding the whole frame; a band of a row tiler classifies its halo rows too) and that grid has a table
+void attach_tile_flags(nrdhip_instance& I, DenoiserState& d, ReblurParams& p) {
+    p.c.tileFlags = nullptr;
+    p.tileFlagsOut = nullptr;
+    p.tileInv = nullptr;
+    const ReblurParams q = on_all_rows(p, I.resH);
+    if (!p.c.tileTable || q.c.tileY0 != p.c.tileY0 || q.c.tilesY != p.c.tilesY)
+        return;
+    auto t = I.tileTables.find({p.c.tilesX, p.c.tilesY});
+    if (t == I.tileTables.end() || !t->second.dev)
+        return;
+    uint8_t* f = nullptr;
+    auto it = d.tileFlags.find({p.c.tilesX, p.c.tilesY});
+    if (it != d.tileFlags.end())
+        f = it->second;
+    else if (!I.capturing) {
+        const size_t bytes = (size_t)t->second.blocks + 8; // (the scalar read fetches the aligned dword around a byte)
+        if (hipMalloc((void**)&f, bytes) != hipSuccess || hipMemsetAsync(f, 0, bytes, I.tableStream) != hipSuccess) {
+            (void)hipGetLastError();
+            if (f)
+                (void)hipFree(f);
+            f = nullptr;
+        }
+        d.tileFlags[{p.c.tilesX, p.c.tilesY}] = f;
+    }
+    if (!f)
+        return;
+    p.c.tileFlags = f;
+    p.tileFlagsOut = f;
+    p.tileInv = t->second.dev + t->second.blocks;
+}
+
 void build_reference(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     using RT = nrd::ResourceType;
     ReferenceParams p;
@@ -712,6 +750,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     auto P = [&](int i) { return enc_perm(pb + i); };
     auto T = [&](int i) { return enc_trans(tb + i); };
     ReblurParams p = make_reblur_params(I, d, c, s);
+    attach_tile_flags(I, d, p);
 
     float n = (float)d.nsig;
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
@@ -856,6 +895,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     auto P = [&](int i) { return enc_perm(pb + i); };
     auto T = [&](int i) { return enc_trans(tb + i); };
     ReblurParams p = make_reblur_params(I, d, c, s);
+    attach_tile_flags(I, d, p);
     p.relax = 1;
     p.maxASpec = (float)std::min<uint32_t>(r.specularMaxAccumulatedFrameNum, 63);
     p.maxFastASpec = (float)std::min<uint32_t>(r.specularMaxFastAccumulatedFrameNum, 63);
@@ -912,7 +952,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     }
     AtrousParams a;
     std::memset(&a, 0, sizeof(a));
-    a.c = c;
+    a.c = p.c; // (with the tile flags of this denoiser's ClassifyTiles)
     a.depthSens = std::max(r.depthThreshold, 0.001f) * 4.0f;
     a.histThreshold = (float)r.spatialVarianceEstimationHistoryThreshold;
     a.specularVarianceBoost = r.specularVarianceBoost;
@@ -1088,17 +1128,22 @@ const uint32_t* tile_table(nrdhip_instance& I, int tilesX, int tilesY, hipStream
     if (I.capturing)
         return nullptr;
     const int blocks = xcd_grid_blocks(tilesX, tilesY);
+    if (I.tileTables.size() >= 64)
+        return nullptr; // (a caller resizing the rect every frame: the shapes beyond the first 64 compute their tiles)
     nrdhip_instance::TileTable& T = I.tileTables[{tilesX, tilesY}];
     std::vector<uint32_t>& host = T.host;
-    host.assign((size_t)blocks, 0xffffffffu);
+    host.assign((size_t)blocks + (size_t)tilesX * tilesY, 0xffffffffu);
+    T.blocks = (uint32_t)blocks;
     FrameConsts c;
     std::memset(&c, 0, sizeof(c));
     c.tilesX = tilesX;
     c.tilesY = tilesY;
     for (int b = 0; b < blocks; b++) {
         int tx, ty;
-        if (xcd_tile_kj(c, b & 7, b >> 3, tx, ty))
+        if (xcd_tile_kj(c, b & 7, b >> 3, tx, ty)) {
             host[(size_t)b] = (uint32_t)tx | ((uint32_t)ty << 16);
+            host[(size_t)blocks + (size_t)ty * tilesX + tx] = (uint32_t)b;
+        }
     }
     uint32_t* dev = nullptr;
     if (hipMalloc((void**)&dev, host.size() * sizeof(uint32_t)) != hipSuccess ||
@@ -1123,6 +1168,7 @@ int flatten(nrdhip_instance& I, const uint32_t* ids, uint32_t n, std::vector<Fla
     if (!derive_consts(I, c, I.error))
         return (int)nrd::Result::INVALID_ARGUMENT;
     if (forLaunch) {
+        I.tableStream = st;
         c.tileTable = tile_table(I, c.tilesX, c.tilesY, st);
         c.tilesPerXcd = xcd_grid_blocks(c.tilesX, c.tilesY) / 8;
     }
@@ -1341,6 +1387,10 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
     for (auto& t : inst->tileTables)
         if (t.second.dev)
             (void)hipFree(t.second.dev);
+    for (auto& d : inst->denoisers)
+        for (auto& f : d.tileFlags)
+            if (f.second)
+                (void)hipFree(f.second);
     release_graphs(*inst);
     delete inst;
 }

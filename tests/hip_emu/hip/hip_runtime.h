@@ -402,6 +402,10 @@ inline hipError_t hipMemset(void* p, int v, size_t n) {
     std::memset(p, v, n);
     return hipSuccess;
 }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    std::memset(p, v, n);
+    return hipSuccess;
+}
 inline hipError_t hipMemset2DAsync(void* p, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
     for (size_t y = 0; y < h; y++)
         std::memset((char*)p + y * pitch, v, w);
