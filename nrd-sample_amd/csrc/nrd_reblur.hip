@@ -389,25 +389,6 @@ __global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
     if (y < c.ownY0 || y >= c.ownY1)
         return;
     const int gy0 = y + c.yOff;
-    // The loads of ALL the run's pixels go out before the first result is stored: the output planes may alias the inputs as far as the
-    // compiler can tell, so with load - compute - store per pixel the four pixels of a thread were four dependent memory round trips
-    // (0.077 ms at 4K for 32 bytes per pixel: 3.4 TB/s); the positions are clamped, the loads unconditional
-    uint2 g0[NRD_CT_TILES], gl[NRD_CT_TILES], gr[NRD_CT_TILES], sOwn[NRD_CT_TILES], sL[NRD_CT_TILES], sR[NRD_CT_TILES];
-#pragma unroll
-    for (int k = 0; k < NRD_CT_TILES; k++) {
-        const int x = imin(((int)blockIdx.x * NRD_CT_TILES + k) * 16 + (int)threadIdx.x, c.W - 1);
-        const bool ownIsDiff = ((((uint32_t)x ^ (uint32_t)gy0) ^ c.frameIndex) & 1u) == (uint32_t)p.phaseDiff;
-        const PlaneRef& ownIn = ownIsDiff ? p.rawDiff : p.rawSpec;
-        const PlaneRef& otherIn = ownIsDiff ? p.rawSpec : p.rawDiff;
-        const int xl = imax(x - 1, 0), xr = imin(x + 1, c.W - 1);
-        g0[k] = ld_guide(p.guide, x, y);
-        gl[k] = ld_guide(p.guide, xl, y);
-        gr[k] = ld_guide(p.guide, xr, y);
-        sOwn[k] = ld<uint2>(ownIn, x >> 1, y, 8);
-        sL[k] = ld<uint2>(otherIn, xl >> 1, y, 8);
-        sR[k] = ld<uint2>(otherIn, xr >> 1, y, 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < NRD_CT_TILES; k++) {
         const int x = ((int)blockIdx.x * NRD_CT_TILES + k) * 16 + (int)threadIdx.x;
@@ -415,40 +396,73 @@ __global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
             continue;
         // the pixel carries the signal whose phase matches its colour; its neighbours carry the other one
         const bool ownIsDiff = ((((uint32_t)x ^ (uint32_t)gy0) ^ c.frameIndex) & 1u) == (uint32_t)p.phaseDiff;
-        const PlaneRef& ownOut = ownIsDiff ? p.inDiff : p.inSpec;
-        const PlaneRef& otherOut = ownIsDiff ? p.inSpec : p.inDiff;
-        const Guide g = decode_guide(g0[k], c.denoisingRange);
-        if (g.sky) {
-            st<uint2>(ownOut, x, y, 8, uint2{0u, 0u});
-            st<uint2>(otherOut, x, y, 8, uint2{0u, 0u});
-            continue;
+        const PlaneRef& ownIn = ownIsDiff ? p.rawDiff : p.rawSpec;
+        const PlaneRef& otherIn = ownIsDiff ? p.rawSpec : p.rawDiff;
+        const int xl = imax(x - 1, 0), xr = imin(x + 1, c.W - 1);
+        const uint2 g0 = ld_guide(p.guide, x, y), gl = ld_guide(p.guide, xl, y), gr = ld_guide(p.guide, xr, y);
+#ifndef NRD_CHECKER_UNIFORM_LOADS
+#define NRD_CHECKER_UNIFORM_LOADS 1
+#endif
+        uint2 sOwn, sL, sR;
+        if (NRD_CHECKER_UNIFORM_LOADS) {
+            // texel x >> 1 of BOTH input planes (one is the pixel's own signal, the other its right neighbour's for an even x - xr >> 1 == x >> 1 -
+            // or its left neighbour's for an odd one), each from ONE plane for the whole wave; only the third texel - the neighbour on the far
+            // side - comes from a plane picked per lane
+            const uint2 d0 = ld<uint2>(p.rawDiff, x >> 1, y, 8), s0 = ld<uint2>(p.rawSpec, x >> 1, y, 8);
+            const bool even = (x & 1) == 0;
+            const uint2 far = ld<uint2>(otherIn, (even ? xl : xr) >> 1, y, 8);
+            sOwn = ownIsDiff ? d0 : s0;
+            const uint2 near = ownIsDiff ? s0 : d0;
+            sL = even ? far : near;
+            sR = even ? near : far;
+        } else {
+            sOwn = ld<uint2>(ownIn, x >> 1, y, 8);
+            sL = ld<uint2>(otherIn, xl >> 1, y, 8);
+            sR = ld<uint2>(otherIn, xr >> 1, y, 8);
         }
-        const f4 v = unpack_h4(sOwn[k]);
-        // checkerboard resolve of the other signal (k_prepare_inputs, the same expressions)
-        const float invDz = rcp_(0.03f * fmax2(absf(g.z), 1e-6f));
-        float wn[2];
-        bool ok[2];
-        const f4 vn[2] = {unpack_h4(sL[k]), unpack_h4(sR[k])};
-        const uint2 gn2[2] = {gl[k], gr[k]};
+        const Guide g = decode_guide(g0, c.denoisingRange);
+        // The two results leave as ONE store per output plane, the value picked per lane (own / resolved signal): every store instruction
+        // then writes whole rows of one plane. Picking the PLANE per lane instead had each instruction write every other texel of two
+        // planes - half-filled lines twice (NRD_CHECKER_PLANE_STORES = 1: that form, kept for the A/B of profiles/r05_ab_prepare_checker.txt)
+        uint2 wOwn = {0u, 0u}, wOther = {0u, 0u};
+        if (!g.sky) {
+            const f4 v = unpack_h4(sOwn);
+            // checkerboard resolve of the other signal (k_prepare_inputs, the same expressions)
+            const float invDz = rcp_(0.03f * fmax2(absf(g.z), 1e-6f));
+            float wn[2];
+            bool ok[2];
+            const f4 vn[2] = {unpack_h4(sL), unpack_h4(sR)};
+            const uint2 gn2[2] = {gl, gr};
 #pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const int px = x + (n ? 1 : -1);
-            const Guide gn = decode_guide(gn2[n], c.denoisingRange);
-            ok[n] = px >= 0 && px < c.W && !gn.sky;
-            const float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
-            wn[n] = ok[n] ? w : 0.0f;
+            for (int n = 0; n < 2; n++) {
+                const int px = x + (n ? 1 : -1);
+                const Guide gn = decode_guide(gn2[n], c.denoisingRange);
+                ok[n] = px >= 0 && px < c.W && !gn.sky;
+                const float w = smoothstep01(1.0f - absf(gn.z - g.z) * invDz);
+                wn[n] = ok[n] ? w : 0.0f;
+            }
+            if (!(wn[0] + wn[1] > 0.0f)) { // depth edge on both sides: plain mean of whatever exists
+                wn[0] = ok[0] ? 1.0f : 0.0f;
+                wn[1] = ok[1] ? 1.0f : 0.0f;
+            }
+            const float wsum = wn[0] + wn[1];
+            f4 acc = wn[0] > 0.0f ? mul4(vn[0], wn[0]) : f4{0, 0, 0, 0};
+            acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
+            const float inv = rcp_(wsum);
+            const f4 vo = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
+            wOwn = pack_h4(v);
+            wOther = pack_h4(vo);
         }
-        if (!(wn[0] + wn[1] > 0.0f)) { // depth edge on both sides: plain mean of whatever exists
-            wn[0] = ok[0] ? 1.0f : 0.0f;
-            wn[1] = ok[1] ? 1.0f : 0.0f;
+#ifndef NRD_CHECKER_PLANE_STORES
+#define NRD_CHECKER_PLANE_STORES 0
+#endif
+        if (NRD_CHECKER_PLANE_STORES) {
+            st<uint2>(ownIsDiff ? p.inDiff : p.inSpec, x, y, 8, wOwn);
+            st<uint2>(ownIsDiff ? p.inSpec : p.inDiff, x, y, 8, wOther);
+        } else {
+            st<uint2>(p.inDiff, x, y, 8, uint2{ownIsDiff ? wOwn.x : wOther.x, ownIsDiff ? wOwn.y : wOther.y});
+            st<uint2>(p.inSpec, x, y, 8, uint2{ownIsDiff ? wOther.x : wOwn.x, ownIsDiff ? wOther.y : wOwn.y});
         }
-        const float wsum = wn[0] + wn[1];
-        f4 acc = wn[0] > 0.0f ? mul4(vn[0], wn[0]) : f4{0, 0, 0, 0};
-        acc = wn[1] > 0.0f ? fma4(vn[1], wn[1], acc) : acc;
-        const float inv = rcp_(wsum);
-        const f4 vo = wsum > 0.0f ? mul4(acc, inv) : f4{0, 0, 0, 0};
-        st<uint2>(ownOut, x, y, 8, pack_h4(v));
-        st<uint2>(otherOut, x, y, 8, pack_h4(vo));
     }
 }
 
