@@ -770,16 +770,40 @@ NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE
 #endif
 // the j-th tile of XCD k in this launch's direction: from the table when the launch has one. `tflag` = the tile's ClassifyTiles flag when
 // the launch carries the flags in table order (FrameConsts::tileFlags), -1 when it must be read from the Tiles plane
+// Values that must sit in scalar registers HERE: the kernel-argument loads behind them are issued together, in front of this point - one
+// round trip - instead of one by one where the compiler first needs each (it sinks them behind the branches: a wave of Blur made four
+// dependent trips to the argument segment before its first vector load). Later uses of the same arguments reuse the registers. The host
+// emulation defines the macros away.
+#ifndef NRD_PIN_SGPRS8
+#define NRD_PIN_SGPRS8(a, b, c, d, e, f, g, h) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d), "s"(e), "s"(f), "s"(g), "s"(h))
+#endif
+#ifndef NRD_PIN_PLANES // plane pointers + pitches a kernel's first vector loads need: pinned at kernel entry, they travel with the tile look-up's arguments
+#define NRD_PIN_PLANES3(A, B, C) asm volatile("" ::"s"((A).p), "s"((A).pitch), "s"((B).p), "s"((B).pitch), "s"((C).p), "s"((C).pitch))
+#define NRD_PIN_PLANES4(A, B, C, D) asm volatile("" ::"s"((A).p), "s"((A).pitch), "s"((B).p), "s"((B).pitch), "s"((C).p), "s"((C).pitch), "s"((D).p), "s"((D).pitch))
+#define NRD_PIN_PLANES 1
+#endif
+#ifndef NRD_PIN_ARGS // 0: the A/B switch of profiles/r05_ab_pinned_arguments.txt (arguments load where the compiler puts them)
+#define NRD_PIN_ARGS 1
+#endif
 NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty, int& tflag) {
     tflag = -1;
-    if (NRD_TILE_TABLE && c.tileTable) {
-        const int jd = c.reverse ? c.tilesPerXcd - 1 - j : j;
-        const uint32_t e = NRD_SCALAR_U32(c.tileTable + (jd * 8 + k));
-        if (NRD_TILE_FLAGS && c.tileFlags)
-            tflag = (int)NRD_TILE_TEXEL((uintptr_t)c.tileFlags + (uint32_t)(jd * 8 + k), 1);
-        tx = (int)(e & 0xffffu);
-        ty = (int)(e >> 16) + c.tileY0;
-        return e != 0xffffffffu;
+    if (NRD_TILE_TABLE) {
+        const uint32_t* const table = c.tileTable;
+        const uint8_t* const flags = c.tileFlags;
+        const int perXcd = c.tilesPerXcd, reverse = c.reverse, tileY0 = c.tileY0;
+        if (NRD_PIN_ARGS) { // (W and the owned rows: what the caller tests its pixel against right after)
+            const int W = c.W, ownY0 = c.ownY0, ownY1 = c.ownY1;
+            NRD_PIN_SGPRS8(table, flags, perXcd, reverse, tileY0, W, ownY0, ownY1);
+        }
+        if (table) {
+            const int jd = reverse ? perXcd - 1 - j : j;
+            const uint32_t e = NRD_SCALAR_U32(table + (jd * 8 + k));
+            if (NRD_TILE_FLAGS && flags)
+                tflag = (int)NRD_TILE_TEXEL((uintptr_t)flags + (uint32_t)(jd * 8 + k), 1);
+            tx = (int)(e & 0xffffu);
+            ty = (int)(e >> 16) + tileY0;
+            return e != 0xffffffffu;
+        }
     }
     return xcd_tile_kj(c, k, j, tx, ty);
 }

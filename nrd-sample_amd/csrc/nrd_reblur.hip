@@ -858,6 +858,13 @@ template <int VARIANT, int MODE, bool HAS_DIFF, bool HAS_SPEC>
 // 4 waves per SIMD (<= 128 VGPRs, a handful of spilled dwords) beat 3 waves with everything in registers; the SH flavours
 // carry 16 more registers of tap data and stay at 3
 __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(MODE >= 3 ? (VARIANT == 0 ? (MODE == 4 ? NRD_RELAX_SH_PRE_WAVES : NRD_SH_PRE_WAVES) : 3) : ((VARIANT != 0 && MODE == 0) ? (VARIANT == 2 ? NRD_POST_WAVES : NRD_TAP_WAVES) : (VARIANT == 0 ? NRD_PRE_WAVES : 4))) void k_spatial(const ReblurParams p) {
+    if (NRD_PIN_ARGS) { // the planes of the first vector loads (nrd_device.h NRD_PIN_SGPRS8)
+        if (VARIANT != 0 && MODE == 0) {
+            const PlaneRef* tapIn = VARIANT == 1 ? p.tapA : p.tapB;
+            NRD_PIN_PLANES3(tapIn[0], tapIn[HAS_DIFF && HAS_SPEC ? 1 : 0], p.data1);
+        } else
+            NRD_PIN_PLANES3(p.guide, HAS_DIFF ? p.inDiff : p.inSpec, p.inSpec);
+    }
     int x, y, tx, ty, tflag;
     if (!my_pixel(p.c, x, y, tx, ty, tflag)) // (one wave per workgroup measured 6-16 % SLOWER here: the four quarters of a tile land on
         return;                              // four CUs and stop sharing an L1 - profiles/r02_ab_tile_traversal.txt)
@@ -1273,6 +1280,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAV
 #endif
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_FUSED_WAVES) void k_prepass_temporal_accumulation(const ReblurParams p) {
+    if (NRD_PIN_ARGS)
+        NRD_PIN_PLANES3(p.guide, HAS_DIFF ? p.inDiff : p.inSpec, p.inSpec);
     int x, y, tx, ty, tflag;
     if (!my_pixel(p.c, x, y, tx, ty, tflag))
         return;
@@ -1326,6 +1335,8 @@ __global__ __launch_bounds__(256) void k_history_fix(const ReblurParams p) {
     __shared__ float tile[NSIG][400];    // fast luma history
     __shared__ float tileCur[NSIG][400]; // incoming luma (anti-firefly only)
     const FrameConsts& c = p.c;
+    if (NRD_PIN_ARGS)
+        NRD_PIN_PLANES4(p.guide, p.data1Tmp, p.tmp2, p.fast);
     int tx, ty, tflag;
     if (!xcd_tile(c, tx, ty, tflag))
         return;
@@ -1571,6 +1582,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(SH ? 1 : NRD_TS_WAVES) void k
     constexpr int SIG_SPEC = HAS_DIFF ? 1 : 0;
     __shared__ float tile[NSIG][400];
     const FrameConsts& c = p.c;
+    if (NRD_PIN_ARGS)
+        NRD_PIN_PLANES4(p.guide, p.hist, p.inMV, p.data2);
     int tx, ty, tflag;
     if (!xcd_tile(c, tx, ty, tflag))
         return;

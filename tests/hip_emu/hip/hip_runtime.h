@@ -43,6 +43,10 @@
 #define NRD_WAVES_PER_EU(n)
 // nrd_device.h: the scalar-path read of a per-tile texel (an aligned dword on the device) as the plain 1- / 2-byte read it stands for
 #define NRD_TILE_TEXEL(addr, bytes) ((bytes) == 1 ? (uint32_t)*(const uint8_t*)(addr) : (uint32_t)*(const uint16_t*)(addr))
+#define NRD_PIN_SGPRS8(a, b, c, d, e, f, g, h) ((void)0) // nrd_device.h: kernel-argument loads issued together
+#define NRD_PIN_PLANES3(A, B, C) ((void)0)
+#define NRD_PIN_PLANES4(A, B, C, D) ((void)0)
+#define NRD_PIN_PLANES 1
 #define NRD_SCALAR_U32(ptr) (*(const uint32_t*)(ptr)) // nrd_device.h: a dword through the scalar data path
 #define __shared__ static
 
