@@ -1569,11 +1569,11 @@ NRD_DEV bool blend_stab(const FootPos& fp, const uint32_t (&raw)[4], int half, u
     return fp.sane && wsum > 0.0f;
 }
 
-#ifndef NRD_TS_WAVES // waves per SIMD the register allocator aims for in TemporalStabilization of the flavours without SH (1: no bound). Unbounded the
+#ifndef NRD_TS_WAVES // waves per SIMD the register allocator aims for in TemporalStabilization (1: no bound). Unbounded the
 #define NRD_TS_WAVES 8 // kernel takes 49 VGPRs but 106 SGPRs = 7 waves; held to 8 waves' budget: 0.1128 -> 0.1084 ms at 4K (profiles/r05_ab_ts_waves_ct_tiles.txt)
 #endif
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH>
-__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(SH ? 1 : NRD_TS_WAVES) void k_temporal_stabilization(const ReblurParams p) {
+__global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_TS_WAVES) void k_temporal_stabilization(const ReblurParams p) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
