@@ -785,13 +785,14 @@ NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE
 #ifndef NRD_PIN_ARGS // 0: the A/B switch of profiles/r05_ab_pinned_arguments.txt (arguments load where the compiler puts them)
 #define NRD_PIN_ARGS 1
 #endif
-NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty, int& tflag) {
+// (`pin` false: a kernel at its register limit leaves the arguments where the compiler loads them)
+NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx, int& ty, int& tflag, const bool pin = true) {
     tflag = -1;
     if (NRD_TILE_TABLE) {
         const uint32_t* const table = c.tileTable;
         const uint8_t* const flags = c.tileFlags;
         const int perXcd = c.tilesPerXcd, reverse = c.reverse, tileY0 = c.tileY0;
-        if (NRD_PIN_ARGS) { // (W and the owned rows: what the caller tests its pixel against right after)
+        if (NRD_PIN_ARGS && pin) { // (W and the owned rows: what the caller tests its pixel against right after)
             const int W = c.W, ownY0 = c.ownY0, ownY1 = c.ownY1;
             NRD_PIN_SGPRS8(table, flags, perXcd, reverse, tileY0, W, ownY0, ownY1);
         }
@@ -811,9 +812,9 @@ NRD_DEV bool xcd_tile_of(const FrameConsts& c, const int k, const int j, int& tx
     int tflag;
     return xcd_tile_of(c, k, j, tx, ty, tflag);
 }
-NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty, int& tflag) { // one 16 x 16 workgroup per tile
+NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty, int& tflag, const bool pin = true) { // one 16 x 16 workgroup per tile
     const int b = (int)blockIdx.x;
-    return xcd_tile_of(c, b & 7, b >> 3, tx, ty, tflag);
+    return xcd_tile_of(c, b & 7, b >> 3, tx, ty, tflag, pin);
 }
 NRD_DEV bool xcd_tile(const FrameConsts& c, int& tx, int& ty) {
     int tflag;

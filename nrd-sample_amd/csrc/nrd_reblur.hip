@@ -158,8 +158,8 @@ NRD_DEV bool tile_is_sky(const PlaneRef& tiles, int tx, int ty, int tflag) { ret
 NRD_DEV bool tile_is_sky(const ReblurParams& p, int tx, int ty, int tflag) { return tile_is_sky(p.tiles, tx, ty, tflag); }
 
 // pixel of this thread inside its XCD-swizzled tile; false = nothing to do
-NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty, int& tflag) {
-    if (!xcd_tile(c, tx, ty, tflag))
+NRD_DEV bool my_pixel(const FrameConsts& c, int& x, int& y, int& tx, int& ty, int& tflag, const bool pin = true) {
+    if (!xcd_tile(c, tx, ty, tflag, pin))
         return false;
     x = tx * 16 + (int)threadIdx.x;
     y = ty * 16 + (int)threadIdx.y;
@@ -1280,10 +1280,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAV
 #endif
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_FUSED_WAVES) void k_prepass_temporal_accumulation(const ReblurParams p) {
-    if (NRD_PIN_ARGS)
-        NRD_PIN_PLANES3(p.guide, HAS_DIFF ? p.inDiff : p.inSpec, p.inSpec);
+    // (no arguments pinned at entry here: the kernel sits at its register limit - the orthographic flavour spilled 68 bytes with them, and
+    // the perspective one gained nothing: profiles/r05_ab_pinned_arguments.txt)
     int x, y, tx, ty, tflag;
-    if (!my_pixel(p.c, x, y, tx, ty, tflag))
+    if (!my_pixel(p.c, x, y, tx, ty, tflag, false))
         return;
     spatial_pixel<0, 0, HAS_DIFF, HAS_SPEC, true>(p, x, y, tx, ty, tflag);
 }
