@@ -6,6 +6,7 @@ for wl in reblur_d_1080p reblur_ds_sigma_1440p relax_ds_sh_4k relax_ds_4k reblur
   timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-frozen-leg --no-young-leg --no-graph-leg 2>/dev/null | tail -1 >> $out
 done
 timeout 300 python bench.py --workload reblur_ds_4k --checkerboard --no-cpu-baseline --no-frozen-leg --no-young-leg --no-graph-leg 2>/dev/null | tail -1 >> $out
+timeout 300 python bench.py --workload relax_ds_sh_4k --atrous 8 --no-cpu-baseline --no-frozen-leg --no-young-leg --no-graph-leg 2>/dev/null | tail -1 >> $out
 timeout 300 python bench.py --workload reblur_ds_4k --roll 90 --no-cpu-baseline --no-frozen-leg --no-young-leg --no-graph-leg 2>/dev/null | tail -1 >> $out
 python - $out <<'PY'
 import json, sys
