@@ -61,9 +61,12 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_PRE_WAVES // PrePass: waves per SIMD
 #define NRD_PRE_WAVES 4
 #endif
-#ifndef NRD_FUSED_DEPTH // taps in flight: the PrePass half of the fused PrePass + TemporalAccumulation kernel (115 VGPRs either way: the
-#define NRD_FUSED_DEPTH 5 // reprojection half sets the register count, 4 waves per SIMD; depth 2 / 3 / 4 / 5: 0.3504 / 0.3462 / 0.3515 / 0.3442 ms)
+#ifndef NRD_FUSED_SEQ_FOOTPRINTS // the fused kernel fetches its two history footprints one after the other (ta_pixel SEQ_FOOT)
+#define NRD_FUSED_SEQ_FOOTPRINTS 1
 #endif
+#ifndef NRD_FUSED_DEPTH // taps in flight: the PrePass half of the fused PrePass + TemporalAccumulation kernel. With both footprints in one round trip
+#define NRD_FUSED_DEPTH 2 // the reprojection half set the register count (115-119 VGPRs at any depth, 4 waves; depth 5 fastest); with sequential
+#endif                    // footprints depth 2 fits 93 VGPRs = 5 waves (depth 3: 20 bytes of scratch)
 #ifndef NRD_TAP_WAVES // 104 VGPRs at 4 waves; capped at 102 for a fifth wave: Blur 0.202 -> 0.198 ms, PostBlur 0.179 -> 0.1705
 #define NRD_TAP_WAVES 5  // (depth 6 / 8 at 5 waves: equal; depth 12 / 16 at 4 waves: slower - profiles/r03_ab_tap_texels.txt)
 #endif
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
 // the unrolled tap loop stays one basic block)
 // the per-pixel body of TemporalAccumulation (defined with its kernel below): `ctex` = the pixel's PrePass result as it would sit in
 // Tmp1 (packed fp16 words), `hitDist` = the tracked specular hit distance as it would sit in the hit tracker
-template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX, bool SEQ_FOOT = false>
 NRD_DEV void ta_pixel(const ReblurParams& p, int x, int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], float hitDist);
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
 NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y);
@@ -844,7 +847,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig])); // (fused frame: TemporalStabilization still reads it)
     }
     if constexpr (FUSED) { // on into TemporalAccumulation with what Tmp1 and the hit tracker would have held
-        ta_pixel<HAS_DIFF, HAS_SPEC, false, false>(p, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f);
+        ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(p, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f);
         return;
     }
     // the signals of the pixel share one texel of the output plane: one store
@@ -1100,7 +1103,7 @@ NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y) {
     st<uint32_t>(p.data2, x, y, 4, 0u);
 }
 
-template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
+template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX, bool SEQ_FOOT>
 NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], const float hitDist) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
@@ -1140,7 +1143,13 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         vv = vOk ? tv : -10.0f;
     }
     FootPos vpos = foot_pos(c, vu, vv);
-    if (HAS_SPEC)
+    // SEQ_FOOT (the fused PrePass + TemporalAccumulation kernel): the virtual-motion footprint is fetched AFTER everything that hangs on the
+    // surface-motion one has been reduced to a handful of values - a second round trip per wave, but 32 registers of raw footprint texels
+    // less: with 2 PrePass taps in flight the fused kernel fits 93 VGPRs = 5 waves per SIMD, 0.343 -> 0.326 ms (profiles/
+    // r05_ab_sequential_footprints.txt). The stand-alone TemporalAccumulation kernels (SH / RELAX flavours, separate passes) wait for memory,
+    // not for issue slots: there the second round trip costs 0-6 % and both footprints stay one trip (same file).
+    constexpr bool SEQ = SEQ_FOOT && HAS_SPEC;
+    if (HAS_SPEC && !SEQ)
         load_foot(p, vpos, vraw);
     Footprint smb = foot_weights(c, spos, sraw.g, NvPrev, r.XvPrev, g.n, g.mat, minMatAny, threshold);
     bool smbOk = historyOk && smb.wsum > 0.0f;
@@ -1189,6 +1198,19 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
             parallax = sqrt_(fma_(dx, dx, dy * dy));
         }
         float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
+        const float inY = signal_luma(in, RELAX);
+        f4 smbHist = smbOk ? blend4(smb, sraw.t, sw) : in;
+        float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : inY;
+        f4 smb1 = {0, 0, 0, 0};
+        if (SH)
+            smb1 = smbOk ? blend4(smb, sraw.t, sw + S1) : unpack_h4(ctex[sw + S1]);
+        float m2smb = 0.0f;
+        if (RELAX)
+            m2smb = smbOk ? blend1(smb, sraw.m, SIG_SPEC) : inY * inY;
+        if (SEQ) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_foot(p, vpos, vraw);
+        }
         Footprint vmb = foot_weights(c, vpos, vraw.g, NvPrev, r.XvPrev, g.n, g.mat, p.minMatSpec, threshold);
         uint32_t vmbBits = vmb.bits;
         bool vmbOk = vmb.wsum > 0.0f;
@@ -1206,10 +1228,7 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         blendA(vmb, vraw.a, dA, sA);
         float Avmb = vmbOk ? fmin2(sA + 1.0f, p.maxASpec) : 0.0f;
         f4 vmbHist = vmbOk ? blend4(vmb, vraw.t, sw) : in;
-        const float inY = signal_luma(in, RELAX);
         float vmbFast = vmbOk ? blend1(vmb, vraw.f, SIG_SPEC) : inY;
-        f4 smbHist = smbOk ? blend4(smb, sraw.t, sw) : in;
-        float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : inY;
         if (!smbOk)
             Asmb = 0.0f;
         float A = lerpf(Asmb, Avmb, amount);
@@ -1226,14 +1245,12 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         outw[sw] = pack_h4(lerp4(hist, in, nonLin));
         if (SH) {
             f4 in1 = unpack_h4(ctex[sw + S1]);
-            f4 smb1 = smbOk ? blend4(smb, sraw.t, sw + S1) : in1;
             f4 vmb1 = vmbOk ? blend4(vmb, vraw.t, sw + S1) : in1;
             outw[sw + S1] = pack_h4(lerp4(lerp4(smb1, vmb1, amount), in1, nonLin));
         }
         fastw |= (uint32_t)f2h(lerpf(fastHist, inY, rcp_(1.0f + fmin2(A, p.maxFastASpec)))) << (8 * lo);
         if (RELAX) {
             float m2 = inY * inY;
-            float m2smb = smbOk ? blend1(smb, sraw.m, SIG_SPEC) : m2;
             float m2vmb = vmbOk ? blend1(vmb, vraw.m, SIG_SPEC) : m2;
             m2w |= (uint32_t)f2h(lerpf(lerpf(m2smb, m2vmb, amount), m2, nonLin)) << (8 * lo);
         }
@@ -1276,7 +1293,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAV
 
 // PrePass + TemporalAccumulation of the REBLUR radiance flavours in ONE launch (spatial_pixel<..., FUSED>)
 #ifndef NRD_FUSED_WAVES
-#define NRD_FUSED_WAVES 4
+#define NRD_FUSED_WAVES 5
 #endif
 template <bool HAS_DIFF, bool HAS_SPEC>
 __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_FUSED_WAVES) void k_prepass_temporal_accumulation(const ReblurParams p) {
