@@ -1713,8 +1713,21 @@ NRDHIP_API int nrdhip_denoise(nrdhip_instance* inst, const uint32_t* ids, uint32
     { // the tile table of the frame's grid is made BEFORE the capture begins (an allocation + copy; nothing of the kind may run inside it)
         FrameConsts c;
         std::string err;
-        if (I.commonSet && derive_consts(I, c, err))
-            (void)tile_table(I, c.tilesX, c.tilesY, st);
+        if (I.commonSet && derive_consts(I, c, err)) {
+            I.tableStream = st;
+            c.tileTable = tile_table(I, c.tilesX, c.tilesY, st);
+            c.tilesPerXcd = xcd_grid_blocks(c.tilesX, c.tilesY) / 8;
+            // ... and the launch-order flag buffers of the REBLUR / RELAX denoisers of this list (attach_tile_flags allocates on first use)
+            for (uint32_t i = 0; i < n; i++) {
+                DenoiserState* d = find(I, ids[i]);
+                if (d && (d->kind == Kind::REBLUR || d->kind == Kind::RELAX)) {
+                    ReblurParams q;
+                    std::memset(&q, 0, sizeof(q));
+                    q.c = c;
+                    attach_tile_flags(I, *d, q);
+                }
+            }
+        }
     }
     struct CaptureFlag {
         bool& f;
