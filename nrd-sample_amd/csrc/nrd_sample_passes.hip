@@ -52,56 +52,81 @@ NRD_DEV float gauss_weight(int r2) {
     return r2 == 1 ? 0.60653066f : r2 == 2 ? 0.36787944f : r2 == 4 ? 0.13533528f : r2 == 5 ? 0.082084999f : 0.018315639f;
 }
 
+// One workgroup = one 16 x 16 tile. Every texel of the (16 + 4 STEP)^2 window around it is read by up to 24 pixels of the tile, and what a tap
+// needs from it - the gradient, the view position of the TAP (unclamped uv, the clamped texel's depth: SampleLevel( gNearestClamp ) :66) and
+// the decoded normal - does not depend on which pixel asks: it is decoded ONCE per window position into LDS (one array per component:
+// neighbouring lanes read neighbouring words), and a tap is 7 LDS reads + ~18 instructions instead of a gather + two conversions + an
+// octahedron decode with its normalisation + a view-position reconstruction (1625 -> ~700 VALU instructions per pixel; this pass is five
+// dependent launches over 1 / 25 of the frame's pixels, so what it costs is the instructions of a wave, profiles/r05_ab_confidence_blur.txt).
+// The values are the per-tap code's, expression by expression.
+template <int STEP>
 __global__ __launch_bounds__(256) void k_confidence_blur(const ConfidenceParams p) {
-    int x = (int)(blockIdx.x * 16 + threadIdx.x), y = (int)(blockIdx.y * 16 + threadIdx.y);
+    constexpr int T = 16 + 4 * STEP, N = T * T;
+    __shared__ float sG[N], sXx[N], sXy[N], sXz[N], sNx[N], sNy[N], sNz[N];
+    const int tid = (int)threadIdx.y * 16 + (int)threadIdx.x;
+    const int x0 = (int)blockIdx.x * 16 - 2 * STEP, y0 = (int)blockIdx.y * 16 - 2 * STEP;
+    constexpr int TRIPS = (N + 255) / 256;
+    uint2 raw[TRIPS];
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) { // all loads of the thread first
+        const int i = imin(tid + 256 * k, N - 1);
+        const int ly = i / T, lx = i - ly * T;
+        const int px = imin(imax(x0 + lx, 0), p.W - 1), py = imin(imax(y0 + ly, 0), p.H - 1);
+        raw[k] = ld<uint2>(p.in, px, py, 8);
+    }
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+        const int i = tid + 256 * k;
+        if (i < N) {
+            const int ly = i / T, lx = i - ly * T;
+            const f4 d = unpack_h4(raw[k]);
+            const float u = ((float)(x0 + lx) + 0.5f) * p.invW, v = ((float)(y0 + ly) + 0.5f) * p.invH;
+            const float z = d.w / FP16_VIEWZ_SCALE;
+            const f3 Xv = reconstruct_view(p.frustum, u, v, z, p.ortho);
+            const f3 Nv = oct_decode(d.y, d.z);
+            sG[i] = d.x;
+            sXx[i] = Xv.x;
+            sXy[i] = Xv.y;
+            sXz[i] = Xv.z;
+            sNx[i] = Nv.x;
+            sNy[i] = Nv.y;
+            sNz[i] = Nv.z;
+        }
+    }
+    __syncthreads();
+    const int x = (int)(blockIdx.x * 16 + threadIdx.x), y = (int)(blockIdx.y * 16 + threadIdx.y);
     if (x >= p.W || y >= p.H)
         return;
-    uint2 raw0 = ld<uint2>(p.in, x, y, 8);
-    f4 d0 = unpack_h4(raw0);
-    float z0 = d0.w / FP16_VIEWZ_SCALE;
-    bool last = p.step == 5;
+    const uint2 raw0 = ld<uint2>(p.in, x, y, 8); // (the texel itself: its words travel on to the output)
+    const int ci = ((int)threadIdx.y + 2 * STEP) * T + (int)threadIdx.x + 2 * STEP;
+    const f3 Xv0 = {sXx[ci], sXy[ci], sXz[ci]};
+    const float z0 = Xv0.z;
+    const bool last = STEP == 5;
     if (absf(z0) > SAMPLE_INF) { // :42-46
         st<uint2>(p.out, x, y, 8, uint2{(raw0.x & 0xffff0000u) | (uint32_t)f2h(last ? 1.0f : 0.0f), raw0.y});
         return;
     }
-    float u0 = ((float)x + 0.5f) * p.invW, v0 = ((float)y + 0.5f) * p.invH;
-    f3 Xv0 = reconstruct_view(p.frustum, u0, v0, z0, p.ortho);
-    f3 Nv0 = oct_decode(d0.y, d0.z);
+    const f3 Nv0 = {sNx[ci], sNy[ci], sNz[ci]};
     // GetGeometryWeightParams (:18-28)
     float frustumSize = p.rectW * p.unproject * lerpf(absf(Xv0.z), 1.0f, absf(p.ortho));
     float ga = 1.0f / (0.02f * frustumSize);
     float gb = -(dot3(Nv0, Xv0) * ga);
-    float gradient = d0.x, sum = 1.0f;
-    // all 24 gathers first (nearest, clamp-to-edge: SampleLevel( gNearestClamp ) :66), arithmetic after
-    uint2 raw[24];
-    int k = 0;
+    float gradient = sG[ci], sum = 1.0f;
 #pragma unroll
     for (int i = -2; i <= 2; i++)
 #pragma unroll
         for (int j = -2; j <= 2; j++) {
             if (i == 0 && j == 0)
                 continue;
-            int px = imin(imax(x + i * p.step, 0), p.W - 1), py = imin(imax(y + j * p.step, 0), p.H - 1);
-            raw[k++] = ld<uint2>(p.in, px, py, 8);
-        }
-    k = 0;
-#pragma unroll
-    for (int i = -2; i <= 2; i++)
-#pragma unroll
-        for (int j = -2; j <= 2; j++) {
-            if (i == 0 && j == 0)
-                continue;
-            f4 d = unpack_h4(raw[k++]);
-            float u = ((float)(x + i * p.step) + 0.5f) * p.invW, v = ((float)(y + j * p.step) + 0.5f) * p.invH;
+            const int q = ci + (j * T + i) * STEP;
             float w = gauss_weight(i * i + j * j);
-            float z = d.w / FP16_VIEWZ_SCALE;
-            f3 Xv = reconstruct_view(p.frustum, u, v, z, p.ortho);
+            const f3 Xv = {sXx[q], sXy[q], sXz[q]};
             float NoX = dot3(Nv0, Xv);
             w *= smoothstep01(1.0f - absf(fma_(NoX, ga, gb))); // Math::SmoothStep( 1, 0, |x| ) == smoothstep( saturate( 1 - |x| ) )
-            f3 Nv = oct_decode(d.y, d.z);
+            const f3 Nv = {sNx[q], sNy[q], sNz[q]};
             float NoN = sat(dot3(Nv0, Nv));
             w *= NoN * NoN;
-            gradient = fma_(d.x, w, gradient);
+            gradient = fma_(sG[q], w, gradient);
             sum += w;
         }
     gradient /= sum;
@@ -390,7 +415,13 @@ NRDHIP_API int nrdhip_confidence_blur(const nrdhip_confidence_blur_desc* d, void
         p.in = plane(even ? d->ping : d->pong, d->pitch_bytes, d->width, d->height);
         p.out = plane(even ? d->pong : d->ping, d->pitch_bytes, d->width, d->height);
         p.step = (int)(1u + i);
-        hipLaunchKernelGGL(k_confidence_blur, grid, dim3(16, 16, 1), 0, s, p);
+        switch (p.step) {
+        case 1: hipLaunchKernelGGL(k_confidence_blur<1>, grid, dim3(16, 16, 1), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(k_confidence_blur<2>, grid, dim3(16, 16, 1), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(k_confidence_blur<3>, grid, dim3(16, 16, 1), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(k_confidence_blur<4>, grid, dim3(16, 16, 1), 0, s, p); break;
+        default: hipLaunchKernelGGL(k_confidence_blur<5>, grid, dim3(16, 16, 1), 0, s, p); break;
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
