@@ -9,6 +9,8 @@
 // Both are streaming, one pixel per lane, HBM-bound; no LDS, no MFMA.
 #include "nrd_device.h"
 
+#include <cstring>
+
 #include "../../include/nrd_frontend.h"
 #include "../../include/nrdhip.h"
 
@@ -99,6 +101,10 @@ struct ComposeParams {
     uint32_t hairMat;
     PlaneRef diff, spec, dSh0, dSh1, sSh0, sSh1, nr, viewz, bcm, outDiff, outSpec;
     float v2w[9], frustum[4], invW, invH;
+    // base colour / metalness arrive as 8-bit codes: the 256 values NRD_SrgbToLinear( code / 255 ) and code / 255 can take, computed once on the
+    // host with the very functions the kernel used to call per pixel (three divisions + three pow through log2 / exp2 polynomials: ~165 of
+    // the pass's instructions) and read here from the argument segment
+    float srgbLut[256], unorm8Lut[256];
 };
 
 NRD_DEV float4_ ld_h4(const PlaneRef& P, int x, int y) {
@@ -144,9 +150,9 @@ __global__ __launch_bounds__(256) void k_compose(const ComposeParams p) {
     float3_ diffFactor = {1.0f, 1.0f, 1.0f}, specFactor = {1.0f, 1.0f, 1.0f};
     if (p.bcm.p && (uint32_t)materialID != p.hairMat) {
         uint32_t b = ld<uint32_t>(p.bcm, x, y, 4);
-        float3_ baseColor = {NRD_SrgbToLinear((float)(b & 255u) / 255.0f), NRD_SrgbToLinear((float)((b >> 8) & 255u) / 255.0f), NRD_SrgbToLinear((float)((b >> 16) & 255u) / 255.0f)};
+        float3_ baseColor = {p.srgbLut[b & 255u], p.srgbLut[(b >> 8) & 255u], p.srgbLut[(b >> 16) & 255u]};
         float3_ albedo, Rf0;
-        NRD_ConvertBaseColorMetalnessToAlbedoRf0(baseColor, (float)(b >> 24) / 255.0f, albedo, Rf0);
+        NRD_ConvertBaseColorMetalnessToAlbedoRf0(baseColor, p.unorm8Lut[b >> 24], albedo, Rf0);
         NRD_MaterialFactors(N, V, albedo, Rf0, roughness, diffFactor, specFactor);
     }
     if (p.outDiff.p)
@@ -228,6 +234,17 @@ NRDHIP_API int nrdhip_compose(const nrdhip_compose_desc* d, void* hip_stream) {
         p.frustum[i] = d->camera_frustum[i];
     p.invW = d->inv_rect_size[0];
     p.invH = d->inv_rect_size[1];
+    static const struct Luts {
+        float srgb[256], unorm8[256];
+        Luts() {
+            for (int i = 0; i < 256; i++) {
+                unorm8[i] = (float)i / 255.0f;
+                srgb[i] = NRD_SrgbToLinear((float)i / 255.0f);
+            }
+        }
+    } luts;
+    std::memcpy(p.srgbLut, luts.srgb, sizeof(p.srgbLut));
+    std::memcpy(p.unorm8Lut, luts.unorm8, sizeof(p.unorm8Lut));
     dim3 grid((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), 1);
     hipLaunchKernelGGL(k_compose, grid, dim3(64, 4, 1), 0, (hipStream_t)hip_stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
