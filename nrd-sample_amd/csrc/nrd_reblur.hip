@@ -523,8 +523,17 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
     uint4 ctap[NSIG];
     if (TAP) {
 #pragma unroll
-        for (int sig = 0; sig < NSIG; sig++)
-            ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
+        for (int sig = 0; sig < NSIG; sig++) {
+            // one 16-byte buffer load per texel (NRD_CENTRE_B128): left to the compiler the load is split - the guide half in front of the per-pixel
+            // sky test, the signal half behind it with 64-bit address arithmetic - and the set-up waits for a second round trip
+#ifndef NRD_CENTRE_B128
+#define NRD_CENTRE_B128 1
+#endif
+            if (NRD_CENTRE_B128)
+                ctap[sig] = ldb<uint4>(plane_buf(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], 0), x, y, 16);
+            else
+                ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
+        }
     }
     Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
