@@ -59,6 +59,11 @@ struct FrameConsts {
     float w2v[9], w2vPrev[9], v2w[9], v2wPrev[9];
     float camDelta[3];
     float unproject, minRectDimMulUnproject;
+    // pixel offset of a view-space tangent vector T scaled to one pixel of blur radius at the pixel's depth (kernel_basis_px below):
+    // d(px) = +-jcx (T.x - rx T.z), d(py) = +-jcy (T.y - ry T.z) with (rx, ry, 1) the pixel's view ray; jcx = 0.5 W pj0 unproject / pj4,
+    // jcy = -0.5 H pj1 unproject / pj4 (orthographic: no T.z term). The depth cancels: a world radius of `radius` pixels at depth z is
+    // radius * unproject * |z|, and the perspective divide takes the |z| back
+    float jcx, jcy;
     float denoisingRange, disocclusionThreshold, splitScreen;
     float disoccAlt; // CommonSettings::disocclusionThresholdAlternate, blended in per pixel by IN_DISOCCLUSION_THRESHOLD_MIX when ...
     int mixAvail;    // ... CommonSettings::isDisocclusionThresholdMixAvailable
@@ -121,7 +126,9 @@ NRD_DEV f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 NRD_DEV f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 NRD_DEV f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 NRD_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
-NRD_DEV f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+NRD_DEV f3 cross3(f3 a, f3 b) { return {fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))}; }
+NRD_DEV f3 fma3(f3 a, float s, f3 c) { return {fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z)}; }
+NRD_DEV f3 neg3(f3 a) { return {-a.x, -a.y, -a.z}; }
 NRD_DEV f3 rot3(const float* m, f3 v) {
     return {fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[5], v.z, fma_(m[4], v.y, m[3] * v.x)), fma_(m[8], v.z, fma_(m[7], v.y, m[6] * v.x))};
 }
@@ -508,9 +515,10 @@ NRD_HD uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t salt) {
 NRD_DEV void basis3(f3 n, f3& t, f3& b) {
     float sz = n.z >= 0.0f ? 1.0f : -1.0f;
     float a = -rcps_(sz + n.z);
-    float bb = n.x * n.y * a;
-    t = {1.0f + sz * n.x * n.x * a, sz * bb, -sz * n.x};
-    b = {bb, sz + n.y * n.y * a, -n.y};
+    float nxa = n.x * a, sx = sz * n.x;
+    float bb = nxa * n.y;
+    t = {fma_(sx, nxa, 1.0f), sz * bb, -sx};
+    b = {bb, fma_(n.y * a, n.y, sz), -n.y};
 }
 
 // perspective: the view-space xy of a pixel scale with z; orthographic: they do not
@@ -549,12 +557,15 @@ NRD_DEV uint32_t material_class(uint32_t m, uint32_t floor_) { return m > floor_
 // (orthographic: |zs * geoB + (ga0 + gax px + gay gy)| - geoB holds the z coefficient, ga0 absorbs the plane offset)
 struct PixelGeo {
     f3 Xv, Nv;
+    float rx, ry; // perspective: the pixel's view ray (rx, ry, 1); orthographic: its view-space xy
     float absZ, frustumSize;
     float ga0, gax, gay, geoB;
 };
 NRD_DEV PixelGeo pixel_geo(const FrameConsts& c, const Guide& g, int x, int gy, float planeDistSensitivity) {
     PixelGeo p;
-    p.Xv = reconstruct_px(c.pv, (float)x, (float)gy, g.z);
+    p.rx = fma_(c.pv[2], (float)x, c.pv[0]);
+    p.ry = fma_(c.pv[3], (float)gy, c.pv[1]);
+    p.Xv = {zpersp(g.z) * p.rx, zpersp(g.z) * p.ry, g.z}; // == reconstruct_px(c.pv, x, gy, g.z)
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
     p.frustumSize = c.minRectDimMulUnproject * zpersp(p.absZ);
@@ -577,6 +588,27 @@ NRD_DEV float strand_normal_relax(const FrameConsts& c, uint32_t mat, float absZ
     if (mat != c.strandMat)
         return 1.0f;
     return lerpf(0.25f, 1.0f, sat(c.strandThickness * wrcp_(c.unproject * zpersp(absZ))));
+}
+// Pixel offsets of a view-space tangent pair (T, B) of the blur kernel PER PIXEL OF BLUR RADIUS - the pixel-space Jacobian of the
+// projection at the pixel, applied to the kernel basis scaled to the world size of one pixel at the pixel's depth (unproject |z|).
+// Round 6: the perspective divide cancels that depth - with (rx, ry, 1) the view ray, d(px) / d(X.x) |z| unproject = sign(z) jcx and
+// the z column is -rx times the x column - so the Jacobian is two frame constants, the ray and a sign: 10 instructions and no
+// reciprocal where rounds 2-5 spent ~36 (rcp of clip w, the NDC position, four mul / fma / mul chains per signal). The taps of a pass
+// are then J * radius * disk. j = {T -> px, T -> py, B -> px, B -> py}
+NRD_DEV float signed_by(float k, float z) { return u2f(f2u(k) ^ (f2u(z) & 0x80000000u)); } // k * sign(z), exact
+NRD_DEV void kernel_basis_px(const FrameConsts& c, float z, float rx, float ry, f3 T, f3 B, float (&j)[4]) {
+    if (ORTHO) {
+        j[0] = c.jcx * T.x;
+        j[1] = c.jcy * T.y;
+        j[2] = c.jcx * B.x;
+        j[3] = c.jcy * B.y;
+        return;
+    }
+    const float sx = signed_by(c.jcx, z), sy = signed_by(c.jcy, z);
+    j[0] = sx * fma_(-rx, T.z, T.x);
+    j[1] = sy * fma_(-ry, T.z, T.y);
+    j[2] = sx * fma_(-rx, B.z, B.x);
+    j[3] = sy * fma_(-ry, B.z, B.y);
 }
 // plane-distance term of a tap from its precomputed linear part ga = ga0 + gax px + gay gy
 NRD_DEV float geo_plane(const PixelGeo& p, float ga, float zs) { return ORTHO ? fma_(zs, p.geoB, ga) : fma_(zs, ga, p.geoB); }
@@ -761,6 +793,21 @@ NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE
 // One dword through the scalar data path (uniform address, read-only for the launch): constant address space = s_load_dword
 #ifndef NRD_SCALAR_U32 // (the host emulation of the tests reads the plain word)
 #define NRD_SCALAR_U32(ptr) (*(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(ptr))
+#endif
+// true when the predicate holds on every active lane of the wave (a scalar: the branch on it is wave-uniform). The host emulation of the
+// tests takes the lane's own predicate - which runs BOTH sides of such a branch through the bit-exactness tests, lane by lane.
+#ifndef NRD_WAVE_ALL
+#define NRD_WAVE_ALL(pred) (__builtin_amdgcn_ballot_w64(!(pred)) == 0ull)
+#endif
+// The kernel arguments once more, as values the compiler cannot tie to the copies it already holds: a second-half-of-the-kernel reads its
+// constants with fresh s_loads where it needs them instead of keeping the first half's wide loads alive in between (the fused PrePass +
+// TemporalAccumulation kernel held 32 SGPRs of camera matrices across its tap loop for the reprojection behind it and ran out of scalar
+// registers). The host emulation of the tests defines it as the identity.
+#ifndef NRD_RELOAD_ARGS
+#define NRD_RELOAD_ARGS(T, p, q)                                                                 \
+    const __attribute__((address_space(4))) T* q##_ptr = (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr(); /* `p` is the kernel's only argument */ \
+    asm volatile("" : "+s"(q##_ptr));                                                            \
+    const T& q = *(const T*)q##_ptr /* (the address-space inference pass turns loads through it back into constant-address loads) */
 #endif
 #ifndef NRD_TILE_TABLE // 0: every wave computes its tile (xcd_tile_kj) - the A/B switch of profiles/r05_ab_tile_table.txt
 #define NRD_TILE_TABLE 1

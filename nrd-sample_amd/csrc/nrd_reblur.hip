@@ -476,10 +476,59 @@ __global__ __launch_bounds__(256) void k_prepare_checker(const ReblurParams p) {
 // the unrolled tap loop stays one basic block)
 // the per-pixel body of TemporalAccumulation (defined with its kernel below): `ctex` = the pixel's PrePass result as it would sit in
 // Tmp1 (packed fp16 words), `hitDist` = the tracked specular hit distance as it would sit in the hit tracker
+// (`geo`: the pixel's view-space position, normal and view vector when the caller has them already - the fused kernel's PrePass half)
+struct TaGeo {
+    f3 Xv, Nv, V;
+    float roughA; // 1 / roughness tolerance of the specular signal (KernelUnit::roughA; the default flavour's rcp_ sequence), < 0: not available
+};
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX, bool SEQ_FOOT = false>
-NRD_DEV void ta_pixel(const ReblurParams& p, int x, int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], float hitDist);
+NRD_DEV void ta_pixel(const ReblurParams& p, int x, int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], float hitDist, const TaGeo* geo = nullptr);
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
 NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y);
+
+// ---- kernel set-up of a signal: the part that hangs on the pixel's geometry and roughness only, not on the pass -------------------------
+// Round 6 ("63 % of Blur is per-pixel set-up + tap positions, computed three times per pixel per frame"): the kernel
+// basis in pixels per pixel of radius (nrd_device.h kernel_basis_px) and the four roughness-only terms of the specular signal are
+// computed ONCE per frame, by the PrePass, which hands them to Blur and PostBlur through two planes as fp16 (KernelBasis 8 bytes per
+// signal, KernelTerms 8 bytes): ~330 of Blur's 534 set-up instructions become one 16-byte and one 8-byte load. RELAX's only spatial
+// pass is the PrePass: it computes the same terms and stores nothing. Explicit-fma audit of the basis on the way (cross products,
+// mirror directions: mul + fma instead of mul + mul + sub), and the dominant direction without the mirror vector R in between.
+struct KernelUnit {
+    float j[4];                           // pixel offsets of the kernel's tangent / bitangent per pixel of blur radius (kernel_basis_px)
+    float smc, angle0, roughA, hitFactor; // GetSpecMagicCurve(roughness), lobe half angle, 1 / roughness tolerance, hit distance factor
+};
+template <bool IS_SPEC>
+NRD_DEV KernelUnit kernel_unit(const ReblurParams& p, const PixelGeo& pg, const float z, const f3 V, const float rough) {
+    KernelUnit k;
+    f3 T, B;
+    basis3(pg.Nv, T, B);
+    if (IS_SPEC) {
+        const float NoV = dot3(pg.Nv, V);
+        const float df = spec_dominant_factor(rough);
+        // dominant direction D = normalize(N + (R - N) df), R = 2 NoV N - V the mirror direction: N (1 + (2 NoV - 1) df) - V df
+        const float alpha = fma_(fma_(NoV, 2.0f, -1.0f), df, 1.0f);
+        const f3 D = normalize3({fma_(pg.Nv.x, alpha, -(V.x * df)), fma_(pg.Nv.y, alpha, -(V.y * df)), fma_(pg.Nv.z, alpha, -(V.z * df))});
+        const float NoD = dot3(pg.Nv, D);
+        if (NoD < 0.999f && rough < 0.95f) {
+            const float n2 = 2.0f * NoD;
+            const f3 Dr = {fma_(pg.Nv.x, n2, -D.x), fma_(pg.Nv.y, n2, -D.y), fma_(pg.Nv.z, n2, -D.z)}; // D mirrored at N
+            T = normalize3(cross3(D, pg.Nv)); // == cross(N, Dr): the N x N term vanishes
+            B = cross3(Dr, T);
+            T = mul3(T, lerpf(fma_(rough, 0.5f, 0.5f), 1.0f, NoD)); // skew toward the view direction at grazing angles
+        }
+        k.smc = spec_magic_curve(rough);
+        k.angle0 = spec_lobe_half_angle(rough);
+        k.roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction))); // (weight-class: the hwt flavour's v_rcp_f32)
+        k.hitFactor = reblur_hitdist_factor(p.hp, rough);
+    } else {
+        k.smc = 1.0f;
+        k.angle0 = spec_lobe_half_angle(1.0f);
+        k.roughA = 0.0f;
+        k.hitFactor = p.hitFactorDiff;
+    }
+    kernel_basis_px(p.c, z, pg.rx, pg.ry, T, B, k.j);
+    return k;
+}
 
 // FUSED (PrePass of the REBLUR radiance flavours only): the pixel goes straight on into TemporalAccumulation - that pass reads the
 // PrePass result at its OWN pixel only (Tmp1, hit tracker), so the result stays in registers: no Tmp1 store + load (32 B/px at two
@@ -535,6 +584,18 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
         }
     }
+    // REBLUR Blur / PostBlur: the kernel set-up the PrePass left for this pixel (KernelUnit), in flight with the centre texels
+    constexpr bool RELAX_MODE = MODE == 1 || MODE == 4;
+#ifndef NRD_KSETUP_PLANES // 0 (timing only, A/B of profiles/r06_ab_kernel_setup_planes.txt): every pass computes its kernel set-up, nothing is stored
+#define NRD_KSETUP_PLANES 1
+#endif
+    constexpr bool KSETUP_READ = NRD_KSETUP_PLANES && VARIANT != 0, KSETUP_WRITE = NRD_KSETUP_PLANES && VARIANT == 0 && !RELAX_MODE;
+    uint2 kbw[NSIG], ktw = {0u, 0u};
+    if (KSETUP_READ) {
+        load_texel<8 * NSIG>(p.kBasis, x, y, kbw);
+        if (HAS_SPEC)
+            ktw = ld<uint2>(p.kTerms, x, y, 8);
+    }
     Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
@@ -557,18 +618,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
     const NormalCodes ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
-    f3 V = to_viewer(pg.Xv);
-    // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic: no
-    // perspective divide and no z terms
-    float inv = 1.0f, kuz = 0.0f, kvz = 0.0f;
-    if (!ORTHO) {
-        inv = rcps_(c.pj[4] * g.z);
-        float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
-        float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
-        kuz = c.pj[2] - nu * c.pj[4];
-        kvz = c.pj[3] - nv * c.pj[4];
-    }
-    float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
+    f3 V = to_viewer(pg.Xv); // (only the PrePass needs it: Blur / PostBlur read the kernel basis)
     // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
     // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
     constexpr bool PER_PIXEL = VARIANT == 1;
@@ -593,6 +643,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
     float wsum[NSIG], minHit[NSIG], hitNormS[NSIG];
     float jtx[NSIG], jty[NSIG], jbx[NSIG], jby[NSIG], m2w2[NSIG], hitA[NSIG], hitB[NSIG], roughA[NSIG], roughB[NSIG];
     bool active[NSIG];
+    float kuRoughA = 0.0f; // (the specular signal's KernelUnit::roughA as computed: the fused kernel's TemporalAccumulation half uses it again)
     constexpr int srcBpt = VARIANT == 0 ? 8 : RBPT;
 #pragma unroll
     for (int sig = 0; sig < NSIG; sig++) {
@@ -608,12 +659,30 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
         src1Ps[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec1 : &p.inDiff1) : &inP;
         sum1[sig] = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
-        float hitNorm = isSpec ? reblur_hitdist_norm(pg.absZ, p.hp, rough) : fma_(pg.absZ, p.hp[1], p.hp[0]) * p.hitFactorDiff;
+        // the pass-independent part of the set-up: computed here (PrePass), or as the PrePass stored it (taps are placed on the tangent
+        // plane linearised at the centre: KernelUnit::j)
+        KernelUnit ku;
+        if (KSETUP_READ) {
+            const f4 jb = unpack_h4(kbw[sig]), kt = unpack_h4(ktw);
+            ku.j[0] = jb.x, ku.j[1] = jb.y, ku.j[2] = jb.z, ku.j[3] = jb.w;
+            ku.smc = isSpec ? kt.x : 1.0f;
+            ku.angle0 = isSpec ? kt.y : spec_lobe_half_angle(1.0f);
+            ku.roughA = isSpec ? kt.z : 0.0f;
+            ku.hitFactor = isSpec ? kt.w : p.hitFactorDiff;
+        } else {
+            ku = isSpec ? kernel_unit<true>(p, pg, g.z, V, rough) : kernel_unit<false>(p, pg, g.z, V, rough);
+            if (KSETUP_WRITE) { // (stored at once: nothing of it stays live across the tap loop)
+                kbw[sig] = pack_h4({ku.j[0], ku.j[1], ku.j[2], ku.j[3]});
+                if (isSpec)
+                    ktw = pack_h4({ku.smc, ku.angle0, ku.roughA, ku.hitFactor});
+            }
+        }
+        float hitNorm = fma_(pg.absZ, p.hp[1], p.hp[0]) * ku.hitFactor;
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
         float A = isSpec ? specA : diffA;
         float nonLin = VARIANT == 0 ? 1.0f : rcp_(1.0f + A);
-        float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
+        float smc = ku.smc;
         float radius;
         if (VARIANT == 0) {
             radius = (isSpec ? p.specularPrepassBlurRadius : p.diffusePrepassBlurRadius) * hitDistFactor * smc;
@@ -625,30 +694,11 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         }
         sum[sig] = center;
         wsum[sig] = 1.0f;
-        minHit[sig] = hitDist;
+        minHit[sig] = center.w; // (PrePass: hit distance tracking, in units of the signal's w channel until the end)
         hitNormS[sig] = hitNorm;
         active[sig] = radius > 0.0f;
-        float worldRadius = radius * c.unproject * zpersp(pg.absZ);
-        f3 T, B;
-        basis3(pg.Nv, T, B);
-        if (isSpec) {
-            float NoV = dot3(pg.Nv, V);
-            f3 R = sub3(mul3(pg.Nv, 2.0f * NoV), V);
-            float df = spec_dominant_factor(rough);
-            f3 D = normalize3(add3(pg.Nv, mul3(sub3(R, pg.Nv), df)));
-            float NoD = dot3(pg.Nv, D);
-            if (NoD < 0.999f && rough < 0.95f) {
-                f3 Dr = sub3(mul3(pg.Nv, 2.0f * NoD), D);
-                T = normalize3(cross3(pg.Nv, Dr));
-                B = cross3(Dr, T);
-                float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
-                T = mul3(T, skew);
-            }
-        }
-        T = mul3(T, worldRadius);
-        B = mul3(B, worldRadius);
-        jtx[sig] = ju * fma_(c.pj[0], T.x, kuz * T.z), jty[sig] = jv * fma_(c.pj[1], T.y, kvz * T.z);
-        jbx[sig] = ju * fma_(c.pj[0], B.x, kuz * B.z), jby[sig] = jv * fma_(c.pj[1], B.y, kvz * B.z);
+        jtx[sig] = ku.j[0] * radius, jty[sig] = ku.j[1] * radius;
+        jbx[sig] = ku.j[2] * radius, jby[sig] = ku.j[3] * radius;
         if (PER_PIXEL) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk, 4 fma per tap
             const float a = fma_(rc, jtx[sig], rs * jbx[sig]), b = fma_(rc, jbx[sig], -(rs * jtx[sig]));
             const float cc = fma_(rc, jty[sig], rs * jby[sig]), d = fma_(rc, jby[sig], -(rs * jty[sig]));
@@ -657,7 +707,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             jty[sig] = cc;
             jby[sig] = d;
         }
-        float angle = spec_lobe_half_angle(rough) * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
+        float angle = ku.angle0 * lerpf(p.lobeAngleFraction, 1.0f, nonLin);
         // (weight-class reciprocals from here on - wrcp_: the hwt flavour's v_rcp_f32; everything above feeds the tap coordinates and stays exact)
         float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN));
         normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
@@ -665,10 +715,18 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         float hitScale = relaxIn ? wrcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
         hitA[sig] = hitScale * wrcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
         hitB[sig] = -center.w * hitA[sig];
-        roughA[sig] = wrcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction)));
+        roughA[sig] = ku.roughA;
+        if (isSpec)
+            kuRoughA = ku.roughA;
         roughB[sig] = -rough * roughA[sig];
         if (TAP)
             roughA[sig] = roughA[sig] * (1.0f / 1023.0f); // applies to the tap's roughness CODE
+    }
+
+    if (KSETUP_WRITE) { // for this frame's Blur / PostBlur
+        store_texel<8 * NSIG>(p.kBasis, x, y, kbw);
+        if (HAS_SPEC)
+            st<uint2>(p.kTerms, x, y, 8, ktw);
     }
 
     // ---- tap loop: ONE software pipeline over the 8 taps of every signal ----------------------------------------------------
@@ -719,12 +777,18 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
             }
         };
-        auto gather = [&](const int T, const float fpx, const float fpy) {
+        auto gather = [&](auto fastTag, const int T, const float fpx, const float fpy) {
             const int sig = sig_of(T);
-            // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
-            const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
-            inWin[T] = (cxf == fpx) & (cyf == fpy);
-            const int px = (int)cxf, gpy = (int)cyf;
+            int px, gpy;
+            if constexpr (decltype(fastTag)::value) { // every tap of the wave is inside its window (allInside below): no clamp, no test
+                inWin[T] = true;
+                px = (int)fpx, gpy = (int)fpy;
+            } else {
+                // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
+                const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
+                inWin[T] = (cxf == fpx) & (cyf == fpy);
+                px = (int)cxf, gpy = (int)cyf;
+            }
             if constexpr (TAP) { // ONE gather: {guide part | signal}
                 graw[T] = ldb<uint4>(srcB[sig], px, gpy, 16);
                 return;
@@ -742,14 +806,14 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig]) : uint2{0u, 0u};
             }
         };
-        auto issue = [&](const int T) {
+        auto issue = [&](auto fastTag, const int T) {
             const int sig = sig_of(T);
             float ox, oy;
             tap_offset(tap_of(T), ox, oy);
             const float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], cx)));
             const float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], cy)));
             gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
-            gather(T, fpx, fpy);
+            gather(fastTag, T, fpx, fpy);
         };
         // a tap's texels -> its guide fields and its signal
         auto decode = [&](const int T, Guide& gs, f4& sv) {
@@ -779,9 +843,14 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         };
         auto accumulate = [&](const int T, const f4 sv, float w, const bool valid) {
             const int sig = sig_of(T);
-            if (VARIANT == 0) {
-                // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): a rejected tap is
-                // selected out component by component
+            // A rejected tap enters with weight 0 - one select. Blur / PostBlur read internal planes (always finite); the PrePass reads
+            // caller-owned inputs (garbage allowed on sky / outside the rect): there the texel of a rejected tap was zeroed before it was
+            // decoded (consume), so NaN / Inf never meet the weight 0 (round 6: one straight-line block per tap in the PrePass as well -
+            // five selects and the branch the compiler formed around them less)
+#ifndef NRD_PRE_STRAIGHT // 0 (timing only): the PrePass selects a rejected tap out component by component, as rounds 1-5 did
+#define NRD_PRE_STRAIGHT 1
+#endif
+            if (VARIANT == 0 && !NRD_PRE_STRAIGHT) {
                 f4 acc = fma4(sv, w, sum[sig]);
                 sum[sig] = {valid ? acc.x : sum[sig].x, valid ? acc.y : sum[sig].y, valid ? acc.z : sum[sig].z, valid ? acc.w : sum[sig].w};
                 if (SH) {
@@ -789,21 +858,29 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                     sum1[sig] = {valid ? acc1.x : sum1[sig].x, valid ? acc1.y : sum1[sig].y, valid ? acc1.z : sum1[sig].z, valid ? acc1.w : sum1[sig].w};
                 }
                 wsum[sig] = valid ? wsum[sig] + w : wsum[sig];
-                minHit[sig] = (valid & (w > 0.0f)) ? fmin2(minHit[sig], sv.w * hitNormS[sig]) : minHit[sig];
-            } else {
-                // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0 - one select
-                w = valid ? w : 0.0f;
-                sum[sig] = fma4(sv, w, sum[sig]);
-                if (SH)
-                    sum1[sig] = fma4(unpack_h4(sraw1[T]), w, sum1[sig]);
-                wsum[sig] += w;
+                minHit[sig] = (valid & (w > 0.0f)) ? fmin2(minHit[sig], sv.w) : minHit[sig];
+                return;
             }
+            w = valid ? w : 0.0f;
+            sum[sig] = fma4(sv, w, sum[sig]);
+            if (SH)
+                sum1[sig] = fma4(unpack_h4(sraw1[T]), w, sum1[sig]);
+            wsum[sig] += w;
+            if (VARIANT == 0) // tracked hit distance: the smallest hit distance CODE among the taps that count (the scale is applied once, at the end)
+                minHit[sig] = w > 0.0f ? fmin2(minHit[sig], sv.w) : minHit[sig];
         };
         auto consume = [&](const int T) {
             const int sig = sig_of(T), t = tap_of(T);
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
             Guide gs;
             f4 sv;
+            if (VARIANT == 0 && NRD_PRE_STRAIGHT) { // the validity of a PrePass tap hangs on its guide texel only: decided first, and a rejected tap's signal texels read as zeros
+                const Guide gq = decode_guide(uint2{graw[T].x, graw[T].y}, c.denoisingRange);
+                const bool ok = tap_valid(T, gq);
+                sraw[T] = uint2{ok ? sraw[T].x : 0u, ok ? sraw[T].y : 0u};
+                if (SH)
+                    sraw1[T] = uint2{ok ? sraw1[T].x : 0u, ok ? sraw1[T].y : 0u};
+            }
             decode(T, gs, sv);
             const bool valid = tap_valid(T, gs);
             float w = g_poisson8[t][2];
@@ -814,20 +891,42 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight_prescaled(fma_(sv.w, hitA[sig], hitB[sig])));
             accumulate(T, sv, w, valid);
         };
-        {
+        auto pipeline = [&](auto fastTag) {
 #pragma unroll
             for (int T = 0; T < DEPTH; T++)
-                issue(T);
+                issue(fastTag, T);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int T = 0; T < NT; T++) {
                 if (T + DEPTH < NT)
-                    issue(T + DEPTH);
+                    issue(fastTag, T + DEPTH);
                 __builtin_amdgcn_sched_barrier(0);
                 consume(T);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        // Round 6: the window test of a tap (two clamps, two compares) is provably true for most waves - every lane at least `reach` pixels
+        // from the frame's edges and from the first / last held row, and every kernel smaller than the reach: |offset| <= |J column| (the disk
+        // has radius 1), floor() and the roundings of the three fma stay below 1 pixel - so such a wave runs a copy of the tap loop without
+        // it (same results by construction; 4 of ~66 instructions per tap). Everybody else - frame borders, kernels stretched beyond the
+        // reach at grazing view angles - takes the loop with the test.
+#ifndef NRD_WINDOW_FAST_PATH
+#define NRD_WINDOW_FAST_PATH 0
+#endif
+        bool allInside = false;
+        if (NRD_WINDOW_FAST_PATH) {
+            float b2 = 0.0f; // largest squared column length of any signal's Jacobian (rows: x, y)
+#pragma unroll
+            for (int sig = 0; sig < NSIG; sig++)
+                b2 = fmax2(b2, fmax2(fma_(jtx[sig], jtx[sig], jbx[sig] * jbx[sig]), fma_(jty[sig], jty[sig], jby[sig] * jby[sig])));
+            const float rin = (float)(reach - 1);
+            const bool inside = (b2 <= rin * rin) & (loX == x - reach) & (hiX == x + reach) & (loY == gy0 - reach) & (hiY == gy0 + reach);
+            allInside = NRD_WAVE_ALL(inside);
         }
+        if (allInside)
+            pipeline(std::true_type{});
+        else
+            pipeline(std::false_type{});
     }
     uint2 outw[RBPT / 8];
 #pragma unroll
@@ -852,11 +951,21 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             if (SH)
                 outw[sig * (sb / 8) + 1] = pack_h4(res1);
         }
-        if (VARIANT == 0 && isSpec)
+        if (VARIANT == 0 && isSpec) {
+            minHit[sig] = minHit[sig] * hitNormS[sig];
             st<uint16_t>(p.hitTrack, x, y, 2, f2h(minHit[sig])); // (fused frame: TemporalStabilization still reads it)
+        }
     }
     if constexpr (FUSED) { // on into TemporalAccumulation with what Tmp1 and the hit tracker would have held
-        ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(p, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f);
+#ifndef NRD_FUSED_RELOAD_ARGS
+#define NRD_FUSED_RELOAD_ARGS 1
+#endif
+        if (NRD_FUSED_RELOAD_ARGS) {
+            NRD_RELOAD_ARGS(ReblurParams, p, q); // (nrd_device.h: the reprojection's constants are loaded behind the tap loop, not held across it)
+            const TaGeo tg = {pg.Xv, pg.Nv, V, (HAS_SPEC && !HW_TRANSCENDENTALS) ? kuRoughA : -1.0f};
+            ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(q, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f, &tg);
+        } else
+            ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(p, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f);
         return;
     }
     // the signals of the pixel share one texel of the output plane: one store
@@ -1113,7 +1222,7 @@ NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y) {
 }
 
 template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX, bool SEQ_FOOT>
-NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], const float hitDist) {
+NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Guide& g, const uint2 (&ctex)[((SH ? 16 : 8) * ((HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0))) / 8], const float hitDist, const TaGeo* geo) {
     constexpr int NSIG = (HAS_DIFF ? 1 : 0) + (HAS_SPEC ? 1 : 0);
     constexpr int sb = SH ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
     constexpr int RBPT = sb * NSIG;
@@ -1127,9 +1236,9 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
     float confD = (HAS_DIFF && c.confAvail) ? sample_confidence(p.confD, u, v) : 1.0f;
     // the sample binds ONE texture to both confidence slots (Source/NRDSample.cpp:457, :462): fetch it once then
     float confS = (HAS_SPEC && c.confAvail) ? ((HAS_DIFF && p.confS.p == p.confD.p) ? confD : sample_confidence(p.confS, u, v)) : 1.0f;
-    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
-    f3 Nv = rot3(c.w2v, g.n);
-    f3 V = to_viewer(Xv);
+    f3 Xv = geo ? geo->Xv : reconstruct_px(c.pv, (float)x, (float)gy0, g.z);
+    f3 Nv = geo ? geo->Nv : rot3(c.w2v, g.n);
+    f3 V = geo ? geo->V : to_viewer(Xv);
     float NoV = absf(dot3(Nv, V));
     Reproj r = reproject(c, Xv, u, v, mvRaw);
     f3 NvPrev = rot3(c.w2vPrev, g.n);
@@ -1230,7 +1339,7 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         for (int i = 0; i < 4; i++)
             prevRough = fma_((float)(vraw.g[i].x & 1023u) * (1.0f / 1023.0f), vmb.w[i], prevRough);
         prevRough *= rcp_(vmb.wsum);
-        float roughA = rcp_(lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction)));
+        float roughA = (geo && geo->roughA >= 0.0f) ? geo->roughA : rcp_(lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction)));
         float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
         float amount = vmbOk ? spec_dominant_factor(g.roughness) * vmb.wsum * rconf : 0.0f;
         float dA, sA;

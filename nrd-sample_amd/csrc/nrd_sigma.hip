@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_sigma_classify_tiles(const SigmaParams 
                 lit = 1;
             else {
                 shadowed = 1;
-                r = fmin2(pen / (c.unproject * zpersp(absf(z))), 255.0f);
+                r = fmin2(pen * rcp_(c.unproject * zpersp(absf(z))), 255.0f);
             }
         }
     }
@@ -144,34 +144,25 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
         return;
     }
     float pixelWorld = c.unproject * zpersp(absZ);
-    float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
+    float radiusPx = lit ? (float)(tile >> 8) : pen * rcp_(pixelWorld);
     radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
-    float worldRadius = radiusPx * pixelWorld;
     const int gy0 = y + c.yOff;
     Guide g = decode_guide(graw, c.denoisingRange);
-    f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
+    const float rx = fma_(c.pv[2], (float)x, c.pv[0]), ry = fma_(c.pv[3], (float)gy0, c.pv[1]); // view ray (orthographic: view-space xy)
+    f3 Xv = {zpersp(z) * rx, zpersp(z) * ry, z};
     f3 Nv = rot3(c.w2v, g.n);
     float frustumSize = c.minRectDimMulUnproject * zpersp(absZ);
-    float geoA = 1.0f / (p.planeDistanceSensitivity * frustumSize);
+    float geoA = rcp_(p.planeDistanceSensitivity * frustumSize);
     float gax = Nv.x * c.pv[2] * geoA, gay = Nv.y * c.pv[3] * geoA;
     // plane distance of a tap = |zs * (ga0 + gax px + gay gy) + geoB|; orthographic: |zs * geoB + (ga0 + gax px + gay gy)|
     float ga0 = ORTHO ? (fma_(Nv.x, c.pv[0], Nv.y * c.pv[1]) - dot3(Nv, Xv)) * geoA : fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
     float geoB = ORTHO ? Nv.z * geoA : -dot3(Nv, Xv) * geoA;
     f3 T, B;
     basis3(Nv, T, B);
-    T = mul3(T, worldRadius);
-    B = mul3(B, worldRadius);
-    float inv = 1.0f, kuz = 0.0f, kvz = 0.0f; // pixel-space Jacobian of the projection (orthographic: no divide, no z terms)
-    if (!ORTHO) {
-        inv = 1.0f / (c.pj[4] * z);
-        float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
-        float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
-        kuz = c.pj[2] - nu * c.pj[4];
-        kvz = c.pj[3] - nv * c.pj[4];
-    }
-    float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
-    float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
-    float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
+    float ju[4]; // the kernel basis in pixels per pixel of radius (nrd_device.h kernel_basis_px: the depth cancels, no reciprocal)
+    kernel_basis_px(c, z, rx, ry, T, B, ju);
+    float jtx = ju[0] * radiusPx, jty = ju[1] * radiusPx;
+    float jbx = ju[2] * radiusPx, jby = ju[3] * radiusPx;
     constexpr bool PER_PIXEL = PASS == 0; // Blur rotates per pixel, PostBlur per frame (coalesced gathers)
     uint32_t h = hash_px(PER_PIXEL ? (uint32_t)x : 0u, PER_PIXEL ? (uint32_t)gy0 : 0u, c.frameIndex, 17u + (uint32_t)PASS);
     float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
@@ -217,9 +208,9 @@ __global__ __launch_bounds__(256) void k_sigma_blur(const SigmaParams p) {
             }
         }
     }
-    st<uint2>(outSh, x, y, 8, pack_h4(mul4(sum, 1.0f / wsum)));
+    st<uint2>(outSh, x, y, 8, pack_h4(mul4(sum, rcp_(wsum))));
     if (PASS == 0)
-        st<uint16_t>(p.pen1, x, y, 2, f2h(penW > 0.0f ? penSum / penW : 0.0f));
+        st<uint16_t>(p.pen1, x, y, 2, f2h(penW > 0.0f ? penSum * rcp_(penW) : 0.0f));
 }
 
 NRD_DEV void store_out(const SigmaParams& p, int x, int y, uint32_t packed) {
@@ -388,7 +379,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(COPY ? 8 : 2) void k_sigma_te
             wsum = ok ? wsum + bw[i] : wsum;
         }
         if (wsum > 0.0f) {
-            hist = mul4(sum, 1.0f / wsum);
+            hist = mul4(sum, rcp_(wsum));
             have = true;
         }
     }

@@ -134,6 +134,8 @@ bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH
 
     c.unproject = 1.0f / (0.5f * (float)c.H * absf(c.pj[1]));
     c.minRectDimMulUnproject = (float)std::min(c.W, c.H) * c.unproject;
+    c.jcx = 0.5f * (float)c.W * c.pj[0] * c.unproject * c.pj[4]; // (pj[4] = +-1)
+    c.jcy = -0.5f * (float)c.H * c.pj[1] * c.unproject * c.pj[4];
     c.denoisingRange = cs.denoisingRange;
     c.disocclusionThreshold = cs.disocclusionThreshold;
     c.disoccAlt = cs.disocclusionThresholdAlternate;

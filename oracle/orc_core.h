@@ -98,6 +98,7 @@ struct Consts {
     float w2v[9] = {}, w2vPrev[9] = {}, v2w[9] = {}, v2wPrev[9] = {};
     float camDelta[3] = {}; // camera position prev - current (world)
     float unproject = 0, minRectDimMulUnproject = 0;
+    float jcx = 0, jcy = 0; // kernel basis -> pixels per pixel of radius: d(px) = +-jcx (T.x - rx T.z), d(py) = +-jcy (T.y - ry T.z) (csrc/nrd_device.h kernel_basis_px)
     float denoisingRange = 0, disocclusionThreshold = 0, splitScreen = 0;
     float disoccAlt = 0;   // CommonSettings::disocclusionThresholdAlternate, blended in per pixel by IN_DISOCCLUSION_THRESHOLD_MIX when ...
     bool mixAvail = false; // ... CommonSettings::isDisocclusionThresholdMixAvailable
@@ -109,6 +110,23 @@ struct Consts {
     bool mvWorld = false, confAvail = false, reset = false;
     float rot[64][2] = {};
 };
+
+static inline float signed_by(float k, float z) { return u2f(f2u(k) ^ (f2u(z) & 0x80000000u)); } // k * sign(z), exact
+// pixel offsets of a view-space tangent pair per pixel of blur radius (csrc/nrd_device.h kernel_basis_px: the depth cancels)
+static inline void kernel_basis_px(const Consts& c, float z, float rx, float ry, f3 T, f3 B, float (&j)[4]) {
+    if (c.ortho) {
+        j[0] = c.jcx * T.x;
+        j[1] = c.jcy * T.y;
+        j[2] = c.jcx * B.x;
+        j[3] = c.jcy * B.y;
+        return;
+    }
+    const float sx = signed_by(c.jcx, z), sy = signed_by(c.jcy, z);
+    j[0] = sx * fma_(-rx, T.z, T.x);
+    j[1] = sy * fma_(-ry, T.z, T.y);
+    j[2] = sx * fma_(-rx, B.z, B.x);
+    j[3] = sy * fma_(-ry, B.z, B.y);
+}
 
 bool derive_consts(const nrd::CommonSettings& cs, int resW, int resH, int frameH, int yOff, int ownY0, int ownRows, Consts& c, std::string& err, int histY0 = 0, int histRows = 0);
 

@@ -80,7 +80,7 @@ static inline f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 static inline f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 static inline f3 mul3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 static inline float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
-static inline f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline f3 cross3(f3 a, f3 b) { return {fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))}; }
 static inline f3 normalize3(f3 a) {
     float l2 = dot3(a, a);
     float inv = rsqrt_(fmax2(l2, 1e-30f));
@@ -355,10 +355,8 @@ static inline float spec_magic_curve(float roughness) {
 }
 
 // REBLUR hit distance normalisation: (A + |z| B) * lerp(1, C, 2^(D r^2))
-static inline float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) {
-    float e = exp2_poly(hp[3] * roughness * roughness);
-    return fma_(absViewZ, hp[1], hp[0]) * lerpf(1.0f, hp[2], e);
-}
+static inline float reblur_hitdist_factor(const float* hp, float roughness) { return lerpf(1.0f, hp[2], exp2_poly(hp[3] * roughness * roughness)); } // the roughness-dependent factor
+static inline float reblur_hitdist_norm(float absViewZ, const float* hp, float roughness) { return fma_(absViewZ, hp[1], hp[0]) * reblur_hitdist_factor(hp, roughness); }
 
 // specular lobe half angle: atan(r^2 * k / (1 - k)), k = 0.75
 static inline float spec_lobe_half_angle(float roughness) {
@@ -386,9 +384,10 @@ static inline uint32_t hash_px(uint32_t x, uint32_t y, uint32_t frame, uint32_t 
 static inline void basis3(f3 n, f3& t, f3& b) {
     float sz = n.z >= 0.0f ? 1.0f : -1.0f;
     float a = -rcps_(sz + n.z);
-    float bb = n.x * n.y * a;
-    t = {1.0f + sz * n.x * n.x * a, sz * bb, -sz * n.x};
-    b = {bb, sz + n.y * n.y * a, -n.y};
+    float nxa = n.x * a, sx = sz * n.x;
+    float bb = nxa * n.y;
+    t = {fma_(sx, nxa, 1.0f), sz * bb, -sx};
+    b = {bb, fma_(n.y * a, n.y, sz), -n.y};
 }
 
 } // namespace orc

@@ -23,7 +23,9 @@ enum Perm { P_GUIDE_A, P_GUIDE_B, P_DATA1_A, P_DATA1_B, P_HIST, P_FAST_A, P_FAST
 enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_PREP_D, T_PREP_S, T_PREP_D1, T_PREP_S1, T_NUM,
              // REBLUR only (RELAX keeps its A-trous ping-pong at these indices): tap texels of Blur / PostBlur, see TapTexel below.
              // _A: HistoryFix -> Blur, _B: Blur -> PostBlur; one plane per signal
-             T_TAP_D_A = T_NUM, T_TAP_S_A, T_TAP_D_B, T_TAP_S_B };
+             T_TAP_D_A = T_NUM, T_TAP_S_A, T_TAP_D_B, T_TAP_S_B,
+             // REBLUR only: the pass-independent kernel set-up of a pixel (KernelUnit), PrePass -> Blur, PostBlur
+             T_KBASIS, T_KTERMS };
 
 const float MAX_ACCUM = 63.0f;
 const float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
@@ -144,6 +146,7 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
 // per-pixel geometry shared by the bilateral passes
 struct PixelGeo {
     f3 Xv, Nv;
+    float rx, ry; // perspective: the pixel's view ray (rx, ry, 1); orthographic: its view-space xy
     float absZ, frustumSize;
     float ga0, gax, gay, geoB; // plane-distance weight: |zs * (ga0 + gax px + gay gy) + geoB|
     bool ortho;                // orthographic: |zs * geoB + (ga0 + gax px + gay gy)| (geoB = z coefficient, ga0 absorbs the offset)
@@ -151,7 +154,9 @@ struct PixelGeo {
 
 static inline PixelGeo pixel_geo(const Consts& c, const Guide& g, int x, int gy, float planeDistSensitivity) {
     PixelGeo p;
-    p.Xv = reconstruct_px(c.pv, (float)x, (float)gy, g.z);
+    p.rx = fma_(c.pv[2], (float)x, c.pv[0]);
+    p.ry = fma_(c.pv[3], (float)gy, c.pv[1]);
+    p.Xv = {(c.ortho ? 1.0f : g.z) * p.rx, (c.ortho ? 1.0f : g.z) * p.ry, g.z}; // == reconstruct_px(c.pv, x, gy, g.z)
     p.Nv = rot3(c.w2v, g.n);
     p.absZ = absf(g.z);
     p.ortho = c.ortho;
@@ -191,6 +196,45 @@ static inline f3 to_viewer(const Consts& c, f3 Xv) {
 // Spatial filter shared by PrePass / Blur / PostBlur
 // --------------------------------------------------------------------------------------------------
 enum Variant { PRE = 0, BLUR = 1, POST = 2 };
+
+// Kernel set-up of a signal: the part that hangs on the pixel's geometry and roughness only, not on the pass (csrc/nrd_reblur.hip
+// KernelUnit). REBLUR computes it in the PrePass and hands it to Blur / PostBlur as fp16 through the KernelBasis / KernelTerms planes.
+struct KernelUnit {
+    float j[4];                           // pixel offsets of the kernel's tangent / bitangent per pixel of blur radius
+    float smc, angle0, roughA, hitFactor; // GetSpecMagicCurve(roughness), lobe half angle, 1 / roughness tolerance, hit distance factor
+};
+static inline KernelUnit kernel_unit(const Consts& c, const nrd::ReblurSettings& s, const PixelGeo& pg, float z, f3 V, float rough, bool isSpec) {
+    const float* hp = &s.hitDistanceParameters.A;
+    KernelUnit k;
+    f3 T, B;
+    basis3(pg.Nv, T, B);
+    if (isSpec) {
+        const float NoV = dot3(pg.Nv, V);
+        const float df = spec_dominant_factor(rough);
+        // dominant direction D = normalize(N + (R - N) df), R = 2 NoV N - V the mirror direction: N (1 + (2 NoV - 1) df) - V df
+        const float alpha = fma_(fma_(NoV, 2.0f, -1.0f), df, 1.0f);
+        const f3 D = normalize3({fma_(pg.Nv.x, alpha, -(V.x * df)), fma_(pg.Nv.y, alpha, -(V.y * df)), fma_(pg.Nv.z, alpha, -(V.z * df))});
+        const float NoD = dot3(pg.Nv, D);
+        if (NoD < 0.999f && rough < 0.95f) {
+            const float n2 = 2.0f * NoD;
+            const f3 Dr = {fma_(pg.Nv.x, n2, -D.x), fma_(pg.Nv.y, n2, -D.y), fma_(pg.Nv.z, n2, -D.z)}; // D mirrored at N
+            T = normalize3(cross3(D, pg.Nv)); // == cross(N, Dr)
+            B = cross3(Dr, T);
+            T = mul3(T, lerpf(fma_(rough, 0.5f, 0.5f), 1.0f, NoD));
+        }
+        k.smc = spec_magic_curve(rough);
+        k.angle0 = spec_lobe_half_angle(rough);
+        k.roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
+        k.hitFactor = reblur_hitdist_factor(hp, rough);
+    } else {
+        k.smc = 1.0f;
+        k.angle0 = spec_lobe_half_angle(1.0f);
+        k.roughA = 0.0f;
+        k.hitFactor = reblur_hitdist_factor(hp, 1.0f);
+    }
+    kernel_basis_px(c, z, pg.rx, pg.ry, T, B, k.j);
+    return k;
+}
 
 // --------------------------------------------------------------------------------------------------
 // K1 PrepareInputs - recorded only when checkerboardMode != OFF or hitDistanceReconstructionMode != OFF (the sample's default
@@ -404,6 +448,9 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const bool sh = k.d.sh;
     const bool tap = variant != PRE && tap_texels(k.d); // Blur / PostBlur on tap texels: io.in[sig] (and Blur's io.out[sig]) are tap planes
     const Plane& TILES = k.trans(T_TILES);
+    const bool kernelSetup = k.d.kind == Kind::REBLUR; // PrePass -> Blur, PostBlur (RELAX has no reader)
+    const Plane& KB = k.trans(kernelSetup ? T_KBASIS : T_TILES);
+    const Plane& KT = k.trans(kernelSetup ? T_KTERMS : T_TILES);
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             // a tile without geometry (ClassifyTiles): PrePass and PostBlur write nothing there - what they would write is read by nobody
@@ -432,17 +479,6 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
             int gy0 = y + c.yOff;
             PixelGeo pg = pixel_geo(c, g, x, gy0, s.planeDistanceSensitivity);
             f3 V = to_viewer(c, pg.Xv);
-            // pixel-space Jacobian of the projection at the centre (taps are placed on the linearised tangent plane); orthographic:
-            // no perspective divide and no z terms
-            float inv = 1.0f, kuz = 0.0f, kvz = 0.0f;
-            if (!c.ortho) {
-                inv = rcps_(c.pj[4] * g.z);
-                float nu = fma_(c.pj[0], pg.Xv.x, c.pj[2] * g.z) * inv;
-                float nv = fma_(c.pj[1], pg.Xv.y, c.pj[3] * g.z) * inv;
-                kuz = c.pj[2] - nu * c.pj[4];
-                kvz = c.pj[3] - nv * c.pj[4];
-            }
-            float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
             // Poisson rotation: per frame for PrePass / PostBlur (neighbouring pixels then gather neighbouring texels), per 2x2 quad for Blur
             bool perPixel = variant == BLUR;
             uint32_t h = hash_px(perPixel ? (uint32_t)x >> BLUR_ROTATION_SHIFT : 0u, perPixel ? (uint32_t)gy0 >> BLUR_ROTATION_SHIFT : 0u, c.frameIndex, (uint32_t)variant + 1u); // one rotation per 2x2 quad
@@ -460,12 +496,30 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     center = rgb_to_ycocg4(center);
                 f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
                 const f4 center1 = sum1;
-                float hitNorm = reblur_hitdist_norm(pg.absZ, hp, rough);
+                // the pass-independent part of the set-up: computed by the PrePass; REBLUR's Blur / PostBlur take what it stored (fp16)
+                KernelUnit ku;
+                if (variant == PRE) {
+                    ku = kernel_unit(c, s, pg, g.z, V, rough, isSpec);
+                    if (kernelSetup) {
+                        st_h4(KB, x, y, {ku.j[0], ku.j[1], ku.j[2], ku.j[3]}, sig * 8);
+                        if (isSpec)
+                            st_h4(KT, x, y, {ku.smc, ku.angle0, ku.roughA, ku.hitFactor}, 0);
+                    }
+                } else {
+                    const f4 jb = ld_h4(KB, x, y, sig * 8);
+                    ku.j[0] = jb.x, ku.j[1] = jb.y, ku.j[2] = jb.z, ku.j[3] = jb.w;
+                    ku.smc = 1.0f, ku.angle0 = spec_lobe_half_angle(1.0f), ku.roughA = 0.0f, ku.hitFactor = reblur_hitdist_factor(hp, 1.0f);
+                    if (isSpec) {
+                        const f4 kt = ld_h4(KT, x, y, 0);
+                        ku.smc = kt.x, ku.angle0 = kt.y, ku.roughA = kt.z, ku.hitFactor = kt.w;
+                    }
+                }
+                float hitNorm = fma_(pg.absZ, hp[1], hp[0]) * ku.hitFactor;
                 float hitDist = center.w * hitNorm;
                 float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
                 float A = isSpec ? specA : diffA;
                 float nonLin = variant == PRE ? 1.0f : rcp_(1.0f + A);
-                float smc = isSpec ? spec_magic_curve(rough) : 1.0f;
+                float smc = ku.smc;
                 float radius;
                 if (variant == PRE) {
                     radius = (isSpec ? s.specularPrepassBlurRadius : s.diffusePrepassBlurRadius) * hitDistFactor * smc;
@@ -477,39 +531,19 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 }
                 f4 sum = center;
                 float wsum = 1.0f;
-                float minHit = hitDist;
+                float minHitW = center.w; // (PrePass: hit distance tracking, in units of the signal's w channel until the end)
                 if (radius > 0.0f) {
-                    float worldRadius = radius * c.unproject * (c.ortho ? 1.0f : pg.absZ);
-                    // kernel basis in view space
-                    f3 T, B;
-                    basis3(pg.Nv, T, B);
-                    if (isSpec) {
-                        float NoV = dot3(pg.Nv, V);
-                        f3 R = sub3(mul3(pg.Nv, 2.0f * NoV), V);
-                        float df = spec_dominant_factor(rough);
-                        f3 D = normalize3(add3(pg.Nv, mul3(sub3(R, pg.Nv), df)));
-                        float NoD = dot3(pg.Nv, D);
-                        if (NoD < 0.999f && rough < 0.95f) {
-                            f3 Dr = sub3(mul3(pg.Nv, 2.0f * NoD), D);
-                            T = normalize3(cross3(pg.Nv, Dr));
-                            B = cross3(Dr, T);
-                            float skew = lerpf(0.5f + 0.5f * rough, 1.0f, NoD);
-                            T = mul3(T, skew);
-                        }
-                    }
-                    T = mul3(T, worldRadius);
-                    B = mul3(B, worldRadius);
                     // pixel offsets per unit of the (rotated) Poisson coordinates
-                    float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
-                    float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
-                    float angle = spec_lobe_half_angle(rough) * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
+                    float jtx = ku.j[0] * radius, jty = ku.j[1] * radius;
+                    float jbx = ku.j[2] * radius, jby = ku.j[3] * radius;
+                    float angle = ku.angle0 * lerpf(s.lobeAngleFraction, 1.0f, nonLin);
                     float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN)); // (weight-class from here on: orc_math.h NRD_HW_TRANSCENDENTALS)
                     normalW *= strand_normal_relax(c, g.mat, absf(g.z)); // CommonSettings::strandMaterialID: thin strands relax the normal test
                     float normalW2 = nw_param(normalW);
                     float hitScale = relaxIn ? wrcp_(fmax2(center.w, 1e-3f)) : 1.0f; // RELAX hit distances are world units: compare relatively
                     float hitA = hitScale * wrcp_(lerpf(1e-6f, 1.0f, fmin2(nonLin, smc))) * EXP_WEIGHT_SCALE; // (the exponent's scale folded in: exp_weight_prescaled)
                     float hitB = -center.w * hitA;
-                    float roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * s.roughnessFraction)));
+                    float roughA = ku.roughA;
                     float roughB = -rough * roughA;
                     if (variant == BLUR) { // per-pixel rotation folded into the Jacobian (J . R): the taps then are the unrotated disk
                         const float a = fma_(rc, jtx, rs * jbx), b = fma_(rc, jbx, -(rs * jtx));
@@ -528,20 +562,18 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         const int loX = std::max(x - io.reach, 0), hiX = std::min(x + io.reach, c.W - 1);
                         const int loY = std::max(gy0 - io.reach, std::max(c.yOff, 0)), hiY = std::min(gy0 + io.reach, std::min(c.yOff + c.resH, c.H) - 1);
                         bool valid = fpx >= (float)loX && fpx <= (float)hiX && fpy >= (float)loY && fpy <= (float)hiY;
-                        // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): rejected taps are skipped.
-                        // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0, its texel
-                        // fetched at the position clamped into the window - no per-component select in the kernels.
-                        if (variant == PRE && !valid)
-                            continue;
+                        // A rejected tap enters with weight 0, its texel fetched at the position clamped into the window - no per-component
+                        // select in the kernels. Blur / PostBlur read internal planes (always finite); the PrePass reads caller-owned inputs
+                        // (garbage allowed on sky / outside the rect): there a rejected tap's signal texels read as zeros.
                         int px = (int)clampf(fpx, (float)loX, (float)hiX), py = (int)clampf(fpy, (float)loY, (float)hiY) - c.yOff;
                         TapTexel tt = {};
                         if (tap)
                             tt = ld_tap(*io.in[sig], px, py);
                         Guide gs = tap ? unpack_tap_guide(tt.w0, tt.w1, c.denoisingRange) : load_guide(G, px, py, c.denoisingRange);
                         valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
-                        if (variant == PRE && !valid)
-                            continue;
                         f4 sv = tap ? tap_signal(tt) : load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
+                        if (variant == PRE && !valid)
+                            sv = {0, 0, 0, 0};
                         if (relaxIn && !RELAX_LINEAR_RGB)
                             sv = rgb_to_ycocg4(sv);
                         float w = 0.0f;
@@ -558,10 +590,10 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         }
                         sum = fma4(sv, w, sum);
                         if (sh)
-                            sum1 = fma4(load_sh1(io, sig, px, py, variant == PRE), w, sum1);
+                            sum1 = fma4((variant == PRE && !valid) ? f4{0, 0, 0, 0} : load_sh1(io, sig, px, py, variant == PRE), w, sum1);
                         wsum += w;
                         if (w > 0.0f)
-                            minHit = fmin2(minHit, sv.w * hitNorm);
+                            minHitW = fmin2(minHitW, sv.w);
                     }
                 }
                 float invw = wrcp_(wsum);
@@ -578,7 +610,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                 if (sh)
                     st_h4(*io.out[sig], x, y, res1, io.outOff[sig] + 8);
                 if (variant == PRE && isSpec)
-                    st_h(HT, x, y, minHit);
+                    st_h(HT, x, y, minHitW * hitNorm);
             }
         }
 }
@@ -1506,6 +1538,9 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
     trans.push_back({"REBLUR::Tap_Spec_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
     trans.push_back({"REBLUR::Tap_Diff_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
     trans.push_back({"REBLUR::Tap_Spec_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
+    // kernel set-up of a pixel (PrePass -> Blur, PostBlur): basis 4 x fp16 per signal, roughness terms 4 x fp16 (specular)
+    trans.push_back({"REBLUR::KernelBasis", (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT), 8u * d.nsig, 1});
+    trans.push_back({"REBLUR::KernelTerms", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.hasSpec ? 1 : 16)});
 }
 
 // the tap planes of the signals present, diffuse first (base = T_TAP_D_A or T_TAP_D_B)
@@ -1528,6 +1563,12 @@ void reblur_build(Instance& I, DenoiserState& d) {
     ReblurReach rr = reblur_reach(s);
     const float GB = (float)GUIDE_BYTES; // guide texel bytes
     const bool tap = tap_texels(d);
+    const float ks = 8.0f * n + (d.hasSpec ? 8.0f : 0.0f); // kernel set-up texels: KernelBasis (8 bytes per signal) + KernelTerms (specular)
+    auto push_kernel_setup = [&](std::vector<uint32_t>& list) {
+        list.push_back(T(T_KBASIS));
+        if (d.hasSpec)
+            list.push_back(T(T_KTERMS));
+    };
     {
         Pass p;
         p.name = "REBLUR::ClassifyTiles";
@@ -1599,7 +1640,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PrePassTemporalAccumulation";
         p.kernel = "nrd_reblur_prepass_temporal_accumulation";
         p.haloRows = (uint16_t)rr.pre;
-        p.bytesPerPixel = GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + (d.hasSpec ? 2 : 0);
+        p.bytesPerPixel = GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + (d.hasSpec ? 2 : 0) + ks;
         p.read = {P(P_GUIDE_A + cur)};
         p.read.insert(p.read.end(), prepassInputs.begin(), prepassInputs.end());
         for (uint32_t r : {P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))})
@@ -1607,6 +1648,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         if (I.common.isDisocclusionThresholdMixAvailable)
             p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_HITTRACK), T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
+        push_kernel_setup(p.written);
         p.reprojected = {P(P_GUIDE_A + (cur ^ 1)), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             if (y1 <= y0)
@@ -1625,10 +1667,11 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PrePass";
         p.kernel = "nrd_reblur_prepass";
         p.haloRows = (uint16_t)rr.pre;
-        p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0);
+        p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0) + ks;
         p.read = {P(P_GUIDE_A + cur)};
         p.read.insert(p.read.end(), prepassInputs.begin(), prepassInputs.end());
         p.written = {T(T_TMP1), T(T_HITTRACK)};
+        push_kernel_setup(p.written);
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { prepass_rows(I, d, c, y0, y1, &I.trans[d.transBase + T_TMP1]); };
         d.passes.push_back(p);
     }
@@ -1682,6 +1725,9 @@ void reblur_build(Instance& I, DenoiserState& d) {
             p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
             p.written = {T(T_TMP2)};
         }
+        p.bytesPerPixel += ks;
+        push_kernel_setup(p.read);
+        push_kernel_setup(p.own);
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
             const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
@@ -1712,6 +1758,9 @@ void reblur_build(Instance& I, DenoiserState& d) {
             p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
             p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
         }
+        p.bytesPerPixel += ks;
+        push_kernel_setup(p.read);
+        push_kernel_setup(p.own);
         p.written = {P(P_HIST)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};

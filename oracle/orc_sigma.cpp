@@ -87,7 +87,7 @@ void classify_tiles(Instance& I, DenoiserState& d, const Consts& c, int ty0, int
                         flags |= 2u;
                     else {
                         flags |= 1u;
-                        maxR = fmax2(maxR, fmin2(pen / (c.unproject * (c.ortho ? 1.0f : absf(z))), 255.0f));
+                        maxR = fmax2(maxR, fmin2(pen * rcp_(c.unproject * (c.ortho ? 1.0f : absf(z))), 255.0f));
                     }
                 }
             uint32_t r = (uint32_t)floorf(maxR + 0.999f);
@@ -149,34 +149,25 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
                 continue;
             }
             float pixelWorld = c.unproject * (c.ortho ? 1.0f : absZ);
-            float radiusPx = lit ? (float)(tile >> 8) : pen / pixelWorld;
+            float radiusPx = lit ? (float)(tile >> 8) : pen * rcp_(pixelWorld);
             radiusPx = fmin2(radiusPx, MAX_PIXEL_RADIUS);
-            float worldRadius = radiusPx * pixelWorld;
             int gy0 = y + c.yOff;
             Guide g = load_guide(G, x, y, c.denoisingRange);
-            f3 Xv = reconstruct_px(c.pv, (float)x, (float)gy0, z);
+            const float rx = fma_(c.pv[2], (float)x, c.pv[0]), ry = fma_(c.pv[3], (float)gy0, c.pv[1]); // view ray (orthographic: view-space xy)
+            f3 Xv = {(c.ortho ? 1.0f : z) * rx, (c.ortho ? 1.0f : z) * ry, z};
             f3 Nv = rot3(c.w2v, g.n);
             float frustumSize = c.minRectDimMulUnproject * (c.ortho ? 1.0f : absZ);
-            float geoA = 1.0f / (s.planeDistanceSensitivity * frustumSize);
+            float geoA = rcp_(s.planeDistanceSensitivity * frustumSize);
             float gax = Nv.x * c.pv[2] * geoA, gay = Nv.y * c.pv[3] * geoA;
             // plane distance of a tap = |zs * (ga0 + gax px + gay gy) + geoB|; orthographic: |zs * geoB + (ga0 + gax px + gay gy)|
             float ga0 = c.ortho ? (fma_(Nv.x, c.pv[0], Nv.y * c.pv[1]) - dot3(Nv, Xv)) * geoA : fma_(Nv.x, c.pv[0], fma_(Nv.y, c.pv[1], Nv.z)) * geoA;
             float geoB = c.ortho ? Nv.z * geoA : -dot3(Nv, Xv) * geoA;
             f3 T, B;
             basis3(Nv, T, B);
-            T = mul3(T, worldRadius);
-            B = mul3(B, worldRadius);
-            float inv = 1.0f, kuz = 0.0f, kvz = 0.0f; // pixel-space Jacobian of the projection (orthographic: no divide, no z terms)
-            if (!c.ortho) {
-                inv = 1.0f / (c.pj[4] * z);
-                float nu = fma_(c.pj[0], Xv.x, c.pj[2] * z) * inv;
-                float nv = fma_(c.pj[1], Xv.y, c.pj[3] * z) * inv;
-                kuz = c.pj[2] - nu * c.pj[4];
-                kvz = c.pj[3] - nv * c.pj[4];
-            }
-            float ju = 0.5f * (float)c.W * inv, jv = -0.5f * (float)c.H * inv;
-            float jtx = ju * fma_(c.pj[0], T.x, kuz * T.z), jty = jv * fma_(c.pj[1], T.y, kvz * T.z);
-            float jbx = ju * fma_(c.pj[0], B.x, kuz * B.z), jby = jv * fma_(c.pj[1], B.y, kvz * B.z);
+            float ju[4]; // the kernel basis in pixels per pixel of radius (orc_core.h kernel_basis_px)
+            kernel_basis_px(c, z, rx, ry, T, B, ju);
+            float jtx = ju[0] * radiusPx, jty = ju[1] * radiusPx;
+            float jbx = ju[2] * radiusPx, jby = ju[3] * radiusPx;
             bool perPixel = pass == 0; // Blur rotates per pixel, PostBlur per frame
             uint32_t h = hash_px(perPixel ? (uint32_t)x : 0u, perPixel ? (uint32_t)gy0 : 0u, c.frameIndex, 17u + (uint32_t)pass);
             float rc = c.rot[h & 63u][0], rs = c.rot[h & 63u][1];
@@ -219,9 +210,9 @@ void blur(Instance& I, DenoiserState& d, const Consts& c, int y0, int y1, int pa
                         penW += w;
                     }
                 }
-            st_h4(outSh, x, y, mul4(sum, 1.0f / wsum));
+            st_h4(outSh, x, y, mul4(sum, rcp_(wsum)));
             if (pass == 0)
-                st_h(outPen, x, y, penW > 0.0f ? penSum / penW : 0.0f);
+                st_h(outPen, x, y, penW > 0.0f ? penSum * rcp_(penW) : 0.0f);
         }
 }
 
@@ -338,7 +329,7 @@ void temporal_stabilization(Instance& I, DenoiserState& d, const Consts& c, int 
                         wsum += bw[i];
                     }
                     if (wsum > 0.0f) {
-                        hist = mul4(sum, 1.0f / wsum);
+                        hist = mul4(sum, rcp_(wsum));
                         have = true;
                     }
                 }

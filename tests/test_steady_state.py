@@ -20,7 +20,7 @@ def bench_settings(api, scene, dens):
     return bench.settings_of(api, scene, dens)
 
 
-def run_pair(pkg, api, oracle, hip, dens, w, h, threads, exact=True, dolly=0.004):
+def run_pair(pkg, api, oracle, hip, dens, w, h, threads, exact=True, dolly=0.004, frames=FRAMES, first_checked=FIRST_CHECKED):
     # (frames are rendered on the GPU - a 1080p frame takes numpy ~2 s - and copied to the host for the oracle)
     scene = pkg.synth.Scene(w, h, dolly=dolly, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR", device="cuda:0")
     dd = [api.Denoiser[x] for x in dens]
@@ -29,16 +29,16 @@ def run_pair(pkg, api, oracle, hip, dens, w, h, threads, exact=True, dolly=0.004
     oracle.lib.orc_set_threads(ho.nrd.handle, threads)
     hg = pkg.harness.Harness(hip, dd, w, h)
     checked = 0
-    for f in range(FRAMES):
+    for f in range(frames):
         fr = scene.frame(f)
         cs = scene.common_settings(api, fr, f, reset=(f == 0))
         ho.frame(cs, ho.upload(util.host_frame(fr)), st)
         hg.frame(cs, hg.upload(fr), st)
-        if f >= FIRST_CHECKED:
+        if f >= first_checked:
             bad = util.compare_all(ho, hg, exact=exact, ulp=1)
             assert bad == [], "frame %d: %s" % (f + 1, bad)
             checked += 1
-    assert checked == FRAMES - FIRST_CHECKED
+    assert checked == frames - first_checked
     return ho, hg
 
 
@@ -70,3 +70,13 @@ def test_steady_state_config3_720p_against_oracle(pkg, api, oracle, hip):
     """BASELINE config 3's denoiser set (REBLUR_DIFFUSE_SPECULAR + SIGMA_SHADOW_TRANSLUCENCY) at 1280x720, 36 frames: bit-exact on frames 31..36,
     the RGBA8 shadow included"""
     run_pair(pkg, api, oracle, hip, ["REBLUR_DIFFUSE_SPECULAR", "SIGMA_SHADOW_TRANSLUCENCY"], 1280, 720, 128)
+
+
+def test_steady_state_4k_against_oracle(pkg, api, oracle, hip):
+    """The headline AT THE HEADLINE'S SIZE in the regime the headline is timed in (VERDICT r5 "what's weak" 1b): REBLUR_DIFFUSE_SPECULAR 3840x2160 at
+    bench.py's settings_of, 34 frames from a restart (the bench pre-rolls 27 + 5 warm-up = 32 before its first timed frame), frames 33 and 34
+    compared bit for bit - every OUT_* plane and every pool plane. The oracle takes ~1 s per 4K frame on the box's host threads."""
+    ho, hg = run_pair(pkg, api, oracle, hip, ["REBLUR_DIFFUSE_SPECULAR"], 3840, 2160, 256, frames=34, first_checked=32)
+    sat = saturated(hg)
+    print("share of accumulation-speed codes at the cap after 34 frames at 4K: %.3f" % sat)
+    assert sat > 0.5
