@@ -53,11 +53,6 @@ struct ReblurParams {
     // tapA: HistoryFix -> Blur, tapB: Blur -> PostBlur
     int tapTex;
     PlaneRef tapA[2], tapB[2];
-    // REBLUR (every flavour): the kernel set-up of a pixel that depends on its geometry and roughness only (nrd_reblur.hip KernelUnit),
-    // written by the PrePass, read by Blur and PostBlur at their own pixel. kBasis: 4 x fp16 per signal {T -> px, T -> py, B -> px, B -> py}
-    // per pixel of blur radius, diffuse first; kTerms (specular): {magic curve, lobe half angle, 1 / roughness tolerance, hit distance factor}
-    int kernelSetup;
-    PlaneRef kBasis, kTerms;
     // ClassifyTiles only: the tile flags once more in LAUNCH order (FrameConsts::tileFlags of the passes behind it) through the inverse of
     // the tile table (tile -> forward launch index); nullptr when those passes launch over another grid than ClassifyTiles
     uint8_t* tileFlagsOut;

@@ -487,12 +487,13 @@ template <bool HAS_DIFF, bool HAS_SPEC, bool SH, bool RELAX>
 NRD_DEV void ta_sky_stores(const ReblurParams& p, int x, int y);
 
 // ---- kernel set-up of a signal: the part that hangs on the pixel's geometry and roughness only, not on the pass -------------------------
-// Round 6 ("63 % of Blur is per-pixel set-up + tap positions, computed three times per pixel per frame"): the kernel
-// basis in pixels per pixel of radius (nrd_device.h kernel_basis_px) and the four roughness-only terms of the specular signal are
-// computed ONCE per frame, by the PrePass, which hands them to Blur and PostBlur through two planes as fp16 (KernelBasis 8 bytes per
-// signal, KernelTerms 8 bytes): ~330 of Blur's 534 set-up instructions become one 16-byte and one 8-byte load. RELAX's only spatial
-// pass is the PrePass: it computes the same terms and stores nothing. Explicit-fma audit of the basis on the way (cross products,
-// mirror directions: mul + fma instead of mul + mul + sub), and the dominant direction without the mirror vector R in between.
+// Round 6: restated - the kernel basis in pixels per pixel of radius without the perspective divide (nrd_device.h
+// kernel_basis_px), explicit fma in the cross products / mirror directions, the dominant direction without the mirror vector R in
+// between: ~60 instructions less per signal and pass, +1.9 % on the frame. Handing this part from the PrePass to Blur / PostBlur through
+// planes (24 bytes per pixel as fp16: -290 instructions in each of the two passes) was built and measured SLOWER: Blur +9 %, the
+// PrePass + TemporalAccumulation kernel +8 % for its 24 bytes of stores, PostBlur -3 %, frame -3.3 % (profiles/
+// r06_ab_kernel_setup_planes.txt; the code lives in tools/variants/kernel_setup_planes.patch): in these kernels a byte per pixel costs
+// what ~10 instructions cost, and a cold load at the head of a wave more.
 struct KernelUnit {
     float j[4];                           // pixel offsets of the kernel's tangent / bitangent per pixel of blur radius (kernel_basis_px)
     float smc, angle0, roughA, hitFactor; // GetSpecMagicCurve(roughness), lobe half angle, 1 / roughness tolerance, hit distance factor
@@ -584,18 +585,6 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
         }
     }
-    // REBLUR Blur / PostBlur: the kernel set-up the PrePass left for this pixel (KernelUnit), in flight with the centre texels
-    constexpr bool RELAX_MODE = MODE == 1 || MODE == 4;
-#ifndef NRD_KSETUP_PLANES // 0 (timing only, A/B of profiles/r06_ab_kernel_setup_planes.txt): every pass computes its kernel set-up, nothing is stored
-#define NRD_KSETUP_PLANES 1
-#endif
-    constexpr bool KSETUP_READ = NRD_KSETUP_PLANES && VARIANT != 0, KSETUP_WRITE = NRD_KSETUP_PLANES && VARIANT == 0 && !RELAX_MODE;
-    uint2 kbw[NSIG], ktw = {0u, 0u};
-    if (KSETUP_READ) {
-        load_texel<8 * NSIG>(p.kBasis, x, y, kbw);
-        if (HAS_SPEC)
-            ktw = ld<uint2>(p.kTerms, x, y, 8);
-    }
     Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
@@ -618,7 +607,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
     const NormalCodes ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
-    f3 V = to_viewer(pg.Xv); // (only the PrePass needs it: Blur / PostBlur read the kernel basis)
+    f3 V = to_viewer(pg.Xv);
     // Poisson rotation: per frame for PrePass / PostBlur - the 64 lanes of a wave (16x4 pixels) then gather 16x4-shaped texel
     // groups that coalesce into a few cache lines instead of 64 L1 lookups per load; per 2x2 quad for Blur (decorrelation; the lanes of a quad share cache lines)
     constexpr bool PER_PIXEL = VARIANT == 1;
@@ -659,24 +648,8 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         // SH mode: the SH1 texel rides along with exactly the weights of SH0 (separate IN_*_SH1 plane in the PrePass)
         src1Ps[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec1 : &p.inDiff1) : &inP;
         sum1[sig] = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
-        // the pass-independent part of the set-up: computed here (PrePass), or as the PrePass stored it (taps are placed on the tangent
-        // plane linearised at the centre: KernelUnit::j)
-        KernelUnit ku;
-        if (KSETUP_READ) {
-            const f4 jb = unpack_h4(kbw[sig]), kt = unpack_h4(ktw);
-            ku.j[0] = jb.x, ku.j[1] = jb.y, ku.j[2] = jb.z, ku.j[3] = jb.w;
-            ku.smc = isSpec ? kt.x : 1.0f;
-            ku.angle0 = isSpec ? kt.y : spec_lobe_half_angle(1.0f);
-            ku.roughA = isSpec ? kt.z : 0.0f;
-            ku.hitFactor = isSpec ? kt.w : p.hitFactorDiff;
-        } else {
-            ku = isSpec ? kernel_unit<true>(p, pg, g.z, V, rough) : kernel_unit<false>(p, pg, g.z, V, rough);
-            if (KSETUP_WRITE) { // (stored at once: nothing of it stays live across the tap loop)
-                kbw[sig] = pack_h4({ku.j[0], ku.j[1], ku.j[2], ku.j[3]});
-                if (isSpec)
-                    ktw = pack_h4({ku.smc, ku.angle0, ku.roughA, ku.hitFactor});
-            }
-        }
+        // the pass-independent part of the set-up (taps are placed on the tangent plane linearised at the centre: KernelUnit::j)
+        const KernelUnit ku = isSpec ? kernel_unit<true>(p, pg, g.z, V, rough) : kernel_unit<false>(p, pg, g.z, V, rough);
         float hitNorm = fma_(pg.absZ, p.hp[1], p.hp[0]) * ku.hitFactor;
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
@@ -721,12 +694,6 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         roughB[sig] = -rough * roughA[sig];
         if (TAP)
             roughA[sig] = roughA[sig] * (1.0f / 1023.0f); // applies to the tap's roughness CODE
-    }
-
-    if (KSETUP_WRITE) { // for this frame's Blur / PostBlur
-        store_texel<8 * NSIG>(p.kBasis, x, y, kbw);
-        if (HAS_SPEC)
-            st<uint2>(p.kTerms, x, y, 8, ktw);
     }
 
     // ---- tap loop: ONE software pipeline over the 8 taps of every signal ----------------------------------------------------

@@ -227,9 +227,7 @@ namespace rb { // REBLUR
 enum Perm { GUIDE_A, GUIDE_B, DATA1_A, DATA1_B, HIST, FAST_A, FAST_B, STAB_A, STAB_B };
 enum Trans { TILES, TMP1, TMP2, DATA1_TMP, DATA2, HITTRACK, PREP_D, PREP_S, PREP_D1, PREP_S1, AT_A, AT_B, // PREP_*: PrepareInputs outputs; AT_*: RELAX only
              // REBLUR only: tap texels of Blur / PostBlur (nrd_device.h), _A HistoryFix -> Blur, _B Blur -> PostBlur, one plane per signal
-             TAP_D_A = AT_A, TAP_S_A, TAP_D_B, TAP_S_B,
-             // REBLUR only: the pass-independent kernel set-up of a pixel, PrePass -> Blur, PostBlur (nrd_reblur.hip KernelUnit)
-             KBASIS, KTERMS };
+             TAP_D_A = AT_A, TAP_S_A, TAP_D_B, TAP_S_B };
 } // namespace rb
 namespace sg { // SIGMA
 enum Perm { GUIDE_A, GUIDE_B, HIST_A, HIST_B };
@@ -276,9 +274,6 @@ void describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector<PoolPl
         trans.push_back({"REBLUR::Tap_Spec_A", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
         trans.push_back({"REBLUR::Tap_Diff_B", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
         trans.push_back({"REBLUR::Tap_Spec_B", F::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
-        // kernel set-up of a pixel (PrePass -> Blur, PostBlur): basis 4 x fp16 per signal, roughness terms 4 x fp16 (specular)
-        trans.push_back({"REBLUR::KernelBasis", d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT, 8u * d.nsig, 1});
-        trans.push_back({"REBLUR::KernelTerms", F::RGBA16_SFLOAT, 8, (uint16_t)(d.hasSpec ? 1 : 16)});
     } else if (d.kind == Kind::RELAX) { // same slot order as REBLUR for the shared front half; moments live in the STAB slots
         F fmtRad = d.nsig == 2 ? F::RGBA32_UINT : F::RGBA16_SFLOAT;
         F fmtLum = d.nsig == 2 ? F::RG16_SFLOAT : F::R16_SFLOAT;
@@ -743,11 +738,6 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
             p.tapA[sgl] = TP(rb::TAP_D_A + sgl);
             p.tapB[sgl] = TP(rb::TAP_D_B + sgl);
         }
-    p.kernelSetup = d.kind == Kind::REBLUR ? 1 : 0;
-    if (p.kernelSetup) {
-        p.kBasis = TP(rb::KBASIS);
-        p.kTerms = TP(rb::KTERMS);
-    }
     p.maxASpec = p.maxA;
     p.maxFastASpec = p.maxFastA;
     p.relax = 0;
@@ -767,12 +757,6 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     float n = (float)d.nsig;
     float nr = n * (d.sh ? 2.0f : 1.0f); // radiance texels per pixel (SH mode doubles them)
     float sp = d.hasSpec ? 2.0f : 0.0f;
-    const float ks = 8.0f * n + (d.hasSpec ? 8.0f : 0.0f); // kernel set-up texels: KernelBasis (8 bytes per signal) + KernelTerms (specular)
-    auto push_kernel_setup = [&](std::vector<uint32_t>& list) {
-        list.push_back(T(rb::KBASIS));
-        if (d.hasSpec)
-            list.push_back(T(rb::KTERMS));
-    };
     uint16_t blurHalo = (uint16_t)p.reachBlur, postHalo = (uint16_t)p.reachPost, preHalo = (uint16_t)p.reachPre;
     const float GB = (float)GUIDE_BYTES; // guide texel bytes
     const bool tap = tap_texels(d);
@@ -791,7 +775,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         // PrePass + TemporalAccumulation in one launch (nrd_reblur.hip spatial_pixel<..., FUSED>): TemporalAccumulation reads the PrePass
         // result at its own pixel only, so it stays in registers - Tmp1 is neither written nor read, the guide is fetched once
         Dispatch x{"REBLUR::PrePassTemporalAccumulation", "nrd_reblur_prepass_temporal_accumulation", preHalo,
-                   GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + sp + ks, {}, {}, nullptr};
+                   GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         push_prepass_inputs(d, pm, tb, x.read);
         for (uint32_t r : {P(rb::GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1))})
@@ -799,16 +783,14 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         if (c.mixAvail)
             x.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         x.written = {T(rb::HITTRACK), T(rb::TMP2), P(rb::FAST_A + cur), T(rb::DATA1_TMP), T(rb::DATA2)};
-        push_kernel_setup(x.written);
         x.reprojected = {P(rb::GUIDE_A + (cur ^ 1)), P(rb::HIST), P(rb::FAST_A + (cur ^ 1)), P(rb::DATA1_A + (cur ^ 1))};
         x.launch = [p](hipStream_t st) { launch_reblur_prepass_temporal_accumulation(p, st); };
         d.dispatches.push_back(x);
     } else {
-        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * nr + 8 * nr + sp + ks, {}, {}, nullptr};
+        Dispatch x{"REBLUR::PrePass", "nrd_reblur_prepass", preHalo, GB + 8 * nr + 8 * nr + sp, {}, {}, nullptr};
         x.read = {P(rb::GUIDE_A + cur)};
         push_prepass_inputs(d, pm, tb, x.read);
         x.written = {T(rb::TMP1), T(rb::HITTRACK)};
-        push_kernel_setup(x.written);
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 0, st); };
         d.dispatches.push_back(x);
     }
@@ -842,7 +824,7 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, (tap ? 2 + 16 * n + 16 * n : GB + 2 + 8 * nr + 8 * nr) + ks, {}, {}, nullptr};
+        Dispatch x{"REBLUR::Blur", "nrd_reblur_blur", blurHalo, tap ? 2 + 16 * n + 16 * n : GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
         if (tap) { // the tap texels carry the guide: no guide plane access
             x.read = {P(rb::DATA1_A + cur)};
             push_tap_planes(d, tb, rb::TAP_D_A, x.read);
@@ -853,23 +835,19 @@ void build_reblur(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
             x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP1)};
             x.written = {T(rb::TMP2)};
         }
-        push_kernel_setup(x.read);
         x.own = {P(rb::DATA1_A + cur)};
-        push_kernel_setup(x.own);
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 1, st); };
         d.dispatches.push_back(x);
     }
     {
-        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, (tap ? 2 + 16 * n + 8 * nr : GB + 2 + 8 * nr + 8 * nr) + ks, {}, {}, nullptr};
+        Dispatch x{"REBLUR::PostBlur", "nrd_reblur_post_blur", postHalo, tap ? 2 + 16 * n + 8 * nr : GB + 2 + 8 * nr + 8 * nr, {}, {}, nullptr};
         if (tap) {
             x.read = {P(rb::DATA1_A + cur)};
             push_tap_planes(d, tb, rb::TAP_D_B, x.read);
         } else
             x.read = {P(rb::GUIDE_A + cur), P(rb::DATA1_A + cur), T(rb::TMP2)};
         x.written = {P(rb::HIST)};
-        push_kernel_setup(x.read);
         x.own = {P(rb::DATA1_A + cur)};
-        push_kernel_setup(x.own);
         x.launch = [p](hipStream_t st) { launch_reblur_spatial(p, 2, st); };
         d.dispatches.push_back(x);
     }

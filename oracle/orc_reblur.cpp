@@ -23,9 +23,7 @@ enum Perm { P_GUIDE_A, P_GUIDE_B, P_DATA1_A, P_DATA1_B, P_HIST, P_FAST_A, P_FAST
 enum Trans { T_TILES, T_TMP1, T_TMP2, T_DATA1, T_DATA2, T_HITTRACK, T_PREP_D, T_PREP_S, T_PREP_D1, T_PREP_S1, T_NUM,
              // REBLUR only (RELAX keeps its A-trous ping-pong at these indices): tap texels of Blur / PostBlur, see TapTexel below.
              // _A: HistoryFix -> Blur, _B: Blur -> PostBlur; one plane per signal
-             T_TAP_D_A = T_NUM, T_TAP_S_A, T_TAP_D_B, T_TAP_S_B,
-             // REBLUR only: the pass-independent kernel set-up of a pixel (KernelUnit), PrePass -> Blur, PostBlur
-             T_KBASIS, T_KTERMS };
+             T_TAP_D_A = T_NUM, T_TAP_S_A, T_TAP_D_B, T_TAP_S_B };
 
 const float MAX_ACCUM = 63.0f;
 const float MIN_CONVERGED_RADIUS_SCALE = 0.25f;
@@ -197,8 +195,7 @@ static inline f3 to_viewer(const Consts& c, f3 Xv) {
 // --------------------------------------------------------------------------------------------------
 enum Variant { PRE = 0, BLUR = 1, POST = 2 };
 
-// Kernel set-up of a signal: the part that hangs on the pixel's geometry and roughness only, not on the pass (csrc/nrd_reblur.hip
-// KernelUnit). REBLUR computes it in the PrePass and hands it to Blur / PostBlur as fp16 through the KernelBasis / KernelTerms planes.
+// Kernel set-up of a signal: the part that hangs on the pixel's geometry and roughness only, not on the pass (csrc/nrd_reblur.hip KernelUnit)
 struct KernelUnit {
     float j[4];                           // pixel offsets of the kernel's tangent / bitangent per pixel of blur radius
     float smc, angle0, roughA, hitFactor; // GetSpecMagicCurve(roughness), lobe half angle, 1 / roughness tolerance, hit distance factor
@@ -448,9 +445,6 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
     const bool sh = k.d.sh;
     const bool tap = variant != PRE && tap_texels(k.d); // Blur / PostBlur on tap texels: io.in[sig] (and Blur's io.out[sig]) are tap planes
     const Plane& TILES = k.trans(T_TILES);
-    const bool kernelSetup = k.d.kind == Kind::REBLUR; // PrePass -> Blur, PostBlur (RELAX has no reader)
-    const Plane& KB = k.trans(kernelSetup ? T_KBASIS : T_TILES);
-    const Plane& KT = k.trans(kernelSetup ? T_KTERMS : T_TILES);
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < c.W; x++) {
             // a tile without geometry (ClassifyTiles): PrePass and PostBlur write nothing there - what they would write is read by nobody
@@ -496,24 +490,8 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                     center = rgb_to_ycocg4(center);
                 f4 sum1 = sh ? load_sh1(io, sig, x, y, variant == PRE) : f4{0, 0, 0, 0};
                 const f4 center1 = sum1;
-                // the pass-independent part of the set-up: computed by the PrePass; REBLUR's Blur / PostBlur take what it stored (fp16)
-                KernelUnit ku;
-                if (variant == PRE) {
-                    ku = kernel_unit(c, s, pg, g.z, V, rough, isSpec);
-                    if (kernelSetup) {
-                        st_h4(KB, x, y, {ku.j[0], ku.j[1], ku.j[2], ku.j[3]}, sig * 8);
-                        if (isSpec)
-                            st_h4(KT, x, y, {ku.smc, ku.angle0, ku.roughA, ku.hitFactor}, 0);
-                    }
-                } else {
-                    const f4 jb = ld_h4(KB, x, y, sig * 8);
-                    ku.j[0] = jb.x, ku.j[1] = jb.y, ku.j[2] = jb.z, ku.j[3] = jb.w;
-                    ku.smc = 1.0f, ku.angle0 = spec_lobe_half_angle(1.0f), ku.roughA = 0.0f, ku.hitFactor = reblur_hitdist_factor(hp, 1.0f);
-                    if (isSpec) {
-                        const f4 kt = ld_h4(KT, x, y, 0);
-                        ku.smc = kt.x, ku.angle0 = kt.y, ku.roughA = kt.z, ku.hitFactor = kt.w;
-                    }
-                }
+                // the pass-independent part of the set-up (csrc/nrd_reblur.hip KernelUnit)
+                const KernelUnit ku = kernel_unit(c, s, pg, g.z, V, rough, isSpec);
                 float hitNorm = fma_(pg.absZ, hp[1], hp[0]) * ku.hitFactor;
                 float hitDist = center.w * hitNorm;
                 float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
@@ -1538,9 +1516,6 @@ void reblur_describe(DenoiserState& d, std::vector<PoolPlane>& perm, std::vector
     trans.push_back({"REBLUR::Tap_Spec_A", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
     trans.push_back({"REBLUR::Tap_Diff_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasDiff ? 1 : 16)});
     trans.push_back({"REBLUR::Tap_Spec_B", (uint32_t)nrd::Format::RGBA32_UINT, 16, (uint16_t)(tap && d.hasSpec ? 1 : 16)});
-    // kernel set-up of a pixel (PrePass -> Blur, PostBlur): basis 4 x fp16 per signal, roughness terms 4 x fp16 (specular)
-    trans.push_back({"REBLUR::KernelBasis", (uint32_t)(d.nsig == 2 ? nrd::Format::RGBA32_UINT : nrd::Format::RGBA16_SFLOAT), 8u * d.nsig, 1});
-    trans.push_back({"REBLUR::KernelTerms", (uint32_t)nrd::Format::RGBA16_SFLOAT, 8, (uint16_t)(d.hasSpec ? 1 : 16)});
 }
 
 // the tap planes of the signals present, diffuse first (base = T_TAP_D_A or T_TAP_D_B)
@@ -1563,12 +1538,6 @@ void reblur_build(Instance& I, DenoiserState& d) {
     ReblurReach rr = reblur_reach(s);
     const float GB = (float)GUIDE_BYTES; // guide texel bytes
     const bool tap = tap_texels(d);
-    const float ks = 8.0f * n + (d.hasSpec ? 8.0f : 0.0f); // kernel set-up texels: KernelBasis (8 bytes per signal) + KernelTerms (specular)
-    auto push_kernel_setup = [&](std::vector<uint32_t>& list) {
-        list.push_back(T(T_KBASIS));
-        if (d.hasSpec)
-            list.push_back(T(T_KTERMS));
-    };
     {
         Pass p;
         p.name = "REBLUR::ClassifyTiles";
@@ -1640,7 +1609,7 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PrePassTemporalAccumulation";
         p.kernel = "nrd_reblur_prepass_temporal_accumulation";
         p.haloRows = (uint16_t)rr.pre;
-        p.bytesPerPixel = GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + (d.hasSpec ? 2 : 0) + ks;
+        p.bytesPerPixel = GB + 8 * nr + 8 + GB + 2 + 8 * nr + 2 * n + 8 * nr + 2 * n + 2 + 4 + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
         p.read.insert(p.read.end(), prepassInputs.begin(), prepassInputs.end());
         for (uint32_t r : {P(P_GUIDE_A + (cur ^ 1)), enc_slot(RT::IN_MV), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))})
@@ -1648,7 +1617,6 @@ void reblur_build(Instance& I, DenoiserState& d) {
         if (I.common.isDisocclusionThresholdMixAvailable)
             p.read.push_back(enc_slot(RT::IN_DISOCCLUSION_THRESHOLD_MIX));
         p.written = {T(T_HITTRACK), T(T_TMP2), P(P_FAST_A + cur), T(T_DATA1), T(T_DATA2)};
-        push_kernel_setup(p.written);
         p.reprojected = {P(P_GUIDE_A + (cur ^ 1)), P(P_HIST), P(P_FAST_A + (cur ^ 1)), P(P_DATA1_A + (cur ^ 1))};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             if (y1 <= y0)
@@ -1667,11 +1635,10 @@ void reblur_build(Instance& I, DenoiserState& d) {
         p.name = "REBLUR::PrePass";
         p.kernel = "nrd_reblur_prepass";
         p.haloRows = (uint16_t)rr.pre;
-        p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0) + ks;
+        p.bytesPerPixel = GB + 8 * nr + 8 * nr + (d.hasSpec ? 2 : 0);
         p.read = {P(P_GUIDE_A + cur)};
         p.read.insert(p.read.end(), prepassInputs.begin(), prepassInputs.end());
         p.written = {T(T_TMP1), T(T_HITTRACK)};
-        push_kernel_setup(p.written);
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) { prepass_rows(I, d, c, y0, y1, &I.trans[d.transBase + T_TMP1]); };
         d.passes.push_back(p);
     }
@@ -1725,9 +1692,6 @@ void reblur_build(Instance& I, DenoiserState& d) {
             p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP1)};
             p.written = {T(T_TMP2)};
         }
-        p.bytesPerPixel += ks;
-        push_kernel_setup(p.read);
-        push_kernel_setup(p.own);
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};
             const int sb = d.sh ? 16 : 8; // bytes per signal in the radiance texels: SH0 (+ SH1 at +8 in SH mode)
@@ -1758,9 +1722,6 @@ void reblur_build(Instance& I, DenoiserState& d) {
             p.bytesPerPixel = GB + 2 + 8 * nr + 8 * nr;
             p.read = {P(P_GUIDE_A + cur), P(P_DATA1_A + cur), T(T_TMP2)};
         }
-        p.bytesPerPixel += ks;
-        push_kernel_setup(p.read);
-        push_kernel_setup(p.own);
         p.written = {P(P_HIST)};
         p.run = [](Instance& I, DenoiserState& d, const Consts& c, int y0, int y1) {
             Ctx k{I, d, c, (int)(d.frameCounter & 1)};

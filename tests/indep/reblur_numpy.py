@@ -161,10 +161,9 @@ def exp2_poly3(x):
 
 
 def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_index, denoising_range, s, exp_hit_weight=False,
-            angle_normal_weight=False, no_reach=False, f32_guide=False, one_step_sqrt=False, poly3_exp2=False, arc_normal_weight=False, extras=None):
+            angle_normal_weight=False, no_reach=False, f32_guide=False, one_step_sqrt=False, poly3_exp2=False, arc_normal_weight=False):
     """REBLUR_DIFFUSE_SPECULAR PrePass of one frame (perspective, no jitter, radiance mode, full frame). `s`: dict of the
-    ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16).
-    extras (dict): receives "basis" [H, W, 2, 4] and "terms" [H, W, 4] (float64) - what the PrePass stores for Blur / PostBlur."""
+    ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16)."""
     H, W = viewz.shape
     M = np.asarray(view_to_clip, np.float64)
     sgn = 1.0 if M[11] > 0 else -1.0
@@ -223,18 +222,6 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
             B2 = np.cross(Dr, T2)
             T2 = T2 * ((0.5 + 0.5 * rough)[..., None] + (1.0 - (0.5 + 0.5 * rough)[..., None]) * NoD)
             T, B = np.where(skewed[..., None], T2, T), np.where(skewed[..., None], B2, B)
-        # what the PrePass hands to Blur / PostBlur (round 6: REBLUR::KernelBasis / KernelTerms, fp16): the kernel basis projected to pixel offsets
-        # per PIXEL of blur radius - the general Jacobian above applied to the basis scaled to the world size of one pixel at this depth
-        # (the build evaluates a closed form in which the depth has cancelled: an independent derivation of the same four numbers) - and the
-        # specular signal's roughness-only terms
-        pw = (unproject * absz)[..., None]
-        Tu, Bu = T * pw, B * pw
-        if extras is not None:
-            extras.setdefault("basis", np.zeros((H, W, 2, 4)))[:, :, sig] = np.stack([ju * (pj[0] * Tu[..., 0] + kuz * Tu[..., 2]), jv * (pj[1] * Tu[..., 1] + kvz * Tu[..., 2]),
-                                                                                   ju * (pj[0] * Bu[..., 0] + kuz * Bu[..., 2]), jv * (pj[1] * Bu[..., 1] + kvz * Bu[..., 2])], -1)
-            if is_spec:
-                extras["terms"] = np.stack([smc, np.arctan(3.0 * np.clip(rough, 0, 1) ** 2), 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1)),
-                                            1.0 + (hp[2] - 1.0) * np.exp2(hp[3] * rough * rough)], -1)
         T, B = T * world_radius[..., None], B * world_radius[..., None]
         jtx, jty = ju * (pj[0] * T[..., 0] + kuz * T[..., 2]), jv * (pj[1] * T[..., 1] + kvz * T[..., 2])
         jbx, jby = ju * (pj[0] * B[..., 0] + kuz * B[..., 2]), jv * (pj[1] * B[..., 1] + kvz * B[..., 2])
@@ -300,14 +287,12 @@ def normal_weight(cosa, normal_w, upstream):
     return smoothstep01(1.0 - 2.0 * np.clip(1.0 - cosa, 0, 1) * normal_w * normal_w)
 
 
-def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_view, frame_index, denoising_range, s, upstream=False, kbasis=None, kterms=None):
+def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_view, frame_index, denoising_range, s, upstream=False):
     """REBLUR_DIFFUSE_SPECULAR Blur (post = False) / PostBlur (post = True) of one frame on tap texels: `sig_in` [H, W, 2, 4] fp16 = the
     signal halves of the tap texels the pass gathers (HistoryFix's for Blur, Blur's for PostBlur), `speeds` [H, W] uint16 = Data1 (diffuse
     | specular accumulation speed in quarter frames). Differences from the PrePass: the radius comes from the accumulation speed
     (converged pixels blur less, PostBlur twice as far), the normal-weight lobe narrows with it, Blur rotates its disk per 2x2 pixel
     quad (PostBlur per frame), a rejected tap enters with weight 0, no hit-distance tracking. Returns [H, W, 2, 4] fp16.
-    Round 6: the kernel basis (pixel offsets per pixel of radius) and the specular signal's roughness-only terms are INPUTS - `kbasis`
-    [H, W, 2, 4] / `kterms` [H, W, 4] fp16, the planes the PrePass stored (REBLUR::KernelBasis / KernelTerms).
     upstream = True: the DEFAULT build flavour - Blur rotates per PIXEL, hit-distance weight exp(-3 |x|), normal weight on the chord."""
     H, W = viewz.shape
     M = np.asarray(view_to_clip, np.float64)
@@ -351,22 +336,35 @@ def blur_pass(post, viewz, packed_nr, sig_in, speeds, view_to_clip, world_to_vie
         center = plane.astype(np.float64)
         rough = rough_g if is_spec else np.ones_like(rough_g)
         min_mat = s["minMaterialForSpecular"] if is_spec else s["minMaterialForDiffuse"]
-        kt = kterms.astype(np.float64)
-        hn = (hp[0] + absz * hp[1]) * (kt[..., 3] if is_spec else 1.0 + (hp[2] - 1.0) * np.exp2(hp[3]))
+        hn = hitdist_norm(absz, hp, rough)
         hdf = np.clip(center[..., 3] * hn / frustum, 0, 1)
         non_lin = 1.0 / (1.0 + A_all[sig])
-        smc = kt[..., 0] if is_spec else np.ones_like(rough)
+        smc = spec_magic_curve(rough) if is_spec else np.ones_like(rough)
         r = s["maxBlurRadius"] * (MIN_CONVERGED_RADIUS_SCALE + (1.0 - MIN_CONVERGED_RADIUS_SCALE) * non_lin) * (hdf + (1.0 - hdf) * non_lin) + s["minBlurRadius"]
         r = r * (POST_BLUR_RADIUS_SCALE if post else 1.0) * smc
         radius = r if s["maxBlurRadius"] != 0.0 else np.zeros_like(r)
         active = radius > 0
-        ju_ = kbasis[:, :, sig].astype(np.float64) * radius[..., None]  # pixel offsets of the tangent / bitangent at this radius
-        jtx, jty, jbx, jby = ju_[..., 0], ju_[..., 1], ju_[..., 2], ju_[..., 3]
-        angle = (kt[..., 1] if is_spec else np.arctan(3.0)) * (s["lobeAngleFraction"] + (1.0 - s["lobeAngleFraction"]) * non_lin)
+        world_radius = radius * unproject * absz
+        T, B = basis(Nv)
+        if is_spec:
+            NoV = (Nv * V).sum(-1, keepdims=True)
+            R = Nv * 2.0 * NoV - V
+            D = normalize(Nv + (R - Nv) * spec_dominant_factor(rough)[..., None])
+            NoD = (Nv * D).sum(-1, keepdims=True)
+            skewed = (NoD[..., 0] < 0.999) & (rough < 0.95)
+            Dr = Nv * 2.0 * NoD - D
+            T2 = normalize(np.cross(Nv, Dr))
+            B2 = np.cross(Dr, T2)
+            T2 = T2 * ((0.5 + 0.5 * rough)[..., None] + (1.0 - (0.5 + 0.5 * rough)[..., None]) * NoD)
+            T, B = np.where(skewed[..., None], T2, T), np.where(skewed[..., None], B2, B)
+        T, B = T * world_radius[..., None], B * world_radius[..., None]
+        jtx, jty = ju * (pj[0] * T[..., 0] + kuz * T[..., 2]), jv * (pj[1] * T[..., 1] + kvz * T[..., 2])
+        jbx, jby = ju * (pj[0] * B[..., 0] + kuz * B[..., 2]), jv * (pj[1] * B[..., 1] + kvz * B[..., 2])
+        angle = np.arctan(3.0 * np.clip(rough, 0, 1) ** 2) * (s["lobeAngleFraction"] + (1.0 - s["lobeAngleFraction"]) * non_lin)
         normal_w = 1.0 / np.maximum(angle, NORMAL_ANGLE_MIN)
         hitA = 1.0 / (1e-6 + (1.0 - 1e-6) * np.minimum(non_lin, smc))
         hitB = -center[..., 3] * hitA
-        roughA = kt[..., 2]
+        roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
         roughB = -rough * roughA
         acc, wsum = center.copy(), np.ones((H, W))
         for t in range(8):

@@ -42,9 +42,8 @@ def test_emulated_dispatch_lists_match(pkg, api, oracle, emulated):
     # REBLUR_DIFFUSE_SPECULAR algorithmic bytes / pixel / frame: SURVEY.md 8d estimated ~352 with 8-byte guides (this build's guide
     # texel since round 3): 408 of round 2 + 16 (HistoryFix writes tap texels) + 16 (Blur writes them; its guide read is gone)
     # - 6 x 8 (the 8-byte guide texel) = 392 with separate passes; the fused PrePass + TemporalAccumulation dispatch neither writes nor
-    # reads Tmp1 (-32), fetches the guide once (-8) and does not read the hit tracker back (-2): 350. Round 6: the PrePass writes the
-    # kernel set-up of a pixel (KernelBasis 16 + KernelTerms 8 bytes), Blur and PostBlur read it instead of recomputing it: + 3 x 24 = 422
-    assert 418 < total < 426
+    # reads Tmp1 (-32), fetches the guide once (-8) and does not read the hit tracker back (-2): 350
+    assert 346 < total < 354
 
 
 @pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["REBLUR_DIFFUSE"], ["REBLUR_SPECULAR"]])
