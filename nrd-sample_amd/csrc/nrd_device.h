@@ -799,6 +799,10 @@ NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE
 #ifndef NRD_WAVE_ALL
 #define NRD_WAVE_ALL(pred) (__builtin_amdgcn_ballot_w64(!(pred)) == 0ull)
 #endif
+// two values the optimiser must treat as unknown from here on (an identity: no instruction)
+#ifndef NRD_OPAQUE2
+#define NRD_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#endif
 // The kernel arguments once more, as values the compiler cannot tie to the copies it already holds: a second-half-of-the-kernel reads its
 // constants with fresh s_loads where it needs them instead of keeping the first half's wide loads alive in between (the fused PrePass +
 // TemporalAccumulation kernel held 32 SGPRs of camera matrices across its tap loop for the reprojection behind it and ran out of scalar

@@ -773,12 +773,13 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig]) : uint2{0u, 0u};
             }
         };
+        float cxq = cx, cyq = cy; // (the fast copy of the loop reads the centre through these: see pipeline)
         auto issue = [&](auto fastTag, const int T) {
             const int sig = sig_of(T);
             float ox, oy;
             tap_offset(tap_of(T), ox, oy);
-            const float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], cx)));
-            const float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], cy)));
+            const float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], decltype(fastTag)::value ? cxq : cx)));
+            const float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], decltype(fastTag)::value ? cyq : cy)));
             gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
             gather(fastTag, T, fpx, fpy);
         };
@@ -859,6 +860,10 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             accumulate(T, sv, w, valid);
         };
         auto pipeline = [&](auto fastTag) {
+            // (the two copies of the loop must stay two: left alone, the compiler hoists what their heads have in common - the positions of
+            // ALL taps - in front of the branch and holds it in registers: the fast copy takes the centre through an opaque identity)
+            if (decltype(fastTag)::value)
+                NRD_OPAQUE2(cxq, cyq);
 #pragma unroll
             for (int T = 0; T < DEPTH; T++)
                 issue(fastTag, T);

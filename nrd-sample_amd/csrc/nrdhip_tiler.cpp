@@ -109,7 +109,8 @@ struct nrdhip_tiler {
     // round 5: six groups per REBLUR frame, each queued IN FRONT of the next dispatch's strips-first exchange on the in-order side stream,
     // put 13 latencies on a frame's critical path where 7 belong (profiles/r05_exchange_overlap_solo.json) - and are awaited by the SAME
     // list's next call, right before its first dispatch that reads previous-frame state: another list's call (SIGMA, then REBLUR, then
-    // REFERENCE inside one frame) does not wait for them. One event per identifier list.
+    // REFERENCE inside one frame) does not wait for them unless it shares a denoiser with the sender (wait_deferred_sharing). One event per
+    // identifier list, at most 16 lists (deferred_slot).
     struct DeferredSlot {
         std::vector<uint32_t> ids;
         hipEvent_t ev = nullptr;
@@ -318,8 +319,17 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
             return fail(T, INVALID, std::string(d[i].name) + " reads " + std::to_string(d[i].halo_rows) + " rows beyond its band, the band stores " +
                                         std::to_string(T.halo) + ": recreate the bands with nrdhip_required_halo() rows");
     }
-    if (T.planIds == std::vector<uint32_t>(ids, ids + n) && T.planSig == sig)
+    // the kernels must not trust previous-frame rows the plan never refreshes: the instance is told which local rows are current (owned
+    // rows +- reprojRows; a footprint beyond them is rejected instead of being read from stale halo rows). Applied on EVERY call, cached
+    // plan or not (the window is state of the instance - another caller, or a tiler before this one, may have moved it)
+    auto apply_window = [&]() -> int {
+        int32_t band[5];
+        if (nrdhip_get_band(T.inst, band) != 0 || nrdhip_set_history_rows(T.inst, band[2] - (int32_t)T.reprojRows, (uint32_t)band[3] + 2u * T.reprojRows) != 0)
+            return fail(T, FAILURE, "nrdhip_set_history_rows");
         return 0;
+    };
+    if (T.planIds == std::vector<uint32_t>(ids, ids + n) && T.planSig == sig)
+        return apply_window();
     T.plan.assign(count, PlanEntry{});
     auto has = [](const uint32_t* v, uint32_t num, uint32_t code) { return std::find(v, v + num, code) != v + num; };
     // Rows of previous-frame state a band needs beyond its own: the motion allowance the stored halo leaves on top of the widest spatial
@@ -346,13 +356,8 @@ int build_plan(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
         reproj = provable ? std::min<uint32_t>(T.halo, T.halo - std::min(maxReach, T.halo) + 2u) : T.halo;
     }
     T.reprojRows = reproj;
-    {
-        // the kernels must not trust previous-frame rows the plan below never refreshes: tell the instance which local rows are current
-        // (owned rows +- reproj); a footprint beyond them is rejected instead of being read from stale halo rows
-        int32_t band[5];
-        if (nrdhip_get_band(T.inst, band) != 0 || nrdhip_set_history_rows(T.inst, band[2] - (int32_t)reproj, (uint32_t)band[3] + 2u * reproj) != 0)
-            return fail(T, FAILURE, "nrdhip_set_history_rows");
-    }
+    if ((r = apply_window()) != 0)
+        return r;
     // how far dispatch j reads into plane `code` (read_rows: 0 = own pixel, N = spatial footprint, NRDHIP_READ_REPROJECTED)
     auto reach_into = [&](uint32_t j, uint32_t code) -> uint32_t {
         for (uint32_t k = 0; k < d[j].read_num; k++)
@@ -395,10 +400,35 @@ int wait_deferred(nrdhip_tiler& T, nrdhip_tiler::DeferredSlot& slot, hipStream_t
     }
     return 0;
 }
-nrdhip_tiler::DeferredSlot* deferred_slot(nrdhip_tiler& T, const uint32_t* ids, uint32_t n) {
+// Every pending group of a list that shares a denoiser with `ids` (a denoiser may appear in two different lists - [REBLUR] one
+// frame, [REBLUR, SIGMA] the next, or the same identifiers in another order - and ITS permanent rows are what must have arrived, whatever
+// list sent them): the exact list is the common case, any intersection the rule
+int wait_deferred_sharing(nrdhip_tiler& T, const uint32_t* ids, uint32_t n, hipStream_t stream) {
+    for (auto& s : T.deferred) {
+        if (!s.pending)
+            continue;
+        bool shares = false;
+        for (uint32_t i = 0; i < n && !shares; i++)
+            shares = std::find(s.ids.begin(), s.ids.end(), ids[i]) != s.ids.end();
+        if (shares)
+            if (int r = wait_deferred(T, s, stream))
+                return r;
+    }
+    return 0;
+}
+nrdhip_tiler::DeferredSlot* deferred_slot(nrdhip_tiler& T, const uint32_t* ids, uint32_t n, hipStream_t stream) {
     for (auto& s : T.deferred)
         if (s.ids.size() == n && std::equal(s.ids.begin(), s.ids.end(), ids))
             return &s;
+    if (T.deferred.size() >= 16) { // a caller that keeps inventing lists: drain and start over instead of growing one event per list for ever
+        for (auto& s : T.deferred) {
+            if (wait_deferred(T, s, stream))
+                return nullptr;
+            if (s.ev)
+                (void)hipEventDestroy(s.ev);
+        }
+        T.deferred.clear();
+    }
     nrdhip_tiler::DeferredSlot s;
     s.ids.assign(ids, ids + n);
     if (!T.hostOrdered() && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess)
@@ -515,6 +545,8 @@ NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     if (!T)
         return;
     TilerDeviceScope scope(*T);
+    if (T->inst && T->world > 1)
+        (void)nrdhip_set_history_rows(T->inst, 0, 0); // the instance outlives its tiler: every stored row is current again
     if (T->comm)
         g_rccl.CommDestroy(T->comm);
     if (T->commStream)
@@ -573,7 +605,7 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
     int r = build_plan(*T, ids, n);
     if (r)
         return r;
-    nrdhip_tiler::DeferredSlot* slot = deferred_slot(*T, ids, n);
+    nrdhip_tiler::DeferredSlot* slot = deferred_slot(*T, ids, n, st);
     if (!slot)
         return fail(*T, FAILURE, "hipEventCreate");
     const bool up = T->rank > 0, down = T->rank < T->world - 1;
@@ -581,7 +613,7 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
     for (uint32_t i = 0; i < T->plan.size(); i++) {
         // the rows THIS list sent behind its previous call must have arrived before its first reader of previous-frame state runs
         // (the dispatches in front of it - ClassifyTiles - run while they are still travelling)
-        if (i == T->firstPrevRead && (r = wait_deferred(*T, *slot, st)) != 0)
+        if (i == T->firstPrevRead && (r = wait_deferred_sharing(*T, ids, n, st)) != 0)
             return r;
         const PlanEntry& e = T->plan[i];
         uint32_t strip = 0;
@@ -627,7 +659,7 @@ NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* T, const uint32_t* ids, uint32
         }
         laterAll.insert(laterAll.end(), e.later.begin(), e.later.end());
     }
-    if (T->firstPrevRead >= T->plan.size() && (r = wait_deferred(*T, *slot, st)) != 0) // (a list without a reader of previous-frame state)
+    if (T->firstPrevRead >= T->plan.size() && (r = wait_deferred_sharing(*T, ids, n, st)) != 0) // (a list without a reader of previous-frame state)
         return r;
     if (!laterAll.empty()) { // ONE group behind the last dispatch: nothing of it is read before this list's next call
         std::vector<Op> lops;

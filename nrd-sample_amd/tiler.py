@@ -430,7 +430,9 @@ class Tiler:
     def finish(self, ids=None):
         """wait for the exchanges still in flight (rows only the next frame reads): all of them, or (`ids`) those the dispatch list `ids` sent
         behind its previous call - another list's call inside the same frame (SIGMA, then REBLUR, then REFERENCE) does not wait for them"""
-        keys = list(self._deferred) if ids is None else [tuple(ids)]
+        # (`ids`: every list that SHARES a denoiser with it - the same denoiser may appear in two lists, [REBLUR] one frame, [REBLUR, SIGMA] the
+        # next, and its permanent rows must have arrived whichever list sent them: csrc/nrdhip_tiler.cpp wait_deferred_sharing)
+        keys = list(self._deferred) if ids is None else [k for k in list(self._deferred) if set(k) & set(ids)]
         for k in keys:
             for w in self._deferred.pop(k, []):
                 w.wait()
