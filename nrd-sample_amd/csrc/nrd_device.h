@@ -794,15 +794,6 @@ NRD_DEV uint32_t ld_tile_u8(const PlaneRef& P, int tx, int ty) { return NRD_TILE
 #ifndef NRD_SCALAR_U32 // (the host emulation of the tests reads the plain word)
 #define NRD_SCALAR_U32(ptr) (*(const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(ptr))
 #endif
-// true when the predicate holds on every active lane of the wave (a scalar: the branch on it is wave-uniform). The host emulation of the
-// tests takes the lane's own predicate - which runs BOTH sides of such a branch through the bit-exactness tests, lane by lane.
-#ifndef NRD_WAVE_ALL
-#define NRD_WAVE_ALL(pred) (__builtin_amdgcn_ballot_w64(!(pred)) == 0ull)
-#endif
-// two values the optimiser must treat as unknown from here on (an identity: no instruction)
-#ifndef NRD_OPAQUE2
-#define NRD_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#endif
 // The kernel arguments once more, as values the compiler cannot tie to the copies it already holds: a second-half-of-the-kernel reads its
 // constants with fresh s_loads where it needs them instead of keeping the first half's wide loads alive in between (the fused PrePass +
 // TemporalAccumulation kernel held 32 SGPRs of camera matrices across its tap loop for the reprojection behind it and ran out of scalar

@@ -744,18 +744,12 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 oy = VARIANT == 0 ? p.tapsPre[t][1] : p.tapsPost[t][1];
             }
         };
-        auto gather = [&](auto fastTag, const int T, const float fpx, const float fpy) {
+        auto gather = [&](const int T, const float fpx, const float fpy) {
             const int sig = sig_of(T);
-            int px, gpy;
-            if constexpr (decltype(fastTag)::value) { // every tap of the wave is inside its window (allInside below): no clamp, no test
-                inWin[T] = true;
-                px = (int)fpx, gpy = (int)fpy;
-            } else {
-                // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
-                const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
-                inWin[T] = (cxf == fpx) & (cyf == fpy);
-                px = (int)cxf, gpy = (int)cyf;
-            }
+            // inside the (never empty) window <=> clamping leaves the position unchanged; NaN positions compare unequal
+            const float cxf = __builtin_amdgcn_fmed3f(fpx, loXf, hiXf), cyf = __builtin_amdgcn_fmed3f(fpy, loYf, hiYf);
+            inWin[T] = (cxf == fpx) & (cyf == fpy);
+            const int px = (int)cxf, gpy = (int)cyf;
             if constexpr (TAP) { // ONE gather: {guide part | signal}
                 graw[T] = ldb<uint4>(srcB[sig], px, gpy, 16);
                 return;
@@ -773,15 +767,14 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 sraw1[T] = SH ? ldb<uint2>(src1B[sig], px, gpy, srcBpt, srcOffs[sig]) : uint2{0u, 0u};
             }
         };
-        float cxq = cx, cyq = cy; // (the fast copy of the loop reads the centre through these: see pipeline)
-        auto issue = [&](auto fastTag, const int T) {
+        auto issue = [&](const int T) {
             const int sig = sig_of(T);
             float ox, oy;
             tap_offset(tap_of(T), ox, oy);
-            const float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], decltype(fastTag)::value ? cxq : cx)));
-            const float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], decltype(fastTag)::value ? cyq : cy)));
+            const float fpx = __builtin_floorf(fma_(ox, jtx[sig], fma_(oy, jbx[sig], cx)));
+            const float fpy = __builtin_floorf(fma_(ox, jty[sig], fma_(oy, jby[sig], cy)));
             gaT[T] = fma_(pg.gax, fpx, fma_(pg.gay, fpy, pg.ga0));
-            gather(fastTag, T, fpx, fpy);
+            gather(T, fpx, fpy);
         };
         // a tap's texels -> its guide fields and its signal
         auto decode = [&](const int T, Guide& gs, f4& sv) {
@@ -811,14 +804,10 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         };
         auto accumulate = [&](const int T, const f4 sv, float w, const bool valid) {
             const int sig = sig_of(T);
-            // A rejected tap enters with weight 0 - one select. Blur / PostBlur read internal planes (always finite); the PrePass reads
-            // caller-owned inputs (garbage allowed on sky / outside the rect): there the texel of a rejected tap was zeroed before it was
-            // decoded (consume), so NaN / Inf never meet the weight 0 (round 6: one straight-line block per tap in the PrePass as well -
-            // five selects and the branch the compiler formed around them less)
-#ifndef NRD_PRE_STRAIGHT // 0 (timing only): the PrePass selects a rejected tap out component by component, as rounds 1-5 did
-#define NRD_PRE_STRAIGHT 1
-#endif
-            if (VARIANT == 0 && !NRD_PRE_STRAIGHT) {
+            if (VARIANT == 0) {
+                // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): a rejected tap is
+                // selected out component by component (a straight-line form - the texel of a rejected tap zeroed before it is decoded, one
+                // select on the weight - measured +0.2 % on the headline and -2 % on RELAX SH's PrePass: tools/variants/window_fast_path_prepass_straight.patch)
                 f4 acc = fma4(sv, w, sum[sig]);
                 sum[sig] = {valid ? acc.x : sum[sig].x, valid ? acc.y : sum[sig].y, valid ? acc.z : sum[sig].z, valid ? acc.w : sum[sig].w};
                 if (SH) {
@@ -826,29 +815,23 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                     sum1[sig] = {valid ? acc1.x : sum1[sig].x, valid ? acc1.y : sum1[sig].y, valid ? acc1.z : sum1[sig].z, valid ? acc1.w : sum1[sig].w};
                 }
                 wsum[sig] = valid ? wsum[sig] + w : wsum[sig];
+                // tracked hit distance: the smallest hit distance CODE among the taps that count (the scale is applied once, at the end: a
+                // product with a positive constant is monotone under rounding, so the minimum commutes with it exactly)
                 minHit[sig] = (valid & (w > 0.0f)) ? fmin2(minHit[sig], sv.w) : minHit[sig];
-                return;
+            } else {
+                // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0 - one select
+                w = valid ? w : 0.0f;
+                sum[sig] = fma4(sv, w, sum[sig]);
+                if (SH)
+                    sum1[sig] = fma4(unpack_h4(sraw1[T]), w, sum1[sig]);
+                wsum[sig] += w;
             }
-            w = valid ? w : 0.0f;
-            sum[sig] = fma4(sv, w, sum[sig]);
-            if (SH)
-                sum1[sig] = fma4(unpack_h4(sraw1[T]), w, sum1[sig]);
-            wsum[sig] += w;
-            if (VARIANT == 0) // tracked hit distance: the smallest hit distance CODE among the taps that count (the scale is applied once, at the end)
-                minHit[sig] = w > 0.0f ? fmin2(minHit[sig], sv.w) : minHit[sig];
         };
         auto consume = [&](const int T) {
             const int sig = sig_of(T), t = tap_of(T);
             const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
             Guide gs;
             f4 sv;
-            if (VARIANT == 0 && NRD_PRE_STRAIGHT) { // the validity of a PrePass tap hangs on its guide texel only: decided first, and a rejected tap's signal texels read as zeros
-                const Guide gq = decode_guide(uint2{graw[T].x, graw[T].y}, c.denoisingRange);
-                const bool ok = tap_valid(T, gq);
-                sraw[T] = uint2{ok ? sraw[T].x : 0u, ok ? sraw[T].y : 0u};
-                if (SH)
-                    sraw1[T] = uint2{ok ? sraw1[T].x : 0u, ok ? sraw1[T].y : 0u};
-            }
             decode(T, gs, sv);
             const bool valid = tap_valid(T, gs);
             float w = g_poisson8[t][2];
@@ -859,46 +842,22 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             w *= lerpf(p.minHitDistanceWeight, 1.0f, exp_weight_prescaled(fma_(sv.w, hitA[sig], hitB[sig])));
             accumulate(T, sv, w, valid);
         };
-        auto pipeline = [&](auto fastTag) {
-            // (the two copies of the loop must stay two: left alone, the compiler hoists what their heads have in common - the positions of
-            // ALL taps - in front of the branch and holds it in registers: the fast copy takes the centre through an opaque identity)
-            if (decltype(fastTag)::value)
-                NRD_OPAQUE2(cxq, cyq);
+        // (round 6: a second copy of the loop without the window test for waves whose taps are provably inside - 4 of ~66 instructions per
+        // tap - measured +0.4 % at best and costs Blur 9 registers: profiles/r06_ab_window_fast_path.txt, tools/variants/window_fast_path_prepass_straight.patch)
+        {
 #pragma unroll
             for (int T = 0; T < DEPTH; T++)
-                issue(fastTag, T);
+                issue(T);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int T = 0; T < NT; T++) {
                 if (T + DEPTH < NT)
-                    issue(fastTag, T + DEPTH);
+                    issue(T + DEPTH);
                 __builtin_amdgcn_sched_barrier(0);
                 consume(T);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        // Round 6: the window test of a tap (two clamps, two compares) is provably true for most waves - every lane at least `reach` pixels
-        // from the frame's edges and from the first / last held row, and every kernel smaller than the reach: |offset| <= |J column| (the disk
-        // has radius 1), floor() and the roundings of the three fma stay below 1 pixel - so such a wave runs a copy of the tap loop without
-        // it (same results by construction; 4 of ~66 instructions per tap). Everybody else - frame borders, kernels stretched beyond the
-        // reach at grazing view angles - takes the loop with the test.
-#ifndef NRD_WINDOW_FAST_PATH
-#define NRD_WINDOW_FAST_PATH 0
-#endif
-        bool allInside = false;
-        if (NRD_WINDOW_FAST_PATH) {
-            float b2 = 0.0f; // largest squared column length of any signal's Jacobian (rows: x, y)
-#pragma unroll
-            for (int sig = 0; sig < NSIG; sig++)
-                b2 = fmax2(b2, fmax2(fma_(jtx[sig], jtx[sig], jbx[sig] * jbx[sig]), fma_(jty[sig], jty[sig], jby[sig] * jby[sig])));
-            const float rin = (float)(reach - 1);
-            const bool inside = (b2 <= rin * rin) & (loX == x - reach) & (hiX == x + reach) & (loY == gy0 - reach) & (hiY == gy0 + reach);
-            allInside = NRD_WAVE_ALL(inside);
         }
-        if (allInside)
-            pipeline(std::true_type{});
-        else
-            pipeline(std::false_type{});
     }
     uint2 outw[RBPT / 8];
 #pragma unroll

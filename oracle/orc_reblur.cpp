@@ -540,18 +540,20 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         const int loX = std::max(x - io.reach, 0), hiX = std::min(x + io.reach, c.W - 1);
                         const int loY = std::max(gy0 - io.reach, std::max(c.yOff, 0)), hiY = std::min(gy0 + io.reach, std::min(c.yOff + c.resH, c.H) - 1);
                         bool valid = fpx >= (float)loX && fpx <= (float)hiX && fpy >= (float)loY && fpy <= (float)hiY;
-                        // A rejected tap enters with weight 0, its texel fetched at the position clamped into the window - no per-component
-                        // select in the kernels. Blur / PostBlur read internal planes (always finite); the PrePass reads caller-owned inputs
-                        // (garbage allowed on sky / outside the rect): there a rejected tap's signal texels read as zeros.
+                        // PrePass reads caller-owned inputs (garbage allowed on sky / outside the rect): rejected taps are skipped.
+                        // Blur / PostBlur read internal planes (always finite): a rejected tap enters with weight 0, its texel
+                        // fetched at the position clamped into the window - no per-component select in the kernels.
+                        if (variant == PRE && !valid)
+                            continue;
                         int px = (int)clampf(fpx, (float)loX, (float)hiX), py = (int)clampf(fpy, (float)loY, (float)hiY) - c.yOff;
                         TapTexel tt = {};
                         if (tap)
                             tt = ld_tap(*io.in[sig], px, py);
                         Guide gs = tap ? unpack_tap_guide(tt.w0, tt.w1, c.denoisingRange) : load_guide(G, px, py, c.denoisingRange);
                         valid = valid && !gs.sky && !material_mismatch(g.mat, gs.mat, minMat);
-                        f4 sv = tap ? tap_signal(tt) : load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
                         if (variant == PRE && !valid)
-                            sv = {0, 0, 0, 0};
+                            continue;
+                        f4 sv = tap ? tap_signal(tt) : load_signal(*io.in[sig], px, py, io.inOff[sig], occIn);
                         if (relaxIn && !RELAX_LINEAR_RGB)
                             sv = rgb_to_ycocg4(sv);
                         float w = 0.0f;
@@ -568,7 +570,7 @@ void spatial_filter(Ctx& k, Variant variant, const SpatialIO& io, int y0, int y1
                         }
                         sum = fma4(sv, w, sum);
                         if (sh)
-                            sum1 = fma4((variant == PRE && !valid) ? f4{0, 0, 0, 0} : load_sh1(io, sig, px, py, variant == PRE), w, sum1);
+                            sum1 = fma4(load_sh1(io, sig, px, py, variant == PRE), w, sum1);
                         wsum += w;
                         if (w > 0.0f)
                             minHitW = fmin2(minHitW, sv.w);

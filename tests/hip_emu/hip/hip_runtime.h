@@ -47,8 +47,6 @@
 #define NRD_PIN_PLANES3(A, B, C) ((void)0)
 #define NRD_PIN_PLANES4(A, B, C, D) ((void)0)
 #define NRD_PIN_PLANES 1
-#define NRD_OPAQUE2(a, b) ((void)0) // nrd_device.h: values hidden from the optimiser (an identity)
-#define NRD_WAVE_ALL(pred) (pred) // nrd_device.h: wave-uniform fast paths are taken lane by lane here (both sides get tested)
 #define NRD_RELOAD_ARGS(T, p, q) const T& q = (p) // nrd_device.h: the kernel arguments read afresh (scalar register pressure)
 #define NRD_SCALAR_U32(ptr) (*(const uint32_t*)(ptr)) // nrd_device.h: a dword through the scalar data path
 #define __shared__ static
