@@ -15,6 +15,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -474,6 +475,16 @@ Params directed(Params q, bool reverse) {
     return q;
 }
 
+// a stream capture in progress on `st` - the library's own (NRDHIP_FLAG_GRAPH) or the caller's: no allocation, no copy may be issued
+bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return status != hipStreamCaptureStatusNone;
+}
+
 // ClassifyTiles' flags in launch order for the passes behind it (FrameConsts::tileFlags): usable when those passes launch over the grid
 // ClassifyTiles runs on (one instance holding the whole frame; a band of a row tiler classifies its halo rows too) and that grid has a table
 void attach_tile_flags(nrdhip_instance& I, DenoiserState& d, ReblurParams& p) {
@@ -490,9 +501,9 @@ void attach_tile_flags(nrdhip_instance& I, DenoiserState& d, ReblurParams& p) {
     auto it = d.tileFlags.find({p.c.tilesX, p.c.tilesY});
     if (it != d.tileFlags.end())
         f = it->second;
-    else if (!I.capturing) {
+    else if (!I.capturing && !stream_is_capturing(I.tableStream)) {
         const size_t bytes = (size_t)t->second.blocks + 8; // (the scalar read fetches the aligned dword around a byte)
-        if (hipMalloc((void**)&f, bytes) != hipSuccess || hipMemsetAsync(f, 0, bytes, I.tableStream) != hipSuccess) {
+        if (hipMalloc((void**)&f, bytes) != hipSuccess || hipMemset(f, 0, bytes) != hipSuccess) { // (blocking, once per shape: complete for every stream)
             (void)hipGetLastError();
             if (f)
                 (void)hipFree(f);
@@ -1127,8 +1138,8 @@ const uint32_t* tile_table(nrdhip_instance& I, int tilesX, int tilesY, hipStream
     auto it = I.tileTables.find({tilesX, tilesY});
     if (it != I.tileTables.end())
         return it->second.dev;
-    if (I.capturing)
-        return nullptr;
+    if (I.capturing || stream_is_capturing(st))
+        return nullptr; // (inside the library's OR THE CALLER'S stream capture nothing may be allocated or copied; not remembered: the next plain launch builds it)
     const int blocks = xcd_grid_blocks(tilesX, tilesY);
     if (I.tileTables.size() >= 64)
         return nullptr; // (a caller resizing the rect every frame: the shapes beyond the first 64 compute their tiles)
@@ -1147,9 +1158,11 @@ const uint32_t* tile_table(nrdhip_instance& I, int tilesX, int tilesY, hipStream
             host[(size_t)blocks + (size_t)ty * tilesX + tx] = (uint32_t)b;
         }
     }
+    // a BLOCKING copy, once per shape for the life of the instance: the table is then complete for every stream that will ever read it (ADVICE
+    // r5: an asynchronous upload is ordered on the creating stream only - a strip launched on another stream could read it half-written)
     uint32_t* dev = nullptr;
     if (hipMalloc((void**)&dev, host.size() * sizeof(uint32_t)) != hipSuccess ||
-        hipMemcpyAsync(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+        hipMemcpy(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
         if (dev)
             (void)hipFree(dev);
@@ -1247,6 +1260,17 @@ struct DeviceScope {
             (void)hipSetDevice(prev);
     }
 };
+
+// the instances alive in this process: a row tiler that is destroyed AFTER its instance (destructor order of a host language) must
+// not touch it (nrdhip_tiler.cpp nrdhip_tiler_destroy)
+static std::mutex g_liveMutex;
+static std::vector<const nrdhip_instance*> g_live;
+namespace nrdhip {
+bool instance_is_live(const nrdhip_instance* inst) {
+    std::lock_guard<std::mutex> lock(g_liveMutex);
+    return std::find(g_live.begin(), g_live.end(), inst) != g_live.end();
+}
+} // namespace nrdhip
 
 extern "C" {
 
@@ -1358,6 +1382,10 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
         nrdhip_destroy(I);
         return (int)nrd::Result::FAILURE;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_liveMutex);
+        g_live.push_back(I);
+    }
     *out = I;
     return 0;
 }
@@ -1394,6 +1422,10 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
             if (f.second)
                 (void)hipFree(f.second);
     release_graphs(*inst);
+    {
+        std::lock_guard<std::mutex> lock(g_liveMutex);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), (const nrdhip_instance*)inst), g_live.end());
+    }
     delete inst;
 }
 

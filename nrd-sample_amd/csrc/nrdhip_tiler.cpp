@@ -92,6 +92,10 @@ RcclApi g_rccl;
 
 } // namespace
 
+namespace nrdhip {
+bool instance_is_live(const nrdhip_instance* inst); // nrdhip.cpp
+}
+
 struct nrdhip_tiler {
     nrdhip_instance* inst = nullptr;
     int rank = 0, world = 1;
@@ -545,8 +549,8 @@ NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     if (!T)
         return;
     TilerDeviceScope scope(*T);
-    if (T->inst && T->world > 1)
-        (void)nrdhip_set_history_rows(T->inst, 0, 0); // the instance outlives its tiler: every stored row is current again
+    if (T->world > 1 && nrdhip::instance_is_live(T->inst))
+        (void)nrdhip_set_history_rows(T->inst, 0, 0); // an instance that outlives its tiler: every stored row is current again
     if (T->comm)
         g_rccl.CommDestroy(T->comm);
     if (T->commStream)

@@ -91,6 +91,8 @@ typedef void* hipGraphExec_t;
 typedef void* hipGraphNode_t;
 enum hipStreamCaptureMode { hipStreamCaptureModeThreadLocal = 1 };
 enum hipGraphExecUpdateResult { hipGraphExecUpdateSuccess = 0 };
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return 1; }
 inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 1; }
 inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
