@@ -56,9 +56,13 @@ def parse():
                     help="default: reblur_ds_4k on one GPU (the headline metric), reblur_ds_8k row-tiled for --gpus N > 1 (BASELINE config 5)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the workload's frame split into N row bands; weak = every rank a full band of a W x (H N) frame")
-    ap.add_argument("--tiler", default="python", choices=["python", "native"],
-                    help="N > 1: python = nrd-sample_amd/tiler.py over torch.distributed P2P; native = the C++ row tiler below the C-ABI "
-                         "(nrdhip_tiler_*, RCCL send / recv groups on a side stream)")
+    ap.add_argument("--tiler", default="auto", choices=["auto", "python", "native"],
+                    help="N > 1: native = the C++ row tiler below the C-ABI (nrdhip_tiler_*, RCCL send / recv groups on a side stream: the path "
+                         "north_star describes); python = nrd-sample_amd/tiler.py over torch.distributed P2P; auto (default) = native FIRST - a two-frame "
+                         "probe on every rank - and the Python tiler with the reason in config.native_tiler when it raises or does not come back")
+    ap.add_argument("--native-deadline", type=float, default=180.0, help="--tiler auto: seconds the native tiler's set-up + probe may take before the "
+                    "run restarts itself with --tiler python (a hung RCCL call cannot be cancelled inside the process)")
+    ap.add_argument("--native-note", default=None, help=argparse.SUPPRESS)  # set by that restart: why the native tiler was abandoned
     ap.add_argument("--no-native-leg", action="store_true", help="N > 1 with the Python tiler: do not run the C++ / RCCL tiler afterwards")
     ap.add_argument("--no-identity-check", action="store_true", help="N > 1, strong scaling: skip the tiled-vs-single-instance comparison")
     ap.add_argument("--even-bands", action="store_true", help="N > 1, strong scaling: split the frame into bands of equal HEIGHT instead of "
@@ -205,7 +209,14 @@ def main():
         import datetime
 
         # a stuck exchange should end the run with an error within minutes, not sit on the node for the default half hour
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        if args.native_note is not None and os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+            # this process replaced one that abandoned the native tiler (--tiler auto below). Under torchrun the key-value store lives in the
+            # launcher and still holds the abandoned run's rendezvous keys: the same store, behind a prefix of its own
+            store = dist.PrefixStore("python_tiler_restart", dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=False,
+                                                                           timeout=datetime.timedelta(seconds=300)))
+            dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         # first communication of the group is one every rank takes part in (batched P2P between row neighbours comes later)
         hello = torch.ones(1, device=dev)
         dist.all_reduce(hello)
@@ -247,8 +258,59 @@ def main():
         from nrd_sample_amd.tiler import TiledRunner
 
         frame_h = wl_h if strong else wl_h * world
-        runner = TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of,
-                             tiler=args.tiler, motion_rows=args.motion_rows, balance=strong and not args.even_bands)
+
+        def make_runner(kind):
+            return TiledRunner(pkg, hip, dev, dens, w, frame_h, rank, world, args.unique_frames, args.dolly, settings_of,
+                               tiler=kind, motion_rows=args.motion_rows, balance=strong and not args.even_bands)
+
+        if args.tiler == "auto":
+            # The value of record should come from the C++ tiler (ncclSend / ncclRecv groups below the C-ABI). Its RCCL calls have executed on
+            # one GPU only (tests/test_rccl_loopback.py), so it is tried under two guards: an exception on ANY rank sends every rank to the
+            # Python tiler (the ranks agree through one all_reduce), and a probe that does not come back within --native-deadline makes every
+            # rank replace itself with the same command + --tiler python (a hung collective cannot be cancelled from inside the process).
+            import threading
+
+            def restart_with_python_tiler():
+                note = "native tiler: set-up + two-frame probe not finished after %g s on rank %d" % (args.native_deadline, rank)
+                sys.stderr.write(note + " - restarting with --tiler python\n")
+                sys.stderr.flush()
+                # a fresh rendezvous: the ranks replace themselves milliseconds apart, and a late one must not find the key-value store of the
+                # abandoned run still answering on the old port (rank 0 hosts it) - under torchrun the launcher hosts it: the port stays and
+                # the restarted ranks meet behind a key prefix instead (init_process_group above)
+                if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") != "True" and os.environ.get("MASTER_PORT", "").isdigit():
+                    os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+                os.execv(sys.executable, [sys.executable] + sys.argv + ["--tiler", "python", "--native-note", note])
+
+            guard = threading.Timer(args.native_deadline, restart_with_python_tiler)
+            guard.daemon = True
+            guard.start()
+            err = None
+            try:
+                if os.environ.get("NRD_BENCH_NATIVE_FAIL_RANK") in (str(rank), "all"):  # (tests/test_bench_flow.py: the fallback itself is tested)
+                    raise RuntimeError("injected failure of the native tiler on rank %d" % rank)
+                runner = make_runner("native")
+                for f in range(2):
+                    runner.step(f, reset=(f == 0))
+                runner.finish()
+                torch.cuda.synchronize() if dev != "cpu" else None
+            except Exception as e:  # (reported in config.native_tiler)
+                err = "%s: %s" % (type(e).__name__, e)
+            if world > 1:
+                okf = torch.tensor([0.0 if err else 1.0], device=dev)
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                if float(okf.item()) == 0.0 and err is None:
+                    err = "another rank's native tiler raised"
+            guard.cancel()
+            if err is None:
+                args.tiler = "native"
+            else:
+                args.native_note = err
+                args.tiler = "python"
+                runner = None
+                torch.cuda.empty_cache() if dev != "cpu" else None
+                runner = make_runner("python")
+        else:
+            runner = make_runner(args.tiler)
         band_h = runner.band.layout["own_rows"]
 
     def accum_length(runner):
@@ -299,6 +361,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        runner.local_ms_per_step = dt / args.steps * 1e3  # this rank's own wall time (the value of record is the max over ranks)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -313,7 +376,9 @@ def main():
     rank_ms = native_leg = identical = None
     tiled = world > 1 or args.force_tiled
     if world > 1:
-        mine = sum(v[0] for v in per_pass.values()) if per_pass else float("nan")
+        # GPU-busy ms per frame of this rank: the sum of its dispatch times; the C++ tiler steps the dispatches itself (no per-dispatch events):
+        # its ranks report their wall time per frame instead
+        mine = sum(v[0] for v in per_pass.values()) if per_pass else getattr(runner, "local_ms_per_step", float("nan"))
         mt = torch.tensor([mine], dtype=torch.float64, device=dev)
         gathered = [torch.zeros_like(mt) for _ in range(world)]
         dist.all_gather(gathered, mt)
@@ -430,7 +495,7 @@ def main():
         watchdog = threading.Timer(args.extras_deadline, give_up)
         watchdog.daemon = True
         watchdog.start()
-    if tiled and args.tiler == "python" and not args.no_native_leg:
+    if tiled and args.tiler == "python" and not args.no_native_leg and args.native_note is None:  # (--tiler python given explicitly: the C++ tiler as a second leg)
         # The value of record is the Python tiler's (its transport, PyTorch's RCCL binding, is the proven one). The C++ tiler below
         # the C-ABI (ncclSend / ncclRecv groups on a side stream) runs the same workload afterwards, reported beside it; whatever
         # goes wrong there must not cost the line above.
@@ -463,6 +528,9 @@ def main():
             os._exit(0)
         if native_leg is not None:
             out["config"]["native_tiler"] = native_leg
+        elif tiled:
+            out["config"]["native_tiler"] = {"used_for_value": args.tiler == "native", "transport": "rccl" if backend == "nccl" else "caller callbacks over torch.distributed (%s)" % backend,
+                                             "fallback_reason": args.native_note}
         if identical is not None:
             out["config"]["tiled_bit_identical"] = identical["identical"]
             out["config"]["tiled_bit_identical_detail"] = identical["detail"]

@@ -251,6 +251,12 @@ NRDHIP_API int nrdhip_tiler_exchange_inputs(nrdhip_tiler* tiler, const uint32_t*
 NRDHIP_API int nrdhip_tiler_denoise(nrdhip_tiler* tiler, const uint32_t* identifiers, uint32_t n, void* hip_stream);
 /* make `hip_stream` wait for rows still travelling (those only the next frame reads); call before reading pool planes / at exit */
 NRDHIP_API int nrdhip_tiler_finish(nrdhip_tiler* tiler, void* hip_stream);
+/* Bring-up on ONE GPU: one real exchange group of the RCCL transport - ncclGroupStart, ncclSend + ncclRecv addressed to THIS rank,
+ * ncclGroupEnd - through the very code every halo exchange runs (run_ops on the side stream, evCompute -> side stream -> evComm ->
+ * `hip_stream`, or with `deferred` != 0 the event a deferred group is awaited through): `bytes` bytes of device memory `src` arrive in
+ * `dst` behind everything enqueued on `hip_stream` so far, and `hip_stream` waits for them. Needs nrdhip_tiler_rccl_init (a world of 1
+ * is fine: the communicator then has one rank). tests/test_rccl_loopback.py; the sample has no counterpart (config 5 of BASELINE.json) */
+NRDHIP_API int nrdhip_tiler_rccl_loopback(nrdhip_tiler* tiler, const void* src, void* dst, size_t bytes, int deferred, void* hip_stream);
 NRDHIP_API int nrdhip_tiler_halo(nrdhip_tiler* tiler, uint32_t* rows);
 /* out = {bytes sent, dispatches run as strips + interior, exchanges waited for in-frame, deferred exchanges} */
 NRDHIP_API int nrdhip_tiler_stats(nrdhip_tiler* tiler, uint64_t out[4]);

@@ -446,6 +446,8 @@ class Backend:
             self._sig("tiler_destroy", None, [C.c_void_p])
             self._sig("tiler_rccl_unique_id", C.c_int, [C.c_void_p])
             self._sig("tiler_rccl_init", C.c_int, [C.c_void_p, C.c_void_p])
+            if hasattr(self.lib, self.prefix + "tiler_rccl_loopback"):
+                self._sig("tiler_rccl_loopback", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p])
             self._sig("tiler_exchange_inputs", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
             self._sig("tiler_denoise", C.c_int, [C.c_void_p, C.POINTER(_u32), _u32, C.c_void_p])
             self._sig("tiler_finish", C.c_int, [C.c_void_p, C.c_void_p])

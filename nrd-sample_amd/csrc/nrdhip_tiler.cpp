@@ -545,6 +545,38 @@ NRDHIP_API int nrdhip_tiler_rccl_init(nrdhip_tiler* T, const void* unique_id128)
     return make_side_stream(*T);
 }
 
+NRDHIP_API int nrdhip_tiler_rccl_loopback(nrdhip_tiler* T, const void* src, void* dst, size_t bytes, int deferred, void* stream) {
+    if (!T || !src || !dst || !bytes || T->custom)
+        return INVALID;
+    if (!T->comm)
+        return fail(*T, INVALID, "nrdhip_tiler_rccl_init has not been called");
+    TilerDeviceScope scope(*T);
+    hipStream_t st = (hipStream_t)stream;
+    // [send, recv] toward one peer, the order ops_of gives every neighbour - the peer being this rank
+    const std::vector<Op> ops = {Op{true, (uint8_t*)const_cast<void*>(src), bytes, T->rank}, Op{false, (uint8_t*)dst, bytes, T->rank}};
+    int r = comm_after_compute(*T, st);
+    if (!r)
+        r = run_ops(*T, ops, T->commStream);
+    if (r)
+        return r;
+    if (!deferred) { // an in-frame exchange: the compute stream goes on behind evComm
+        if (hipEventRecord(T->evComm, T->commStream) != hipSuccess || hipStreamWaitEvent(st, T->evComm, 0) != hipSuccess)
+            return fail(*T, FAILURE, "hipEventRecord / hipStreamWaitEvent");
+        T->exchanges++;
+        return 0;
+    }
+    // a deferred group: its own event, awaited where the list's next call would await it
+    const uint32_t id = 0xffffffffu;
+    nrdhip_tiler::DeferredSlot* slot = deferred_slot(*T, &id, 1, st);
+    if (!slot)
+        return fail(*T, FAILURE, "hipEventCreate");
+    if (hipEventRecord(slot->ev, T->commStream) != hipSuccess)
+        return fail(*T, FAILURE, "hipEventRecord");
+    slot->pending = true;
+    T->deferredExchanges++;
+    return wait_deferred_sharing(*T, &id, 1, st);
+}
+
 NRDHIP_API void nrdhip_tiler_destroy(nrdhip_tiler* T) {
     if (!T)
         return;

@@ -70,8 +70,41 @@ def test_two_rank_bench_line_on_the_emulated_backend(emulated, tmp_path):
     assert (d["n_gpus"], d["scaling"], d["steps"]) == (2, "strong", 8) and d["value"] > 0
     assert sum(c["band_rows"]) == 448 and len(c["rank_ms"]) == 2 and all(t > 0 for t in c["rank_ms"])
     assert c["tiled_bit_identical"] is True, c.get("tiled_bit_identical_detail")
-    assert "value" in c["native_tiler"], c["native_tiler"]
+    # round 6: --tiler auto tries the C++ tiler FIRST (two-frame probe on every rank) and the value of record comes from it
+    assert c["native_tiler"]["used_for_value"] is True and c["native_tiler"]["fallback_reason"] is None, c["native_tiler"]
+    assert "native tiler" in c["workload"]
     assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_two_rank_bench_python_tiler_with_native_leg(emulated, tmp_path):
+    """--tiler python: the Python tiler is the value of record and the C++ tiler runs as a second leg beside it (rounds 3-5's default)"""
+    d = run_two_ranks(tmp_path, ["--tiler", "python"])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and all(t > 0 for t in c["rank_ms"])
+    assert "value" in c["native_tiler"], c["native_tiler"]
+    assert c["tiled_bit_identical"] is True, c.get("tiled_bit_identical_detail")
+
+
+def test_two_rank_bench_falls_back_to_the_python_tiler(emulated, tmp_path, monkeypatch):
+    """--tiler auto, the C++ tiler raising on every rank: the ranks agree through one all_reduce, move to the Python tiler and the line says why"""
+    monkeypatch.setenv("NRD_BENCH_NATIVE_FAIL_RANK", "all")
+    d = run_two_ranks(tmp_path, ["--no-identity-check"])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and all(t > 0 for t in c["rank_ms"])
+    assert c["native_tiler"]["used_for_value"] is False and "injected failure" in c["native_tiler"]["fallback_reason"], c["native_tiler"]
+    assert "python tiler" in c["workload"]
+
+
+def test_two_rank_bench_restarts_with_the_python_tiler_when_the_native_probe_hangs(emulated, tmp_path, monkeypatch):
+    """--tiler auto, the C++ tiler raising on ONE rank only: the other rank's probe then waits for rows that never come (what a stuck ncclRecv
+    looks like). After --native-deadline every rank replaces itself with the same command + --tiler python, the restarted ranks meet again
+    behind a key prefix of the launcher's store, and the line of record carries the reason"""
+    monkeypatch.setenv("NRD_BENCH_NATIVE_FAIL_RANK", "1")
+    d = run_two_ranks(tmp_path, ["--no-identity-check", "--native-deadline", "20"])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and all(t > 0 for t in c["rank_ms"])
+    assert c["native_tiler"]["used_for_value"] is False and "not finished after 20 s" in c["native_tiler"]["fallback_reason"], c["native_tiler"]
+    assert "python tiler" in c["workload"]
 
 
 def test_two_rank_bench_watchdog_prints_the_line_and_ends_the_run(emulated, tmp_path):
@@ -81,7 +114,7 @@ def test_two_rank_bench_watchdog_prints_the_line_and_ends_the_run(emulated, tmp_
     c = d["config"]
     assert d["n_gpus"] == 2 and d["value"] > 0 and len(c["rank_ms"]) == 2
     assert c["tiled_bit_identical"] is None and "watchdog" in c["tiled_bit_identical_detail"]
-    assert "error" in c["native_tiler"] or "value" in c["native_tiler"]
+    assert "error" in c["native_tiler"] or "value" in c["native_tiler"] or "used_for_value" in c["native_tiler"]
 
 
 def test_four_rank_bench_line_on_the_emulated_backend(emulated, tmp_path):
@@ -97,4 +130,4 @@ def test_eight_rank_bench_line_on_the_emulated_backend(emulated, tmp_path):
     d = run_two_ranks(tmp_path, [], world=8, frame="32,2560")
     c = d["config"]
     assert d["n_gpus"] == 8 and len(c["rank_ms"]) == 8 and len(c["band_rows"]) == 8 and sum(c["band_rows"]) == 2560
-    assert c["tiled_bit_identical"] is True and "value" in c["native_tiler"], c
+    assert c["tiled_bit_identical"] is True and c["native_tiler"]["used_for_value"] is True, c
