@@ -164,6 +164,19 @@ NRD_DEV float rsqrt_(float x) {
     return r;
 }
 NRD_DEV float sqrt_(float x) { return x * rsqrt_(x); } // sqrt_(0) = 0
+// x^(1/3) for positive, normal, finite x (ledger row 19; the only consumer is TAA's XyzToLab, Shaders/Taa.cs.hlsl:43-54, whose
+// pow(x, 0.333333) it stands in for): Newton on the INVERSE cube root - y <- y (4 - x y^3) / 3, division-free, three steps from a
+// magic-constant seed (3.5 % -> 1.8e-3 -> 6.5e-6 -> rounding) - then x y^2. 19 instructions where exp2_poly(0.333333 log2_poly(x)) took
+// ~50, eight times per pixel. Relative error 4.1e-7 against the cube root, <= 5e-6 against x^0.333333 on [0.008856, 1e6]
+// (tests/test_oracle_math.py) - the shader's own pow is exp2(y log2 x) on 1-ULP hardware units, no closer than that.
+NRD_DEV float cbrt_pos_(float x) {
+    float y = u2f(0x54A21D2Au - f2u(x) / 3u);
+    const float c = x * (1.0f / 3.0f);
+    y = y * fma_(-c, (y * y) * y, 4.0f / 3.0f);
+    y = y * fma_(-c, (y * y) * y, 4.0f / 3.0f);
+    y = y * fma_(-c, (y * y) * y, 4.0f / 3.0f);
+    return (x * y) * y;
+}
 NRD_DEV f3 normalize3(f3 a) {
     float l2 = dot3(a, a);
     float inv = rsqrt_(fmax2(l2, 1e-30f));
@@ -194,6 +207,27 @@ NRD_DEV float wsqrt_(float x) { return HW_TRANSCENDENTALS ? __builtin_amdgcn_sqr
 #define NRD_FP16_MAX 65504.0f
 NRD_DEV float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 NRD_DEV uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)clampf(f, -NRD_FP16_MAX, NRD_FP16_MAX)); }
+// b - a of two fp16 values that sit in the low / high halves of 32-bit words, rounded once to fp32: ONE v_fma_mix_f32 (b * 1.0 + (-a),
+// the halves converted inside the instruction) where convert, convert, subtract takes three. The same single rounding as the float
+// subtraction of the converted values - the host emulation of the tests and the oracle compute exactly that. (Written as
+// fma_(h2f(b), 1.0f, -h2f(a)) the compiler folds the multiplication by one away and is back at three instructions.)
+template <bool HI_B, bool HI_A>
+NRD_DEV float hdiff_(uint32_t wb, uint32_t wa) {
+#ifdef NRD_NO_DEVICE_ASM
+    return h2f((uint16_t)(HI_B ? wb >> 16 : wb & 0xffffu)) - h2f((uint16_t)(HI_A ? wa >> 16 : wa & 0xffffu));
+#else
+    float r;
+    if constexpr (!HI_B && !HI_A)
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wb), "v"(wa));
+    else if constexpr (HI_B && !HI_A)
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wb), "v"(wa));
+    else if constexpr (!HI_B && HI_A)
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wb), "v"(wa));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(wb), "v"(wa));
+    return r;
+#endif
+}
 NRD_DEV f4 unpack_h4(uint2 v) { return {h2f((uint16_t)(v.x & 0xffffu)), h2f((uint16_t)(v.x >> 16)), h2f((uint16_t)(v.y & 0xffffu)), h2f((uint16_t)(v.y >> 16))}; }
 // RGBA16_SNORM texel (the sample's DIRECTIONAL_OCCLUSION data format, Source/NRDSample.cpp:2937): v = max(int16 / 32767, -1)
 NRD_DEV float sn2f(uint32_t h) { return fmax2((float)(int16_t)(uint16_t)h * (1.0f / 32767.0f), -1.0f); }

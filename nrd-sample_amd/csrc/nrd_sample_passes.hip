@@ -225,7 +225,6 @@ struct TaaParams {
 };
 
 NRD_DEV float positive_rcp(float x) { return rcp_(fmax2(x, 1e-15f)); }
-NRD_DEV float pow_pos(float x, float y) { return x > 0.0f ? exp2_poly(y * log2_poly(x)) : 0.0f; }
 NRD_DEV f3 taa_tonemap(const TaaParams& p, f3 c) { // ApplyTonemap (Shared.hlsli:337-347)
     if (!p.tonemap)
         return c;
@@ -240,9 +239,22 @@ NRD_DEV f4 sample_linear_clamp(const PlaneRef& P, float u, float v, int w, int h
     y0 = clampf(y0, -1.0f, (float)h);
     int ix0 = imin(imax((int)x0, 0), w - 1), ix1 = imin(imax((int)x0 + 1, 0), w - 1);
     int iy0 = imin(imax((int)y0, 0), h - 1), iy1 = imin(imax((int)y0 + 1, 0), h - 1);
-    f4 a = unpack_h4(ld<uint2>(P, ix0, iy0, 8)), b = unpack_h4(ld<uint2>(P, ix1, iy0, 8));
-    f4 c = unpack_h4(ld<uint2>(P, ix0, iy1, 8)), d = unpack_h4(ld<uint2>(P, ix1, iy1, 8));
-    return lerp4(lerp4(a, b, fx), lerp4(c, d, fx), fy);
+    // lerp(a, b, t) = fma(b - a, t, a) on fp16 texels: the difference is ONE v_fma_mix_f32 that reads both halves as they are (hdiff_,
+    // nrd_device.h: the same single rounding as the subtraction of the converted values), and the blend a second one with a as its fp16
+    // addend: 2 instructions per channel where convert, convert, subtract, fma took 4 - 16 channels x 5 samples per pixel
+    const uint2 ta = ld<uint2>(P, ix0, iy0, 8), tb = ld<uint2>(P, ix1, iy0, 8), tc = ld<uint2>(P, ix0, iy1, 8), td = ld<uint2>(P, ix1, iy1, 8);
+    float r[4];
+    {
+        const float t0 = fma_(hdiff_<false, false>(tb.x, ta.x), fx, h2f((uint16_t)(ta.x & 0xffffu))), b0 = fma_(hdiff_<false, false>(td.x, tc.x), fx, h2f((uint16_t)(tc.x & 0xffffu)));
+        const float t1 = fma_(hdiff_<true, true>(tb.x, ta.x), fx, h2f((uint16_t)(ta.x >> 16))), b1 = fma_(hdiff_<true, true>(td.x, tc.x), fx, h2f((uint16_t)(tc.x >> 16)));
+        const float t2 = fma_(hdiff_<false, false>(tb.y, ta.y), fx, h2f((uint16_t)(ta.y & 0xffffu))), b2 = fma_(hdiff_<false, false>(td.y, tc.y), fx, h2f((uint16_t)(tc.y & 0xffffu)));
+        const float t3 = fma_(hdiff_<true, true>(tb.y, ta.y), fx, h2f((uint16_t)(ta.y >> 16))), b3 = fma_(hdiff_<true, true>(td.y, tc.y), fx, h2f((uint16_t)(tc.y >> 16)));
+        r[0] = lerpf(t0, b0, fy);
+        r[1] = lerpf(t1, b1, fy);
+        r[2] = lerpf(t2, b2, fy);
+        r[3] = lerpf(t3, b3, fy);
+    }
+    return {r[0], r[1], r[2], r[3]};
 }
 // BicubicFilterNoCorners (Shared.hlsli:349-387)
 NRD_DEV f4 bicubic_no_corners(const TaaParams& p, float sx, float sy) {
@@ -283,24 +295,23 @@ NRD_DEV f3 rgb_to_xyz(f3 c) { // Color::RgbToXyz (sRGB primaries, D65, Y in 0..1
     return {100.0f * fma_(0.1804808f, c.z, fma_(0.3575843f, c.y, 0.4123908f * c.x)), 100.0f * fma_(0.0721923f, c.z, fma_(0.7151687f, c.y, 0.2126390f * c.x)),
             100.0f * fma_(0.9505322f, c.z, fma_(0.1191948f, c.y, 0.0193308f * c.x))};
 }
-NRD_DEV f3 xyz_to_lab(f3 x) { // Taa.cs.hlsl:43-54
+NRD_DEV f3 xyz_to_lab(f3 x) { // Taa.cs.hlsl:43-54; pow(x, 0.333333) = cbrt_pos_ (nrd_device.h, ledger row 19)
     x = {x.x * (1.0f / 95.0489f), x.y * (1.0f / 100.0f), x.z * (1.0f / 108.8840f)};
-    float yIn = x.y;
-    float fx = x.x > 0.008856f ? pow_pos(x.x, 0.333333f) : fma_(7.787f, x.x, 16.0f / 116.0f);
-    float fy = x.y > 0.008856f ? pow_pos(x.y, 0.333333f) : fma_(7.787f, x.y, 16.0f / 116.0f);
-    float fz = x.z > 0.008856f ? pow_pos(x.z, 0.333333f) : fma_(7.787f, x.z, 16.0f / 116.0f);
+    float fx = x.x > 0.008856f ? cbrt_pos_(x.x) : fma_(7.787f, x.x, 16.0f / 116.0f);
+    float fy = x.y > 0.008856f ? cbrt_pos_(x.y) : fma_(7.787f, x.y, 16.0f / 116.0f);
+    float fz = x.z > 0.008856f ? cbrt_pos_(x.z) : fma_(7.787f, x.z, 16.0f / 116.0f);
     // NOTE: as in the shader, "l" is computed from the ALREADY transformed y
-    (void)yIn;
-    float l = fy > 0.008856f ? fma_(116.0f, pow_pos(fy, 0.333333f), -16.0f) : 903.3f * fy;
+    float l = fy > 0.008856f ? fma_(116.0f, cbrt_pos_(fy), -16.0f) : 903.3f * fy;
     return {l, 500.0f * (fx - fy), 200.0f * (fy - fz)};
 }
-NRD_DEV f3 clamp_aabb(f3 center, f3 ext, f3 prev) { // Color::ClampAabb: clip towards the box centre
+NRD_DEV f3 clamp_aabb(f3 center, f3 ext, f3 prev, bool& moved) { // Color::ClampAabb: clip towards the box centre
     f3 d = sub3(prev, center);
     f3 dn = {absf(d.x * positive_rcp(ext.x)), absf(d.y * positive_rcp(ext.y)), absf(d.z * positive_rcp(ext.z))};
     float maxd = fmax2(dn.x, fmax2(dn.y, dn.z));
     float r = positive_rcp(maxd);
     f3 t = {fma_(d.x, r, center.x), fma_(d.y, r, center.y), fma_(d.z, r, center.z)};
-    return maxd > 1.0f ? t : prev;
+    moved = maxd > 1.0f;
+    return moved ? t : prev;
 }
 
 __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
     const int ci = (tidy + 2) * 20 + tidx + 2;
     float centerZ = sTile[ci].w;
     float minViewZ = absf(centerZ);
-    int offx = 2, offy = 2;
+    int mi = ci; // window index of the closest-depth neighbour (offseti of the shader, :72, :94-98)
     const bool want5x5 = centerZ < 0.0f;
 #pragma unroll
     for (int dy = 0; dy <= 4; dy++)
@@ -349,8 +360,7 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
                 input = c;
             else if (viewZ < minViewZ) {
                 minViewZ = viewZ;
-                offx = dx;
-                offy = dy;
+                mi = si;
             }
             // r2 = LengthSquared( offset / BORDER - 1.0 ) with the INTEGER division of the shader (:103): -1,-1,0,0,1 per axis
             const int qx = dx / 2 - 1, qy = dy / 2 - 1;
@@ -365,7 +375,6 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
     m2 = mul3(m2, rs);
     f3 sigma = {sqrt_(absf(m2.x - m1.x * m1.x)) * 2.0f, sqrt_(absf(m2.y - m1.y * m1.y)) * 2.0f, sqrt_(absf(m2.z - m1.z * m1.z)) * 2.0f}; // TAA_SIGMA_SCALE
     // previous pixel position (:118-119): motion of the closest-depth neighbour
-    const int mi = (tidy + offy) * 20 + tidx + offx;
     const float2 mxy = sMvXY[mi];
     float pu = fma_(mxy.x, p.invW, u), pv = fma_(mxy.y, p.invH, v);
     f4 history = bicubic_no_corners(p, sat(pu) * p.Wp, sat(pv) * p.Hp);
@@ -374,10 +383,17 @@ __global__ __launch_bounds__(256) void k_taa(const TaaParams p) {
     mixRate = mixRate * rcp_(1.0f + mixRate);
     bool inScreen = sat(pu) == pu && sat(pv) == pv;
     mixRate = inScreen ? mixRate : 1.0f;
-    f3 clamped = clamp_aabb(m1, sigma, hist);
-    f3 a = xyz_to_lab(rgb_to_xyz(clamped)), b = xyz_to_lab(rgb_to_xyz(hist));
-    f3 dl = sub3(a, b);
-    float diff = sqrt_(dot3(dl, dl)) * (1.0f / (2.3f * 3.0f)); // JND = 2.3
+    bool moved;
+    f3 clamped = clamp_aabb(m1, sigma, hist, moved);
+    // Disocclusion #2: the Lab distance between the history and its clamped copy. A history inside the box comes back unchanged - the two
+    // conversions then return the same bits and the distance is an exact 0 (sqrt_(0) = 0): the eight cube roots are skipped for it
+    // (a wave of a converged image skips them altogether)
+    float diff = 0.0f;
+    if (moved) {
+        f3 a = xyz_to_lab(rgb_to_xyz(clamped)), b = xyz_to_lab(rgb_to_xyz(hist));
+        f3 dl = sub3(a, b);
+        diff = sqrt_(dot3(dl, dl)) * (1.0f / (2.3f * 3.0f)); // JND = 2.3
+    }
     mixRate = sat(mixRate + diff);
     float t = fmax2(mixRate, p.taa);
     f3 r = {lerpf(clamped.x, input.x, t), lerpf(clamped.y, input.y, t), lerpf(clamped.z, input.z, t)};

@@ -623,6 +623,10 @@ NRDHIP_API void orc_exp2_neg_array(const float* x, float* out, uint32_t n) {
     for (uint32_t i = 0; i < n; i++)
         out[i] = exp2_poly_neg(x[i]);
 }
+NRDHIP_API void orc_cbrt_array(const float* x, float* out, uint32_t n) { // (ledger row 19: TAA's pow(x, 0.333333))
+    for (uint32_t i = 0; i < n; i++)
+        out[i] = cbrt_pos_(x[i]);
+}
 NRDHIP_API uint32_t orc_pack_nr(float nx, float ny, float nz, float roughness, uint32_t mat) { return pack_normal_roughness({nx, ny, nz}, roughness, mat); }
 NRDHIP_API void orc_unpack_nr(uint32_t p, float* out5) {
     NormalRoughness r = unpack_normal_roughness(p);

@@ -62,6 +62,16 @@ static inline float rsqrt_(float x) {
     return r;
 }
 static inline float sqrt_(float x) { return x * rsqrt_(x); } // sqrt_(0) = 0
+// x^(1/3), x positive / normal / finite (ledger row 19: TAA's pow(x, 0.333333), Shaders/Taa.cs.hlsl:45-47): Newton on the inverse cube
+// root, y <- y (4 - x y^3) / 3, three steps from a magic-constant seed, then x y^2
+static inline float cbrt_pos_(float x) {
+    float y = u2f(0x54A21D2Au - f2u(x) / 3u);
+    const float c = x * (1.0f / 3.0f);
+    y = y * fma_(-c, (y * y) * y, 4.0f / 3.0f);
+    y = y * fma_(-c, (y * y) * y, 4.0f / 3.0f);
+    y = y * fma_(-c, (y * y) * y, 4.0f / 3.0f);
+    return (x * y) * y;
+}
 // NRD_HW_TRANSCENDENTALS = 1 (liboracle_hwt.so, the checker of libnrdhip_hwt.so; csrc/nrd_device.h has the rule): the WEIGHT-CLASS
 // reciprocals / square roots / exponentials of the spatial filters are the GPU's transcendental instructions there (1 ULP each); here
 // they are the correctly rounded IEEE results at the same places - the two sides then differ by roundings of weights only, and the

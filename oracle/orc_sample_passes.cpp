@@ -122,7 +122,6 @@ struct Taa {
     float Wp, Hp, invW, invH, invRW, invRH;
 };
 inline float positive_rcp(float x) { return rcp_(fmax2(x, 1e-15f)); }
-inline float pow_pos(float x, float y) { return x > 0.0f ? exp2_poly(y * log2_poly(x)) : 0.0f; }
 inline f4 ld4(const void* base, uint32_t pitch, int x, int y) {
     const H4* t = texel(base, pitch, x, y);
     return {f16_to_f32(t->v[0]), f16_to_f32(t->v[1]), f16_to_f32(t->v[2]), f16_to_f32(t->v[3])};
@@ -186,12 +185,12 @@ inline f3 rgb_to_xyz(f3 c) {
     return {100.0f * fma_(0.1804808f, c.z, fma_(0.3575843f, c.y, 0.4123908f * c.x)), 100.0f * fma_(0.0721923f, c.z, fma_(0.7151687f, c.y, 0.2126390f * c.x)),
             100.0f * fma_(0.9505322f, c.z, fma_(0.1191948f, c.y, 0.0193308f * c.x))};
 }
-inline f3 xyz_to_lab(f3 x) { // Taa.cs.hlsl:43-54 ("l" is computed from the already transformed y, as in the shader)
+inline f3 xyz_to_lab(f3 x) { // Taa.cs.hlsl:43-54 ("l" is computed from the already transformed y, as in the shader); pow(x, 0.333333) = cbrt_pos_ (ledger row 19)
     x = {x.x * (1.0f / 95.0489f), x.y * (1.0f / 100.0f), x.z * (1.0f / 108.8840f)};
-    float fx = x.x > 0.008856f ? pow_pos(x.x, 0.333333f) : fma_(7.787f, x.x, 16.0f / 116.0f);
-    float fy = x.y > 0.008856f ? pow_pos(x.y, 0.333333f) : fma_(7.787f, x.y, 16.0f / 116.0f);
-    float fz = x.z > 0.008856f ? pow_pos(x.z, 0.333333f) : fma_(7.787f, x.z, 16.0f / 116.0f);
-    float l = fy > 0.008856f ? fma_(116.0f, pow_pos(fy, 0.333333f), -16.0f) : 903.3f * fy;
+    float fx = x.x > 0.008856f ? cbrt_pos_(x.x) : fma_(7.787f, x.x, 16.0f / 116.0f);
+    float fy = x.y > 0.008856f ? cbrt_pos_(x.y) : fma_(7.787f, x.y, 16.0f / 116.0f);
+    float fz = x.z > 0.008856f ? cbrt_pos_(x.z) : fma_(7.787f, x.z, 16.0f / 116.0f);
+    float l = fy > 0.008856f ? fma_(116.0f, cbrt_pos_(fy), -16.0f) : 903.3f * fy;
     return {l, 500.0f * (fx - fy), 200.0f * (fy - fz)};
 }
 inline f3 clamp_aabb(f3 center, f3 ext, f3 prev) {

@@ -48,6 +48,7 @@
 #define NRD_PIN_PLANES4(A, B, C, D) ((void)0)
 #define NRD_PIN_PLANES 1
 #define NRD_RELOAD_ARGS(T, p, q) const T& q = (p) // nrd_device.h: the kernel arguments read afresh (scalar register pressure)
+#define NRD_NO_DEVICE_ASM 1 // nrd_device.h: instruction-level forms (hdiff_) fall back to the plain expressions they equal
 #define NRD_SCALAR_U32(ptr) (*(const uint32_t*)(ptr)) // nrd_device.h: a dword through the scalar data path
 #define __shared__ static
 

@@ -130,6 +130,29 @@ def test_per_tap_sequences_of_the_default_flavour(oracle):
     assert np.abs(got.astype(np.float64) / want - 1.0).max() <= 8.1e-5
 
 
+def test_cube_root_of_the_lab_conversion(oracle):
+    """ledger row 19 (csrc/nrd_device.h == oracle/orc_math.h cbrt_pos_): TAA's XyzToLab takes pow(x, 0.333333) (Shaders/Taa.cs.hlsl:45-47)
+    as the cube root - Newton on the inverse cube root, three steps. Over the range the conversion can see (x > 0.008856; XYZ of an fp16
+    colour stays below 1e5): relative error <= 5e-7 against the cube root and <= 5e-6 against x ** 0.333333 in float64, monotone"""
+    L = oracle.lib
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.orc_cbrt_array.restype = None
+    L.orc_cbrt_array.argtypes = [fp, fp, ctypes.c_uint32]
+    x = np.sort(np.exp(np.random.default_rng(3).uniform(np.log(0.008856), np.log(1e6), 4000000)).astype(np.float32))
+    got = np.empty_like(x)
+    L.orc_cbrt_array(x.ctypes.data_as(fp), got.ctypes.data_as(fp), x.size)
+    x64 = x.astype(np.float64)
+    assert np.abs(got / np.cbrt(x64) - 1.0).max() <= 5e-7
+    assert np.abs(got / x64 ** 0.333333 - 1.0).max() <= 5e-6
+    assert (np.diff(got.astype(np.float64)) >= -1e-6 * got[1:]).all()  # monotone to within twice its error bound
+    # exact cubes come back to within one ULP
+    c = np.arange(1, 60, dtype=np.float32)
+    out = np.empty_like(c)
+    cubes = (c * c * c).astype(np.float32)
+    L.orc_cbrt_array(cubes.ctypes.data_as(fp), out.ctypes.data_as(fp), c.size)
+    assert np.abs(out / c - 1.0).max() <= 2.4e-7
+
+
 def test_unorm10_decode_sequence_is_the_ieee_quotient():
     """nrd_device.h unorm10_: q = x * r; q' = fma(fma(-q, 1023, x), r, q) with r = fl(1/1023) equals the correctly rounded x / 1023
     (what the oracle's `/` computes) for every 10-bit x - checked in exact rational arithmetic with one rounding per operation"""
