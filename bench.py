@@ -127,21 +127,27 @@ def cpu_run(pkg, orc, denoiser_names, settings_of, device, w, h, warm, frames, t
 
 
 def cpu_baseline(pkg, denoiser_names, settings_of, device, w, h):
-    """Oracle (scalar C++ port of the same passes, oracle/) on a bounded sample of the same workload (SURVEY.md 8d / BASELINE.md 4):
-    (ii) all hardware threads, row-striped, at the workload's own frame size (1 warm-up + 2 timed frames), and (i) ONE thread on
-    a 640x360 instance of the same pipeline (1 warm-up + 2 timed frames; a single thread needs ~30 s per 4K frame). Frames are
+    """Oracle (scalar C++ port of the same passes, oracle/) on a bounded sample of the same workload (SURVEY.md 8d / BASELINE.md 4): all
+    hardware threads at the workload's own frame size (1 warm-up + 2 timed frames: `value`), and - VERDICT r5 item 7 - ONE thread and all
+    threads on the SAME smaller frame (1920 x 1080 of the same pipeline, 1 warm-up + 2 timed frames each; a single thread needs ~30 s per
+    4K frame) with their ratio. The oracle hands rows out in small chunks to persistent workers (oracle/orc_core.cpp pool_run). Frames are
     rendered on the GPU and copied to the host."""
     if not os.path.exists(graft.ORACLE_LIB):
         return None
     orc = graft.oracle_backend()  # the only use of oracle/ outside tests/ and smoke(): the reported CPU baseline
-    cores = min(os.cpu_count() or 1, h // 8)
+    cores = min(os.cpu_count() or 1, h)
     warm, frames = 1, 2
     multi = cpu_run(pkg, orc, denoiser_names, settings_of, device, w, h, warm, frames, cores)
-    sw, sh = 640, 360
+    sw, sh = min(w, 1920), min(h, 1080)
+    scores = min(os.cpu_count() or 1, sh)
     single = cpu_run(pkg, orc, denoiser_names, settings_of, device, sw, sh, warm, frames, 1)
+    same = cpu_run(pkg, orc, denoiser_names, settings_of, device, sw, sh, warm, frames, scores)
     return {"value": round(multi, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d (the workload's frame), %d frames after %d warm-up, same pipeline (%s), oracle/ row-striped over %d threads"
+            "sample": "%dx%d (the workload's frame), %d frames after %d warm-up, same pipeline (%s), oracle/ rows in chunks over %d persistent threads"
                       % (w, h, frames, warm, "+".join(denoiser_names), cores),
+            "same_size": {"frame": "%dx%d" % (sw, sh), "frames": frames, "warmup": warm, "unit": "Mpixels/s",
+                          "one_thread": round(single, 4), "all_threads": round(same, 3), "threads": scores,
+                          "ratio": round(same / single, 1) if single > 0 else None},
             "single_thread": {"value": round(single, 4), "unit": "Mpixels/s", "cores": 1,
                               "sample": "%dx%d instance of the same pipeline, %d frames after %d warm-up, one thread" % (sw, sh, frames, warm)}}
 

@@ -9,8 +9,12 @@
 #include "../include/nrdhip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 
 namespace orc {
 
@@ -213,6 +217,85 @@ static bool classify(nrd::Denoiser dn, DenoiserState& d) {
     return true;
 }
 
+// ---- persistent worker pool of the oracle (process-wide, grows to the largest thread count asked for, never shrinks) -------------
+namespace {
+struct Pool {
+    std::mutex m;
+    std::condition_variable wake, done;
+    std::vector<std::thread>* workers = new std::vector<std::thread>(); // (heap: a forked child abandons the parent's handles, below)
+    pid_t owner = getpid();
+    const std::function<void(int)>* job = nullptr;
+    std::atomic<int> next{0};
+    int tasks = 0, active = 0, allowed = 0;
+    uint64_t generation = 0;
+    bool quit = false;
+    std::mutex callers; // one parallel region at a time (instances on several host threads take turns)
+
+    void work(const std::function<void(int)>& f, int nTasks) {
+        for (int k = next.fetch_add(1, std::memory_order_relaxed); k < nTasks; k = next.fetch_add(1, std::memory_order_relaxed))
+            f(k);
+    }
+    void loop(int index) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            wake.wait(lk, [&] { return quit || (generation != seen && index < allowed); });
+            if (quit)
+                return;
+            seen = generation;
+            const std::function<void(int)>* f = job;
+            const int nTasks = tasks;
+            lk.unlock();
+            work(*f, nTasks);
+            lk.lock();
+            if (--active == 0)
+                done.notify_one();
+        }
+    }
+    void run(int threads, int nTasks, const std::function<void(int)>& f) {
+        std::lock_guard<std::mutex> one(callers);
+        const int helpers = std::min(threads, nTasks) - 1; // the caller works too
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (owner != getpid()) { // a forked child: the parent's workers do not exist here - start over (their handles are left alone)
+                workers = new std::vector<std::thread>();
+                owner = getpid();
+            }
+            while ((int)workers->size() < helpers) {
+                const int index = (int)workers->size();
+                workers->emplace_back([this, index] { loop(index); });
+            }
+            job = &f;
+            tasks = nTasks;
+            next.store(0, std::memory_order_relaxed);
+            active = helpers;
+            allowed = helpers;
+            generation++;
+        }
+        wake.notify_all();
+        work(f, nTasks);
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return active == 0; });
+        job = nullptr;
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        wake.notify_all();
+        if (owner == getpid())
+            for (auto& t : *workers)
+                t.join();
+    }
+};
+Pool& pool() {
+    static Pool P;
+    return P;
+}
+void pool_run(int threads, int nTasks, const std::function<void(int)>& f) { pool().run(threads, nTasks, f); }
+} // namespace
+
 static void run_pass(Instance& I, DenoiserState& d, const Consts& c, Pass& p) {
     int y0 = c.ownY0, y1 = c.ownY1;
     if (p.allRows) { // every row the band stores (csrc/nrdhip.cpp on_all_rows)
@@ -228,14 +311,16 @@ static void run_pass(Instance& I, DenoiserState& d, const Consts& c, Pass& p) {
         p.run(I, d, c, y0, y1);
         return;
     }
-    std::vector<std::thread> th;
-    int rows = y1 - y0;
-    for (int t = 0; t < n; t++) {
-        int a = y0 + (int)((int64_t)rows * t / n), b = y0 + (int)((int64_t)rows * (t + 1) / n);
-        th.emplace_back([&, a, b] { p.run(I, d, c, a, b); });
-    }
-    for (auto& t : th)
-        t.join();
+    // Rows in small chunks handed out through one atomic counter to persistent workers (round 6: the baseline bench.py reports used to
+    // spawn `threads` std::threads per pass over a STATIC split - a frame whose upper third is sky kept a third of them idle, and 256
+    // spawns x 7 passes per frame cost more than the passes of a small frame). A chunk is a few rows: every pass writes rows of its own
+    // range only, so any partition of [y0, y1) gives the same planes.
+    const int rows = y1 - y0;
+    const int chunk = std::max(1, rows / (n * 8));
+    pool_run(n, (rows + chunk - 1) / chunk, [&](int k) {
+        const int a = y0 + k * chunk, b = std::min(y1, a + chunk);
+        p.run(I, d, c, a, b);
+    });
 }
 
 struct Flat {

@@ -47,6 +47,8 @@ def test_default_bench_line_on_the_emulated_backend(monkeypatch, capsys, pkg, em
     assert set(c["graph_replay"]) == {"workload", "band_64x32"} and c["graph_replay"]["workload"]["graph_stats"]["direct"] > 0  # (no graphs in the emulation)
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "sample" in b and b["unit"] == "Mpixels/s"
+    ss = b["same_size"]  # one thread and all threads on the SAME frame
+    assert ss["one_thread"] > 0 and ss["all_threads"] > 0 and ss["threads"] >= 1 and ss["ratio"] > 0
 
 
 def run_two_ranks(tmp_path, extra, world=2, frame="48,448"):

@@ -278,6 +278,37 @@ def test_determinism(request, pkg, api, backend):
     assert util.compare_all(runs[0], runs[1], exact=True) == []
 
 
+def test_oracle_worker_pool(pkg, api, oracle):
+    """oracle/orc_core.cpp pool_run (round 6): rows are handed out in small chunks to persistent workers. More threads than rows, thread
+    counts that change between frames and two instances driven from two host threads at once must all give the planes of one thread"""
+    import threading
+
+    w, h = 96, 80
+    D = api.Denoiser
+    dens = [D.REBLUR_DIFFUSE_SPECULAR, D.RELAX_DIFFUSE]
+    scene = pkg.synth.Scene(w, h, dolly=0.02)
+    frames = [scene.frame(f) for f in range(3)]
+
+    def run(threads_per_frame, out, key):
+        hz = pkg.harness.Harness(oracle, dens, w, h)
+        st = util.default_settings(api, scene, dens)
+        for f, fr in enumerate(frames):
+            oracle.lib.orc_set_threads(hz.nrd.handle, threads_per_frame[f])
+            hz.frame(scene.common_settings(api, fr, f, reset=(f == 0)), hz.upload(fr), st)
+        out[key] = hz
+
+    res = {}
+    run([1, 1, 1], res, "one")
+    run([300, 3, 64], res, "many")
+    assert util.compare_all(res["one"], res["many"], exact=True) == []
+    ts = [threading.Thread(target=run, args=([7, 16, 2], res, "a")), threading.Thread(target=run, args=([5, 1, 33], res, "b"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert util.compare_all(res["one"], res["a"], exact=True) == [] and util.compare_all(res["one"], res["b"], exact=True) == []
+
+
 # ---- RELAX: fixed point (linear RGB + world-space hit distance in, same out) -------------------------------------------------
 @pytest.mark.parametrize("backend", BACKENDS_EMU)
 def test_relax_fixed_point(request, pkg, api, backend):
