@@ -57,6 +57,11 @@ struct ReblurParams {
     // the tile table (tile -> forward launch index); nullptr when those passes launch over another grid than ClassifyTiles
     uint8_t* tileFlagsOut;
     const uint32_t* tileInv;
+    // The roughness-only terms of the specular kernel set-up as a table over the 10-bit roughness code of the guide (nrd_reblur.hip
+    // rough_terms): 1024 x {dominant factor, magic curve, lobe half angle, hit distance factor} = 16 KB per denoiser, written by the first
+    // workgroup of every ClassifyTiles launch with the very functions a pixel would evaluate, read back by the spatial passes with one
+    // 16-byte load per pixel (nullptr: the denoiser has no specular signal)
+    float* roughLut;
 };
 
 // one RELAX A-trous iteration (nrd_reblur.hip k_relax_atrous)

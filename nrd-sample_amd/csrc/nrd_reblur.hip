@@ -205,6 +205,29 @@ NRD_DEV bool my_pixel_w(const FrameConsts& c, int& x, int& y, int& tx, int& ty) 
 #ifndef NRD_CT_TILES // tiles per ClassifyTiles workgroup (a horizontal run)
 #define NRD_CT_TILES 4
 #endif
+// ---- roughness-only terms of the specular kernel set-up -------------------------------------------------------------------------
+// Two exp2 polynomials, two software square roots, an arctangent: ~90 instructions that hang on the 10-bit roughness code of the pixel
+// alone, evaluated in the PrePass, Blur and PostBlur of every specular pixel. Round 6: ClassifyTiles tabulates them per frame (1024
+// codes, the same functions) and a pixel fetches its entry with ONE 16-byte load issued as soon as its guide texel is in, consumed by the
+// specular signal's set-up BEHIND the geometry and the diffuse signal's set-up (a sched_barrier holds that order: round 5 measured
+// the table with the load in front of its consumer and found the round trip cost what the instructions saved - profiles/r05_ab_roughness_table.txt)
+#ifndef NRD_ROUGH_LUT
+#define NRD_ROUGH_LUT 1
+#endif
+struct RoughTerms {
+    float df, smc, angle0, hitFactor; // spec_dominant_factor, spec_magic_curve, spec_lobe_half_angle, reblur_hitdist_factor
+};
+NRD_DEV RoughTerms rough_terms(const float* hp, const float rough) {
+    return {spec_dominant_factor(rough), spec_magic_curve(rough), spec_lobe_half_angle(rough), reblur_hitdist_factor(hp, rough)};
+}
+// a pixel's entry: issued by the caller right behind its guide texel (`code` = the low 10 bits of the guide's depth word)
+NRD_DEV uint4 rough_terms_load(const float* lut, const uint32_t code) { return *reinterpret_cast<const uint4*>(lut + (code & 1023u) * 4u); }
+NRD_DEV RoughTerms rough_terms_of(const uint4 raw) { return {u2f(raw.x), u2f(raw.y), u2f(raw.z), u2f(raw.w)}; }
+// the dominant factor alone (the reprojection passes: virtual motion, its blend amount): one dword of the pixel's entry - the guide's depth
+// word read as a float IS the depth, so the code is still in its low bits
+NRD_DEV float dominant_factor_of(const ReblurParams& p, const Guide& g) {
+    return NRD_ROUGH_LUT ? p.roughLut[(f2u(g.z) & 1023u) * 4u] : spec_dominant_factor(g.roughness);
+}
 __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     const FrameConsts& c = p.c;
     // a streaming pass without neighbour reads: plain 2-D grid (the XCD traversal of the other passes costs a wave ~700 cycles of
@@ -247,6 +270,15 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
         // when the other passes' grid is this grid: nrdhip.cpp tile_flags)
         if (p.tileFlagsOut)
             p.tileFlagsOut[p.tileInv[(uint32_t)(ty - c.tileY0) * (uint32_t)c.tilesX + (uint32_t)(tx0 + tid)]] = sGeo[tid] ? 0 : 1;
+    }
+    // the roughness table of this frame's settings (ReblurParams::roughLut): 4 codes per thread of the first workgroup
+    if (NRD_ROUGH_LUT && p.roughLut && blockIdx.x == 0 && blockIdx.y == 0) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const uint32_t code = (uint32_t)(tid + 256 * k);
+            const RoughTerms t = rough_terms(p.hp, (float)code * (1.0f / 1023.0f)); // (the roughness decode_guide gives a pixel of this code)
+            *reinterpret_cast<float4*>(p.roughLut + code * 4u) = float4{t.df, t.smc, t.angle0, t.hitFactor};
+        }
     }
 }
 
@@ -499,13 +531,13 @@ struct KernelUnit {
     float smc, angle0, roughA, hitFactor; // GetSpecMagicCurve(roughness), lobe half angle, 1 / roughness tolerance, hit distance factor
 };
 template <bool IS_SPEC>
-NRD_DEV KernelUnit kernel_unit(const ReblurParams& p, const PixelGeo& pg, const float z, const f3 V, const float rough) {
+NRD_DEV KernelUnit kernel_unit(const ReblurParams& p, const PixelGeo& pg, const float z, const f3 V, const float rough, const RoughTerms& rt) {
     KernelUnit k;
     f3 T, B;
     basis3(pg.Nv, T, B);
     if (IS_SPEC) {
         const float NoV = dot3(pg.Nv, V);
-        const float df = spec_dominant_factor(rough);
+        const float df = rt.df;
         // dominant direction D = normalize(N + (R - N) df), R = 2 NoV N - V the mirror direction: N (1 + (2 NoV - 1) df) - V df
         const float alpha = fma_(fma_(NoV, 2.0f, -1.0f), df, 1.0f);
         const f3 D = normalize3({fma_(pg.Nv.x, alpha, -(V.x * df)), fma_(pg.Nv.y, alpha, -(V.y * df)), fma_(pg.Nv.z, alpha, -(V.z * df))});
@@ -517,10 +549,10 @@ NRD_DEV KernelUnit kernel_unit(const ReblurParams& p, const PixelGeo& pg, const 
             B = cross3(Dr, T);
             T = mul3(T, lerpf(fma_(rough, 0.5f, 0.5f), 1.0f, NoD)); // skew toward the view direction at grazing angles
         }
-        k.smc = spec_magic_curve(rough);
-        k.angle0 = spec_lobe_half_angle(rough);
+        k.smc = rt.smc;
+        k.angle0 = rt.angle0;
         k.roughA = wrcp_(lerpf(0.01f, 1.0f, sat(rough * p.roughnessFraction))); // (weight-class: the hwt flavour's v_rcp_f32)
-        k.hitFactor = reblur_hitdist_factor(p.hp, rough);
+        k.hitFactor = rt.hitFactor;
     } else {
         k.smc = 1.0f;
         k.angle0 = spec_lobe_half_angle(1.0f);
@@ -585,7 +617,8 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
                 ctap[sig] = ld<uint4>(tapIn[(HAS_SPEC && sig == SIG_SPEC) ? 1 : 0], x, y, 16);
         }
     }
-    Guide g = TAP ? unpack_tap_guide(ctap[0].x, ctap[0].y, c.denoisingRange) : decode_guide(ld_guide(p.guide, x, y), c.denoisingRange);
+    const uint2 gtex = TAP ? uint2{ctap[0].x, ctap[0].y} : ld_guide(p.guide, x, y);
+    Guide g = decode_guide(gtex, c.denoisingRange);
     if (g.sky) {
         for (int sig = 0; sig < NSIG; sig++) {
             if (TAP && VARIANT == 1) { // the guide part travels on (PostBlur takes its sky test from it)
@@ -604,6 +637,10 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
             ta_sky_stores<HAS_DIFF, HAS_SPEC, false, false>(p, x, y);
         return;
     }
+    // the specular signal's roughness terms: requested now, needed behind the diffuse signal's set-up
+    uint4 rtRaw = {0u, 0u, 0u, 0u};
+    if (NRD_ROUGH_LUT && HAS_SPEC)
+        rtRaw = rough_terms_load(p.roughLut, gtex.x);
     const int gy0 = y + c.yOff;
     PixelGeo pg = pixel_geo(c, g, x, gy0, p.planeDistanceSensitivity);
     const NormalCodes ncodes = normal_codes(g.nw); // the taps' normal weights work on the 10-bit codes (nrd_device.h normal_cos)
@@ -649,7 +686,10 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         src1Ps[sig] = VARIANT == 0 ? (isSpec ? &p.inSpec1 : &p.inDiff1) : &inP;
         sum1[sig] = SH ? unpack_h4(ld<uint2>(*src1Ps[sig], x, y, srcBpt, srcOffs[sig] + (VARIANT == 0 ? 0 : 8))) : f4{0, 0, 0, 0};
         // the pass-independent part of the set-up (taps are placed on the tangent plane linearised at the centre: KernelUnit::j)
-        const KernelUnit ku = isSpec ? kernel_unit<true>(p, pg, g.z, V, rough) : kernel_unit<false>(p, pg, g.z, V, rough);
+        if (NRD_ROUGH_LUT && isSpec && HAS_DIFF)
+            __builtin_amdgcn_sched_barrier(0); // (the table entry is consumed here, behind everything that does not need it)
+        const RoughTerms rt = !isSpec ? RoughTerms{0.0f, 0.0f, 0.0f, 0.0f} : (NRD_ROUGH_LUT ? rough_terms_of(rtRaw) : rough_terms(p.hp, rough));
+        const KernelUnit ku = isSpec ? kernel_unit<true>(p, pg, g.z, V, rough, rt) : kernel_unit<false>(p, pg, g.z, V, rough, rt);
         float hitNorm = fma_(pg.absZ, p.hp[1], p.hp[0]) * ku.hitFactor;
         float hitDist = center.w * hitNorm;
         float hitDistFactor = sat(hitDist * rcp_(pg.frustumSize));
@@ -974,9 +1014,9 @@ struct Footprint {
 // (Source/NRDSample.cpp:3869-3876: objects that travel with the camera, e.g. a first-person weapon) keep their VIEW-space
 // position from frame to frame, so their virtual point is projected as it stands in the current view instead of being carried
 // back through the camera motion. The test is wave-uniform off when no material is named (the sample's setting, Shared.hlsli:44).
-NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float roughness, uint32_t mat, float& vu, float& vv) {
+// (`f` = spec_dominant_factor of the pixel's roughness: dominant_factor_of below)
+NRD_DEV bool virtual_uv(const FrameConsts& c, const Reproj& r, float hitDist, float f, uint32_t mat, float& vu, float& vv) {
     f3 toCam = ORTHO ? rot3(c.v2w, f3{0.0f, 0.0f, r.zPrev >= 0.0f ? 1.0f : -1.0f}) : normalize3(r.Xw); // direction camera -> surface
-    float f = spec_dominant_factor(roughness);
     f3 Xvirt = add3(r.Xw, mul3(toCam, hitDist * f));
     f3 XvirtPrev = add3(Xvirt, sub3(r.XwPrev, r.Xw));
     f3 rel = sub3(XvirtPrev, {c.camDelta[0], c.camDelta[1], c.camDelta[2]});
@@ -1179,6 +1219,7 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
     float threshold = thrBase * c.minRectDimMulUnproject * zpersp(absf(r.zPrev));
     uint32_t minMatAny = p.minMatDiff < p.minMatSpec ? p.minMatDiff : p.minMatSpec;
     const bool historyOk = c.historyOk != 0;
+    const float domFactor = HAS_SPEC ? dominant_factor_of(p, g) : 0.0f;
     // ---- both footprints: positions, then ALL their gathers, then validation
     FootPos spos = foot_pos(c, r.su, r.sv);
     FootRaw<RBPT, LBPT, RELAX> sraw, vraw;
@@ -1187,7 +1228,7 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
     bool vOk = false;
     if (HAS_SPEC) {
         float tu, tv;
-        vOk = virtual_uv(c, r, hitDist, g.roughness, g.mat, tu, tv) && historyOk;
+        vOk = virtual_uv(c, r, hitDist, domFactor, g.mat, tu, tv) && historyOk;
         vu = vOk ? tu : -10.0f; // an unusable virtual position lands outside: no texel validates (bits 0, weight 0)
         vv = vOk ? tv : -10.0f;
     }
@@ -1272,7 +1313,7 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         prevRough *= rcp_(vmb.wsum);
         float roughA = (geo && geo->roughA >= 0.0f) ? geo->roughA : rcp_(lerpf(0.01f, 1.0f, sat(g.roughness * p.roughnessFraction)));
         float rconf = smoothstep01(1.0f - absf((prevRough - g.roughness) * roughA));
-        float amount = vmbOk ? spec_dominant_factor(g.roughness) * vmb.wsum * rconf : 0.0f;
+        float amount = vmbOk ? domFactor * vmb.wsum * rconf : 0.0f;
         float dA, sA;
         blendA(vmb, vraw.a, dA, sA);
         float Avmb = vmbOk ? fmin2(sA + 1.0f, p.maxASpec) : 0.0f;
@@ -1727,7 +1768,7 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_TS_WAVES) void k_temporal
     FootPos vpos = spos;
     if (HAS_SPEC) {
         float tu, tv;
-        bool vOk = virtual_uv(c, r, hitDist, g.roughness, g.mat, tu, tv) && amount > 0.0f;
+        bool vOk = virtual_uv(c, r, hitDist, dominant_factor_of(p, g), g.mat, tu, tv) && amount > 0.0f;
         vpos = foot_pos(c, vOk ? tu : -10.0f, vOk ? tv : -10.0f); // unusable virtual position: lands outside, never validates
         load_stab(p, vpos, LBPT, vraw);
     }

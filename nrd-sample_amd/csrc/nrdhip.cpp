@@ -136,6 +136,9 @@ struct DenoiserState {
     std::vector<Dispatch> dispatches;
     // ClassifyTiles' per-tile flags in launch order (FrameConsts::tileFlags), one device buffer per grid shape this denoiser ran on
     std::map<std::pair<int, int>, uint8_t*> tileFlags;
+    // roughness-only terms of the specular kernel set-up by roughness code (ReblurParams::roughLut): 16 KB, REBLUR / RELAX denoisers with a
+    // specular signal, allocated with the instance, rewritten by every ClassifyTiles launch
+    float* roughLut = nullptr;
 };
 
 inline uint32_t enc_perm(uint32_t i) { return i; }
@@ -653,6 +656,7 @@ ReblurParams make_reblur_params(nrdhip_instance& I, DenoiserState& d, const Fram
     p.hp[2] = s.hitDistanceParameters.C;
     p.hp[3] = s.hitDistanceParameters.D;
     p.hitFactorDiff = reblur_hitdist_factor(p.hp, 1.0f);
+    p.roughLut = d.roughLut;
     p.planeDistanceSensitivity = s.planeDistanceSensitivity;
     p.lobeAngleFraction = s.lobeAngleFraction;
     p.roughnessFraction = s.roughnessFraction;
@@ -1303,18 +1307,27 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
         d.identifier = desc->denoisers[i].identifier;
         if (find(*I, d.identifier)) {
             g_createError = "non unique identifier";
-            delete I;
+            nrdhip_destroy(I); // (frees what the denoisers in front of this one hold)
             return (int)nrd::Result::NON_UNIQUE_IDENTIFIER;
         }
         if (desc->denoisers[i].denoiser >= (uint32_t)nrd::Denoiser::MAX_NUM || !classify((nrd::Denoiser)desc->denoisers[i].denoiser, d)) {
             g_createError = "unsupported denoiser";
-            delete I;
+            nrdhip_destroy(I);
             return (int)nrd::Result::UNSUPPORTED;
         }
         d.permBase = (uint32_t)permDesc.size();
         d.transBase = (uint32_t)transDesc.size();
         describe(d, permDesc, transDesc);
         d.permEnd = (uint32_t)permDesc.size();
+        if ((d.kind == Kind::REBLUR || d.kind == Kind::RELAX) && d.hasSpec) {
+            if (hipMalloc((void**)&d.roughLut, 1024 * 4 * sizeof(float)) != hipSuccess || hipMemset(d.roughLut, 0, 1024 * 4 * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();
+                g_createError = "hipMalloc failed (is a HIP device visible?)";
+                I->denoisers.push_back(d);
+                nrdhip_destroy(I);
+                return (int)nrd::Result::FAILURE;
+            }
+        }
         I->denoisers.push_back(d);
     }
     auto make = [&](std::vector<PoolPlane>& descs, std::vector<Plane>& planes) -> bool {
@@ -1417,10 +1430,13 @@ NRDHIP_API void nrdhip_destroy(nrdhip_instance* inst) {
     for (auto& t : inst->tileTables)
         if (t.second.dev)
             (void)hipFree(t.second.dev);
-    for (auto& d : inst->denoisers)
+    for (auto& d : inst->denoisers) {
         for (auto& f : d.tileFlags)
             if (f.second)
                 (void)hipFree(f.second);
+        if (d.roughLut)
+            (void)hipFree(d.roughLut);
+    }
     release_graphs(*inst);
     {
         std::lock_guard<std::mutex> lock(g_liveMutex);

@@ -161,9 +161,18 @@ def exp2_poly3(x):
 
 
 def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_index, denoising_range, s, exp_hit_weight=False,
-            angle_normal_weight=False, no_reach=False, f32_guide=False, one_step_sqrt=False, poly3_exp2=False, arc_normal_weight=False):
+            angle_normal_weight=False, no_reach=False, f32_guide=False, one_step_sqrt=False, poly3_exp2=False, arc_normal_weight=False,
+            relax_in=False, to_ycocg=False):
     """REBLUR_DIFFUSE_SPECULAR PrePass of one frame (perspective, no jitter, radiance mode, full frame). `s`: dict of the
-    ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16)."""
+    ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16).
+    relax_in (round 6): RELAX's PrePass - the inputs carry WORLD-space hit distances (hitDistanceParameters {1, 0, 1, 0}: no normalisation),
+    so the hit-distance weight compares them relative to the centre's (scale 1 / max(hitT, 1e-3)); to_ycocg: the frozen build flavour
+    converts the linear-RGB texels to YCoCg on the way in (the default flavour keeps RELAX in linear RGB)"""
+    def conv(t):
+        if not to_ycocg:
+            return t
+        r, g_, b = t[..., 0], t[..., 1], t[..., 2]
+        return np.stack([0.25 * r + 0.5 * g_ + 0.25 * b, 0.5 * r - 0.5 * b, 0.5 * g_ - 0.25 * r - 0.25 * b, t[..., 3]], -1)
     H, W = viewz.shape
     M = np.asarray(view_to_clip, np.float64)
     sgn = 1.0 if M[11] > 0 else -1.0
@@ -200,7 +209,7 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
     track = np.zeros((H, W), np.float64)
     hp = s["hitDistanceParameters"]
     for sig, (plane, is_spec) in enumerate(((diff, False), (spec, True))):
-        center = plane.astype(np.float64)
+        center = conv(plane.astype(np.float64))
         rough = rough_g if is_spec else np.ones_like(rough_g)
         min_mat = s["minMaterialForSpecular"] if is_spec else s["minMaterialForDiffuse"]
         hn = hitdist_norm(absz, hp, rough)
@@ -228,6 +237,8 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
         angle = np.arctan(3.0 * np.clip(rough, 0, 1) ** 2)  # lerp(lobeAngleFraction, 1, nonLinearAccumSpeed = 1) = 1 in the PrePass
         normal_w = 1.0 / np.maximum(angle, NORMAL_ANGLE_MIN)
         hitA = 1.0 / (1e-6 + (1.0 - 1e-6) * np.minimum(1.0, smc))
+        if relax_in:
+            hitA = hitA / np.maximum(center[..., 3], 1e-3)
         hitB = -center[..., 3] * hitA
         roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
         roughB = -rough * roughA
@@ -238,7 +249,7 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
             in_win = (fpx >= np.maximum(xx - reach, 0)) & (fpx <= np.minimum(xx + reach, W - 1)) & (fpy >= np.maximum(yy - reach, 0)) & (fpy <= np.minimum(yy + reach, H - 1))
             px, py = np.clip(fpx, 0, W - 1).astype(np.int64), np.clip(fpy, 0, H - 1).astype(np.int64)
             zs, ns, rs_, ms = z[py, px], n[py, px], rough_g[py, px], mat[py, px]
-            sv = plane[py, px].astype(np.float64)
+            sv = conv(plane[py, px].astype(np.float64))
             valid = in_win & active & ~sky[py, px] & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
             w = POISSON8[t, 2] * smoothstep01(1.0 - np.abs(zs * (gax * fpx + gay * fpy + ga0) + geoB))
             cosa = normal_cos(n, ns, f32_guide)

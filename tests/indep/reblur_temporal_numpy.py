@@ -152,10 +152,19 @@ def pack_speeds(a_diff, a_spec):
     return (q(a_diff) | (q(a_spec) << 8)).astype(np.uint16)
 
 
-def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_prev, hit_track, conf, history_ok):
+def luma_of(v, rec709):
+    """luminance of a radiance texel [..., 4]: channel 0 (YCoCg planes) or Rec.709 of linear RGB (RELAX in the default build flavour)"""
+    return 0.2126 * v[..., 0] + 0.7152 * v[..., 1] + 0.0722 * v[..., 2] if rec709 else v[..., 0]
+
+
+def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_prev, hit_track, conf, history_ok, relax=None):
     """tmp1 / hist: [H, W, 2, 4] fp16 (diffuse, specular); fast_prev [H, W, 2] fp16; speeds_prev [H, W] uint16; hit_track [H, W] fp16.
-    Returns tmp2 [H, W, 2, 4] fp16, fast [H, W, 2] fp16, speeds uint16, data2 uint32"""
+    Returns tmp2 [H, W, 2, 4] fp16, fast [H, W, 2] fp16, speeds uint16, data2 uint32.
+    relax = dict(moments_prev [H, W, 2] fp16, max_a_spec, max_fast_spec, rec709): RELAX's TemporalAccumulation (round 6) - the same two
+    footprints; per-signal history caps; the fast history and a second-moment history (returned in info["moments"]) of the LUMINANCE of the
+    linear-RGB texel; bits 16..23 of data2 carry the reprojection quality of the specular history for the A-trous relaxation"""
     H, W = c.H, c.W
+    rec709 = bool(relax and relax["rec709"])
     z, n, rough, mat = gcur
     sky = ~(np.abs(z) <= c.range)
     yy, xx = np.mgrid[0:H, 0:W]
@@ -167,30 +176,40 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
     Nv_prev = n @ c.w2v_prev.T
     threshold = c.disocclusion * c.min_dim_unproject * np.abs(r["z_prev"])
     max_a, max_fast = float(min(s["maxAccumulatedFrameNum"], 63)), float(min(s["maxFastAccumulatedFrameNum"], 63))
+    max_a_s = float(min(relax["max_a_spec"], 63)) if relax else max_a
+    max_fast_s = float(min(relax["max_fast_spec"], 63)) if relax else max_fast
     min_any = min(s["minMaterialForDiffuse"], s["minMaterialForSpecular"])
     smb = footprint(c, r["su"], r["sv"], Nv_prev, r["Xv_prev"], n, mat, min_any, threshold, gprev)
     smb_ok = history_ok & (smb["wsum"] > 0)
     pd, ps = unpack_speeds(speeds_prev)
     prev_d = np.where(smb_ok, np.minimum(fetch(c, pd, smb) + 1.0, max_a), 0.0)
-    prev_s = np.where(smb_ok, np.minimum(fetch(c, ps, smb) + 1.0, max_a), 0.0)
+    prev_s = np.where(smb_ok, np.minimum(fetch(c, ps, smb) + 1.0, max_a_s), 0.0)
     quality = np.where(smb_ok, smb["wsum"], 0.0)
     data2 = np.where(smb_ok, smb["bits"], 0).astype(np.int64)
     t1, hs, fp = tmp1.astype(np.float64), hist.astype(np.float64), fast_prev.astype(np.float64)
     out = np.zeros((H, W, 2, 4))
     fast = np.zeros((H, W, 2))
+    moments = np.zeros((H, W, 2))
+    mp = relax["moments_prev"].astype(np.float64) if relax else None
     cD = sample_confidence(conf, u, v)
     # ---- diffuse
     cin = t1[:, :, 0]
+    cY = luma_of(cin, rec709)
     A = prev_d * cD
     A = A * (quality + (1.0 - quality) / (1.0 + A))
     non_lin = 1.0 / (1.0 + A)
     h = np.where(smb_ok[..., None], fetch(c, hs[:, :, 0], smb), cin)
-    fh = np.where(smb_ok, fetch(c, fp[..., 0], smb), cin[..., 0])
+    fh = np.where(smb_ok, fetch(c, fp[..., 0], smb), cY)
     out[:, :, 0] = h + (cin - h) * non_lin[..., None]
-    fast[..., 0] = fh + (cin[..., 0] - fh) / (1.0 + np.minimum(A, max_fast))
+    fast[..., 0] = fh + (cY - fh) / (1.0 + np.minimum(A, max_fast))
+    if relax:
+        m2 = cY * cY
+        m2p = np.where(smb_ok, fetch(c, mp[..., 0], smb), m2)
+        moments[..., 0] = m2p + (m2 - m2p) * non_lin
     out_d = A
     # ---- specular
     cin = t1[:, :, 1]
+    cY = luma_of(cin, rec709)
     hd = hit_track.astype(np.float64)
     Xpar = (r["Xw_prev"] - c.cam_delta) @ c.w2v.T
     okp, pu, pv_ = c.project(Xpar)
@@ -204,11 +223,11 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
     roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
     rconf = sp.smoothstep01(1.0 - np.abs((prev_rough - rough) * roughA))
     amount = np.where(vmb_ok, sp.spec_dominant_factor(rough) * vmb["wsum"] * rconf, 0.0)
-    A_vmb = np.where(vmb_ok, np.minimum(fetch(c, ps, vmb) + 1.0, max_a), 0.0)
+    A_vmb = np.where(vmb_ok, np.minimum(fetch(c, ps, vmb) + 1.0, max_a_s), 0.0)
     vh = np.where(vmb_ok[..., None], fetch(c, hs[:, :, 1], vmb), cin)
-    vf = np.where(vmb_ok, fetch(c, fp[..., 1], vmb), cin[..., 0])
+    vf = np.where(vmb_ok, fetch(c, fp[..., 1], vmb), cY)
     sh_ = np.where(smb_ok[..., None], fetch(c, hs[:, :, 1], smb), cin)
-    sf = np.where(smb_ok, fetch(c, fp[..., 1], smb), cin[..., 0])
+    sf = np.where(smb_ok, fetch(c, fp[..., 1], smb), cY)
     A_smb = np.where(smb_ok, A_smb, 0.0)
     A = A_smb + (A_vmb - A_smb) * amount
     A = A * cD  # one texture is bound to both confidence slots (Source/NRDSample.cpp:457, :462)
@@ -216,18 +235,25 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
     A = A * (q + (1.0 - q) / (1.0 + A))
     if s["responsiveRoughnessThreshold"] > 0.0:
         t = sp.smoothstep01(rough / s["responsiveRoughnessThreshold"])
-        A = np.minimum(A, s["responsiveMinAccum"] + (max_a - s["responsiveMinAccum"]) * t)
+        A = np.minimum(A, s["responsiveMinAccum"] + (max_a_s - s["responsiveMinAccum"]) * t)
     non_lin = 1.0 / (1.0 + A)
     h = sh_ + (vh - sh_) * amount[..., None]
     fh = sf + (vf - sf) * amount
     out[:, :, 1] = h + (cin - h) * non_lin[..., None]
-    fast[..., 1] = fh + (cin[..., 0] - fh) / (1.0 + np.minimum(A, max_fast))
+    fast[..., 1] = fh + (cY - fh) / (1.0 + np.minimum(A, max_fast_s))
     data2 = data2 | (np.where(vmb_ok, vmb["bits"], 0) << 4) | (np.floor(np.clip(amount, 0, 1) * 255.0 + 0.5).astype(np.int64) << 8)
+    if relax:
+        m2 = cY * cY
+        m2s = np.where(smb_ok, fetch(c, mp[..., 1], smb), m2)
+        m2v = np.where(vmb_ok, fetch(c, mp[..., 1], vmb), m2)
+        m2h = m2s + (m2v - m2s) * amount
+        moments[..., 1] = m2h + (m2 - m2h) * non_lin
+        data2 = data2 | (np.floor(np.clip(q, 0, 1) * 255.0 + 0.5).astype(np.int64) << 16)
     speeds = pack_speeds(out_d, A)
-    out[sky], fast[sky] = 0.0, 0.0
+    out[sky], fast[sky], moments[sky] = 0.0, 0.0, 0.0
     speeds = np.where(sky, 0, speeds).astype(np.uint16)
     data2 = np.where(sky, 0, data2).astype(np.uint32)
-    return f16(out), f16(fast), speeds, data2, dict(amount=amount, smb_ok=smb_ok, vmb_ok=vmb_ok)
+    return f16(out), f16(fast), speeds, data2, dict(amount=amount, smb_ok=smb_ok, vmb_ok=vmb_ok, moments=f16(moments))
 
 
 def pixel_geo(c, z, n, sens):
@@ -263,9 +289,14 @@ def pack_tap_guide(viewz, packed_nr, denoising_range=None):
     return sp.guide_words(viewz, packed_nr, denoising_range=denoising_range)
 
 
-def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=False):
-    """returns signal [H, W, 2, 4] fp16 (what goes into the tap texels), speeds uint16, tap guide words (w0, w1)"""
+def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=False, relax=None):
+    """returns signal [H, W, 2, 4] fp16 (what goes into the tap texels), speeds uint16, tap guide words (w0, w1).
+    relax = dict(moments [H, W, 2] fp16, normal_power, accel, spatial, temporal, reset, max_fast_spec, rec709): RELAX's HistoryFix (round 6) -
+    the reconstruction's normal weight is pow(N.Ns, historyFixEdgeStoppingNormalPower), the clamp works on the luminance of the texel
+    (scaling r, g, b together in linear RGB), a clamped pixel accelerates its history by accelerationAmount, and a history farther from the
+    fast 5x5 mean than spatialSigmaScale x spatial sigma + temporalSigmaScale x temporal sigma is reset by up to resetAmount (antilag)"""
     H, W = c.H, c.W
+    rec709 = bool(relax and relax["rec709"])
     z, n, rough_g, mat = gcur
     sky = ~(np.abs(z) <= c.range)
     yy, xx = np.mgrid[0:H, 0:W]
@@ -277,6 +308,7 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
     outA = [Ad.copy(), As.copy()]
     nfix, base = float(s["historyFixFrameNum"]), float(s["historyFixBasePixelStride"])
     max_fast = float(min(s["maxFastAccumulatedFrameNum"], 63))
+    max_fast_s = float(min(relax["max_fast_spec"], 63)) if relax else max_fast
     for sig, is_spec in ((0, False), (1, True)):
         A = As if is_spec else Ad
         rough = rough_g if is_spec else np.ones_like(rough_g)
@@ -299,7 +331,10 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
                 ok = fix & inside & (np.abs(zs) <= c.range) & ~((mat != ms) & (np.maximum(mat, ms) >= min_mat))
                 w = 1.0 / (1.0 + i * i + j * j)
                 w = w * sp.smoothstep01(1.0 - np.abs(zs * (pg["gax"] * px + pg["gay"] * py + pg["ga0"]) + pg["geoB"]))
-                w = w * sp.normal_weight(sp.normal_cos(n, n[cy, cx]), normal_w, upstream)  # (upstream: the default build flavour's form)
+                if relax:
+                    w = w * np.power(np.clip(sp.normal_cos(n, n[cy, cx]), 0.0, 1.0), relax["normal_power"])
+                else:
+                    w = w * sp.normal_weight(sp.normal_cos(n, n[cy, cx]), normal_w, upstream)  # (upstream: the default build flavour's form)
                 if is_spec:
                     w = w * sp.smoothstep01(1.0 - np.abs(rough_g[cy, cx] * roughA - rough * roughA))
                 tA = (As if is_spec else Ad)[cy, cx]
@@ -311,12 +346,21 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
             fc = fs[..., sig]
             m1, m2 = moments5x5(c, fc, fc, z)
             sigma = np.sqrt(np.maximum(m2 - m1 * m1, 0.0)) * s["fastHistoryClampingSigmaScale"]
-            Y = val[..., 0]
+            Y = luma_of(val, rec709)
             Yc = np.clip(Y, m1 - sigma, m1 + sigma)
             scale = (Yc + 1e-6) / (Y + 1e-6)
-            val = np.stack([Yc, val[..., 1] * scale, val[..., 2] * scale, val[..., 3]], -1)
+            val = np.stack([val[..., 0] * scale if rec709 else Yc, val[..., 1] * scale, val[..., 2] * scale, val[..., 3]], -1)
             f = np.clip(np.abs(Yc - Y) / np.maximum(np.maximum(Y, Yc), 1e-6), 0, 1)
-            outA[1 if is_spec else 0] = A + (np.minimum(A, max_fast) - A) * f
+            if relax:
+                f = f * np.clip(relax["accel"], 0, 1)
+            a_new = A + (np.minimum(A, max_fast_s if is_spec else max_fast) - A) * f
+            if relax:
+                sig_s = np.sqrt(np.maximum(m2 - m1 * m1, 0.0))
+                sig_t = np.sqrt(np.maximum(relax["moments"].astype(np.float64)[..., sig] - Y * Y, 0.0))
+                thr = relax["spatial"] * sig_s + relax["temporal"] * sig_t
+                over = np.clip(np.abs(Y - m1) / np.maximum(thr, 1e-6) - 1.0, 0, 1)
+                a_new = a_new * (1.0 - np.clip(relax["reset"], 0, 1) * over)
+            outA[1 if is_spec else 0] = a_new
         out[:, :, sig] = val
     out[sky] = 0.0
     speeds = np.where(sky, 0, pack_speeds(outA[0], outA[1])).astype(np.uint16)
@@ -479,6 +523,42 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
 # SIGMA_SHADOW_TRANSLUCENCY: Blur / PostBlur and TemporalStabilization
 # =====================================================================================================================
 SIGMA_MAX_PIXEL_RADIUS, SIGMA_BLUR_REACH, SIGMA_STAB_SIGMA_SCALE = 48.0, 56, 2.0
+
+
+def sigma_classify_tiles(c, z, pen, tile=16):
+    """SIGMA ClassifyTiles (round 6): per 16 x 16 tile - bit 0: some pixel with geometry lies in penumbra (a finite IN_PENUMBRA), bit 1: some
+    pixel with geometry is lit (IN_PENUMBRA = fp16 max, the sample's "no occluder" code, Shaders/TraceOpaque.cs.hlsl:800-801), bits 8..15:
+    the largest penumbra radius of the tile in pixels (world size / pixel size at the depth), rounded up, capped at 255.
+    z [H, W] view depth, pen [H, W] fp16"""
+    H, W = c.H, c.W
+    ty, tx = (H + tile - 1) // tile, (W + tile - 1) // tile
+    geo = np.abs(z) <= c.range
+    p = pen.astype(np.float64)
+    lit = p >= 65504.0
+    r_px = np.minimum(p / (c.unproject * np.maximum(np.abs(z), 1e-300)), 255.0)
+    out = np.zeros((ty, tx), np.uint16)
+    for j in range(ty):
+        for i in range(tx):
+            sl = (slice(j * tile, min((j + 1) * tile, H)), slice(i * tile, min((i + 1) * tile, W)))
+            g, l = geo[sl], lit[sl]
+            flags = (1 if (g & ~l).any() else 0) | (2 if (g & l).any() else 0)
+            m = float(r_px[sl][g & ~l].max()) if (g & ~l).any() else 0.0
+            out[j, i] = flags | (min(int(np.floor(m + 0.999)), 255) << 8)
+    return out
+
+
+def sigma_smooth_tiles(tiles):
+    """SIGMA SmoothTiles: a tile is filtered (bit 0) when its 3 x 3 tile neighbourhood holds BOTH penumbra and lit pixels - a shadow edge
+    passes through or next to it; its radius is the largest of the neighbourhood"""
+    ty, tx = tiles.shape
+    t = tiles.astype(np.int64)
+    out = np.zeros_like(tiles)
+    for j in range(ty):
+        for i in range(tx):
+            nb = t[max(j - 1, 0):j + 2, max(i - 1, 0):i + 2]
+            flags = int(np.bitwise_or.reduce((nb & 3).ravel()))
+            out[j, i] = (1 if flags == 3 else 0) | (int((nb >> 8).max()) << 8)
+    return out
 
 
 def sigma_input_visibility(pen, transl):

@@ -328,6 +328,123 @@ def test_relax_atrous_iterations_independent(request, pkg, api, f, flavour):
     agree("A-trous iteration 1", rad("RELAX::Atrous_B"), tmp.atrous_iteration(c, s, gcur, a0, 1, data2=data2, upstream=upstream), 1.0, max_ulp=1)
 
 
+@pytest.mark.parametrize("f,flavour", [(0, "default"), (2, "default"), (2, "frozen")])
+def test_relax_prepass_independent(request, pkg, api, f, flavour):
+    """RELAX_DIFFUSE_SPECULAR's PrePass (round 6): the spatial pass of tests/indep/reblur_numpy.py on RELAX's input convention - linear RGB
+    (converted to YCoCg on the way in by the frozen flavour only) + world-space hit distances compared relative to the centre's"""
+    upstream = flavour == "default"
+    orc = request.getfixturevalue("oracle" if upstream else "oracle_frozen")
+    D = api.Denoiser
+    den = int(D.RELAX_DIFFUSE_SPECULAR)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    fr = frame(f)
+    hz = pkg.harness.Harness(orc, [D.RELAX_DIFFUSE_SPECULAR], W, H)
+    st = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    cs = scene.common_settings(api, fr, f, reset=True)
+    hz.nrd.new_frame()
+    hz.nrd.set_common_settings(cs)
+    hz.bind(hz.upload(fr))
+    hz.nrd.set_denoiser_settings(den, st)
+    names = [d["name"] for d in hz.nrd.dispatches([den])]
+    assert names[:2] == ["RELAX::ClassifyTiles", "RELAX::PrePass"]
+    hz.nrd.denoise_range([den], 0, 2)
+    tmp1 = hz.pool("RELAX::Tmp1").copy().view(np.float16).reshape(H, W, 2, 4)
+    track = hz.pool("RELAX::SpecHitDistForTracking").copy().view(np.float16).reshape(H, W)
+    s = dict(planeDistanceSensitivity=api.ReblurSettings().planeDistanceSensitivity, roughnessFraction=st.roughnessFraction,
+             minHitDistanceWeight=st.minHitDistanceWeight, diffusePrepassBlurRadius=st.diffusePrepassBlurRadius,
+             specularPrepassBlurRadius=st.specularPrepassBlurRadius, minMaterialForDiffuse=st.minMaterialForDiffuse,
+             minMaterialForSpecular=st.minMaterialForSpecular, hitDistanceParameters=(1.0, 0.0, 1.0, 0.0))
+    want, want_track = ind.prepass(fr["viewz"], fr["normal_roughness"], fr["diff"], fr["spec"], fr["view_to_clip"], fr["world_to_view"], cs.frameIndex,
+                                   cs.denoisingRange, s, exp_hit_weight=upstream, angle_normal_weight=upstream, relax_in=True, to_ycocg=not upstream)
+    # The golden inputs are YCoCg-coded texels fed to RELAX as if they were linear RGB: "colour" channels of both signs whose weighted
+    # sums cancel (0.005 next to a luminance of 1.8), so a channel can sit 61 of ITS OWN ULPs off while the texel is right to 1e-4. Stated
+    # bar: >= 99.99 % of the values within 1 fp16 ULP and EVERY value within 1 ULP of its texel's largest component
+    agree("RELAX PrePass frame %d %s" % (f, flavour), tmp1, want, 0.9999)
+    scale = np.maximum(np.abs(want.astype(np.float64)).max(-1, keepdims=True), 2.0 ** -14)
+    assert (np.abs(tmp1.astype(np.float64) - want.astype(np.float64)) <= 2.0 ** (np.floor(np.log2(scale)) - 10)).all()
+    assert float((ulp16(track, want_track) <= 1).mean()) > 0.98
+
+
+@pytest.mark.parametrize("f,flavour", [(1, "default"), (2, "default"), (3, "default"), (2, "frozen")])
+def test_relax_temporal_passes_independent(request, pkg, api, f, flavour):
+    """RELAX_DIFFUSE_SPECULAR's TemporalAccumulation and HistoryFix (round 6) against the numpy / float64 restatement,
+    each fed the planes the oracle fed its own pass: the two footprints with per-signal history caps, the fast and second-moment histories
+    of the texel's LUMINANCE (Rec.709 of linear RGB in the default flavour, channel 0 of YCoCg in the frozen one), the reprojection quality
+    the A-trous iterations relax their edge stopping by (data2 bits 16..23); HistoryFix: reconstruction with pow(N.Ns, power) as its normal
+    weight, fast-history clamp of the luminance, antilag (acceleration + spatial / temporal sigma reset). Stated bars as for REBLUR"""
+    upstream = flavour == "default"
+    orc = request.getfixturevalue("oracle" if upstream else "oracle_frozen")
+    D = api.Denoiser
+    den = int(D.RELAX_DIFFUSE_SPECULAR)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    hz = pkg.harness.Harness(orc, [D.RELAX_DIFFUSE_SPECULAR], W, H)
+    st = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    rb = api.ReblurSettings()  # what the shared passes take from ReblurSettings' defaults (oracle/orc_reblur.cpp relax_as_reblur)
+    s = dict(maxAccumulatedFrameNum=st.diffuseMaxAccumulatedFrameNum, maxFastAccumulatedFrameNum=st.diffuseMaxFastAccumulatedFrameNum,
+             minMaterialForDiffuse=st.minMaterialForDiffuse, minMaterialForSpecular=st.minMaterialForSpecular, roughnessFraction=st.roughnessFraction,
+             lobeAngleFraction=st.lobeAngleFraction, planeDistanceSensitivity=rb.planeDistanceSensitivity, historyFixFrameNum=st.historyFixFrameNum,
+             historyFixBasePixelStride=st.historyFixBasePixelStride, fastHistoryClampingSigmaScale=st.fastHistoryClampingSigmaScale,
+             responsiveRoughnessThreshold=rb.responsiveAccumulationSettings.roughnessThreshold,
+             responsiveMinAccum=float(rb.responsiveAccumulationSettings.minAccumulatedFrameNum))
+    for g in range(f):
+        fr = frame(g)
+        hz.frame(scene.common_settings(api, fr, g, reset=(g == 0)), hz.upload(fr), {D.RELAX_DIFFUSE_SPECULAR: st})
+    fr, prev = frame(f), frame(f - 1)
+    cs = scene.common_settings(api, fr, f)
+    hz.nrd.new_frame()
+    hz.nrd.set_common_settings(cs)
+    hz.bind(hz.upload(fr))
+    hz.nrd.set_denoiser_settings(den, st)
+    names = [d["name"].split("::")[1] for d in hz.nrd.dispatches([den])]
+    assert names[:4] == ["ClassifyTiles", "PrePass", "TemporalAccumulation", "HistoryFix"]
+    cur, old = ("_A", "_B") if f % 2 == 0 else ("_B", "_A")
+    rad = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2, 4)
+    lum = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2)
+    u16 = lambda name: hz.pool(name).copy().view(np.uint16).reshape(H, W)
+    c = tmp.Consts(fr, W, H, cs.denoisingRange, cs.disocclusionThreshold)
+    gcur = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
+    gprev = ind.decode_guide(prev["viewz"], prev["normal_roughness"])
+    geo = np.abs(gcur[0]) <= cs.denoisingRange
+
+    # ---- TemporalAccumulation
+    hz.nrd.denoise_range([den], 0, 2)
+    tmp1, hist, fast_prev, mom_prev = rad("RELAX::Tmp1"), rad("RELAX::History"), lum("RELAX::FastHistory" + old), lum("RELAX::Moments" + old)
+    speeds_prev = u16("RELAX::HistoryLength" + old)
+    track = hz.pool("RELAX::SpecHitDistForTracking").copy().view(np.float16).reshape(H, W)
+    hz.nrd.denoise_range([den], 2, 1)
+    tmp2, fast, mom, speeds_tmp = rad("RELAX::Tmp2"), lum("RELAX::FastHistory" + cur), lum("RELAX::Moments" + cur), u16("RELAX::HistoryLength_Tmp")
+    data2 = hz.pool("RELAX::Data2").copy().view(np.uint32).reshape(H, W)
+    rx = dict(moments_prev=mom_prev, max_a_spec=st.specularMaxAccumulatedFrameNum, max_fast_spec=st.specularMaxFastAccumulatedFrameNum, rec709=upstream)
+    w_tmp2, w_fast, w_speeds, w_data2, info = tmp.temporal_accumulation(c, s, gcur, gprev, fr["mv"], tmp1, hist, fast_prev, speeds_prev, track, fr["confidence"], True, relax=rx)
+    assert info["smb_ok"][geo].mean() > 0.8 and info["vmb_ok"][geo].mean() > 0.5
+    agree("RELAX TA radiance", tmp2, w_tmp2, 1.0, max_ulp=1)
+    agree("RELAX TA fast history", fast, w_fast, 1.0, max_ulp=1)
+    # (the second moment of this NOISY input spans five decades between neighbouring texels - 1e-5 next to 3.65 on frame 1: where float32 puts a
+    # footprint 1e-6 of a texel off the row float64 puts it exactly on, the outlier below leaks in with that weight: 2 of 6144 values, 3 and 12 ULP)
+    agree("RELAX TA second moment", mom, info["moments"], 0.999)
+    assert float(((data2 & 15) == (w_data2 & 15)).mean()) > 0.995
+    assert float((((data2 >> 4) & 15) == ((w_data2 >> 4) & 15)).mean()) > 0.97
+    for shift in (8, 16):  # virtual-motion amount, reprojection quality of the specular history (unorm8)
+        assert float((np.abs(((data2 >> shift) & 255).astype(np.int32) - ((w_data2 >> shift) & 255).astype(np.int32)) <= 1).mean()) > 0.99, shift
+    for shift in (0, 8):  # accumulation speeds, quarter frames
+        a, b = (speeds_tmp >> shift) & 255, (w_speeds >> shift) & 255
+        assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99 and float((a == b).mean()) > 0.95
+
+    # ---- HistoryFix + fast-history clamp + antilag (fed with the ORACLE's TemporalAccumulation outputs); the result IS the next history
+    hz.nrd.denoise_range([den], 3, 1)
+    new_hist, speeds_cur = rad("RELAX::History"), u16("RELAX::HistoryLength" + cur)
+    al = st.antilagSettings
+    rh = dict(moments=mom, normal_power=st.historyFixEdgeStoppingNormalPower, accel=al.accelerationAmount, spatial=al.spatialSigmaScale,
+              temporal=al.temporalSigmaScale, reset=al.resetAmount, max_fast_spec=st.specularMaxFastAccumulatedFrameNum, rec709=upstream)
+    w_sig, w_speeds_cur, _ = tmp.history_fix(c, s, gcur, tmp2, speeds_tmp, fast, fr["viewz"], fr["normal_roughness"], upstream=upstream, relax=rh)
+    agree("RELAX HistoryFix history", new_hist, w_sig, 1.0, max_ulp=1)
+    for shift in (0, 8):
+        a, b = (speeds_cur >> shift) & 255, (w_speeds_cur >> shift) & 255
+        assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99, shift
+    # (the antilag must have had something to do on these frames: some pixel's history was shortened by the clamp / reset)
+    assert ((speeds_cur & 255) < (speeds_tmp & 255)).any() or ((speeds_cur >> 8) < (speeds_tmp >> 8)).any()
+
+
 @pytest.mark.parametrize("f", [1, 2, 3])
 def test_sigma_passes_independent(pkg, api, oracle, f):
     """SIGMA_SHADOW_TRANSLUCENCY: Blur, PostBlur (penumbra-sized tangent-plane blur of the visibility) and TemporalStabilization
@@ -354,9 +471,17 @@ def test_sigma_passes_independent(pkg, api, oracle, f):
     gcur = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
     gprev = ind.decode_guide(prev["viewz"], prev["normal_roughness"])
     z, n = gcur[0], gcur[1]
-    hz.nrd.denoise_range([den], 0, 2)
+    # ---- ClassifyTiles and SmoothTiles (round 6): the per-tile flags / radii every later pass of the frame is steered by - exact
+    hz.nrd.denoise_range([den], 0, 1)
+    raw_tiles = hz.pool("SIGMA::Tiles").copy().view(np.uint16).reshape((H + 15) // 16, (W + 15) // 16)
+    w_tiles = tmp.sigma_classify_tiles(c, z, fr["penumbra"])
+    assert np.array_equal(raw_tiles & 3, w_tiles & 3), "ClassifyTiles: penumbra / lit flags"
+    dr = np.abs((raw_tiles >> 8).astype(np.int32) - (w_tiles >> 8).astype(np.int32))
+    assert dr.max() <= 1 and float((dr == 0).mean()) >= 0.9, "ClassifyTiles: tile radius (a float32 quotient next to an integer may round up the other way)"
+    hz.nrd.denoise_range([den], 1, 1)
     tiles = hz.pool("SIGMA::SmoothTiles").copy().view(np.uint16).reshape((H + 15) // 16, (W + 15) // 16)
-    assert (tiles & 1).any(), "the scene must have penumbra tiles for this test to mean anything"
+    assert np.array_equal(tiles, tmp.sigma_smooth_tiles(raw_tiles)), "SmoothTiles (fed the oracle's Tiles plane)"
+    assert (tiles & 1).any() and (raw_tiles & 3 == 3).any(), "the scene must have penumbra tiles for this test to mean anything"
     vis = tmp.sigma_input_visibility(fr["penumbra"].astype(np.float64), fr["translucency"])
     w_sh1, w_pen1 = tmp.sigma_blur(c, s, z, n, tiles, fr["penumbra"], vis, cs.frameIndex, 0)
     hz.nrd.denoise_range([den], 2, 1)

@@ -12,7 +12,7 @@ for m in re.finditer(r'^(_ZN[^\n:]*):.*?; Occupancy: \d+', s, re.S|re.M):
     name=m.group(1)
     if pat not in name: continue
     body=m.group(0)
-    code=body.split('s_endpgm')[0]
+    code=body  # (whole function: kernels with an early exit have several s_endpgm)
     vg=re.search(r'; NumVgprs: (\d+)',body); sc=re.search(r'; ScratchSize: (\d+)',body); oc=re.search(r'; Occupancy: (\d+)',body); sg=re.search(r'; TotalNumSgprs: (\d+)',body)
     nv=len(re.findall(r'^\s+v_',code,re.M)); nb=len(re.findall(r'^\s+s_cbranch',code,re.M)); nl=len(re.findall(r'^\s+global_load',code,re.M)); nw=len(re.findall(r'^\s+s_waitcnt vmcnt',code,re.M))
     short=re.sub(r'_ZN6nrdhip\d*(_GLOBAL__N_1|5ortho12_GLOBAL__N_1)?','',name).replace('NS_12ReblurParamsE','')
