@@ -6,6 +6,7 @@
 
 namespace nrdhip {
 
+#define NRDHIP_ROUGH_LUT_FLOATS (4096 + 2048)
 struct ReblurParams {
     FrameConsts c;
     // nrd::ReblurSettings (Source/NRDSample.cpp:563-585 defaults, :4090-4124 per frame)
@@ -60,7 +61,8 @@ struct ReblurParams {
     // The roughness-only terms of the specular kernel set-up as a table over the 10-bit roughness code of the guide (nrd_reblur.hip
     // rough_terms): 1024 x {dominant factor, magic curve, lobe half angle, hit distance factor} = 16 KB per denoiser, written by the first
     // workgroup of every ClassifyTiles launch with the very functions a pixel would evaluate, read back by the spatial passes with one
-    // 16-byte load per pixel (nullptr: the denoiser has no specular signal)
+    // 16-byte load per pixel (nullptr: the denoiser has no specular signal). Behind it (floats 4096 ..): 1024 x {1 - 2^(-200 r^2), log2 r},
+    // the roughness-only terms of TemporalAccumulation's specular accumulation limit. NRDHIP_ROUGH_LUT_FLOATS floats in all
     float* roughLut;
 };
 

@@ -228,6 +228,11 @@ NRD_DEV RoughTerms rough_terms_of(const uint4 raw) { return {u2f(raw.x), u2f(raw
 NRD_DEV float dominant_factor_of(const ReblurParams& p, const Guide& g) {
     return NRD_ROUGH_LUT ? p.roughLut[(f2u(g.z) & 1023u) * 4u] : spec_dominant_factor(g.roughness);
 }
+// second table behind the first (floats 4096 ..): the roughness-only terms of the specular accumulation limit (spec_accum_limit) -
+// {1 - 2^(-200 r^2), log2(r)}: an exp2 and a log2 polynomial, ~47 instructions per pixel of TemporalAccumulation
+constexpr uint32_t ROUGH_LUT_ACCUM = 4096u;
+static_assert(NRDHIP_ROUGH_LUT_FLOATS == 4096 + 2048, "nrd_kernels.h: the allocation holds both tables");
+NRD_DEV float2 accum_terms_of(const ReblurParams& p, const Guide& g) { return *reinterpret_cast<const float2*>(p.roughLut + ROUGH_LUT_ACCUM + (f2u(g.z) & 1023u) * 2u); }
 __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
     const FrameConsts& c = p.c;
     // a streaming pass without neighbour reads: plain 2-D grid (the XCD traversal of the other passes costs a wave ~700 cycles of
@@ -278,6 +283,8 @@ __global__ __launch_bounds__(256) void k_classify_tiles(const ReblurParams p) {
             const uint32_t code = (uint32_t)(tid + 256 * k);
             const RoughTerms t = rough_terms(p.hp, (float)code * (1.0f / 1023.0f)); // (the roughness decode_guide gives a pixel of this code)
             *reinterpret_cast<float4*>(p.roughLut + code * 4u) = float4{t.df, t.smc, t.angle0, t.hitFactor};
+            const float r = (float)code * (1.0f / 1023.0f);
+            *reinterpret_cast<float2*>(p.roughLut + ROUGH_LUT_ACCUM + code * 2u) = float2{1.0f - exp2_poly(-200.0f * r * r), log2_poly(sat(r))};
         }
     }
 }
@@ -1043,12 +1050,17 @@ NRD_DEV float sample_confidence(const PlaneRef& P, float u, float v) {
     return sat(lerpf(a, b, fy));
 }
 
-NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx) {
+// (`at` = the roughness-only terms {1 - 2^(-200 r^2), log2(r)} from the table - accum_terms_of below; nullptr: evaluate them)
+NRD_DEV float spec_accum_limit(float roughness, float NoV, float parallaxPx, const float2* at = nullptr) {
     float acos01sq = sat(1.0f - NoV * 0.99999f);
     float a = sqrt_(acos01sq);
     float b = fma_(roughness, roughness, 1.1f);
     float parallaxSensitivity = (b + a) * rcp_(b - a);
     float powerScale = fma_(parallaxSensitivity * parallaxPx, 2.0f, 1.0f);
+    if (at) { // pow01(r, y) = r <= 0 ? 0 : 2^(y log2 r), r in [0, 1] already
+        const float pw = roughness <= 0.0f ? 0.0f : exp2_poly((0.5f * powerScale) * at->y);
+        return MAX_ACCUM * (at->x * pw);
+    }
     float f = 1.0f - exp2_poly(-200.0f * roughness * roughness);
     f *= pow01(roughness, 0.5f * powerScale);
     return MAX_ACCUM * f;
@@ -1287,7 +1299,8 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
             float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
             parallax = sqrt_(fma_(dx, dx, dy * dy));
         }
-        float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax));
+        const float2 accumTerms = NRD_ROUGH_LUT ? accum_terms_of(p, g) : float2{0.0f, 0.0f};
+        float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax, NRD_ROUGH_LUT ? &accumTerms : nullptr));
         const float inY = signal_luma(in, RELAX);
         f4 smbHist = smbOk ? blend4(smb, sraw.t, sw) : in;
         float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : inY;

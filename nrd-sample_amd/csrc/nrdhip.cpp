@@ -1320,7 +1320,7 @@ NRDHIP_API int nrdhip_create(const nrdhip_create_desc* desc, nrdhip_instance** o
         describe(d, permDesc, transDesc);
         d.permEnd = (uint32_t)permDesc.size();
         if ((d.kind == Kind::REBLUR || d.kind == Kind::RELAX) && d.hasSpec) {
-            if (hipMalloc((void**)&d.roughLut, 1024 * 4 * sizeof(float)) != hipSuccess || hipMemset(d.roughLut, 0, 1024 * 4 * sizeof(float)) != hipSuccess) {
+            if (hipMalloc((void**)&d.roughLut, NRDHIP_ROUGH_LUT_FLOATS * sizeof(float)) != hipSuccess || hipMemset(d.roughLut, 0, NRDHIP_ROUGH_LUT_FLOATS * sizeof(float)) != hipSuccess) {
                 (void)hipGetLastError();
                 g_createError = "hipMalloc failed (is a HIP device visible?)";
                 I->denoisers.push_back(d);
