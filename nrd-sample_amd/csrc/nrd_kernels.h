@@ -82,6 +82,7 @@ struct AtrousParams {
     int it, last, hasDiff, hasSpec, sh;
     PlaneRef guide, data1, data2, hist, mom, in, out, inDiff, inSpec, outDiff, outSpec, inDiff1, inSpec1, outDiff1, outSpec1;
     PlaneRef tiles; // RELAX::Tiles (ClassifyTiles): 1 = the tile has no geometry
+    const float* roughLut; // ReblurParams::roughLut of the denoiser (this frame's ClassifyTiles wrote it): the lobe half angle by roughness code
 };
 
 struct SigmaParams {

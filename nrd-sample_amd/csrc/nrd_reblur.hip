@@ -2066,7 +2066,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
             var = c0[sig].w;
         float sigma = wsqrt_(var);
         invL[sig] = 0.3333f * wrcp_(fma_(p.phi[si], sigma, 1e-4f));
-        float angle = spec_lobe_half_angle(rough) * p.lobeAngleFraction;
+        // (specular: the arctangent of the lobe half angle hangs on the roughness code alone - the table ClassifyTiles wrote, entry word 2)
+        float angle = ((NRD_ROUGH_LUT && isSpec) ? p.roughLut[(f2u(g.z) & 1023u) * 4u + 2u] : spec_lobe_half_angle(rough)) * p.lobeAngleFraction;
         if (isSpec)
             angle += p.lobeSlack;
         float normalW = wrcp_(fmax2(angle, NORMAL_ANGLE_MIN));

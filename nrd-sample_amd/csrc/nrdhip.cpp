@@ -970,6 +970,7 @@ void build_relax(nrdhip_instance& I, DenoiserState& d, const FrameConsts& c) {
     AtrousParams a;
     std::memset(&a, 0, sizeof(a));
     a.c = p.c; // (with the tile flags of this denoiser's ClassifyTiles)
+    a.roughLut = d.roughLut;
     a.depthSens = std::max(r.depthThreshold, 0.001f) * 4.0f;
     a.histThreshold = (float)r.spatialVarianceEstimationHistoryThreshold;
     a.specularVarianceBoost = r.specularVarianceBoost;
