@@ -23,6 +23,34 @@ def test_emulated_kernels_bit_exact(pkg, api, oracle, emulated, dens):
     assert util.compare_all(ho, he, exact=True) == []
 
 
+def roughness_table_run(pkg, api, backend, dens, w, h, frames=3):
+    """frames whose settings CHANGE from one to the next in everything the roughness table of a frame is made from (round 6:
+    ReblurParams::roughLut - hit distance parameters C / D, through the hit distance factor) and in what is evaluated beside it per pixel
+    (roughnessFraction, lobeAngleFraction): a table left over from the frame before would show in every specular pixel"""
+    D = api.Denoiser
+    scene = pkg.synth.Scene(w, h, dolly=0.04, denoiser="RELAX" if dens[0].startswith("RELAX") else "REBLUR")
+    dd = [D[x] for x in dens]
+    hz = pkg.harness.Harness(backend, dd, w, h)
+    for f in range(frames):
+        fr = scene.frame(f)
+        st = util.default_settings(api, scene, dd, minMaterialForDiffuse=0, minMaterialForSpecular=1)
+        for d, s in st.items():
+            if isinstance(s, api.ReblurSettings):
+                s.hitDistanceParameters = api.ReblurHitDistanceParameters(A=3.0 + f, B=0.1, C=20.0 - 6.0 * f, D=-25.0 + 8.0 * f)
+                s.roughnessFraction, s.lobeAngleFraction = 0.15 + 0.1 * f, 0.15 + 0.2 * f
+            elif isinstance(s, api.RelaxSettings):
+                s.roughnessFraction, s.lobeAngleFraction, s.specularLobeAngleSlack = 0.15 + 0.1 * f, 0.5 - 0.15 * f, 0.15 + 0.1 * f
+        hz.frame(scene.common_settings(api, fr, f, reset=(f == 0)), hz.upload(fr), st)
+    return hz
+
+
+@pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["REBLUR_SPECULAR_SH"], ["RELAX_DIFFUSE_SPECULAR"]])
+def test_roughness_table_follows_the_settings_of_every_frame(pkg, api, oracle, emulated, dens):
+    ho = roughness_table_run(pkg, api, oracle, dens, 72, 40)
+    he = roughness_table_run(pkg, api, emulated, dens, 72, 40)
+    assert util.compare_all(ho, he, exact=True) == []
+
+
 def test_emulated_dispatch_lists_match(pkg, api, oracle, emulated):
     D = api.Denoiser
     dens = [D.REBLUR_DIFFUSE_SPECULAR, D.SIGMA_SHADOW_TRANSLUCENCY, D.REFERENCE]

@@ -36,6 +36,18 @@ def report(ha, hb):
     return "; ".join(lines)
 
 
+@pytest.mark.parametrize("dens", [["REBLUR_DIFFUSE_SPECULAR"], ["REBLUR_SPECULAR_SH"], ["RELAX_DIFFUSE_SPECULAR_SH"]])
+def test_roughness_table_follows_the_settings_of_every_frame_hip(pkg, api, oracle, hip, dens):
+    """round 6 (ReblurParams::roughLut): hit distance parameters, roughness and lobe fractions that change with every frame - on the device"""
+    from test_kernels_emulated import roughness_table_run
+
+    oracle_threads = getattr(oracle.lib, "orc_set_threads", None)
+    ho = roughness_table_run(pkg, api, oracle, dens, 480, 270, frames=4)
+    hg = roughness_table_run(pkg, api, hip, dens, 480, 270, frames=4)
+    assert util.compare_all(ho, hg, exact=True) == [], report(ho, hg)
+    assert oracle_threads is not None
+
+
 @pytest.mark.parametrize("dens", VARIANTS)
 def test_hip_matches_oracle(pkg, api, oracle, hip, dens):
     w, h = 480, 270
