@@ -1781,7 +1781,12 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(NRD_TS_WAVES) void k_temporal
     FootPos vpos = spos;
     if (HAS_SPEC) {
         float tu, tv;
-        bool vOk = virtual_uv(c, r, hitDist, dominant_factor_of(p, g), g.mat, tu, tv) && amount > 0.0f;
+        // (the dominant factor is EVALUATED here: from the table it would be one more dependent round trip in front of the virtual footprint's
+        // loads in a kernel that waits for memory, not for issue slots - NRD_ROUGH_LUT_TS 1 is the A/B switch)
+#ifndef NRD_ROUGH_LUT_TS
+#define NRD_ROUGH_LUT_TS 0
+#endif
+        bool vOk = virtual_uv(c, r, hitDist, NRD_ROUGH_LUT_TS ? dominant_factor_of(p, g) : spec_dominant_factor(g.roughness), g.mat, tu, tv) && amount > 0.0f;
         vpos = foot_pos(c, vOk ? tu : -10.0f, vOk ? tv : -10.0f); // unusable virtual position: lands outside, never validates
         load_stab(p, vpos, LBPT, vraw);
     }
