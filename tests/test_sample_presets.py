@@ -125,6 +125,59 @@ def test_oracle_runs_a_recorded_preset(pkg, api, oracle, presets):
     assert np.isfinite(np.asarray(out, dtype=np.float32)).all()
 
 
+ALL_FILES = {"BistroExterior.bin": 39, "BistroInterior.bin": 245, "Claire.bin": 10, "CornellBox.bin": 3, "Kitchen.bin": 3, "ShaderBalls.bin": 41,
+             "transparent-machines-pt1.bin": 2}  # every file of the reference's Tests/ directory (round 6: all seven are fixtures now)
+
+
+def _sane(st, p):  # (field of view: the slider range of Source/NRDSample.cpp:1229 - BistroInterior holds records at 1 degree)
+    s = p.settings
+    ok = 1.0 <= s["camFov"] <= 160.0 and -180.0 <= s["sunAzimuth"] <= 180.0 and -90.0 <= s["sunElevation"] <= 90.0
+    # (two independent sliders: BistroInterior records 214-216 hold a FAST history longer than the main one, 60 / 29)
+    ok = ok and 0 <= s["maxFastAccumulatedFrameNum"] <= st.MAX_HISTORY_FRAME_NUM and 0 <= s["maxAccumulatedFrameNum"] <= st.MAX_HISTORY_FRAME_NUM
+    ok = ok and 0.01 <= s["hitDistScale"] <= 100.0 and 0 <= s["tracingMode"] <= 2 and 0 <= s["denoiser"] <= 2
+    r = p.rotation
+    return ok and np.allclose(r @ r.T, np.eye(3), atol=2e-4) and abs(abs(np.linalg.det(r)) - 1.0) < 1e-3 and bool(np.all(np.isfinite(p.position)))
+
+
+def test_every_record_of_every_reference_test_file_decodes(pkg):
+    """all seven Tests/*.bin of the reference (343 records): whole records, a sane settings block and an orthonormal camera in each"""
+    st = pkg.sample_tests
+    total = 0
+    for name, count in ALL_FILES.items():
+        path = os.path.join(GOLD, name)
+        assert os.path.getsize(path) == count * st.RECORD_SIZE, name
+        ps = st.load_presets(path)
+        assert len(ps) == count
+        bad = [i for i, p in enumerate(ps) if not _sane(st, p)]
+        assert bad == [], (name, bad[:5])
+        total += count
+    assert total == 343
+
+
+@pytest.mark.parametrize("name,index", [("BistroInterior.bin", -1), ("BistroInterior.bin", 86), ("BistroInterior.bin", 214), ("Claire.bin", -1),
+                                        ("ShaderBalls.bin", -1), ("transparent-machines-pt1.bin", -1)])
+def test_emulated_kernels_at_a_recorded_operating_point_of_every_file(pkg, api, oracle, emulated, name, index):
+    """the operating point `Sample::PrepareFrame` derives from a record of each file added in round 6 (field of view, sun, hit distance
+    scale, accumulation lengths, view direction) - the last one, and BistroInterior's odd ones: record 86 (field of view 1 degree), record
+    214 (fast history LONGER than the main one: no clamp) - 2 frames from the forced reset: emulated kernels == oracle on every byte"""
+    st = pkg.sample_tests
+    p = st.load_presets(os.path.join(GOLD, name))[index]
+    ho = _run(pkg, api, oracle, p, 80, 48, 2)
+    he = _run(pkg, api, emulated, p, 80, 48, 2)
+    assert util.compare_all(ho, he, exact=True) == [], name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ALL_FILES))
+def test_first_and_last_record_of_every_reference_test_file_hip(pkg, api, oracle, hip, name):
+    st = pkg.sample_tests
+    ps = st.load_presets(os.path.join(GOLD, name))
+    for i in sorted({0, len(ps) - 1}):
+        ho = _run(pkg, api, oracle, ps[i], 320, 180, 3, threads=8)
+        hg = _run(pkg, api, hip, ps[i], 320, 180, 3)
+        assert util.compare_all(ho, hg, exact=True) == [], "%s record %d" % (name, i)
+
+
 @pytest.mark.gpu
 def test_config3_at_every_distinct_recorded_operating_point(pkg, api, oracle, hip, presets):
     """REBLUR_DIFFUSE_SPECULAR + SIGMA_SHADOW_TRANSLUCENCY at each distinct operating point recorded in BistroExterior.bin (field of
