@@ -2105,7 +2105,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
 #ifndef NRD_ATROUS_DEPTH // taps in flight of the SH gather flavour: 2 keep it at 126 VGPRs = 4 waves per SIMD (4: 132 / 3 waves; profiles/r04_ab_atrous_mask.txt)
 #define NRD_ATROUS_DEPTH 2
 #endif
-    constexpr int DEPTH = LS ? (SH ? 4 : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
+#ifndef NRD_ATROUS_LS_DEPTH // LDS reads in flight per batch of the SH flavours that stage their window (iterations 0-2)
+#define NRD_ATROUS_LS_DEPTH 4
+#endif
+    constexpr int DEPTH = LS ? (SH ? NRD_ATROUS_LS_DEPTH : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
     uint2 graw[8];
     uint2 stex[8][RBPT / 8];
     uint16_t mraw[8][NSIG];
