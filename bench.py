@@ -7,15 +7,19 @@ A "step" is one frame through every pass of the denoiser (ClassifyTiles, PrePass
 PostBlur, TemporalStabilization) with all inputs already resident in HBM. N = 1: the 3840x2160 frame BASELINE.json quotes its
 target on. N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json config 5 - ONE 7680x4320 frame
 (--workload reblur_ds_8k, the default for N > 1) row-tiled into N bands, strong scaling; every rank exchanges halo rows with
-its <= 2 row neighbours between passes (SURVEY.md 8e scheme A) through torch.distributed (backend nccl = RCCL over xGMI,
---tiler python) or through the C++ row tiler below the C-ABI (ncclSend / ncclRecv, --tiler native). --scaling weak keeps the
-round-1 mode: every rank owns a full band of the workload's height (a W x (H N) frame).
+its <= 2 row neighbours between passes (SURVEY.md 8e scheme A) through the C++ row tiler below the C-ABI (ncclSend / ncclRecv
+groups on a side stream, --tiler native) or through torch.distributed (backend nccl = RCCL over xGMI, --tiler python). The
+default, --tiler auto, takes the value from the C++ tiler after a two-frame probe on every rank and falls back to the Python tiler
+with the reason in config.native_tiler. --scaling weak keeps the round-1 mode: every rank owns a full band of the workload's
+height (a W x (H N) frame).
 
 One JSON line on stdout (rank 0). `roofline` is computed for the slowest kernel from HIP events recorded on the launch
 stream around every dispatch of every 8th step of the timed region (--event-stride; the 14 event records idle the GPU for
 ~90 us of such a frame - measured r3: 0.998 ms per frame without any, 1.021 at stride 4 - so the remaining steps enqueue the
-frame exactly as the sample would, with one Denoise call); `cpu_baseline` times the CPU oracle (a scalar C++ port, oracle/) on a
-bounded sample of the same workload on this box's host cores - a reported baseline, not the target.
+frame exactly as the sample would, with one Denoise call); `roofline.frac_geometry` / `pipeline_frac_geometry` count the bytes of
+pixels with geometry only, and `config.full_coverage` (the same scene without sky) is the leg to hold against the 70 % target;
+`cpu_baseline` times the CPU oracle (a scalar C++ port, oracle/, persistent workers) on a bounded sample of the same workload on this
+box's host cores, with one thread and all threads on the same 1080p frame beside it - a reported baseline, not the target.
 """
 import argparse
 import json
