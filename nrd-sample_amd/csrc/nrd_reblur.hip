@@ -1235,7 +1235,23 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
     // ---- both footprints: positions, then ALL their gathers, then validation
     FootPos spos = foot_pos(c, r.su, r.sv);
     FootRaw<RBPT, LBPT, RELAX> sraw, vraw;
-    load_foot(p, spos, sraw);
+#ifndef NRD_TA_LEAN // 1 (A/B): everything that needs the world-space positions is reduced to scalars BEFORE the footprint's 20 loads go out
+#define NRD_TA_LEAN 0
+#endif
+    float accumLimit = 0.0f;
+    if (NRD_TA_LEAN && HAS_SPEC) {
+        f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
+        f3 XparV = rot3(c.w2v, sub3(r.XwPrev, cd));
+        float pu, pv, parallax = 0.0f;
+        if (project(c.pj, XparV, pu, pv)) {
+            float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
+            parallax = sqrt_(fma_(dx, dx, dy * dy));
+        }
+        const float2 accumTerms = NRD_ROUGH_LUT ? accum_terms_of(p, g) : float2{0.0f, 0.0f};
+        accumLimit = spec_accum_limit(g.roughness, NoV, parallax, NRD_ROUGH_LUT ? &accumTerms : nullptr);
+    }
+    if (!NRD_TA_LEAN)
+        load_foot(p, spos, sraw);
     float vu = -10.0f, vv = -10.0f;
     bool vOk = false;
     if (HAS_SPEC) {
@@ -1245,6 +1261,10 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         vv = vOk ? tv : -10.0f;
     }
     FootPos vpos = foot_pos(c, vu, vv);
+    if (NRD_TA_LEAN) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_foot(p, spos, sraw);
+    }
     // SEQ_FOOT (the fused PrePass + TemporalAccumulation kernel): the virtual-motion footprint is fetched AFTER everything that hangs on the
     // surface-motion one has been reduced to a handful of values - a second round trip per wave, but 32 registers of raw footprint texels
     // less: with 2 PrePass taps in flight the fused kernel fits 93 VGPRs = 5 waves per SIMD, 0.343 -> 0.326 ms (profiles/
@@ -1292,15 +1312,18 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
         constexpr int sw = SIG_SPEC * SW;
         constexpr int lo = SIG_SPEC * 2;
         f4 in = unpack_h4(ctex[sw]);
-        f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
-        f3 XparV = rot3(c.w2v, sub3(r.XwPrev, cd));
-        float pu, pv, parallax = 0.0f;
-        if (project(c.pj, XparV, pu, pv)) {
-            float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
-            parallax = sqrt_(fma_(dx, dx, dy * dy));
+        if (!NRD_TA_LEAN) {
+            f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
+            f3 XparV = rot3(c.w2v, sub3(r.XwPrev, cd));
+            float pu, pv, parallax = 0.0f;
+            if (project(c.pj, XparV, pu, pv)) {
+                float dx = (pu - r.su) * (float)c.W, dy = (pv - r.sv) * (float)c.H;
+                parallax = sqrt_(fma_(dx, dx, dy * dy));
+            }
+            const float2 accumTerms = NRD_ROUGH_LUT ? accum_terms_of(p, g) : float2{0.0f, 0.0f};
+            accumLimit = spec_accum_limit(g.roughness, NoV, parallax, NRD_ROUGH_LUT ? &accumTerms : nullptr);
         }
-        const float2 accumTerms = NRD_ROUGH_LUT ? accum_terms_of(p, g) : float2{0.0f, 0.0f};
-        float Asmb = fmin2(prevSpecA, spec_accum_limit(g.roughness, NoV, parallax, NRD_ROUGH_LUT ? &accumTerms : nullptr));
+        float Asmb = fmin2(prevSpecA, accumLimit);
         const float inY = signal_luma(in, RELAX);
         f4 smbHist = smbOk ? blend4(smb, sraw.t, sw) : in;
         float smbFast = smbOk ? blend1(smb, sraw.f, SIG_SPEC) : inY;
