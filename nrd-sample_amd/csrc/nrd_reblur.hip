@@ -61,6 +61,9 @@ NRD_KERNELS_BEGIN
 #ifndef NRD_PRE_WAVES // PrePass: waves per SIMD
 #define NRD_PRE_WAVES 4
 #endif
+#ifndef NRD_TA_LEAN // A/B switch of TemporalAccumulation's register diet. 1: everything that needs the world-space positions (parallax, accumulation
+#define NRD_TA_LEAN 0 // limit, virtual position) is reduced to scalars BEFORE the footprint's 20 loads go out; 3: ... and the fused kernel does not
+#endif               // carry the view position / normal / view vector across the PrePass tap loop (TemporalAccumulation derives them again)
 #ifndef NRD_FUSED_SEQ_FOOTPRINTS // the fused kernel fetches its two history footprints one after the other (ta_pixel SEQ_FOOT)
 #define NRD_FUSED_SEQ_FOOTPRINTS 1
 #endif
@@ -941,7 +944,7 @@ NRD_DEV void spatial_pixel(const ReblurParams& p, const int x, const int y, cons
         if (NRD_FUSED_RELOAD_ARGS) {
             NRD_RELOAD_ARGS(ReblurParams, p, q); // (nrd_device.h: the reprojection's constants are loaded behind the tap loop, not held across it)
             const TaGeo tg = {pg.Xv, pg.Nv, V, (HAS_SPEC && !HW_TRANSCENDENTALS) ? kuRoughA : -1.0f};
-            ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(q, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f, &tg);
+            ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(q, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f, NRD_TA_LEAN >= 3 ? nullptr : &tg);
         } else
             ta_pixel<HAS_DIFF, HAS_SPEC, false, false, NRD_FUSED_SEQ_FOOTPRINTS != 0>(p, x, y, g, outw, HAS_SPEC ? h2f(f2h(minHit[SIG_SPEC])) : 0.0f);
         return;
@@ -1235,9 +1238,6 @@ NRD_DEV void ta_pixel(const ReblurParams& p, const int x, const int y, const Gui
     // ---- both footprints: positions, then ALL their gathers, then validation
     FootPos spos = foot_pos(c, r.su, r.sv);
     FootRaw<RBPT, LBPT, RELAX> sraw, vraw;
-#ifndef NRD_TA_LEAN // 1 (A/B): everything that needs the world-space positions is reduced to scalars BEFORE the footprint's 20 loads go out
-#define NRD_TA_LEAN 0
-#endif
     float accumLimit = 0.0f;
     if (NRD_TA_LEAN && HAS_SPEC) {
         f3 cd = {c.camDelta[0], c.camDelta[1], c.camDelta[2]};
