@@ -1414,7 +1414,10 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU((SH || RELAX) ? NRD_TA_SH_WAV
     uint2 ctex[RBPT / 8];
     load_texel<RBPT>(p.tmp1, x, y, ctex);
     const float hitDist = HAS_SPEC ? h2f(ld<uint16_t>(p.hitTrack, x, y, 2)) : 0.0f;
-    ta_pixel<HAS_DIFF, HAS_SPEC, SH, RELAX>(p, x, y, g, ctex, hitDist);
+#ifndef NRD_TA_SEQ_FOOTPRINTS // 1 (A/B): the stand-alone kernels fetch the virtual-motion footprint behind the surface-motion one too (round 5 measured
+#define NRD_TA_SEQ_FOOTPRINTS 0 // it 0-6 % slower at 113 VGPRs = 4 waves; with NRD_TA_LEAN the SH flavours get below that)
+#endif
+    ta_pixel<HAS_DIFF, HAS_SPEC, SH, RELAX, NRD_TA_SEQ_FOOTPRINTS != 0>(p, x, y, g, ctex, hitDist, nullptr);
 }
 
 // PrePass + TemporalAccumulation of the REBLUR radiance flavours in ONE launch (spatial_pixel<..., FUSED>)
