@@ -162,12 +162,14 @@ def exp2_poly3(x):
 
 def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_index, denoising_range, s, exp_hit_weight=False,
             angle_normal_weight=False, no_reach=False, f32_guide=False, one_step_sqrt=False, poly3_exp2=False, arc_normal_weight=False,
-            relax_in=False, to_ycocg=False):
+            relax_in=False, to_ycocg=False, sh1=None):
     """REBLUR_DIFFUSE_SPECULAR PrePass of one frame (perspective, no jitter, radiance mode, full frame). `s`: dict of the
     ReblurSettings fields used. Returns (Tmp1 [H, W, 2, 4] fp16: filtered diffuse / specular texel, hitTrack [H, W] fp16).
     relax_in (round 6): RELAX's PrePass - the inputs carry WORLD-space hit distances (hitDistanceParameters {1, 0, 1, 0}: no normalisation),
     so the hit-distance weight compares them relative to the centre's (scale 1 / max(hitT, 1e-3)); to_ycocg: the frozen build flavour
-    converts the linear-RGB texels to YCoCg on the way in (the default flavour keeps RELAX in linear RGB)"""
+    converts the linear-RGB texels to YCoCg on the way in (the default flavour keeps RELAX in linear RGB).
+    sh1 = (diffuse SH1 plane, specular SH1 plane) [H, W, 4] fp16 (round 6, the SH denoisers): the second texel of a signal rides along with
+    EXACTLY the weights of the first; a third return value holds its filtered texels [H, W, 2, 4]"""
     def conv(t):
         if not to_ycocg:
             return t
@@ -206,6 +208,7 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
     taps = np.stack([POISSON8[:, 0] * rc - POISSON8[:, 1] * rs, POISSON8[:, 0] * rs + POISSON8[:, 1] * rc], -1).astype(np.float32).astype(np.float64)
     reach = 10 ** 9 if no_reach else int(max(s["diffusePrepassBlurRadius"], s["specularPrepassBlurRadius"]) * 1.1) + 3
     out = np.zeros((H, W, 2, 4), np.float64)
+    out1 = np.zeros((H, W, 2, 4), np.float64)
     track = np.zeros((H, W), np.float64)
     hp = s["hitDistanceParameters"]
     for sig, (plane, is_spec) in enumerate(((diff, False), (spec, True))):
@@ -243,6 +246,7 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
         roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
         roughB = -rough * roughA
         acc, wsum, min_hit = center.copy(), np.ones((H, W)), hit.copy()
+        acc1 = sh1[sig].astype(np.float64) if sh1 is not None else None
         for t in range(8):
             fpx = np.floor(taps[t, 0] * jtx + taps[t, 1] * jbx + xx + 0.5)
             fpy = np.floor(taps[t, 0] * jty + taps[t, 1] * jby + yy + 0.5)
@@ -268,13 +272,17 @@ def prepass(viewz, packed_nr, diff, spec, view_to_clip, world_to_view, frame_ind
             w = w * (s["minHitDistanceWeight"] + (1.0 - s["minHitDistanceWeight"]) * e)
             w = np.where(valid, w, 0.0)
             acc = acc + np.where(valid[..., None], sv, 0.0) * w[..., None]
+            if sh1 is not None:
+                acc1 = acc1 + np.where(valid[..., None], sh1[sig][py, px].astype(np.float64), 0.0) * w[..., None]
             wsum = wsum + w
             min_hit = np.where(valid & (w > 0), np.minimum(min_hit, sv[..., 3] * hn), min_hit)
         res = acc / wsum[..., None]
         out[:, :, sig] = np.where(sky[..., None], 0.0, res)
+        if sh1 is not None:
+            out1[:, :, sig] = np.where(sky[..., None], 0.0, acc1 / wsum[..., None])
         if is_spec:
             track = np.where(sky, 0.0, min_hit)
-    return f16(out), f16(track)
+    return (f16(out), f16(track), f16(out1)) if sh1 is not None else (f16(out), f16(track))
 
 
 def hash_px_arr(x, y, frame, salt):

@@ -162,7 +162,9 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
     Returns tmp2 [H, W, 2, 4] fp16, fast [H, W, 2] fp16, speeds uint16, data2 uint32.
     relax = dict(moments_prev [H, W, 2] fp16, max_a_spec, max_fast_spec, rec709): RELAX's TemporalAccumulation (round 6) - the same two
     footprints; per-signal history caps; the fast history and a second-moment history (returned in info["moments"]) of the LUMINANCE of the
-    linear-RGB texel; bits 16..23 of data2 carry the reprojection quality of the specular history for the A-trous relaxation"""
+    linear-RGB texel; bits 16..23 of data2 carry the reprojection quality of the specular history for the A-trous relaxation.
+    relax["sh1_in"] / relax["sh1_hist"] [H, W, 2, 4] fp16 (the SH denoisers): the second texel of a signal follows the first - same footprints,
+    same blend factors; returned in info["sh1"]"""
     H, W = c.H, c.W
     rec709 = bool(relax and relax["rec709"])
     z, n, rough, mat = gcur
@@ -201,6 +203,12 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
     h = np.where(smb_ok[..., None], fetch(c, hs[:, :, 0], smb), cin)
     fh = np.where(smb_ok, fetch(c, fp[..., 0], smb), cY)
     out[:, :, 0] = h + (cin - h) * non_lin[..., None]
+    sh = relax is not None and relax.get("sh1_in") is not None
+    out1 = np.zeros((H, W, 2, 4))
+    if sh:
+        i1, h1p = relax["sh1_in"].astype(np.float64), relax["sh1_hist"].astype(np.float64)
+        h1 = np.where(smb_ok[..., None], fetch(c, h1p[:, :, 0], smb), i1[:, :, 0])
+        out1[:, :, 0] = h1 + (i1[:, :, 0] - h1) * non_lin[..., None]
     fast[..., 0] = fh + (cY - fh) / (1.0 + np.minimum(A, max_fast))
     if relax:
         m2 = cY * cY
@@ -240,6 +248,11 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
     h = sh_ + (vh - sh_) * amount[..., None]
     fh = sf + (vf - sf) * amount
     out[:, :, 1] = h + (cin - h) * non_lin[..., None]
+    if sh:
+        s1 = np.where(smb_ok[..., None], fetch(c, h1p[:, :, 1], smb), i1[:, :, 1])
+        v1 = np.where(vmb_ok[..., None], fetch(c, h1p[:, :, 1], vmb), i1[:, :, 1])
+        hh = s1 + (v1 - s1) * amount[..., None]
+        out1[:, :, 1] = hh + (i1[:, :, 1] - hh) * non_lin[..., None]
     fast[..., 1] = fh + (cY - fh) / (1.0 + np.minimum(A, max_fast_s))
     data2 = data2 | (np.where(vmb_ok, vmb["bits"], 0) << 4) | (np.floor(np.clip(amount, 0, 1) * 255.0 + 0.5).astype(np.int64) << 8)
     if relax:
@@ -250,10 +263,10 @@ def temporal_accumulation(c, s, gcur, gprev, mv, tmp1, hist, fast_prev, speeds_p
         moments[..., 1] = m2h + (m2 - m2h) * non_lin
         data2 = data2 | (np.floor(np.clip(q, 0, 1) * 255.0 + 0.5).astype(np.int64) << 16)
     speeds = pack_speeds(out_d, A)
-    out[sky], fast[sky], moments[sky] = 0.0, 0.0, 0.0
+    out[sky], fast[sky], moments[sky], out1[sky] = 0.0, 0.0, 0.0, 0.0
     speeds = np.where(sky, 0, speeds).astype(np.uint16)
     data2 = np.where(sky, 0, data2).astype(np.uint32)
-    return f16(out), f16(fast), speeds, data2, dict(amount=amount, smb_ok=smb_ok, vmb_ok=vmb_ok, moments=f16(moments))
+    return f16(out), f16(fast), speeds, data2, dict(amount=amount, smb_ok=smb_ok, vmb_ok=vmb_ok, moments=f16(moments), sh1=f16(out1))
 
 
 def pixel_geo(c, z, n, sens):
@@ -294,7 +307,9 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
     relax = dict(moments [H, W, 2] fp16, normal_power, accel, spatial, temporal, reset, max_fast_spec, rec709): RELAX's HistoryFix (round 6) -
     the reconstruction's normal weight is pow(N.Ns, historyFixEdgeStoppingNormalPower), the clamp works on the luminance of the texel
     (scaling r, g, b together in linear RGB), a clamped pixel accelerates its history by accelerationAmount, and a history farther from the
-    fast 5x5 mean than spatialSigmaScale x spatial sigma + temporalSigmaScale x temporal sigma is reset by up to resetAmount (antilag)"""
+    fast 5x5 mean than spatialSigmaScale x spatial sigma + temporalSigmaScale x temporal sigma is reset by up to resetAmount (antilag).
+    relax["sh1"] [H, W, 2, 4] fp16 (the SH denoisers): the second texel is reconstructed with the first one's weights and its xyz scaled by the
+    clamp's luminance ratio; a fourth return value holds it"""
     H, W = c.H, c.W
     rec709 = bool(relax and relax["rec709"])
     z, n, rough_g, mat = gcur
@@ -305,6 +320,8 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
     Ad, As = unpack_speeds(speeds_tmp)
     fs = fast.astype(np.float64)
     out = np.zeros((H, W, 2, 4))
+    sh1 = relax["sh1"].astype(np.float64) if (relax and relax.get("sh1") is not None) else None
+    out1 = np.zeros((H, W, 2, 4))
     outA = [Ad.copy(), As.copy()]
     nfix, base = float(s["historyFixFrameNum"]), float(s["historyFixBasePixelStride"])
     max_fast = float(min(s["maxFastAccumulatedFrameNum"], 63))
@@ -320,6 +337,8 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
         normal_w = 1.0 / np.maximum(angle, NORMAL_ANGLE_MIN)
         roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
         acc, wsum = val * (1.0 + A)[..., None], 1.0 + A
+        val1 = sh1[:, :, sig].copy() if sh1 is not None else None
+        acc1 = val1 * (1.0 + A)[..., None] if sh1 is not None else None
         for j in range(-2, 3):
             for i in range(-2, 3):
                 if (i == 0 and j == 0) or (abs(i) == 2 and abs(j) == 2):
@@ -340,8 +359,12 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
                 tA = (As if is_spec else Ad)[cy, cx]
                 w = np.where(ok, w * (1.0 + tA), 0.0)
                 acc = acc + t2[cy, cx, sig] * w[..., None]
+                if sh1 is not None:
+                    acc1 = acc1 + sh1[cy, cx, sig] * w[..., None]
                 wsum = wsum + w
         val = np.where(fix[..., None], acc / wsum[..., None], val)
+        if sh1 is not None:
+            val1 = np.where(fix[..., None], acc1 / wsum[..., None], val1)
         if s["maxFastAccumulatedFrameNum"] < s["maxAccumulatedFrameNum"]:
             fc = fs[..., sig]
             m1, m2 = moments5x5(c, fc, fc, z)
@@ -350,6 +373,8 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
             Yc = np.clip(Y, m1 - sigma, m1 + sigma)
             scale = (Yc + 1e-6) / (Y + 1e-6)
             val = np.stack([val[..., 0] * scale if rec709 else Yc, val[..., 1] * scale, val[..., 2] * scale, val[..., 3]], -1)
+            if sh1 is not None:
+                val1 = np.concatenate([val1[..., :3] * scale[..., None], val1[..., 3:]], -1)
             f = np.clip(np.abs(Yc - Y) / np.maximum(np.maximum(Y, Yc), 1e-6), 0, 1)
             if relax:
                 f = f * np.clip(relax["accel"], 0, 1)
@@ -362,8 +387,12 @@ def history_fix(c, s, gcur, tmp2, speeds_tmp, fast, viewz, packed_nr, upstream=F
                 a_new = a_new * (1.0 - np.clip(relax["reset"], 0, 1) * over)
             outA[1 if is_spec else 0] = a_new
         out[:, :, sig] = val
-    out[sky] = 0.0
+        if sh1 is not None:
+            out1[:, :, sig] = val1
+    out[sky], out1[sky] = 0.0, 0.0
     speeds = np.where(sky, 0, pack_speeds(outA[0], outA[1])).astype(np.uint16)
+    if sh1 is not None:
+        return f16(out), speeds, pack_tap_guide(viewz, packed_nr, c.range), f16(out1)
     return f16(out), speeds, pack_tap_guide(viewz, packed_nr, c.range)
 
 
@@ -431,13 +460,16 @@ def temporal_stabilization(c, s, gcur, mv, hist, speeds, data2, stab_prev, hit_t
 # =====================================================================================================================
 # RELAX: one variance-guided A-trous iteration (3x3 taps at stride 2^it), iteration 0 and the middle iterations
 # =====================================================================================================================
-def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=None, upstream=False):
+def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=None, upstream=False, sh1=None):
     """plane_in [H, W, 2, 4] fp16: iteration 0 = History {Y, Co, Cg, hitT}, later = {Y, Co, Cg, variance}; moments [H, W, 2] fp16
     (second luma moment, iteration 0 only); data2 uint32 (reprojection confidence of the specular history in bits 16..23).
     Returns the ping-pong texel {Y, Co, Cg, variance} as fp16.
     upstream = True: the DEFAULT build flavour - the texels are linear {r, g, b, .} and a luminance is Rec.709 of them, the luminance weight
-    is exp(-3 x), the normal weight sits on the chord of the two normals"""
+    is exp(-3 x), the normal weight sits on the chord of the two normals.
+    sh1 [H, W, 2, 4] fp16 (the SH denoisers): filtered with the weights of the first texel; returned as a second value"""
     H, W = c.H, c.W
+    p1 = sh1.astype(np.float64) if sh1 is not None else None
+    out1 = np.zeros((H, W, 2, 4))
     luma = (lambda v: 0.2126 * v[..., 0] + 0.7152 * v[..., 1] + 0.0722 * v[..., 2]) if upstream else (lambda v: v[..., 0])
     z, n, rough_g, mat = gcur
     sky = ~(np.abs(z) <= c.range)
@@ -491,6 +523,7 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
             rough_relax = 1.0 + (conf - 1.0) * np.clip(s["roughnessEdgeStoppingRelaxation"], 0, 1)
         roughA = 1.0 / (0.01 + 0.99 * np.clip(rough * s["roughnessFraction"], 0, 1))
         acc, acc_var, wsum = c0[..., :3].copy(), var.copy(), np.ones((H, W))
+        acc1 = p1[:, :, sig].copy() if p1 is not None else None
         for j in (-1, 0, 1):
             for i in (-1, 0, 1):
                 if i == 0 and j == 0:
@@ -511,12 +544,16 @@ def atrous_iteration(c, s, gcur, plane_in, it, speeds=None, moments=None, data2=
                 w = w * np.maximum(np.exp(-3.0 * dl) if upstream else np.clip(1.0 - dl, 0, 1) ** 2, min_lw)
                 w = np.where(ok, w, 0.0)
                 acc = acc + sv[..., :3] * w[..., None]
+                if p1 is not None:
+                    acc1 = acc1 + p1[cy, cx, sig] * w[..., None]
                 acc_var = acc_var + var_all[cy, cx] * w * w
                 wsum = wsum + w
         out[:, :, sig, :3] = acc / wsum[..., None]
         out[:, :, sig, 3] = acc_var / (wsum * wsum)
-    out[sky] = 0.0
-    return f16(out)
+        if p1 is not None:
+            out1[:, :, sig] = acc1 / wsum[..., None]
+    out[sky], out1[sky] = 0.0, 0.0
+    return (f16(out), f16(out1)) if p1 is not None else f16(out)
 
 
 # =====================================================================================================================

@@ -189,6 +189,21 @@ def agree(name, got, want, min_frac, mask=None, max_ulp=None):
     return frac
 
 
+def agree_texel(name, got, want, min_frac, scale_from=None):
+    """the bar for texels whose components have BOTH signs (YCoCg-coded golden inputs fed to RELAX as linear RGB, SH1 = direction x luminance):
+    weighted sums of such components cancel, so a small component can sit several of ITS OWN ULPs off while the texel is right to 1e-4.
+    At least `min_frac` of the values within 1 fp16 ULP and EVERY value within 1 ULP of its texel's largest component (`scale_from`: of the
+    largest component of THAT texel as well - an SH1 texel is a sum of direction x luminance terms whose directions cancel too, so its
+    scale is the luminance of the signal's first texel)"""
+    frac = agree(name, got, want, min_frac)
+    scale = np.maximum(np.abs(want.astype(np.float64)).max(-1, keepdims=True), 2.0 ** -14)
+    if scale_from is not None:
+        scale = np.maximum(scale, np.abs(scale_from.astype(np.float64)).max(-1, keepdims=True))
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert (err <= 2.0 ** (np.floor(np.log2(scale)) - 10)).all(), "%s: a value farther than 1 ULP of its texel's largest component" % name
+    return frac
+
+
 @pytest.mark.parametrize("f,flavour", [(1, "frozen"), (2, "frozen"), (3, "frozen"), (2, "default"), (3, "default")])
 def test_temporal_passes_independent(request, pkg, api, f, flavour):
     """every pass of the REBLUR_DIFFUSE_SPECULAR frame behind the PrePass against its numpy / float64 restatement, each fed the planes the
@@ -359,9 +374,7 @@ def test_relax_prepass_independent(request, pkg, api, f, flavour):
     # The golden inputs are YCoCg-coded texels fed to RELAX as if they were linear RGB: "colour" channels of both signs whose weighted
     # sums cancel (0.005 next to a luminance of 1.8), so a channel can sit 61 of ITS OWN ULPs off while the texel is right to 1e-4. Stated
     # bar: >= 99.99 % of the values within 1 fp16 ULP and EVERY value within 1 ULP of its texel's largest component
-    agree("RELAX PrePass frame %d %s" % (f, flavour), tmp1, want, 0.9999)
-    scale = np.maximum(np.abs(want.astype(np.float64)).max(-1, keepdims=True), 2.0 ** -14)
-    assert (np.abs(tmp1.astype(np.float64) - want.astype(np.float64)) <= 2.0 ** (np.floor(np.log2(scale)) - 10)).all()
+    agree_texel("RELAX PrePass frame %d %s" % (f, flavour), tmp1, want, 0.9999)
     assert float((ulp16(track, want_track) <= 1).mean()) > 0.98
 
 
@@ -443,6 +456,111 @@ def test_relax_temporal_passes_independent(request, pkg, api, f, flavour):
         assert float((np.abs(a.astype(np.int32) - b.astype(np.int32)) <= 1).mean()) > 0.99, shift
     # (the antilag must have had something to do on these frames: some pixel's history was shortened by the clamp / reset)
     assert ((speeds_cur & 255) < (speeds_tmp & 255)).any() or ((speeds_cur >> 8) < (speeds_tmp >> 8)).any()
+
+
+def with_sh1(fr):
+    """the golden frame plus SH1 planes for the SH denoisers (REBLUR_/RELAX_FrontEnd_PackSh, Shaders/TraceOpaque.cs.hlsl:738-752: direction x
+    luminance of the sample) - built here from the frame's own normals so that oracle and restatement see the same bytes"""
+    fr = dict(fr)
+    n = ind.decode_guide(fr["viewz"], fr["normal_roughness"])[1]
+    for key in ("diff", "spec"):
+        rad = np.asarray(fr[key]).astype(np.float64)
+        lum = 0.2126 * rad[..., 0] + 0.7152 * rad[..., 1] + 0.0722 * rad[..., 2]
+        fr[key + "_sh1"] = np.concatenate([n * lum[..., None], np.zeros(lum.shape + (1,))], -1).astype(np.float16)
+    return fr
+
+
+@pytest.mark.parametrize("f", [1, 3])
+def test_relax_sh_passes_independent(pkg, api, oracle, f):
+    """RELAX_DIFFUSE_SPECULAR_SH - BASELINE config 4's denoiser - pass by pass (round 6): in every pass the second texel of a signal (SH1) must
+    come out as the restatement's, which filters it with EXACTLY the first texel's weights / footprints / blend factors / clamp ratio.
+    PrePass, TemporalAccumulation, HistoryFix, A-trous iterations 0 and 1, default build flavour; each fed the oracle's own planes"""
+    D = api.Denoiser
+    den = int(D.RELAX_DIFFUSE_SPECULAR_SH)
+    scene = pkg.synth.Scene(W, H, dolly=0.03)
+    hz = pkg.harness.Harness(oracle, [D.RELAX_DIFFUSE_SPECULAR_SH], W, H)
+    st = api.RelaxSettings(minMaterialForDiffuse=0, minMaterialForSpecular=1)
+    rb = api.ReblurSettings()
+    s = dict(maxAccumulatedFrameNum=st.diffuseMaxAccumulatedFrameNum, maxFastAccumulatedFrameNum=st.diffuseMaxFastAccumulatedFrameNum,
+             minMaterialForDiffuse=st.minMaterialForDiffuse, minMaterialForSpecular=st.minMaterialForSpecular, roughnessFraction=st.roughnessFraction,
+             lobeAngleFraction=st.lobeAngleFraction, planeDistanceSensitivity=rb.planeDistanceSensitivity, historyFixFrameNum=st.historyFixFrameNum,
+             historyFixBasePixelStride=st.historyFixBasePixelStride, fastHistoryClampingSigmaScale=st.fastHistoryClampingSigmaScale,
+             responsiveRoughnessThreshold=rb.responsiveAccumulationSettings.roughnessThreshold,
+             responsiveMinAccum=float(rb.responsiveAccumulationSettings.minAccumulatedFrameNum),
+             minHitDistanceWeight=st.minHitDistanceWeight, diffusePrepassBlurRadius=st.diffusePrepassBlurRadius,
+             specularPrepassBlurRadius=st.specularPrepassBlurRadius, hitDistanceParameters=(1.0, 0.0, 1.0, 0.0))
+    sa = {k: getattr(st, k) for k in ("depthThreshold", "spatialVarianceEstimationHistoryThreshold", "specularVarianceBoost", "diffusePhiLuminance",
+                                      "specularPhiLuminance", "diffuseMinLuminanceWeight", "specularMinLuminanceWeight", "lobeAngleFraction",
+                                      "specularLobeAngleSlack", "luminanceEdgeStoppingRelaxation", "normalEdgeStoppingRelaxation",
+                                      "roughnessEdgeStoppingRelaxation", "roughnessFraction", "enableRoughnessEdgeStopping", "minMaterialForDiffuse",
+                                      "minMaterialForSpecular")}
+    for g in range(f):
+        fr = with_sh1(frame(g))
+        hz.frame(scene.common_settings(api, fr, g, reset=(g == 0)), hz.upload(fr), {D.RELAX_DIFFUSE_SPECULAR_SH: st})
+    fr, prev = with_sh1(frame(f)), frame(f - 1)
+    cs = scene.common_settings(api, fr, f)
+    hz.nrd.new_frame()
+    hz.nrd.set_common_settings(cs)
+    hz.bind(hz.upload(fr))
+    hz.nrd.set_denoiser_settings(den, st)
+    names = [d["name"].split("::")[1] for d in hz.nrd.dispatches([den])]
+    assert names[:6] == ["ClassifyTiles", "PrePass", "TemporalAccumulation", "HistoryFix", "Atrous0", "Atrous1"]
+    cur, old = ("_A", "_B") if f % 2 == 0 else ("_B", "_A")
+    # 32-byte texels: [signal][SH0 | SH1][4 x fp16]
+    rad = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2, 2, 4)
+    lum = lambda name: hz.pool(name).copy().view(np.float16).reshape(H, W, 2)
+    u16 = lambda name: hz.pool(name).copy().view(np.uint16).reshape(H, W)
+    c = tmp.Consts(fr, W, H, cs.denoisingRange, cs.disocclusionThreshold)
+    gcur = ind.decode_guide(fr["viewz"], fr["normal_roughness"])
+    gprev = ind.decode_guide(prev["viewz"], prev["normal_roughness"])
+
+    # ---- PrePass
+    hz.nrd.denoise_range([den], 0, 2)
+    tmp1 = rad("RELAX::Tmp1")
+    track = hz.pool("RELAX::SpecHitDistForTracking").copy().view(np.float16).reshape(H, W)
+    w0, _, w1 = ind.prepass(fr["viewz"], fr["normal_roughness"], fr["diff"], fr["spec"], fr["view_to_clip"], fr["world_to_view"], cs.frameIndex, cs.denoisingRange,
+                            s, exp_hit_weight=True, angle_normal_weight=True, relax_in=True, sh1=(fr["diff_sh1"], fr["spec_sh1"]))
+    agree_texel("RELAX-SH PrePass SH0", tmp1[:, :, :, 0], w0, 0.9995)
+    agree_texel("RELAX-SH PrePass SH1", tmp1[:, :, :, 1], w1, 0.999, scale_from=w0)
+
+    # ---- TemporalAccumulation
+    hist, fast_prev, mom_prev, speeds_prev = rad("RELAX::History"), lum("RELAX::FastHistory" + old), lum("RELAX::Moments" + old), u16("RELAX::HistoryLength" + old)
+    hz.nrd.denoise_range([den], 2, 1)
+    tmp2, fast, mom, speeds_tmp = rad("RELAX::Tmp2"), lum("RELAX::FastHistory" + cur), lum("RELAX::Moments" + cur), u16("RELAX::HistoryLength_Tmp")
+    data2 = hz.pool("RELAX::Data2").copy().view(np.uint32).reshape(H, W)
+    rx = dict(moments_prev=mom_prev, max_a_spec=st.specularMaxAccumulatedFrameNum, max_fast_spec=st.specularMaxFastAccumulatedFrameNum, rec709=True,
+              sh1_in=np.ascontiguousarray(tmp1[:, :, :, 1]), sh1_hist=np.ascontiguousarray(hist[:, :, :, 1]))
+    w_tmp2, w_fast, w_speeds, w_data2, info = tmp.temporal_accumulation(c, s, gcur, gprev, fr["mv"], np.ascontiguousarray(tmp1[:, :, :, 0]),
+                                                                         np.ascontiguousarray(hist[:, :, :, 0]), fast_prev, speeds_prev, track, fr["confidence"], True, relax=rx)
+    agree("RELAX-SH TA SH0", tmp2[:, :, :, 0], w_tmp2, 1.0, max_ulp=1)
+    agree_texel("RELAX-SH TA SH1", tmp2[:, :, :, 1], info["sh1"], 0.999, scale_from=w_tmp2)  # (direction x luminance: components of both signs - cancelling blends, as in the PrePass)
+    agree("RELAX-SH TA fast history", fast, w_fast, 1.0, max_ulp=1)
+
+    # ---- HistoryFix
+    hz.nrd.denoise_range([den], 3, 1)
+    new_hist, speeds_cur = rad("RELAX::History"), u16("RELAX::HistoryLength" + cur)
+    al = st.antilagSettings
+    rh = dict(moments=mom, normal_power=st.historyFixEdgeStoppingNormalPower, accel=al.accelerationAmount, spatial=al.spatialSigmaScale,
+              temporal=al.temporalSigmaScale, reset=al.resetAmount, max_fast_spec=st.specularMaxFastAccumulatedFrameNum, rec709=True,
+              sh1=np.ascontiguousarray(tmp2[:, :, :, 1]))
+    w_sig, w_speeds_cur, _, w_sig1 = tmp.history_fix(c, s, gcur, np.ascontiguousarray(tmp2[:, :, :, 0]), speeds_tmp, fast, fr["viewz"], fr["normal_roughness"],
+                                                     upstream=True, relax=rh)
+    agree("RELAX-SH HistoryFix SH0", new_hist[:, :, :, 0], w_sig, 1.0, max_ulp=1)
+    agree_texel("RELAX-SH HistoryFix SH1", new_hist[:, :, :, 1], w_sig1, 0.999, scale_from=w_sig)
+
+    # ---- A-trous iterations 0 and 1
+    moments = lum("RELAX::Moments" + cur)
+    hz.nrd.denoise_range([den], 4, 1)
+    a0 = rad("RELAX::Atrous_A")
+    w_a0, w_a0_1 = tmp.atrous_iteration(c, sa, gcur, np.ascontiguousarray(new_hist[:, :, :, 0]), 0, speeds_cur, moments, data2, upstream=True,
+                                        sh1=np.ascontiguousarray(new_hist[:, :, :, 1]))
+    agree("RELAX-SH A-trous 0 SH0", a0[:, :, :, 0], w_a0, 1.0, max_ulp=1)
+    agree_texel("RELAX-SH A-trous 0 SH1", a0[:, :, :, 1], w_a0_1, 0.999, scale_from=w_a0[..., :3])
+    hz.nrd.denoise_range([den], 5, 1)
+    a1 = rad("RELAX::Atrous_B")
+    w_a1, w_a1_1 = tmp.atrous_iteration(c, sa, gcur, np.ascontiguousarray(a0[:, :, :, 0]), 1, data2=data2, upstream=True, sh1=np.ascontiguousarray(a0[:, :, :, 1]))
+    agree("RELAX-SH A-trous 1 SH0", a1[:, :, :, 0], w_a1, 1.0, max_ulp=1)
+    agree_texel("RELAX-SH A-trous 1 SH1", a1[:, :, :, 1], w_a1_1, 0.999, scale_from=w_a1[..., :3])
 
 
 @pytest.mark.parametrize("f", [1, 2, 3])
