@@ -1926,6 +1926,10 @@ __global__ __launch_bounds__(256) void k_validation(const ReblurParams p) {
 // in LDS once - every texel is read by up to 9 pixels - and the taps become LDS reads at compile-time offsets: no per-tap
 // address arithmetic, no bounds tests (a texel outside the frame / the held rows is staged with viewZ = NaN, i.e. as sky).
 // LS = 0 (strides >= 8, window too large for LDS at a useful occupancy): coalesced global gathers, batched.
+#ifndef NRD_ATROUS_SIGNAL_ROUNDS // A/B switch: see k_relax_atrous
+#define NRD_ATROUS_SIGNAL_ROUNDS 0
+#endif
+#define NRD_ATROUS_SIGNAL_ROUNDS_ON (NRD_ATROUS_SIGNAL_ROUNDS != 0)
 #ifndef NRD_ATROUS_WAVES // waves per SIMD the register allocator aims for in the iterations behind the first (the first holds the moments too: 3)
 #define NRD_ATROUS_WAVES 4
 #endif
@@ -2050,8 +2054,8 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
     float sumVar[NSIG], wsum[NSIG], invL[NSIG], normalW2[NSIG], minLw[NSIG];
     uint32_t matFloor[NSIG], matClass[NSIG]; // material test of the taps (nrd_device.h material_class)
     float roughA = 0.0f, roughB = 0.0f, roughRelax = 1.0f;
-#pragma unroll
-    for (int sig = 0; sig < NSIG; sig++) {
+    // everything a signal's taps need (run for both signals in front of the tap loop - or, NRD_ATROUS_SIGNAL_ROUNDS, in front of its own round)
+    auto setup_signal = [&](const int sig) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         const int si = isSpec ? 1 : 0;
         float rough = isSpec ? g.roughness : 1.0f;
@@ -2123,110 +2127,9 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
         sum[sig] = {c0[sig].x, c0[sig].y, c0[sig].z};
         sumVar[sig] = var;
         wsum[sig] = 1.0f;
-    }
-    const bool roughStop = p.roughnessEdgeStopping != 0;
-    // the 8 taps in row-major order as a software pipeline (like k_spatial): DEPTH taps in flight, tap k is consumed right after tap
-    // k + DEPTH is issued, so the arithmetic of a tap runs under the loads of the next ones (LDS flavours: the reads of a batch)
-    constexpr int TI[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, TJ[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-#ifndef NRD_ATROUS_DEPTH // taps in flight of the SH gather flavour: 2 keep it at 126 VGPRs = 4 waves per SIMD (4: 132 / 3 waves; profiles/r04_ab_atrous_mask.txt)
-#define NRD_ATROUS_DEPTH 2
-#endif
-#ifndef NRD_ATROUS_LS_DEPTH // LDS reads in flight per batch of the SH flavours that stage their window (iterations 0-2)
-#define NRD_ATROUS_LS_DEPTH 4
-#endif
-    constexpr int DEPTH = LS ? (SH ? NRD_ATROUS_LS_DEPTH : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
-    uint2 graw[8];
-    uint2 stex[8][RBPT / 8];
-    uint16_t mraw[8][NSIG];
-    bool inside[8];
-    auto issue = [&](const int k) {
-        const int i = TI[k], j = TJ[k];
-        if (LS) {
-            const int q = ci + (j * T + i) * LS;
-            inside[k] = true; // outside texels were staged as sky
-            graw[k] = sG[q];
-#pragma unroll
-            for (int w = 0; w < TW; w++)
-                stex[k][w] = sT[q * TW + w];
-#pragma unroll
-            for (int sig = 0; sig < NSIG; sig++)
-                mraw[k][sig] = FIRST ? (uint16_t)(sM[q] >> (16 * sig)) : (uint16_t)0;
-            return;
-        }
-        int px = x + i * stride, py = y + j * stride;
-        inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
-        int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
-        graw[k] = ld_guide(p.guide, cpx, cpy);
-        load_texel<RBPT>(p.in, cpx, cpy, stex[k]);
-#pragma unroll
-        for (int sig = 0; sig < NSIG; sig++)
-            mraw[k][sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
     };
-    auto consume = [&](const int k) {
-        const int i = TI[k], j = TJ[k];
-        int px = x + i * stride, gy = y + j * stride + c.yOff;
-        Guide gs = decode_guide(graw[k], c.denoisingRange);
-        float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
-        const float nD2 = normal_dist2(normal_codes(g.nw), gs.nw);
-#pragma unroll
-        for (int sig = 0; sig < NSIG; sig++) {
-            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
-            // (bitwise: one basic block - the short-circuit form compiles to an exec-mask detour per operand; the material test as class
-            // equality, nrd_device.h material_class) rejected taps are selected out below
-            const bool matOk = material_class(gs.mat, matFloor[sig]) == matClass[sig];
-            const bool valid = inside[k] & !gs.sky & matOk;
-            float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
-            w *= geoW;
-            w *= normal_weight_m2(nD2, normalW2[sig]);
-            if (isSpec) {
-                float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
-                if (LS)
-                    rw = lerpf(1.0f, rw, roughRelax);
-                w *= roughStop ? rw : 1.0f;
-            }
-            f4 sv = unpack_h4(stex[k][sig * SW]);
-            float vs = sv.w;
-            if (FIRST)
-                vs = fmax2(fma_(-signal_luma(sv, true), signal_luma(sv, true), h2f(mraw[k][sig])), 0.0f);
-            w *= fmax2(exp_weight(absf(signal_luma(sv, true) - c0Y[sig]) * invL[sig]), minLw[sig]);
-            // a rejected tap enters with weight 0 (its texel is a finite value of an internal plane, fetched at the clamped
-            // position): one select on the weight instead of one per accumulated component
-            w = valid ? w : 0.0f;
-            sum[sig] = {fma_(sv.x, w, sum[sig].x), fma_(sv.y, w, sum[sig].y), fma_(sv.z, w, sum[sig].z)};
-            if (SH)
-                sum1[sig] = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
-            sumVar[sig] = fma_(vs, w * w, sumVar[sig]);
-            wsum[sig] += w;
-        }
-    };
-    if constexpr (LS) { // batches of DEPTH LDS reads, then their arithmetic
-#pragma unroll
-        for (int t0 = 0; t0 < 8; t0 += DEPTH) {
-#pragma unroll
-            for (int k = 0; k < DEPTH; k++)
-                issue(t0 + k);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < DEPTH; k++)
-                consume(t0 + k);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++)
-            issue(k);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (k + DEPTH < 8)
-                issue(k + DEPTH);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(k);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int sig = 0; sig < NSIG; sig++) {
+    // a signal's result out (behind the tap loop - or behind its own round)
+    auto finish_signal = [&](const int sig) {
         const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
         float inv = wrcp_(wsum[sig]);
         f3 o = mul3(sum[sig], inv);
@@ -2244,6 +2147,220 @@ __global__ __launch_bounds__(256) NRD_WAVES_PER_EU(FIRST ? 1 : NRD_ATROUS_WAVES)
             if (SH)
                 st<uint2>(p.out, x, y, RBPT, pack_h4(mul4(sum1[sig], inv)), sig * sb + 8);
         }
+    };
+    constexpr bool ROUNDS = NRD_ATROUS_SIGNAL_ROUNDS_ON && NSIG == 2;
+    if constexpr (!ROUNDS) {
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++)
+            setup_signal(sig);
+    }
+    const bool roughStop = p.roughnessEdgeStopping != 0;
+    // the 8 taps in row-major order as a software pipeline (like k_spatial): DEPTH taps in flight, tap k is consumed right after tap
+    // k + DEPTH is issued, so the arithmetic of a tap runs under the loads of the next ones (LDS flavours: the reads of a batch)
+    constexpr int TI[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, TJ[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+#ifndef NRD_ATROUS_DEPTH // taps in flight of the SH gather flavour: 2 keep it at 126 VGPRs = 4 waves per SIMD (4: 132 / 3 waves; profiles/r04_ab_atrous_mask.txt)
+#define NRD_ATROUS_DEPTH 2
+#endif
+#ifndef NRD_ATROUS_LS_DEPTH // LDS reads in flight per batch of the SH flavours that stage their window (iterations 0-2)
+#define NRD_ATROUS_LS_DEPTH 4
+#endif
+    constexpr int DEPTH = LS ? (SH ? NRD_ATROUS_LS_DEPTH : 8) : (SH ? NRD_ATROUS_DEPTH : 8); // 32-byte SH texels: fewer taps in flight keep the kernel within its registers
+    // NRD_ATROUS_SIGNAL_ROUNDS 1 (A/B): with two signals the 8 taps are walked ONCE PER SIGNAL - set-up, taps, result of the diffuse signal
+    // (guide + diffuse texel per tap; the taps' geometry weight and normal distance are kept: 16 registers), then the same for the specular
+    // signal (guide + specular texel, reusing them): only ONE signal's state is live at a time
+    if constexpr (ROUNDS) {
+#ifndef NRD_ATROUS_ROUND_DEPTH // taps in flight inside a round (gather flavours; the staged flavours read a whole round's taps from LDS at once)
+#define NRD_ATROUS_ROUND_DEPTH 2
+#endif
+        constexpr int DEPTHR = LS ? (SH ? 4 : 8) : (SH ? NRD_ATROUS_ROUND_DEPTH : 4);
+        float geoWs[8], nD2s[8];
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++) {
+            const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+            setup_signal(sig);
+            uint2 grawR[8];
+            uint2 stexR[8][SW];
+            uint16_t mrawR[8];
+            bool insideR[8];
+            auto issueR = [&](const int k) {
+                const int i = TI[k], j = TJ[k];
+                if (LS) {
+                    const int q = ci + (j * T + i) * LS;
+                    insideR[k] = true; // outside texels were staged as sky
+                    grawR[k] = sG[q];
+#pragma unroll
+                    for (int w = 0; w < SW; w++)
+                        stexR[k][w] = sT[q * TW + sig * SW + w];
+                    mrawR[k] = FIRST ? (uint16_t)(sM[q] >> (16 * sig)) : (uint16_t)0;
+                    return;
+                }
+                int px = x + i * stride, py = y + j * stride;
+                insideR[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+                int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
+                grawR[k] = ld_guide(p.guide, cpx, cpy);
+                if constexpr (SH) {
+                    const uint4 both = ld<uint4>(p.in, cpx, cpy, RBPT, sig * sb);
+                    stexR[k][0] = uint2{both.x, both.y};
+                    stexR[k][SW - 1] = uint2{both.z, both.w};
+                } else
+                    stexR[k][0] = ld<uint2>(p.in, cpx, cpy, RBPT, sig * sb);
+                mrawR[k] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+            };
+            auto consumeR = [&](const int k) {
+                const int i = TI[k], j = TJ[k];
+                int px = x + i * stride, gy = y + j * stride + c.yOff;
+                Guide gs = decode_guide(grawR[k], c.denoisingRange);
+                if (sig == 0) { // what both signals share of a tap
+                    geoWs[k] = geo_weight(pg, (float)px, (float)gy, gs.z);
+                    nD2s[k] = normal_dist2(normal_codes(g.nw), gs.nw);
+                }
+                const bool matOk = material_class(gs.mat, matFloor[sig]) == matClass[sig];
+                const bool valid = insideR[k] & !gs.sky & matOk;
+                float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
+                w *= geoWs[k];
+                w *= normal_weight_m2(nD2s[k], normalW2[sig]);
+                if (isSpec) {
+                    float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                    if (LS)
+                        rw = lerpf(1.0f, rw, roughRelax);
+                    w *= roughStop ? rw : 1.0f;
+                }
+                f4 sv = unpack_h4(stexR[k][0]);
+                float vs = sv.w;
+                if (FIRST)
+                    vs = fmax2(fma_(-signal_luma(sv, true), signal_luma(sv, true), h2f(mrawR[k])), 0.0f);
+                w *= fmax2(exp_weight(absf(signal_luma(sv, true) - c0Y[sig]) * invL[sig]), minLw[sig]);
+                w = valid ? w : 0.0f;
+                sum[sig] = {fma_(sv.x, w, sum[sig].x), fma_(sv.y, w, sum[sig].y), fma_(sv.z, w, sum[sig].z)};
+                if (SH)
+                    sum1[sig] = fma4(unpack_h4(stexR[k][SW - 1]), w, sum1[sig]);
+                sumVar[sig] = fma_(vs, w * w, sumVar[sig]);
+                wsum[sig] += w;
+            };
+            if constexpr (LS) {
+#pragma unroll
+                for (int t0 = 0; t0 < 8; t0 += DEPTHR) {
+#pragma unroll
+                    for (int k = 0; k < DEPTHR; k++)
+                        issueR(t0 + k);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < DEPTHR; k++)
+                        consumeR(t0 + k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < DEPTHR; k++)
+                    issueR(k);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k + DEPTHR < 8)
+                        issueR(k + DEPTHR);
+                    __builtin_amdgcn_sched_barrier(0);
+                    consumeR(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            finish_signal(sig);
+        }
+    } else {
+        uint2 graw[8];
+        uint2 stex[8][RBPT / 8];
+        uint16_t mraw[8][NSIG];
+        bool inside[8];
+        auto issue = [&](const int k) {
+            const int i = TI[k], j = TJ[k];
+            if (LS) {
+                const int q = ci + (j * T + i) * LS;
+                inside[k] = true; // outside texels were staged as sky
+                graw[k] = sG[q];
+    #pragma unroll
+                for (int w = 0; w < TW; w++)
+                    stex[k][w] = sT[q * TW + w];
+    #pragma unroll
+                for (int sig = 0; sig < NSIG; sig++)
+                    mraw[k][sig] = FIRST ? (uint16_t)(sM[q] >> (16 * sig)) : (uint16_t)0;
+                return;
+            }
+            int px = x + i * stride, py = y + j * stride;
+            inside[k] = ((uint32_t)px < (uint32_t)c.W) & ((uint32_t)(py - loY) <= (uint32_t)(hiY - loY));
+            int cpx = imin(imax(px, 0), c.W - 1), cpy = imin(imax(py, loY), hiY);
+            graw[k] = ld_guide(p.guide, cpx, cpy);
+            load_texel<RBPT>(p.in, cpx, cpy, stex[k]);
+    #pragma unroll
+            for (int sig = 0; sig < NSIG; sig++)
+                mraw[k][sig] = FIRST ? ld<uint16_t>(p.mom, cpx, cpy, LBPT, sig * 2) : (uint16_t)0;
+        };
+        auto consume = [&](const int k) {
+            const int i = TI[k], j = TJ[k];
+            int px = x + i * stride, gy = y + j * stride + c.yOff;
+            Guide gs = decode_guide(graw[k], c.denoisingRange);
+            float geoW = geo_weight(pg, (float)px, (float)gy, gs.z);
+            const float nD2 = normal_dist2(normal_codes(g.nw), gs.nw);
+    #pragma unroll
+            for (int sig = 0; sig < NSIG; sig++) {
+                const bool isSpec = HAS_SPEC && sig == SIG_SPEC;
+                // (bitwise: one basic block - the short-circuit form compiles to an exec-mask detour per operand; the material test as class
+                // equality, nrd_device.h material_class) rejected taps are selected out below
+                const bool matOk = material_class(gs.mat, matFloor[sig]) == matClass[sig];
+                const bool valid = inside[k] & !gs.sky & matOk;
+                float w = (i == 0 || j == 0) ? 0.5f : 0.25f;
+                w *= geoW;
+                w *= normal_weight_m2(nD2, normalW2[sig]);
+                if (isSpec) {
+                    float rw = smoothstep01(1.0f - absf(fma_(gs.roughness, roughA, roughB)));
+                    if (LS)
+                        rw = lerpf(1.0f, rw, roughRelax);
+                    w *= roughStop ? rw : 1.0f;
+                }
+                f4 sv = unpack_h4(stex[k][sig * SW]);
+                float vs = sv.w;
+                if (FIRST)
+                    vs = fmax2(fma_(-signal_luma(sv, true), signal_luma(sv, true), h2f(mraw[k][sig])), 0.0f);
+                w *= fmax2(exp_weight(absf(signal_luma(sv, true) - c0Y[sig]) * invL[sig]), minLw[sig]);
+                // a rejected tap enters with weight 0 (its texel is a finite value of an internal plane, fetched at the clamped
+                // position): one select on the weight instead of one per accumulated component
+                w = valid ? w : 0.0f;
+                sum[sig] = {fma_(sv.x, w, sum[sig].x), fma_(sv.y, w, sum[sig].y), fma_(sv.z, w, sum[sig].z)};
+                if (SH)
+                    sum1[sig] = fma4(unpack_h4(stex[k][sig * SW + (SH ? 1 : 0)]), w, sum1[sig]);
+                sumVar[sig] = fma_(vs, w * w, sumVar[sig]);
+                wsum[sig] += w;
+            }
+        };
+        if constexpr (LS) { // batches of DEPTH LDS reads, then their arithmetic
+    #pragma unroll
+            for (int t0 = 0; t0 < 8; t0 += DEPTH) {
+    #pragma unroll
+                for (int k = 0; k < DEPTH; k++)
+                    issue(t0 + k);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int k = 0; k < DEPTH; k++)
+                    consume(t0 + k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+    #pragma unroll
+            for (int k = 0; k < DEPTH; k++)
+                issue(k);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k + DEPTH < 8)
+                    issue(k + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if constexpr (!ROUNDS) {
+#pragma unroll
+        for (int sig = 0; sig < NSIG; sig++)
+            finish_signal(sig);
     }
 }
 
